@@ -1,0 +1,252 @@
+"""ctypes front-end for the parity oracle.  TEST INFRASTRUCTURE ONLY.
+
+Drives either oracle/libffm_oracle.so (this repo's C restatement, ``kind="oracle"``) or
+oracle/_ref/libftrl_ref.so (the unmodified reference model classes, ``kind="ref"``) through the
+same interface, so tests can compare them bit for bit.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; nothing under ftrl-ffm_amd/ does.
+"""
+import ctypes
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libffm_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libftrl_ref.so")
+REFERENCE_ROOT = "/root/reference"
+
+LR, FM, FFM = 0, 1, 2
+MODEL_TYPES = {"LR": LR, "FM": FM, "FFM": FFM}
+
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
+_c_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+def build(ref=True):
+    """Compile the restatement and, when /root/reference is present, the reference build."""
+    targets = ["oracle"]
+    if ref and os.path.exists(os.path.join(REFERENCE_ROOT, "src", "model", "ffm.cpp")):
+        targets.append("ref")
+    subprocess.check_call(["make", "-s", "-C", HERE, "-j8"] + targets)
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def _i32(a):
+    return None if a is None else a.ctypes.data_as(_c_i32p)
+
+
+def _f32(a):
+    return None if a is None else a.ctypes.data_as(_c_f32p)
+
+
+@dataclass
+class Csr:
+    """A block of rows in the engine's CSR wire format (int32 row_ptr/field/feat/label, f32 val)."""
+    row_ptr: np.ndarray
+    field: np.ndarray
+    feat: np.ndarray
+    val: np.ndarray
+    label: np.ndarray
+
+    @property
+    def n_rows(self):
+        return len(self.row_ptr) - 1
+
+    def rows(self, lo, hi):
+        b, e = int(self.row_ptr[lo]), int(self.row_ptr[hi])
+        return Csr((self.row_ptr[lo:hi + 1] - b).astype(np.int32), self.field[b:e].copy(),
+                   self.feat[b:e].copy(), self.val[b:e].copy(), self.label[lo:hi].copy())
+
+    @staticmethod
+    def from_rows(rows, labels):
+        """rows: list of lists of (field, feat, val)."""
+        row_ptr = np.zeros(len(rows) + 1, np.int32)
+        for i, r in enumerate(rows):
+            row_ptr[i + 1] = row_ptr[i] + len(r)
+        flat = [e for r in rows for e in r]
+        field = np.array([e[0] for e in flat], np.int32)
+        feat = np.array([e[1] for e in flat], np.int32)
+        val = np.array([e[2] for e in flat], np.float32)
+        return Csr(row_ptr, field, feat, val, np.asarray(labels, np.int32))
+
+
+_libs = {}
+
+
+def _lib(kind):
+    if kind in _libs:
+        return _libs[kind]
+    path = ORACLE_SO if kind == "oracle" else REF_SO
+    if not os.path.exists(path):
+        build(ref=(kind == "ref"))
+    lib = ctypes.CDLL(path)
+    p = "fo_" if kind == "oracle" else "fr_"
+    vp = ctypes.c_void_p
+    f = getattr(lib, p + "create")
+    f.restype = vp
+    f.argtypes = [ctypes.c_int] * 4 + [ctypes.c_float] * 4
+    getattr(lib, p + "destroy").argtypes = [vp]
+    getattr(lib, p + "row_len").restype = ctypes.c_int64
+    getattr(lib, p + "row_len").argtypes = [vp]
+    for name in ("train", "predict"):
+        f = getattr(lib, p + name)
+        f.restype = ctypes.c_float
+        f.argtypes = [vp, ctypes.c_int, _c_i32p, _c_i32p, _c_f32p, ctypes.c_int]
+    f = getattr(lib, p + "train_rows")
+    f.restype = ctypes.c_double
+    f.argtypes = [vp, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p, _c_f32p]
+    f = getattr(lib, p + "predict_batch")
+    f.restype = ctypes.c_double
+    f.argtypes = [vp, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p, ctypes.c_int, _c_f32p]
+    getattr(lib, p + "sgn").restype = ctypes.c_float
+    getattr(lib, p + "sgn").argtypes = [ctypes.c_float]
+    getattr(lib, p + "sigmoid").restype = ctypes.c_float
+    getattr(lib, p + "sigmoid").argtypes = [ctypes.c_float]
+    getattr(lib, p + "loss").restype = ctypes.c_double
+    getattr(lib, p + "loss").argtypes = [ctypes.c_int, ctypes.c_double]
+    getattr(lib, p + "maybe_zero_weight").restype = ctypes.c_float
+    getattr(lib, p + "maybe_zero_weight").argtypes = [vp, ctypes.c_float, ctypes.c_float]
+    if kind == "oracle":
+        f = lib.fo_train_batch
+        f.restype = ctypes.c_double
+        f.argtypes = [vp, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p, _c_f32p]
+        f = lib.fo_train_rows_threaded
+        f.restype = ctypes.c_double
+        f.argtypes = [vp, ctypes.c_int, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p,
+                      ctypes.POINTER(ctypes.c_double)]
+        for name in ("bias3", "lin_w", "lin_n", "lin_z", "vec_w", "vec_n", "vec_z"):
+            getattr(lib, "fo_" + name).restype = _c_f32p
+            getattr(lib, "fo_" + name).argtypes = [vp]
+    else:
+        fp7 = [vp] + [_c_f32p] * 7
+        lib.fr_get_state.argtypes = fp7
+        lib.fr_set_state.argtypes = fp7
+        lib.fr_remove_out_range.restype = ctypes.c_int
+        lib.fr_remove_out_range.argtypes = [vp, ctypes.c_int, _c_i32p, _c_i32p, _c_f32p]
+        lib.fr_sgn_int.restype = ctypes.c_int
+        lib.fr_sgn_int.argtypes = [ctypes.c_int]
+    _libs[kind] = (lib, p)
+    return _libs[kind]
+
+
+STATE_KEYS = ("bias3", "lin_w", "lin_n", "lin_z", "vec_w", "vec_n", "vec_z")
+
+
+class CpuModel:
+    """One LR/FM/FFM model on the CPU: ``kind="oracle"`` (restatement) or ``"ref"`` (reference)."""
+
+    def __init__(self, kind, model_type, n_feats, n_fields=1, n_factors=1, w_alpha=1e-4,
+                 w_beta=1.0, w_l1=0.1, w_l2=5.0):
+        self.kind = kind
+        self.lib, self.p = _lib(kind)
+        self.model_type = MODEL_TYPES[model_type] if isinstance(model_type, str) else model_type
+        self.n_feats, self.n_fields, self.n_factors = n_feats, n_fields, n_factors
+        self.h = getattr(self.lib, self.p + "create")(self.model_type, n_feats, n_fields, n_factors,
+                                                      w_alpha, w_beta, w_l1, w_l2)
+        self.row_len = int(getattr(self.lib, self.p + "row_len")(self.h))
+        if kind == "ref":  # the reference ctor leaves random weights behind: start from zeros
+            self.set_state(self.zero_state())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.lib, self.p + "destroy")(self.h)
+            self.h = None
+
+    def zero_state(self):
+        nf, L = self.n_feats, self.row_len
+        return dict(bias3=np.zeros(3, np.float32), lin_w=np.zeros(nf, np.float32),
+                    lin_n=np.zeros(nf, np.float32), lin_z=np.zeros(nf, np.float32),
+                    vec_w=np.zeros((nf, L), np.float32), vec_n=np.zeros((nf, L), np.float32),
+                    vec_z=np.zeros((nf, L), np.float32))
+
+    def _view(self, name, shape):
+        ptr = getattr(self.lib, "fo_" + name)(self.h)
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, np.float32)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape)
+
+    def get_state(self):
+        nf, L = self.n_feats, self.row_len
+        if self.kind == "oracle":
+            shapes = dict(bias3=(3,), lin_w=(nf,), lin_n=(nf,), lin_z=(nf,), vec_w=(nf, L),
+                          vec_n=(nf, L), vec_z=(nf, L))
+            return {k: self._view(k, s).copy() for k, s in shapes.items()}
+        st = self.zero_state()
+        args = [_f32(st[k]) if st[k].size else None for k in STATE_KEYS]
+        self.lib.fr_get_state(self.h, *args)
+        return st
+
+    def set_state(self, st):
+        nf, L = self.n_feats, self.row_len
+        st = {k: np.ascontiguousarray(v, np.float32) for k, v in st.items()}
+        if self.kind == "oracle":
+            shapes = dict(bias3=(3,), lin_w=(nf,), lin_n=(nf,), lin_z=(nf,), vec_w=(nf, L),
+                          vec_n=(nf, L), vec_z=(nf, L))
+            for k, v in st.items():
+                if v.size:
+                    self._view(k, shapes[k])[...] = v.reshape(shapes[k])
+            return
+        args = [(_f32(st[k]) if k in st and st[k].size else None) for k in STATE_KEYS]
+        self.lib.fr_set_state(self.h, *args)
+
+    # --- per-row entry points (reference FtrlModel::train / predict) ---
+    def train(self, row, label):
+        c = Csr.from_rows([row], [label])
+        return float(getattr(self.lib, self.p + "train")(self.h, len(row), _i32(c.field),
+                                                         _i32(c.feat), _f32(c.val), int(label)))
+
+    def predict(self, row, output_prob=False):
+        c = Csr.from_rows([row], [0])
+        return float(getattr(self.lib, self.p + "predict")(self.h, len(row), _i32(c.field),
+                                                           _i32(c.feat), _f32(c.val),
+                                                           int(output_prob)))
+
+    # --- CSR entry points ---
+    def _csr_args(self, c):
+        return (c.n_rows, _i32(c.row_ptr), _i32(c.field), _i32(c.feat), _f32(c.val), _i32(c.label))
+
+    def train_rows(self, c):
+        """Sequential per-sample training in row order.  Returns (logits, loss_sum)."""
+        out = np.zeros(c.n_rows, np.float32)
+        loss = getattr(self.lib, self.p + "train_rows")(self.h, *self._csr_args(c), _f32(out))
+        return out, float(loss)
+
+    def train_batch(self, c):
+        """One mini-batch with the engine's batch semantics (oracle only)."""
+        assert self.kind == "oracle"
+        out = np.zeros(c.n_rows, np.float32)
+        loss = self.lib.fo_train_batch(self.h, *self._csr_args(c), _f32(out))
+        return out, float(loss)
+
+    def predict_batch(self, c, output_prob=False):
+        out = np.zeros(c.n_rows, np.float32)
+        loss = getattr(self.lib, self.p + "predict_batch")(self.h, *self._csr_args(c),
+                                                           int(output_prob), _f32(out))
+        return out, float(loss)
+
+    def train_rows_threaded(self, c, n_threads):
+        """Reference-style threaded epoch (oracle only).  Returns (seconds, loss_sum)."""
+        assert self.kind == "oracle"
+        loss = ctypes.c_double(0.0)
+        sec = self.lib.fo_train_rows_threaded(self.h, int(n_threads), *self._csr_args(c),
+                                              ctypes.byref(loss))
+        return float(sec), float(loss.value)
+
+    # --- scalar helpers ---
+    def sgn(self, x):
+        return float(getattr(self.lib, self.p + "sgn")(x))
+
+    def sigmoid(self, x):
+        return float(getattr(self.lib, self.p + "sigmoid")(x))
+
+    def loss(self, y, logit):
+        return float(getattr(self.lib, self.p + "loss")(int(y), float(logit)))
+
+    def maybe_zero_weight(self, n, z):
+        return float(getattr(self.lib, self.p + "maybe_zero_weight")(self.h, n, z))

@@ -1,0 +1,631 @@
+// engine.hip -- host side of the C ABI in include/ffm_engine.h: owns the model state in HBM and the
+// per-block scratch, and schedules the gfx950 kernels of one block of rows on one HIP stream.
+//
+// Pipeline of one training block (DESIGN.md "Pipeline"):
+//   group_count -> group_alloc -> group_scatter -> group_sort      (kernels_group.h)
+//   {ffm,fm}_row<TRAIN>   lazy refresh + forward -> logit           (kernels_row.h)
+//   [cross-shard sum of the logits when n_shards > 1 -- done by the caller, RCCL]
+//   tmp_grad -> loss_sum
+//   linear_update, bias_update, {ffm,fm}_update                     (kernels_update.h)
+//   group_cleanup
+// There is no CPU fallback anywhere in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ffm_engine.h"
+#include "engine_types.h"
+#include "kernels_group.h"
+#include "kernels_row.h"
+#include "kernels_update.h"
+
+using namespace ftrl_dev;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t err__ = (expr);                                                              \
+    if (err__ != hipSuccess)                                                                \
+      return fail(err__ == hipErrorOutOfMemory ? FFM_E_NOMEM : FFM_E_DEVICE,                \
+                  std::string(#expr) + ": " + hipGetErrorString(err__));                    \
+  } while (0)
+
+enum KernelId {
+  K_GROUP_COUNT, K_GROUP_ALLOC, K_GROUP_SCATTER, K_GROUP_SORT, K_ROW, K_TMP_GRAD, K_LOSS_SUM,
+  K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_GROUP_CLEANUP, K_PREDICT_ROW, K_COUNT
+};
+const char *kKernelNames[K_COUNT] = {
+    "group_count_kernel", "group_alloc_kernel", "group_scatter_kernel", "group_sort_kernel",
+    "row_kernel<train>", "tmp_grad_kernel", "loss_sum_kernel", "linear_update_kernel",
+    "bias_update_kernel", "latent_update_kernel", "group_cleanup_kernel", "row_kernel<predict>"};
+
+struct ProfRec {
+  int kid;
+  hipEvent_t e0, e1;
+};
+
+__global__ void init_weights_kernel(ModelDev m, float mean, float stddev, uint64_t seed) {
+  const int64_t n_lat = static_cast<int64_t>(m.n_feats) * m.row_len;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < n_lat;
+       idx += stride) {
+    const int64_t feat = idx / m.row_len;
+    const int e = static_cast<int>(idx - feat * m.row_len);
+    m.lat[feat * 3 * m.row_len + LAT_W * m.row_len + e] = mean + stddev * normal01(seed, 1, idx);
+  }
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < m.n_feats;
+       i += stride)
+    m.lin_w[i] = mean + stddev * normal01(seed, 0, i);
+}
+
+// Copies one component (n, z or w) of features [feat0, feat0+nf) between the interleaved record
+// layout and a dense [feat][row_len] staging buffer (the reference's save order).
+__global__ void lat_component_copy_kernel(float *lat, int row_len, int comp, float *dense,
+                                          int64_t feat0, int64_t nf, int to_dense) {
+  const int64_t total = nf * row_len;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += stride) {
+    const int64_t f = idx / row_len;
+    const int e = static_cast<int>(idx - f * row_len);
+    float *rec = lat + (feat0 + f) * 3 * row_len + static_cast<int64_t>(comp) * row_len + e;
+    if (to_dense) dense[idx] = *rec; else *rec = dense[idx];
+  }
+}
+
+}  // namespace
+
+struct ffm_engine {
+  ffm_engine_config cfg{};
+  ModelDev m{};
+  Scratch s{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int max_rows = 0, max_nnz = 0, max_row_nnz = 1024;
+  // staging for the host-buffer entry points
+  int *d_row_ptr = nullptr, *d_field = nullptr, *d_feat = nullptr, *d_label = nullptr;
+  float *d_val = nullptr, *d_out = nullptr;
+  double *d_loss_sum = nullptr;
+  int *d_sort_tmp = nullptr;
+  float *d_stage = nullptr;  // dense staging for get/set
+  int64_t stage_floats = 0;
+  std::vector<void *> allocs;
+  // split-phase bookkeeping
+  Rows pending{};
+  bool has_pending = false;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> event_pool;
+
+  template <typename T>
+  int alloc(T **p, size_t count) {
+    void *q = nullptr;
+    if (count == 0) count = 1;
+    hipError_t err = hipMalloc(&q, count * sizeof(T));
+    if (err != hipSuccess)
+      return fail(FFM_E_NOMEM, "hipMalloc of " + std::to_string(count * sizeof(T)) +
+                                   " bytes failed: " + hipGetErrorString(err));
+    allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return FFM_OK;
+  }
+
+  hipEvent_t get_event() {
+    if (!event_pool.empty()) {
+      hipEvent_t e = event_pool.back();
+      event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+  }
+  void prof_begin(int kid) {
+    if (!prof_on) return;
+    ProfRec r{kid, get_event(), get_event()};
+    hipEventRecord(r.e0, stream);
+    prof.push_back(r);
+  }
+  void prof_end() {
+    if (!prof_on) return;
+    hipEventRecord(prof.back().e1, stream);
+  }
+};
+
+#define LAUNCH(e, kid, kernel, grid, block, shmem, ...)                          \
+  do {                                                                           \
+    (e)->prof_begin(kid);                                                        \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, (e)->stream, __VA_ARGS__); \
+    (e)->prof_end();                                                             \
+  } while (0)
+
+extern "C" {
+
+int ffm_engine_abi_version(void) { return FFM_ENGINE_ABI_VERSION; }
+const char *ffm_engine_last_error(void) { return g_last_error.c_str(); }
+
+void ffm_engine_default_config(ffm_engine_config *cfg) {
+  if (!cfg) return;
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->model_type = FFM_MODEL_FFM;  // cmd_option.h:62
+  cfg->n_feats = 10000;
+  cfg->n_fields = 8;
+  cfg->n_factors = 16;
+  cfg->w_alpha = 1e-4f;
+  cfg->w_beta = 1.0f;
+  cfg->w_l1 = 0.1f;
+  cfg->w_l2 = 5.0f;
+  cfg->init_mean = 0.0f;
+  cfg->init_stddev = 0.02f;
+  cfg->seed = 42;
+  cfg->max_batch_rows = 8192;
+  cfg->max_batch_nnz = 8192 * 64;
+  cfg->device_id = 0;
+  cfg->n_shards = 1;
+  cfg->shard_rank = 0;
+}
+
+int64_t ffm_engine_row_len(const ffm_engine *e) { return e ? e->m.row_len : 0; }
+
+void ffm_engine_destroy(ffm_engine *e) {
+  if (!e) return;
+  hipSetDevice(e->cfg.device_id);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  for (auto &r : e->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (auto ev : e->event_pool) hipEventDestroy(ev);
+  for (void *p : e->allocs) hipFree(p);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
+  if (!cfg || !out) return fail(FFM_E_INVALID, "null config or output pointer");
+  *out = nullptr;
+  if (cfg->model_type < FFM_MODEL_LR || cfg->model_type > FFM_MODEL_FFM)
+    return fail(FFM_E_INVALID, "invalid model_type, expect LR(0), FM(1) or FFM(2)");
+  if (cfg->n_feats <= 0) return fail(FFM_E_INVALID, "n_feats must be positive");
+  if (cfg->model_type == FFM_MODEL_FFM && cfg->n_fields <= 0)
+    return fail(FFM_E_INVALID, "n_fields must be positive for FFM");
+  if (cfg->model_type != FFM_MODEL_LR && cfg->n_factors <= 0)
+    return fail(FFM_E_INVALID, "n_factors must be positive for FM/FFM");
+  if (cfg->model_type == FFM_MODEL_FM && cfg->n_factors > kTermsCap)
+    return fail(FFM_E_UNSUPPORTED, "FM n_factors above 2048 is not supported");
+  if (cfg->max_batch_rows <= 0 || cfg->max_batch_nnz <= 0)
+    return fail(FFM_E_INVALID, "max_batch_rows / max_batch_nnz must be positive");
+  if (cfg->n_shards < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->n_shards)
+    return fail(FFM_E_INVALID, "invalid n_shards / shard_rank");
+  if (cfg->n_shards > 1 && cfg->model_type != FFM_MODEL_FFM)
+    return fail(FFM_E_UNSUPPORTED, "field-pair sharding applies to FFM only");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(FFM_E_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (cfg->device_id < 0 || cfg->device_id >= n_dev)
+    return fail(FFM_E_INVALID, "device_id out of range");
+  HIP_TRY(hipSetDevice(cfg->device_id));
+
+  ffm_engine *e = new (std::nothrow) ffm_engine;
+  if (!e) return fail(FFM_E_NOMEM, "host allocation failed");
+  e->cfg = *cfg;
+  e->max_rows = cfg->max_batch_rows;
+  e->max_nnz = cfg->max_batch_nnz;
+  if (cfg->reserved[0] > 0) e->max_row_nnz = cfg->reserved[0];
+  ModelDev &m = e->m;
+  m.type = cfg->model_type;
+  m.n_feats = cfg->n_feats;
+  m.n_fields = cfg->model_type == FFM_MODEL_FFM ? cfg->n_fields : 1;
+  m.n_factors = cfg->model_type == FFM_MODEL_LR ? 0 : cfg->n_factors;
+  m.row_len = cfg->model_type == FFM_MODEL_FFM ? cfg->n_fields * cfg->n_factors
+              : cfg->model_type == FFM_MODEL_FM ? cfg->n_factors : 0;
+  m.n_shards = cfg->n_shards;
+  m.shard_rank = cfg->shard_rank;
+  m.h = Hyper{cfg->w_alpha, cfg->w_beta, cfg->w_l1, cfg->w_l2};
+  if (static_cast<int64_t>(cfg->n_fields) * cfg->n_factors > (1 << 24))
+    { delete e; return fail(FFM_E_UNSUPPORTED, "n_fields*n_factors too large"); }
+
+  int rc = FFM_OK;
+#define TRY_ALLOC(call) do { rc = (call); if (rc != FFM_OK) { ffm_engine_destroy(e); return rc; } } while (0)
+#define TRY_HIP(expr) do { hipError_t err__ = (expr); if (err__ != hipSuccess) { \
+    rc = fail(FFM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(err__)); \
+    ffm_engine_destroy(e); return rc; } } while (0)
+  if (cfg->stream) {
+    e->stream = static_cast<hipStream_t>(cfg->stream);
+  } else {
+    TRY_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+  }
+  const size_t nf = static_cast<size_t>(cfg->n_feats);
+  const size_t n_lat = nf * 3 * static_cast<size_t>(m.row_len);
+  TRY_ALLOC(e->alloc(&m.bias3, 4));
+  TRY_ALLOC(e->alloc(&m.lin_n, nf));
+  TRY_ALLOC(e->alloc(&m.lin_z, nf));
+  TRY_ALLOC(e->alloc(&m.lin_w, nf));
+  TRY_ALLOC(e->alloc(&m.lat, n_lat));
+  const size_t R = static_cast<size_t>(e->max_rows), E = static_cast<size_t>(e->max_nnz);
+  Scratch &s = e->s;
+  TRY_ALLOC(e->alloc(&s.efeat, E));
+  TRY_ALLOC(e->alloc(&s.row_of, E));
+  TRY_ALLOC(e->alloc(&s.occ, E));
+  TRY_ALLOC(e->alloc(&s.uniq, E));
+  TRY_ALLOC(e->alloc(&s.ustart, E));
+  TRY_ALLOC(e->alloc(&s.ucount, E));
+  TRY_ALLOC(e->alloc(&s.multi, E));
+  TRY_ALLOC(e->alloc(&s.counters, 8));
+  TRY_ALLOC(e->alloc(&s.cnt, nf));
+  TRY_ALLOC(e->alloc(&s.fstart, nf));
+  TRY_ALLOC(e->alloc(&s.head, R * static_cast<size_t>(m.n_fields)));
+  TRY_ALLOC(e->alloc(&s.next, E));
+  TRY_ALLOC(e->alloc(&s.logit, R));
+  TRY_ALLOC(e->alloc(&s.tg, R));
+  TRY_ALLOC(e->alloc(&s.loss, R));
+  TRY_ALLOC(e->alloc(&s.svx, R * static_cast<size_t>(m.type == FFM_MODEL_FM ? m.n_factors : 1)));
+  TRY_ALLOC(e->alloc(&e->d_sort_tmp, E));
+  TRY_ALLOC(e->alloc(&e->d_row_ptr, R + 1));
+  TRY_ALLOC(e->alloc(&e->d_field, E));
+  TRY_ALLOC(e->alloc(&e->d_feat, E));
+  TRY_ALLOC(e->alloc(&e->d_val, E));
+  TRY_ALLOC(e->alloc(&e->d_label, R));
+  TRY_ALLOC(e->alloc(&e->d_out, R));
+  TRY_ALLOC(e->alloc(&e->d_loss_sum, 2));
+  e->stage_floats = 16 << 20;  // 64 MiB dense staging for get/set
+  if (static_cast<int64_t>(m.row_len) > e->stage_floats) e->stage_floats = m.row_len;
+  TRY_ALLOC(e->alloc(&e->d_stage, static_cast<size_t>(e->stage_floats)));
+
+  TRY_HIP(hipMemsetAsync(m.bias3, 0, 4 * sizeof(float), e->stream));
+  TRY_HIP(hipMemsetAsync(m.lin_n, 0, nf * sizeof(float), e->stream));
+  TRY_HIP(hipMemsetAsync(m.lin_z, 0, nf * sizeof(float), e->stream));
+  TRY_HIP(hipMemsetAsync(m.lin_w, 0, nf * sizeof(float), e->stream));
+  if (n_lat) TRY_HIP(hipMemsetAsync(m.lat, 0, n_lat * sizeof(float), e->stream));
+  TRY_HIP(hipMemsetAsync(s.cnt, 0, nf * sizeof(int), e->stream));
+  TRY_HIP(hipMemsetAsync(s.counters, 0, 8 * sizeof(int), e->stream));
+  if (!(cfg->flags & FFM_FLAG_SKIP_INIT))
+    hipLaunchKernelGGL(init_weights_kernel, dim3(2048), dim3(256), 0, e->stream, m, cfg->init_mean,
+                       cfg->init_stddev, cfg->seed);
+  TRY_HIP(hipGetLastError());
+  TRY_HIP(hipStreamSynchronize(e->stream));
+#undef TRY_ALLOC
+#undef TRY_HIP
+  *out = e;
+  return FFM_OK;
+}
+
+int ffm_engine_sync(ffm_engine *e) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return FFM_OK;
+}
+
+// ---- dense <-> record layout transfers ----------------------------------------------------
+
+static int vec_transfer(ffm_engine *e, int comp, float *host, bool to_host) {
+  if (!host || e->m.row_len == 0) return FFM_OK;
+  const int64_t RL = e->m.row_len;
+  const int64_t chunk = e->stage_floats / RL;
+  for (int64_t f0 = 0; f0 < e->m.n_feats; f0 += chunk) {
+    const int64_t nf = std::min<int64_t>(chunk, e->m.n_feats - f0);
+    const size_t bytes = static_cast<size_t>(nf * RL) * sizeof(float);
+    if (!to_host) HIP_TRY(hipMemcpyAsync(e->d_stage, host + f0 * RL, bytes, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(lat_component_copy_kernel, dim3(1024), dim3(256), 0, e->stream, e->m.lat,
+                       static_cast<int>(RL), comp, e->d_stage, f0, nf, to_host ? 1 : 0);
+    if (to_host) HIP_TRY(hipMemcpyAsync(host + f0 * RL, e->d_stage, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return FFM_OK;
+}
+
+static int flat_transfer(ffm_engine *e, float *dev, float *host, size_t n, bool to_host) {
+  if (!host) return FFM_OK;
+  HIP_TRY(hipMemcpyAsync(to_host ? host : dev, to_host ? dev : host, n * sizeof(float),
+                         to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return FFM_OK;
+}
+
+int ffm_engine_set_weights(ffm_engine *e, const float *bias, const float *lin_w, const float *vec_w) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  int rc;
+  if ((rc = flat_transfer(e, e->m.bias3 + 0, const_cast<float *>(bias), 1, false))) return rc;
+  if ((rc = flat_transfer(e, e->m.lin_w, const_cast<float *>(lin_w), e->m.n_feats, false))) return rc;
+  return vec_transfer(e, LAT_W, const_cast<float *>(vec_w), false);
+}
+
+int ffm_engine_get_weights(ffm_engine *e, float *bias, float *lin_w, float *vec_w) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  int rc;
+  if ((rc = flat_transfer(e, e->m.bias3 + 0, bias, 1, true))) return rc;
+  if ((rc = flat_transfer(e, e->m.lin_w, lin_w, e->m.n_feats, true))) return rc;
+  return vec_transfer(e, LAT_W, vec_w, true);
+}
+
+int ffm_engine_set_state(ffm_engine *e, const float *bias_n, const float *bias_z,
+                         const float *lin_n, const float *lin_z, const float *vec_n,
+                         const float *vec_z) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  int rc;
+  if ((rc = flat_transfer(e, e->m.bias3 + 1, const_cast<float *>(bias_n), 1, false))) return rc;
+  if ((rc = flat_transfer(e, e->m.bias3 + 2, const_cast<float *>(bias_z), 1, false))) return rc;
+  if ((rc = flat_transfer(e, e->m.lin_n, const_cast<float *>(lin_n), e->m.n_feats, false))) return rc;
+  if ((rc = flat_transfer(e, e->m.lin_z, const_cast<float *>(lin_z), e->m.n_feats, false))) return rc;
+  if ((rc = vec_transfer(e, LAT_N, const_cast<float *>(vec_n), false))) return rc;
+  return vec_transfer(e, LAT_Z, const_cast<float *>(vec_z), false);
+}
+
+int ffm_engine_get_state(ffm_engine *e, float *bias_n, float *bias_z, float *lin_n, float *lin_z,
+                         float *vec_n, float *vec_z) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  int rc;
+  if ((rc = flat_transfer(e, e->m.bias3 + 1, bias_n, 1, true))) return rc;
+  if ((rc = flat_transfer(e, e->m.bias3 + 2, bias_z, 1, true))) return rc;
+  if ((rc = flat_transfer(e, e->m.lin_n, lin_n, e->m.n_feats, true))) return rc;
+  if ((rc = flat_transfer(e, e->m.lin_z, lin_z, e->m.n_feats, true))) return rc;
+  if ((rc = vec_transfer(e, LAT_N, vec_n, true))) return rc;
+  return vec_transfer(e, LAT_Z, vec_z, true);
+}
+
+// ---- one block of rows ---------------------------------------------------------------------
+
+static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *row_ptr,
+                       const void *field, const void *feat, const void *val) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (n_rows < 0 || nnz < 0) return fail(FFM_E_INVALID, "negative n_rows / nnz");
+  if (n_rows > e->max_rows || nnz > e->max_nnz)
+    return fail(FFM_E_CAPACITY, "block exceeds max_batch_rows / max_batch_nnz");
+  if (!row_ptr || (nnz > 0 && (!feat || !val))) return fail(FFM_E_INVALID, "null CSR array");
+  if (e->m.type == FFM_MODEL_FFM && nnz > 0 && !field)
+    return fail(FFM_E_INVALID, "FFM requires the field array (libffm rows)");
+  return FFM_OK;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float *out, int output_prob) {
+  if (rows.n_rows == 0) return;
+  const size_t shmem = row_lds_bytes(e->max_row_nnz, e->m.n_fields);
+  const int kid = train ? K_ROW : K_PREDICT_ROW;
+  if (e->m.type == FFM_MODEL_FM) {
+    if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
+    else LAUNCH(e, kid, fm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
+  } else {
+    if (train) LAUNCH(e, kid, ffm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
+    else LAUNCH(e, kid, ffm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
+  }
+}
+
+int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
+                                    const int32_t *row_ptr, const int32_t *field,
+                                    const int32_t *feat, const float *val, const int32_t *label,
+                                    float *partial_logit) {
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  if (rc) return rc;
+  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
+  e->pending = rows;
+  e->has_pending = true;
+  HIP_TRY(hipMemsetAsync(e->s.counters, 0, 8 * sizeof(int), e->stream));
+  if (nnz > 0) {
+    LAUNCH(e, K_GROUP_COUNT, group_count_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_GROUP_ALLOC, group_alloc_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, e->s);
+    LAUNCH(e, K_GROUP_SCATTER, group_scatter_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, rows, e->s);
+    LAUNCH(e, K_GROUP_SORT, group_sort_kernel, 1024, kGroupThreads, 0, e->s, e->d_sort_tmp);
+  }
+  launch_row_kernel(e, rows, true, nullptr, 0);
+  if (partial_logit && n_rows > 0)
+    HIP_TRY(hipMemcpyAsync(partial_logit, e->s.logit, sizeof(float) * n_rows, hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *logit_out,
+                                   double *loss_sum_out) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (!e->has_pending) return fail(FFM_E_INVALID, "train_update without a preceding train_forward");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  const Rows rows = e->pending;
+  e->has_pending = false;
+  const float *lg = logit ? logit : e->s.logit;
+  if (rows.n_rows > 0)
+    LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->s.tg, e->s.loss, logit_out);
+  if (loss_sum_out)
+    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->s.loss, loss_sum_out);
+  const bool lin_owner = e->m.shard_rank == 0;
+  if (rows.n_rows > 0 && lin_owner)
+    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->s);
+  if (rows.nnz > 0) {
+    if (lin_owner)
+      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, std::min(cdiv(rows.nnz, kUpdThreads), 1024), kUpdThreads, 0, e->m, rows, e->s);
+    if (e->m.type == FFM_MODEL_FFM)
+      LAUNCH(e, K_LATENT_UPDATE, ffm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    else if (e->m.type == FFM_MODEL_FM)
+      LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_GROUP_CLEANUP, group_cleanup_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, e->s);
+  }
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+int ffm_engine_train_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
+                                  const int32_t *row_ptr, const int32_t *field,
+                                  const int32_t *feat, const float *val, const int32_t *label,
+                                  float *logit_out, double *loss_sum_out) {
+  if (e && e->m.n_shards > 1)
+    return fail(FFM_E_INVALID, "sharded engines train with train_forward + all-reduce + train_update");
+  int rc = ffm_engine_train_forward_device(e, n_rows, nnz, row_ptr, field, feat, val, label, nullptr);
+  if (rc) return rc;
+  return ffm_engine_train_update_device(e, nullptr, logit_out, loss_sum_out);
+}
+
+int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
+                                    const int32_t *row_ptr, const int32_t *field,
+                                    const int32_t *feat, const float *val, const int32_t *label,
+                                    int32_t output_prob, float *out, double *loss_sum_out) {
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  if (rc) return rc;
+  if (e->m.n_shards > 1) return fail(FFM_E_UNSUPPORTED, "predict on a sharded engine is not implemented");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
+  launch_row_kernel(e, rows, false, out ? out : e->d_out, output_prob);
+  if (loss_sum_out && label)
+    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, n_rows, e->s.loss, loss_sum_out);
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, const int32_t *field,
+                       const int32_t *feat, const float *val, const int32_t *label, int32_t *nnz_out) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (n_rows < 0) return fail(FFM_E_INVALID, "negative n_rows");
+  if (!row_ptr) return fail(FFM_E_INVALID, "null row_ptr");
+  if (n_rows > e->max_rows) return fail(FFM_E_CAPACITY, "block exceeds max_batch_rows");
+  if (row_ptr[0] != 0) return fail(FFM_E_INVALID, "row_ptr[0] must be 0");
+  for (int r = 0; r < n_rows; r++)
+    if (row_ptr[r + 1] < row_ptr[r]) return fail(FFM_E_INVALID, "row_ptr must be non-decreasing");
+  const int32_t nnz = row_ptr[n_rows];
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  if (rc) return rc;
+  for (int r = 0; r < n_rows; r++)
+    if (row_ptr[r + 1] - row_ptr[r] > e->max_row_nnz)
+      return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  HIP_TRY(hipMemcpyAsync(e->d_row_ptr, row_ptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice, e->stream));
+  if (nnz > 0) {
+    if (field) HIP_TRY(hipMemcpyAsync(e->d_field, field, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_feat, feat, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, e->stream));
+  }
+  if (label && n_rows > 0)
+    HIP_TRY(hipMemcpyAsync(e->d_label, label, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, e->stream));
+  *nnz_out = nnz;
+  return FFM_OK;
+}
+
+static int check_device_errors(ffm_engine *e) {
+  int flags = 0;
+  HIP_TRY(hipMemcpyAsync(&flags, e->s.counters + CNT_ERROR, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (flags & ERR_ROW_TOO_LONG) return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz");
+  return FFM_OK;
+}
+
+int ffm_engine_train_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                           const int32_t *field, const int32_t *feat, const float *val,
+                           const int32_t *label, float *logit_out, double *loss_sum_out) {
+  int32_t nnz = 0;
+  int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
+  if (rc) return rc;
+  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
+  rc = ffm_engine_train_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
+                                     e->d_feat, e->d_val, e->d_label, e->d_out, e->d_loss_sum);
+  if (rc) return rc;
+  if (logit_out && n_rows > 0)
+    HIP_TRY(hipMemcpyAsync(logit_out, e->d_out, sizeof(float) * n_rows, hipMemcpyDeviceToHost, e->stream));
+  if (loss_sum_out)
+    HIP_TRY(hipMemcpyAsync(loss_sum_out, e->d_loss_sum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  return check_device_errors(e);
+}
+
+int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                             const int32_t *field, const int32_t *feat, const float *val,
+                             const int32_t *label, int32_t output_prob, float *out,
+                             double *loss_sum_out) {
+  int32_t nnz = 0;
+  int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(e->s.counters, 0, 8 * sizeof(int), e->stream));
+  rc = ffm_engine_predict_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
+                                       e->d_feat, e->d_val, label ? e->d_label : nullptr,
+                                       output_prob, e->d_out, e->d_loss_sum);
+  if (rc) return rc;
+  if (out && n_rows > 0)
+    HIP_TRY(hipMemcpyAsync(out, e->d_out, sizeof(float) * n_rows, hipMemcpyDeviceToHost, e->stream));
+  if (loss_sum_out) {
+    if (label) HIP_TRY(hipMemcpyAsync(loss_sum_out, e->d_loss_sum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    else *loss_sum_out = 0.0;
+  }
+  return check_device_errors(e);
+}
+
+// ---- profiling -----------------------------------------------------------------------------
+
+int ffm_engine_profile_enable(ffm_engine *e, int32_t on) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (auto &r : e->prof) { e->event_pool.push_back(r.e0); e->event_pool.push_back(r.e1); }
+  e->prof.clear();
+  e->prof_on = on != 0;
+  return FFM_OK;
+}
+
+static int profile_totals(ffm_engine *e, double *ms, int *n) {
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < K_COUNT; k++) { ms[k] = 0.0; n[k] = 0; }
+  for (auto &r : e->prof) {
+    float t = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+    ms[r.kid] += t;
+    n[r.kid]++;
+  }
+  return FFM_OK;
+}
+
+int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms,
+                            char *kernel_name, size_t kernel_name_cap) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  double ms[K_COUNT];
+  int n[K_COUNT];
+  int rc = profile_totals(e, ms, n);
+  if (rc) return rc;
+  int best = 0;
+  for (int k = 1; k < K_COUNT; k++) if (ms[k] > ms[best]) best = k;
+  if (n_launches) *n_launches = n[best];
+  if (total_ms) *total_ms = ms[best];
+  if (kernel_name && kernel_name_cap) {
+    std::string name = kKernelNames[best];
+    if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE)
+      name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +
+             (best == K_LATENT_UPDATE ? "update_kernel" : (best == K_ROW ? "row_kernel<true>" : "row_kernel<false>"));
+    std::snprintf(kernel_name, kernel_name_cap, "%s", name.c_str());
+  }
+  return FFM_OK;
+}
+
+// Text table of every kernel's launches and total time since profiling was enabled.
+int ffm_engine_profile_dump(ffm_engine *e, char *buf, size_t cap) {
+  if (!e || !buf || !cap) return fail(FFM_E_INVALID, "null argument");
+  double ms[K_COUNT];
+  int n[K_COUNT];
+  int rc = profile_totals(e, ms, n);
+  if (rc) return rc;
+  std::string out;
+  char line[160];
+  for (int k = 0; k < K_COUNT; k++) {
+    if (!n[k]) continue;
+    std::snprintf(line, sizeof line, "%-24s launches=%6d total_ms=%10.3f avg_us=%10.2f\n",
+                  kKernelNames[k], n[k], ms[k], 1000.0 * ms[k] / n[k]);
+    out += line;
+  }
+  std::snprintf(buf, cap, "%s", out.c_str());
+  return FFM_OK;
+}
+
+}  // extern "C"

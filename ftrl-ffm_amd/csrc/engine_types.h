@@ -1,0 +1,76 @@
+// engine_types.h -- plain structs handed by value to the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#include "ftrl_math.h"
+
+namespace ftrl_dev {
+
+// One block of rows in CSR (the wire format of include/ffm_engine.h), device pointers.
+struct Rows {
+  int n_rows;
+  int nnz;
+  const int *row_ptr;
+  const int *field;  // may be null (LR / FM: field 0)
+  const int *feat;
+  const float *val;
+  const int *label;  // may be null for predict
+};
+
+// Model state in HBM.
+//   bias3  = {bias, bias_n, bias_z}
+//   lin_*  = [n_feats] each
+//   lat    = [n_feats][3][row_len] floats; component 0 = n, 1 = z, 2 = w.  One feature's
+//            accumulators and weights are one contiguous 3*row_len*4-byte record (7488 B at
+//            n_fields=39, n_factors=16), so a row's gather is nnz coalesced streams.
+struct ModelDev {
+  int type;  // FFM_MODEL_*
+  int n_feats;
+  int n_fields;
+  int n_factors;
+  int row_len;  // n_fields*n_factors (FFM), n_factors (FM), 0 (LR)
+  int n_shards, shard_rank;
+  Hyper h;
+  float *bias3;
+  float *lin_n, *lin_z, *lin_w;
+  float *lat;
+};
+
+enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };
+
+__device__ __forceinline__ float *lat_row(const ModelDev &m, int feat) {
+  return m.lat + static_cast<int64_t>(feat) * 3 * m.row_len;
+}
+
+// Field-pair ownership (include/ffm_engine.h: n_shards / shard_rank).  Both latent slots of a
+// pair (i, field_j) and (j, field_i) belong to the shard that owns {field_i, field_j}.
+__device__ __forceinline__ bool owns_pair(const ModelDev &m, int fa, int fb) {
+  if (m.n_shards <= 1) return true;
+  const int lo = fa < fb ? fa : fb, hi = fa < fb ? fb : fa;
+  return (lo * m.n_fields + hi) % m.n_shards == m.shard_rank;
+}
+
+// Per-block scratch: the block grouped by feature ("postings"), per-row field chains, outputs.
+struct Scratch {
+  int *efeat;     // [nnz] validated feature id, -1 for entries remove_out_range would erase
+  int *row_of;    // [nnz] row of each entry
+  int *occ;       // [nnz] entry indices grouped by feature; ascending inside a group
+  int *uniq;      // [nnz] distinct features of the block (arbitrary order)
+  int *ustart;    // [nnz] start of each distinct feature's group in occ
+  int *ucount;    // [nnz] its number of occurrences
+  int *multi;     // [nnz] indices into uniq of the features that occur more than once
+  int *counters;  // [8]   0 n_uniq, 1 occ cursor, 2 n_multi, 3 error bits
+  int *cnt;       // [n_feats] per-feature counter, all zero between blocks
+  int *fstart;    // [n_feats] group start per feature (valid for features of the block)
+  int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
+  int *next;      // [nnz] next entry of the same row with the same field, -1 at the end
+  float *logit;   // [n_rows] this shard's (partial) logit
+  float *tg;      // [n_rows] tmp_grad = sigmoid(logit) - y
+  double *loss;   // [n_rows] logloss per row
+  float *svx;     // [n_rows*n_factors] FM per-row factor sums (sum_vx, fm.h:24)
+};
+
+enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3 };
+enum { ERR_ROW_TOO_LONG = 1 };
+
+}  // namespace ftrl_dev

@@ -1,0 +1,250 @@
+"""ctypes binding of the C ABI in include/ffm_engine.h (libffm_engine.so, hand-written HIP for
+gfx950).  This is plumbing only: every call goes straight to the shared library, and there is no
+CPU fallback -- if the library or a GPU is missing, loading / Engine() raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libffm_engine.so")
+
+LR, FM, FFM = 0, 1, 2
+MODEL_TYPES = {"LR": LR, "FM": FM, "FFM": FFM}
+FLAG_SKIP_INIT = 1
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ffm_engine error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(ctypes.Structure):
+    """struct ffm_engine_config (include/ffm_engine.h)."""
+    _fields_ = [("model_type", ctypes.c_int32), ("n_feats", ctypes.c_int32),
+                ("n_fields", ctypes.c_int32), ("n_factors", ctypes.c_int32),
+                ("w_alpha", ctypes.c_float), ("w_beta", ctypes.c_float),
+                ("w_l1", ctypes.c_float), ("w_l2", ctypes.c_float),
+                ("init_mean", ctypes.c_float), ("init_stddev", ctypes.c_float),
+                ("seed", ctypes.c_uint64), ("max_batch_rows", ctypes.c_int32),
+                ("max_batch_nnz", ctypes.c_int32), ("device_id", ctypes.c_int32),
+                ("n_shards", ctypes.c_int32), ("shard_rank", ctypes.c_int32),
+                ("stream", ctypes.c_void_p), ("flags", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 7)]
+
+
+# every symbol include/ffm_engine.h declares: (name, restype, argtypes)
+_CSR = [_i32p, _i32p, _i32p, _f32p, _i32p]
+_DCSR = [_vp, _vp, _vp, _vp, _vp]
+ABI = [
+    ("ffm_engine_default_config", None, [ctypes.POINTER(Config)]),
+    ("ffm_engine_create", ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(_vp)]),
+    ("ffm_engine_destroy", None, [_vp]),
+    ("ffm_engine_last_error", ctypes.c_char_p, []),
+    ("ffm_engine_abi_version", ctypes.c_int, []),
+    ("ffm_engine_row_len", ctypes.c_int64, [_vp]),
+    ("ffm_engine_set_weights", ctypes.c_int, [_vp, _f32p, _f32p, _f32p]),
+    ("ffm_engine_get_weights", ctypes.c_int, [_vp, _f32p, _f32p, _f32p]),
+    ("ffm_engine_set_state", ctypes.c_int, [_vp] + [_f32p] * 6),
+    ("ffm_engine_get_state", ctypes.c_int, [_vp] + [_f32p] * 6),
+    ("ffm_engine_train_batch", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR + [_f32p, _f64p]),
+    ("ffm_engine_predict_batch", ctypes.c_int,
+     [_vp, ctypes.c_int32] + _CSR + [ctypes.c_int32, _f32p, _f64p]),
+    ("ffm_engine_train_batch_device", ctypes.c_int,
+     [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [_vp, _vp]),
+    ("ffm_engine_predict_batch_device", ctypes.c_int,
+     [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [ctypes.c_int32, _vp, _vp]),
+    ("ffm_engine_train_forward_device", ctypes.c_int,
+     [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [_vp]),
+    ("ffm_engine_train_update_device", ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    ("ffm_engine_sync", ctypes.c_int, [_vp]),
+    ("ffm_engine_profile_enable", ctypes.c_int, [_vp, ctypes.c_int32]),
+    ("ffm_engine_profile_read", ctypes.c_int,
+     [_vp, _i32p, _f64p, ctypes.c_char_p, ctypes.c_size_t]),
+    ("ffm_engine_profile_dump", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libffm_engine.so and bind every ABI symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s not found: build it with `python ftrl-ffm_amd/build.py` (hipcc, gfx950). "
+            "There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, restype, argtypes in ABI:
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _f(a):
+    return None if a is None else a.ctypes.data_as(_f32p)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_i32p)
+
+
+STATE_KEYS = ("bias3", "lin_w", "lin_n", "lin_z", "vec_w", "vec_n", "vec_z")
+
+
+class Engine:
+    """One LR / FM / FFM model resident in HBM (mirrors ftrl::FtrlModel for blocks of rows)."""
+
+    def __init__(self, model_type="FFM", n_feats=10000, n_fields=8, n_factors=16, w_alpha=1e-4,
+                 w_beta=1.0, w_l1=0.1, w_l2=5.0, init_mean=0.0, init_stddev=0.02, seed=42,
+                 max_batch_rows=8192, max_batch_nnz=None, device_id=0, n_shards=1, shard_rank=0,
+                 stream=None, skip_init=False, max_row_nnz=0):
+        self.lib = load_library()
+        cfg = Config()
+        self.lib.ffm_engine_default_config(ctypes.byref(cfg))
+        cfg.model_type = MODEL_TYPES[model_type] if isinstance(model_type, str) else int(model_type)
+        cfg.n_feats, cfg.n_fields, cfg.n_factors = int(n_feats), int(n_fields), int(n_factors)
+        cfg.w_alpha, cfg.w_beta, cfg.w_l1, cfg.w_l2 = w_alpha, w_beta, w_l1, w_l2
+        cfg.init_mean, cfg.init_stddev, cfg.seed = init_mean, init_stddev, int(seed)
+        cfg.max_batch_rows = int(max_batch_rows)
+        cfg.max_batch_nnz = int(max_batch_nnz if max_batch_nnz else max_batch_rows * 64)
+        cfg.device_id, cfg.n_shards, cfg.shard_rank = int(device_id), int(n_shards), int(shard_rank)
+        cfg.stream = stream
+        cfg.flags = FLAG_SKIP_INIT if skip_init else 0
+        cfg.reserved[0] = int(max_row_nnz)
+        self.cfg = cfg
+        self.h = _vp()
+        self._check(self.lib.ffm_engine_create(ctypes.byref(cfg), ctypes.byref(self.h)))
+        self.model_type = cfg.model_type
+        self.n_feats, self.n_fields, self.n_factors = cfg.n_feats, cfg.n_fields, cfg.n_factors
+        self.row_len = int(self.lib.ffm_engine_row_len(self.h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.lib.ffm_engine_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.ffm_engine_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state ----
+    def zero_state(self):
+        nf, L = self.n_feats, self.row_len
+        return dict(bias3=np.zeros(3, np.float32), lin_w=np.zeros(nf, np.float32),
+                    lin_n=np.zeros(nf, np.float32), lin_z=np.zeros(nf, np.float32),
+                    vec_w=np.zeros((nf, L), np.float32), vec_n=np.zeros((nf, L), np.float32),
+                    vec_z=np.zeros((nf, L), np.float32))
+
+    def get_state(self):
+        st = self.zero_state()
+        b = np.zeros(3, np.float32)
+        vw = st["vec_w"] if self.row_len else None
+        vn = st["vec_n"] if self.row_len else None
+        vz = st["vec_z"] if self.row_len else None
+        self._check(self.lib.ffm_engine_get_weights(self.h, _f(b[0:1]), _f(st["lin_w"]), _f(vw)))
+        self._check(self.lib.ffm_engine_get_state(self.h, _f(b[1:2]), _f(b[2:3]), _f(st["lin_n"]),
+                                                  _f(st["lin_z"]), _f(vn), _f(vz)))
+        st["bias3"] = b
+        return st
+
+    def set_state(self, st):
+        st = {k: np.ascontiguousarray(v, np.float32) for k, v in st.items()}
+        b = st.get("bias3")
+        g = lambda k: st[k] if k in st and st[k].size else None  # noqa: E731
+        self._check(self.lib.ffm_engine_set_weights(
+            self.h, _f(b[0:1].copy()) if b is not None else None, _f(g("lin_w")), _f(g("vec_w"))))
+        self._check(self.lib.ffm_engine_set_state(
+            self.h, _f(b[1:2].copy()) if b is not None else None,
+            _f(b[2:3].copy()) if b is not None else None, _f(g("lin_n")), _f(g("lin_z")),
+            _f(g("vec_n")), _f(g("vec_z"))))
+
+    # ---- blocks of rows in host memory ----
+    def _csr(self, c):
+        fld = c.field if (self.model_type == FFM or c.field is not None) else None
+        return (c.n_rows, _i(c.row_ptr), _i(fld), _i(c.feat), _f(c.val), _i(c.label))
+
+    def train_batch(self, c):
+        """One block with the engine's batch semantics.  Returns (logits, loss_sum)."""
+        out = np.zeros(max(c.n_rows, 1), np.float32)
+        loss = ctypes.c_double(0.0)
+        self._check(self.lib.ffm_engine_train_batch(self.h, *self._csr(c), _f(out),
+                                                    ctypes.byref(loss)))
+        return out[:c.n_rows], float(loss.value)
+
+    def train_rows(self, c):
+        """Row after row (n_rows == 1 per call): the reference's sequential train() loop."""
+        logits = np.zeros(c.n_rows, np.float32)
+        total = 0.0
+        for r in range(c.n_rows):
+            lg, ls = self.train_batch(c.rows(r, r + 1))
+            logits[r] = lg[0]
+            total += ls
+        return logits, total
+
+    def predict_batch(self, c, output_prob=False, with_loss=True):
+        out = np.zeros(max(c.n_rows, 1), np.float32)
+        loss = ctypes.c_double(0.0)
+        n, rp, fld, ft, v, lab = self._csr(c)
+        self._check(self.lib.ffm_engine_predict_batch(self.h, n, rp, fld, ft, v,
+                                                      lab if with_loss else None,
+                                                      int(output_prob), _f(out),
+                                                      ctypes.byref(loss)))
+        return out[:c.n_rows], float(loss.value)
+
+    # ---- blocks already in HBM (raw device addresses as ints) ----
+    def train_batch_device(self, n_rows, nnz, row_ptr, field, feat, val, label, logit_out=None,
+                           loss_sum_out=None):
+        self._check(self.lib.ffm_engine_train_batch_device(self.h, n_rows, nnz, row_ptr, field, feat,
+                                                           val, label, logit_out, loss_sum_out))
+
+    def train_forward_device(self, n_rows, nnz, row_ptr, field, feat, val, label, partial_logit):
+        self._check(self.lib.ffm_engine_train_forward_device(self.h, n_rows, nnz, row_ptr, field,
+                                                             feat, val, label, partial_logit))
+
+    def train_update_device(self, logit, logit_out=None, loss_sum_out=None):
+        self._check(self.lib.ffm_engine_train_update_device(self.h, logit, logit_out, loss_sum_out))
+
+    def predict_batch_device(self, n_rows, nnz, row_ptr, field, feat, val, label, output_prob,
+                             out, loss_sum_out=None):
+        self._check(self.lib.ffm_engine_predict_batch_device(self.h, n_rows, nnz, row_ptr, field,
+                                                             feat, val, label, int(output_prob),
+                                                             out, loss_sum_out))
+
+    def sync(self):
+        self._check(self.lib.ffm_engine_sync(self.h))
+
+    # ---- kernel timing (HIP events on the engine's stream) ----
+    def profile_enable(self, on=True):
+        self._check(self.lib.ffm_engine_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        n = ctypes.c_int32(0)
+        ms = ctypes.c_double(0.0)
+        name = ctypes.create_string_buffer(128)
+        self._check(self.lib.ffm_engine_profile_read(self.h, ctypes.byref(n), ctypes.byref(ms),
+                                                     name, 128))
+        return name.value.decode(), int(n.value), float(ms.value)
+
+    def profile_dump(self):
+        buf = ctypes.create_string_buffer(4096)
+        self._check(self.lib.ffm_engine_profile_dump(self.h, buf, 4096))
+        return buf.value.decode()

@@ -1,0 +1,165 @@
+/*
+ * ffm_engine.h -- C ABI of the MI355X (gfx950) FTRL LR/FM/FFM training engine.
+ *
+ * This is the drop-in boundary for ONE path of massquantity/Ftrl-FFM: the forward + gradient +
+ * FTRL per-coordinate update behind ftrl::FtrlModel (reference src/include/model/ftrl_model.h:14-51)
+ * as called by FtrlOffline::one_epoch (src/task/ftrl_offline.cpp:74-83), FtrlOnline::run_task
+ * (src/task/ftrl_online.cpp:70-80) and Evaluator::run_task (src/eval/evaluate.cpp:23-33).
+ * Plain pointers and sizes only; no C++ or torch types.  Every entry point returns 0 on success
+ * and a negative FFM_E_* code on failure (message via ffm_engine_last_error()); nothing throws.
+ * The library contains no CPU fallback: without a usable HIP device ffm_engine_create fails.
+ *
+ * Wire format of a block of rows ("batch"): CSR over (field, feat, val) entries --
+ *   row_ptr[n_rows+1] int32, field[nnz] int32, feat[nnz] int32, val[nnz] float32, label[n_rows]
+ *   int32 (0/1) -- i.e. the reference's Sample{feat_vec x; int y} (src/include/data/sample.h:6-9,
+ *   src/include/utils/types.h:18-19) flattened.  field may be NULL for LR/FM (libsvm rows, field 0).
+ *   Entries whose feat (FFM: or field) is out of range are ignored exactly as
+ *   FtrlModel::remove_out_range / FFM::remove_out_range erase them (ftrl_model.cpp:36-42,
+ *   ffm.cpp:30-36); the caller's buffers are never modified.
+ *
+ * Batch semantics: all rows of one train call see the weights refreshed from the
+ * call-start (n,z); each touched (n,z) then receives the reference's per-sample update once per
+ * touching (row, pair) in row order.  A call with n_rows == 1 is exactly one reference
+ * FtrlModel::train().
+ */
+#ifndef FFM_ENGINE_H
+#define FFM_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFM_ENGINE_ABI_VERSION 1
+
+/* ModelType, reference src/include/utils/types.h:21-25 */
+enum { FFM_MODEL_LR = 0, FFM_MODEL_FM = 1, FFM_MODEL_FFM = 2 };
+
+enum {
+  FFM_OK = 0,
+  FFM_E_INVALID = -1,   /* bad argument (std::invalid_argument in the reference) */
+  FFM_E_DEVICE = -2,    /* HIP runtime error / no device */
+  FFM_E_NOMEM = -3,     /* device allocation failed */
+  FFM_E_CAPACITY = -4,  /* batch exceeds max_batch_rows / max_batch_nnz */
+  FFM_E_UNSUPPORTED = -5
+};
+
+typedef struct ffm_engine ffm_engine;
+
+/* Replaces config_options (reference src/include/utils/cmd_option.h:29-66) for this path; the
+ * defaults written by ffm_engine_default_config are the reference's (:49-63). */
+typedef struct ffm_engine_config {
+  int32_t model_type;      /* FFM_MODEL_* ; opt.model_type */
+  int32_t n_feats;         /* opt.n_feats   (10000) */
+  int32_t n_fields;        /* opt.n_fields  (8); ignored for LR/FM */
+  int32_t n_factors;       /* opt.n_factors (16); ignored for LR */
+  float w_alpha;           /* 1e-4 */
+  float w_beta;            /* 1.0 */
+  float w_l1;              /* 0.1 */
+  float w_l2;              /* 5.0 */
+  float init_mean;         /* 0.0 */
+  float init_stddev;       /* 0.02 */
+  uint64_t seed;           /* the reference is unseeded (utils.h:30-36); here init is reproducible */
+  int32_t max_batch_rows;  /* capacity of one train/predict call */
+  int32_t max_batch_nnz;   /* capacity in entries of one call */
+  int32_t device_id;       /* HIP device ordinal */
+  /* Field-pair sharding of the latent tensor over the GPUs of a node (FFM; DESIGN.md
+   * "Multi-GPU"): this engine owns the unordered field pairs {f,f'} with
+   * ((min*n_fields+max) % n_shards) == shard_rank, plus bias/linear when shard_rank == 0. */
+  int32_t n_shards;        /* 1 */
+  int32_t shard_rank;      /* 0 */
+  void *stream;            /* hipStream_t to run on; NULL = the engine creates its own */
+  int32_t flags;           /* FFM_FLAG_* */
+  int32_t reserved[7];
+} ffm_engine_config;
+
+enum {
+  FFM_FLAG_SKIP_INIT = 1 /* leave w zeroed; the caller will ffm_engine_set_weights */
+};
+
+void ffm_engine_default_config(ffm_engine_config *cfg);
+
+/* Replaces the FtrlModel / LR / FM / FFM constructors (ftrl_model.cpp:12-34, fm.cpp:9-19,
+ * ffm.cpp:17-28): allocates bias, linear and latent (w,n,z) in HBM, zeroes n,z and draws w from
+ * N(init_mean, init_stddev) with a counter-based generator keyed by cfg->seed. */
+int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out);
+void ffm_engine_destroy(ffm_engine *e);
+const char *ffm_engine_last_error(void);
+int ffm_engine_abi_version(void);
+
+/* Row length of the latent arrays: n_fields*n_factors (FFM), n_factors (FM), 0 (LR). */
+int64_t ffm_engine_row_len(const ffm_engine *e);
+
+/* Replaces direct access to the public members bias / lin_w / vec_w (ftrl_model.h:35-37,
+ * ffm.h:25, fm.h:20).  Host arrays, row-major [feat][row_len] = the reference's save order
+ * (ffm.cpp:138-146).  Any pointer may be NULL to skip that part.  Synchronous. */
+int ffm_engine_set_weights(ffm_engine *e, const float *bias, const float *lin_w, const float *vec_w);
+int ffm_engine_get_weights(ffm_engine *e, float *bias, float *lin_w, float *vec_w);
+
+/* The FTRL accumulators (protected/private in the reference: ftrl_model.h:45-48, ffm.h:30-31,
+ * fm.h:25-26); needed for injected-state parity tests and resumable checkpoints. */
+int ffm_engine_set_state(ffm_engine *e, const float *bias_n, const float *bias_z,
+                         const float *lin_n, const float *lin_z, const float *vec_n,
+                         const float *vec_z);
+int ffm_engine_get_state(ffm_engine *e, float *bias_n, float *bias_z, float *lin_n, float *lin_z,
+                         float *vec_n, float *vec_z);
+
+/* Replaces the loop over FtrlModel::train (ffm.cpp:38-49, fm.cpp:21-32, lr.cpp:9-18) in
+ * FtrlOffline::one_epoch / FtrlOnline::run_task for one block of rows held in HOST memory.
+ * logit_out[n_rows] receives each row's pre-update logit (train()'s return value); *loss_sum_out
+ * the sum of loss(y, logit) (src/include/eval/loss.h:8-12, double).  Either may be NULL.
+ * Synchronous: buffers may be reused on return. */
+int ffm_engine_train_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                           const int32_t *field, const int32_t *feat, const float *val,
+                           const int32_t *label, float *logit_out, double *loss_sum_out);
+
+/* Replaces the loop over FtrlModel::predict (ffm.cpp:51-55, fm.cpp:34-38, lr.cpp:20-24) in
+ * Evaluator::run_task / the eval branch of one_epoch.  Uses the STORED w (no lazy refresh).
+ * out[n_rows] = logit, or sigmoid(logit) when output_prob != 0; label may be NULL, otherwise
+ * *loss_sum_out = sum of loss(y, logit). */
+int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                             const int32_t *field, const int32_t *feat, const float *val,
+                             const int32_t *label, int32_t output_prob, float *out,
+                             double *loss_sum_out);
+
+/* Same two calls for blocks already resident in HBM (all pointers are DEVICE pointers, including
+ * logit_out[n_rows] float and loss_sum_out[1] double; either output may be NULL).  Asynchronous on
+ * the engine's stream; nnz is row_ptr[n_rows], passed so the host never reads device memory. */
+int ffm_engine_train_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
+                                  const int32_t *row_ptr, const int32_t *field,
+                                  const int32_t *feat, const float *val, const int32_t *label,
+                                  float *logit_out, double *loss_sum_out);
+int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
+                                    const int32_t *row_ptr, const int32_t *field,
+                                    const int32_t *feat, const float *val, const int32_t *label,
+                                    int32_t output_prob, float *out, double *loss_sum_out);
+
+/* Split-phase training for field-pair sharding over several GPUs (n_shards > 1): phase 1 groups
+ * the block, refreshes this shard's weights and writes this shard's PARTIAL logits (shard 0 adds
+ * bias + linear) to partial_logit[n_rows] (device); the caller sums them across shards (one RCCL
+ * all-reduce of n_rows floats); phase 2 takes the summed logits and applies the updates this shard
+ * owns.  ffm_engine_train_batch_device == phase 1 + phase 2 with n_shards == 1. */
+int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
+                                    const int32_t *row_ptr, const int32_t *field,
+                                    const int32_t *feat, const float *val, const int32_t *label,
+                                    float *partial_logit);
+int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *logit_out,
+                                   double *loss_sum_out);
+
+/* Blocks until everything queued on the engine's stream has finished. */
+int ffm_engine_sync(ffm_engine *e);
+
+/* Timing of the dominant kernel, measured with HIP events on the engine's stream around every
+ * launch since the last reset (used by bench.py's roofline line). */
+int ffm_engine_profile_enable(ffm_engine *e, int32_t on);
+int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms,
+                            char *kernel_name, size_t kernel_name_cap);
+/* Text table (one line per kernel: launches, total ms, average us) into buf. */
+int ffm_engine_profile_dump(ffm_engine *e, char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFM_ENGINE_H */

@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- train samples/sec + logloss of the FTRL-FFM hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (group -> lazy refresh + forward -> FTRL update) over one
+block of synthetic libffm rows that is already resident in HBM.  Workload at N = 1: BASELINE.json's
+headline shape, FFM n_fields=39 n_factors=16, block = 8192 rows, Zipf(1.1) ids, the per-GPU slice
+of the 33M-feature config (n_feats = 4.125M, 30.9 GB of (w,n,z)).  N > 1: the latent tensor is
+field-pair sharded over the ranks (n_feats = 4.125M * N, block = 8192 * N rows); every rank sees
+the whole block, computes the partial logits of the field pairs it owns, one RCCL all-reduce sums
+them, every rank updates its own slots -- per-GPU work is constant, so scaling is "weak".
+PyTorch is plumbing here (device buffers for the inputs, the process group); every byte of the
+path is moved by the hand-written kernels in ftrl-ffm_amd/csrc behind include/ffm_engine.h.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FIELDS, N_FACTORS, ROWS_PER_GPU = 39, 16, 8192
+FEATS_PER_GPU = 33_000_000 // 8
+PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def algorithmic_bytes_per_row(nnz, k):
+    """every touched state element read once + written once per row, no reuse
+    credit: latent nnz(nnz-1)k*20 + linear nnz*20 + bias 20 + CSR (nnz*12+8) + outputs 12."""
+    return nnz * (nnz - 1) * k * 20 + nnz * 20 + 20 + (nnz * 12 + 8) + 12
+
+
+def kernel_share_bytes_per_row(kernel, nnz, k):
+    """The same total apportioned to the two big kernels so that the shares add up to it:
+    row kernel = read (n,z) + write w of every touched slot (+ CSR, linear refresh, logit);
+    update kernel = write (n,z) of every touched slot (+ linear/bias accumulators, loss)."""
+    sf = nnz * (nnz - 1) * k
+    if "update" in kernel:
+        return sf * 8 + nnz * 8 + 8 + 8
+    return sf * 12 + nnz * 12 + 12 + (nnz * 12 + 8) + 4
+
+
+def cpu_baseline(args, gen_kwargs):
+    """The oracle (CPU restatement of the reference, oracle/ffm_oracle.c) timed on this host on a
+    bounded sample of the same workload.  Checker code, used here only as the reported baseline."""
+    from oracle.pyoracle import CpuModel
+    from ftrl_ffm_amd import synth
+    n_feats = N_FIELDS * 2048  # host-RAM bound sample of the same F / k / nnz / id distribution
+    rows = args.cpu_rows
+    g = synth.Generator(N_FIELDS, n_feats, **gen_kwargs)
+    blk = g.block(rows)
+    best, best_t = 0.0, 1
+    tried = {}
+    ncpu = os.cpu_count() or 1
+    for threads in sorted({1, min(8, ncpu)}):
+        m = CpuModel("oracle", "FFM", n_feats, N_FIELDS, N_FACTORS)
+        st = m.zero_state()
+        rng = np.random.default_rng(5)
+        st["vec_w"][...] = rng.normal(0, 0.02, st["vec_w"].shape).astype(np.float32)
+        st["vec_n"][...] = rng.uniform(0.05, 1.0, st["vec_n"].shape).astype(np.float32)
+        st["vec_z"][...] = rng.normal(0, 0.3, st["vec_z"].shape).astype(np.float32)
+        m.set_state(st)
+        if threads == 1:
+            t0 = time.perf_counter()
+            m.train_rows(blk)
+            sec = time.perf_counter() - t0
+        else:
+            sec, _ = m.train_rows_threaded(blk, threads)
+        tried[threads] = rows / sec
+        if rows / sec > best:
+            best, best_t = rows / sec, threads
+        del m
+    return {"value": round(best, 1), "unit": "samples/s", "cores": best_t, "kind": "port",
+            "sample": "%d rows, FFM F=%d k=%d nnz=%d Zipf(1.1), n_feats=%d, warm state, oracle "
+                      "fo_train_rows at 1 thread and reference-style locked threads at %d; best "
+                      "reported (%s); host has %d cores" % (
+                          rows, N_FIELDS, N_FACTORS, N_FIELDS, n_feats, min(8, ncpu),
+                          ", ".join("%dT=%.0f/s" % kv for kv in sorted(tried.items())), ncpu)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-feats", type=int, default=0, help="override total n_feats")
+    ap.add_argument("--rows", type=int, default=0, help="override rows per step (global)")
+    ap.add_argument("--dist", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--state", default="warm", choices=["warm", "fresh"])
+    ap.add_argument("--n-blocks", type=int, default=8, help="distinct synthetic blocks cycled")
+    ap.add_argument("--cpu-rows", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ftrl_ffm_amd as fa
+    from ftrl_ffm_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    if world > 1 and world != n_gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (n_gpus, world))
+    if n_gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run (one rank per GPU)" % n_gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    fa.build()
+
+    rows = args.rows or ROWS_PER_GPU * n_gpus
+    n_feats = args.n_feats or FEATS_PER_GPU * n_gpus
+    n_feats -= n_feats % N_FIELDS
+    rec_bytes = 3 * N_FIELDS * N_FACTORS * 4
+    free_b, _total_b = torch.cuda.mem_get_info()
+    reduced = False
+    budget = int(free_b * 0.85) - (2 << 30)
+    if n_feats * rec_bytes > budget:  # this round every shard stores full-length records
+        n_feats = budget // rec_bytes
+        n_feats -= n_feats % N_FIELDS
+        reduced = True
+    gen_kwargs = dict(dist=args.dist, seed=42)
+
+    # one side stream carries the engine's kernels and (through torch) the RCCL collective
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    eng = fa.Engine("FFM", n_feats, N_FIELDS, N_FACTORS, max_batch_rows=rows,
+                    max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=world,
+                    shard_rank=rank, stream=stream, seed=42)
+    if args.state == "warm":
+        eng.fill_state(seed=7, n_lo=0.05, n_hi=1.0, z_stddev=0.3)
+
+    # identical synthetic blocks on every rank, uploaded once: resident in HBM before timing
+    gen = synth.Generator(N_FIELDS, n_feats, **gen_kwargs)
+    blocks = []
+    for _ in range(args.n_blocks):
+        b = gen.block(rows)
+        blocks.append(dict(
+            n_rows=b.n_rows, nnz=b.nnz,
+            row_ptr=torch.from_numpy(b.row_ptr).cuda(), field=torch.from_numpy(b.field).cuda(),
+            feat=torch.from_numpy(b.feat).cuda(), val=torch.from_numpy(b.val).cuda(),
+            label=torch.from_numpy(b.label).cuda()))
+    logit = torch.zeros(rows, dtype=torch.float32, device="cuda")
+    loss_sum = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device="cuda")
+
+    def step(i, blk):
+        ptr = lambda t: t.data_ptr()  # noqa: E731
+        out_loss = loss_sum.data_ptr() + 8 * i
+        if world == 1:
+            eng.train_batch_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
+                                   ptr(blk["feat"]), ptr(blk["val"]), ptr(blk["label"]),
+                                   ptr(logit), out_loss)
+        else:
+            eng.train_forward_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]),
+                                     ptr(blk["field"]), ptr(blk["feat"]), ptr(blk["val"]),
+                                     ptr(blk["label"]), ptr(logit))
+            dist.all_reduce(logit)  # the path's one exchange: n_rows partial logits over xGMI
+            eng.train_update_device(ptr(logit), None, out_loss)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, blocks[i % len(blocks)])
+    fence()
+    if not args.no_profile:
+        eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, blocks[(args.warmup + i) % len(blocks)])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kname, klaunches, kms = ("", 0, 0.0)
+    table = ""
+    if not args.no_profile:
+        kname, klaunches, kms = eng.profile_read()
+        table = eng.profile_dump()
+        eng.profile_enable(False)
+    losses = loss_sum[args.warmup:args.warmup + args.steps].cpu().numpy()
+    total_rows = rows * args.steps
+    value = total_rows / elapsed
+    bytes_row = algorithmic_bytes_per_row(N_FIELDS, N_FACTORS)
+
+    if rank == 0:
+        out = {
+            "metric": "train samples/sec + logloss, FFM f=39 k=16", "value": round(value, 1),
+            "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "FFM n_fields=39 n_factors=16 nnz=39, %s ids, block=%d rows, n_feats=%d "
+                            "(%.1f GB of w,n,z per GPU), %s state, reference default hyper-parameters"
+                            % ("Zipf(1.1)" if args.dist == "zipf" else "uniform", rows, n_feats,
+                               n_feats * rec_bytes / 1e9, args.state),
+                "rows_per_step": rows, "n_feats": n_feats, "n_feats_reduced_to_fit": reduced,
+                "sharding": "field-pair x%d, one all-reduce of %d partial logits per step"
+                            % (world, rows) if world > 1 else "none",
+            },
+            "train_logloss": round(float(losses.sum() / total_rows), 6),
+            "step_algorithmic_GBps": round(value * bytes_row / n_gpus / 1e9, 1),
+        }
+        if kname:
+            share = kernel_share_bytes_per_row(kname, N_FIELDS, N_FACTORS) / max(world, 1)
+            avg_s = kms / 1000.0 / max(klaunches, 1)
+            achieved = share * rows / avg_s / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
+                "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
+                "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2), "launches": klaunches,
+                "algorithmic_bytes_per_launch": int(share * rows),
+            }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, gen_kwargs)
+        print(json.dumps(out), flush=True)
+        if table:
+            sys.stderr.write(table)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -44,13 +45,17 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 enum KernelId {
-  K_GROUP_COUNT, K_GROUP_ALLOC, K_GROUP_SCATTER, K_GROUP_SORT, K_ROW, K_TMP_GRAD, K_LOSS_SUM,
-  K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_GROUP_CLEANUP, K_PREDICT_ROW, K_COUNT
+  K_GROUP_COUNT, K_GROUP_ALLOC, K_GROUP_SCATTER, K_GROUP_SORT, K_GROUP_EXPAND, K_ROW, K_TMP_GRAD,
+  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_GROUP_CLEANUP,
+  K_PREDICT_ROW,
+  K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "group_count_kernel", "group_alloc_kernel", "group_scatter_kernel", "group_sort_kernel",
-    "row_kernel<train>", "tmp_grad_kernel", "loss_sum_kernel", "linear_update_kernel",
-    "bias_update_kernel", "latent_update_kernel", "group_cleanup_kernel", "row_kernel<predict>"};
+    "group_expand_kernel", "row_kernel<train>", "tmp_grad_kernel", "loss_sum_kernel",
+    "linear_update_kernel", "bias_update_kernel", "latent_update_kernel", "latent_update_hot_kernel",
+    "group_cleanup_kernel",
+    "row_kernel<predict>"};
 
 struct ProfRec {
   int kid;
@@ -69,6 +74,31 @@ __global__ void init_weights_kernel(ModelDev m, float mean, float stddev, uint64
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < m.n_feats;
        i += stride)
     m.lin_w[i] = mean + stddev * normal01(seed, 0, i);
+}
+
+__global__ void fill_state_kernel(ModelDev m, uint64_t seed, float n_lo, float n_hi, float z_sd) {
+  const int64_t n_lat = static_cast<int64_t>(m.n_feats) * m.row_len;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t t0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  auto unif = [&](uint64_t stream, int64_t idx) {
+    const uint64_t h = mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) + idx);
+    return n_lo + (n_hi - n_lo) * (static_cast<float>(h >> 40) * (1.0f / 16777216.0f));
+  };
+  for (int64_t idx = t0; idx < n_lat; idx += stride) {
+    const int64_t feat = idx / m.row_len;
+    const int e = static_cast<int>(idx - feat * m.row_len);
+    float *rec = m.lat + feat * 3 * m.row_len;
+    rec[LAT_N * m.row_len + e] = unif(11, idx);
+    rec[LAT_Z * m.row_len + e] = z_sd * normal01(seed, 12, idx);
+  }
+  for (int64_t i = t0; i < m.n_feats; i += stride) {
+    m.lin_n[i] = unif(13, i);
+    m.lin_z[i] = z_sd * normal01(seed, 14, i);
+  }
+  if (t0 == 0) {
+    m.bias3[1] = unif(15, 0);
+    m.bias3[2] = z_sd * normal01(seed, 16, 0);
+  }
 }
 
 // Copies one component (n, z or w) of features [feat0, feat0+nf) between the interleaved record
@@ -94,6 +124,9 @@ struct ffm_engine {
   Scratch s{};
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t aux = nullptr;   // side stream: linear + bias chains beside the latent update
+  hipStream_t aux2 = nullptr;  // side stream: hot-feature latent update beside the small-feature one
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   int max_rows = 0, max_nnz = 0, max_row_nnz = 1024;
   // staging for the host-buffer entry points
   int *d_row_ptr = nullptr, *d_field = nullptr, *d_feat = nullptr, *d_label = nullptr;
@@ -106,6 +139,7 @@ struct ffm_engine {
   // split-phase bookkeeping
   Rows pending{};
   bool has_pending = false;
+  bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -131,27 +165,31 @@ struct ffm_engine {
       return e;
     }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
   }
-  void prof_begin(int kid) {
+  void prof_begin(int kid, hipStream_t st) {
     if (!prof_on) return;
     ProfRec r{kid, get_event(), get_event()};
-    hipEventRecord(r.e0, stream);
+    (void)hipEventRecord(r.e0, st);
     prof.push_back(r);
   }
-  void prof_end() {
+  void prof_end(hipStream_t st) {
     if (!prof_on) return;
-    hipEventRecord(prof.back().e1, stream);
+    (void)hipEventRecord(prof.back().e1, st);
   }
 };
 
-#define LAUNCH(e, kid, kernel, grid, block, shmem, ...)                          \
+#define LAUNCH_ON(e, st, kid, kernel, grid, block, shmem, ...)                   \
   do {                                                                           \
-    (e)->prof_begin(kid);                                                        \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, (e)->stream, __VA_ARGS__); \
-    (e)->prof_end();                                                             \
+    (e)->prof_begin(kid, st);                                                    \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, st, __VA_ARGS__); \
+    (e)->prof_end(st);                                                           \
   } while (0)
+#define LAUNCH(e, kid, kernel, grid, block, shmem, ...) \
+  LAUNCH_ON(e, (e)->stream, kid, kernel, grid, block, shmem, __VA_ARGS__)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 extern "C" {
 
@@ -183,12 +221,17 @@ int64_t ffm_engine_row_len(const ffm_engine *e) { return e ? e->m.row_len : 0; }
 
 void ffm_engine_destroy(ffm_engine *e) {
   if (!e) return;
-  hipSetDevice(e->cfg.device_id);
-  if (e->stream) hipStreamSynchronize(e->stream);
-  for (auto &r : e->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
-  for (auto ev : e->event_pool) hipEventDestroy(ev);
-  for (void *p : e->allocs) hipFree(p);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  (void)hipSetDevice(e->cfg.device_id);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (auto &r : e->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
+  for (void *p : e->allocs) (void)hipFree(p);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
+  if (e->aux) (void)hipStreamDestroy(e->aux);
+  if (e->aux2) (void)hipStreamDestroy(e->aux2);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
 
@@ -223,6 +266,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   e->max_rows = cfg->max_batch_rows;
   e->max_nnz = cfg->max_batch_nnz;
   if (cfg->reserved[0] > 0) e->max_row_nnz = cfg->reserved[0];
+  if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   ModelDev &m = e->m;
   m.type = cfg->model_type;
   m.n_feats = cfg->n_feats;
@@ -235,6 +279,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.h = Hyper{cfg->w_alpha, cfg->w_beta, cfg->w_l1, cfg->w_l2};
   if (static_cast<int64_t>(cfg->n_fields) * cfg->n_factors > (1 << 24))
     { delete e; return fail(FFM_E_UNSUPPORTED, "n_fields*n_factors too large"); }
+  if (static_cast<int64_t>(cfg->max_batch_nnz) * ((m.row_len + 63) / 64 + 1) >= (1ll << 31))
+    { delete e; return fail(FFM_E_UNSUPPORTED, "max_batch_nnz * ceil(row_len/64) must stay below 2^31"); }
 
   int rc = FFM_OK;
 #define TRY_ALLOC(call) do { rc = (call); if (rc != FFM_OK) { ffm_engine_destroy(e); return rc; } } while (0)
@@ -247,6 +293,11 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
   }
+  TRY_HIP(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+  TRY_HIP(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
+  TRY_HIP(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
+  TRY_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  TRY_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   const size_t nf = static_cast<size_t>(cfg->n_feats);
   const size_t n_lat = nf * 3 * static_cast<size_t>(m.row_len);
   TRY_ALLOC(e->alloc(&m.bias3, 4));
@@ -259,15 +310,19 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.efeat, E));
   TRY_ALLOC(e->alloc(&s.row_of, E));
   TRY_ALLOC(e->alloc(&s.occ, E));
+  TRY_ALLOC(e->alloc(&s.occ2, E));
   TRY_ALLOC(e->alloc(&s.uniq, E));
   TRY_ALLOC(e->alloc(&s.ustart, E));
   TRY_ALLOC(e->alloc(&s.ucount, E));
   TRY_ALLOC(e->alloc(&s.multi, E));
+  TRY_ALLOC(e->alloc(&s.small, E));
+  TRY_ALLOC(e->alloc(&s.big, E));
   TRY_ALLOC(e->alloc(&s.counters, 8));
   TRY_ALLOC(e->alloc(&s.cnt, nf));
   TRY_ALLOC(e->alloc(&s.fstart, nf));
   TRY_ALLOC(e->alloc(&s.head, R * static_cast<size_t>(m.n_fields)));
   TRY_ALLOC(e->alloc(&s.next, E));
+  TRY_ALLOC(e->alloc(&s.rowtab, R * static_cast<size_t>(m.n_fields)));
   TRY_ALLOC(e->alloc(&s.logit, R));
   TRY_ALLOC(e->alloc(&s.tg, R));
   TRY_ALLOC(e->alloc(&s.loss, R));
@@ -299,6 +354,30 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
 #undef TRY_ALLOC
 #undef TRY_HIP
   *out = e;
+  return FFM_OK;
+}
+
+int ffm_engine_fill_state(ffm_engine *e, uint64_t seed, float n_lo, float n_hi, float z_stddev) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (!(n_lo >= 0.0f) || !(n_hi >= n_lo)) return fail(FFM_E_INVALID, "need 0 <= n_lo <= n_hi");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  hipLaunchKernelGGL(fill_state_kernel, dim3(2048), dim3(256), 0, e->stream, e->m, seed, n_lo, n_hi, z_stddev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return FFM_OK;
+}
+
+int ffm_engine_eval_sigmoid(ffm_engine *e, int32_t n, const float *x, float *y) {
+  if (!e || n < 0 || (n > 0 && (!x || !y))) return fail(FFM_E_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  const int chunk = static_cast<int>(std::min<int64_t>(e->stage_floats / 2, 1 << 22));
+  for (int off = 0; off < n; off += chunk) {
+    const int c = std::min(chunk, n - off);
+    HIP_TRY(hipMemcpyAsync(e->d_stage, x + off, sizeof(float) * c, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(sigmoid_eval_kernel, dim3(cdiv(c, 256)), dim3(256), 0, e->stream, c, e->d_stage, e->d_stage + chunk);
+    HIP_TRY(hipMemcpyAsync(y + off, e->d_stage + chunk, sizeof(float) * c, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   return FFM_OK;
 }
 
@@ -394,7 +473,6 @@ static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *r
   return FFM_OK;
 }
 
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float *out, int output_prob) {
   if (rows.n_rows == 0) return;
@@ -404,8 +482,12 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
     if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
     else LAUNCH(e, kid, fm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
   } else {
-    if (train) LAUNCH(e, kid, ffm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
-    else LAUNCH(e, kid, ffm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
+    const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
+    const int mr = e->max_row_nnz;
+    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, mr, out, output_prob);
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, mr, out, output_prob);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, mr, out, output_prob);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, mr, out, output_prob);
   }
 }
 
@@ -426,6 +508,7 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
     LAUNCH(e, K_GROUP_ALLOC, group_alloc_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, e->s);
     LAUNCH(e, K_GROUP_SCATTER, group_scatter_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, rows, e->s);
     LAUNCH(e, K_GROUP_SORT, group_sort_kernel, 1024, kGroupThreads, 0, e->s, e->d_sort_tmp);
+    LAUNCH(e, K_GROUP_EXPAND, group_expand_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, nnz, e->s);
   }
   launch_row_kernel(e, rows, true, nullptr, 0);
   if (partial_logit && n_rows > 0)
@@ -447,17 +530,41 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   if (loss_sum_out)
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->s.loss, loss_sum_out);
   const bool lin_owner = e->m.shard_rank == 0;
-  if (rows.n_rows > 0 && lin_owner)
+  // the bias and linear chains are short and serial: run them beside the latent update
+  const bool forked = rows.n_rows > 0 && lin_owner && !e->serial;
+  if (rows.n_rows > 0 && lin_owner && e->serial) {
     LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->s);
-  if (rows.nnz > 0) {
-    if (lin_owner)
+    if (rows.nnz > 0)
       LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, std::min(cdiv(rows.nnz, kUpdThreads), 1024), kUpdThreads, 0, e->m, rows, e->s);
-    if (e->m.type == FFM_MODEL_FFM)
-      LAUNCH(e, K_LATENT_UPDATE, ffm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
-    else if (e->m.type == FFM_MODEL_FM)
-      LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
-    LAUNCH(e, K_GROUP_CLEANUP, group_cleanup_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, e->s);
   }
+  const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
+  const bool vec4 = e->m.n_factors % 4 == 0;
+  if (forked || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
+  if (forked) {
+    HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+    LAUNCH_ON(e, e->aux, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->s);
+    if (rows.nnz > 0)
+      LAUNCH_ON(e, e->aux, K_LINEAR_UPDATE, linear_update_kernel, std::min(cdiv(rows.nnz, kUpdThreads), 1024), kUpdThreads, 0, e->m, rows, e->s);
+    HIP_TRY(hipEventRecord(e->ev_join, e->aux));
+  }
+  if (ffm && vec4 && e->serial) {
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel<false>, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+  } else if (ffm && vec4) {
+    // hot features (long sequential chains) beside the bandwidth-shaped small-feature pass
+    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
+    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel<false>, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
+  } else if (ffm) {
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel<true>, 2048, kUpdThreads, 0, e->m, rows, e->s);
+  } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
+    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+  }
+  if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+  if (rows.nnz > 0)
+    LAUNCH(e, K_GROUP_CLEANUP, group_cleanup_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, e->s);
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }
@@ -601,9 +708,11 @@ int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms
   if (total_ms) *total_ms = ms[best];
   if (kernel_name && kernel_name_cap) {
     std::string name = kKernelNames[best];
-    if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE)
+    if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT)
       name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +
-             (best == K_LATENT_UPDATE ? "update_kernel" : (best == K_ROW ? "row_kernel<true>" : "row_kernel<false>"));
+             (best == K_LATENT_UPDATE ? (e->m.type == FFM_MODEL_FM ? "update_kernel" : "update_small_kernel")
+              : best == K_LATENT_UPDATE_HOT ? "update_hot_kernel"
+              : (best == K_ROW ? "row_kernel<train>" : "row_kernel<predict>"));
     std::snprintf(kernel_name, kernel_name_cap, "%s", name.c_str());
   }
   return FFM_OK;

@@ -55,22 +55,28 @@ struct Scratch {
   int *efeat;     // [nnz] validated feature id, -1 for entries remove_out_range would erase
   int *row_of;    // [nnz] row of each entry
   int *occ;       // [nnz] entry indices grouped by feature; ascending inside a group
+  int2 *occ2;     // [nnz] the same groups as {entry, row of the entry}
   int *uniq;      // [nnz] distinct features of the block (arbitrary order)
   int *ustart;    // [nnz] start of each distinct feature's group in occ
   int *ucount;    // [nnz] its number of occurrences
   int *multi;     // [nnz] indices into uniq of the features that occur more than once
+  int *small;     // [nnz] indices into uniq of the features with <= kSmallMax occurrences
+  int *big;       // [nnz] indices into uniq of the others ("hot" features)
   int *counters;  // [8]   0 n_uniq, 1 occ cursor, 2 n_multi, 3 error bits
   int *cnt;       // [n_feats] per-feature counter, all zero between blocks
   int *fstart;    // [n_feats] group start per feature (valid for features of the block)
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
   int *next;      // [nnz] next entry of the same row with the same field, -1 at the end
+  int4 *rowtab;   // [n_rows*n_fields] {feat, val bits, entry, count} of the field's entry in the
+                  //      row; entry = -1 none, -2 several (then head/next list them)
   float *logit;   // [n_rows] this shard's (partial) logit
   float *tg;      // [n_rows] tmp_grad = sigmoid(logit) - y
   double *loss;   // [n_rows] logloss per row
   float *svx;     // [n_rows*n_factors] FM per-row factor sums (sum_vx, fm.h:24)
 };
 
-enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3 };
+enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5 };
+constexpr int kSmallMax = 4;  // occurrences per block up to which a feature takes the "small" path
 enum { ERR_ROW_TOO_LONG = 1 };
 
 }  // namespace ftrl_dev

@@ -51,12 +51,53 @@ __device__ __forceinline__ void nz_step_latent_jside(const Hyper &h, float w, fl
   n = n + g2 * g2;
 }
 
+// std::exp(float) as the reference's C library evaluates it.  glibc >= 2.27 expf (the algorithm of
+// ARM optimized-routines: x*N/ln2 = k + r, 2^(k/N) from a 32-entry table, cubic in r, all in
+// double, one rounding to float) is NOT correctly rounded in ~8e-5 of inputs, so a "more accurate"
+// device exp would differ from the reference in those.  This is that algorithm, with the fused
+// multiply-adds x86-64 glibc's FMA build performs; checked on the host against glibc 2.35 expf on
+// all 2^32 float inputs (tests/test_expf_port.py keeps the same statement in C under test).
+__device__ __forceinline__ float expf_glibc(float x) {
+  const uint64_t T[32] = {
+      0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+      0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+      0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+      0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+      0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+      0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+      0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+      0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+  const uint32_t ix = __float_as_uint(x);
+  const uint32_t abstop = (ix >> 20) & 0x7ff;
+  if (abstop >= 0x42b) {  // |x| >= 88 or NaN
+    if (ix == 0xff800000u) return 0.0f;
+    if (abstop >= 0x7f8) return x + x;
+    if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);  // overflow
+    if (x < -0x1.9fe368p6f) return 0.0f;                         // underflow
+  }
+  const double InvLn2N = 0x1.71547652b82fep+0 * 32;
+  const double Shift = 0x1.8p+52;
+  const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32,
+               C2 = 0x1.62e42ff0c52d6p-1 / 32;
+  const double xd = static_cast<double>(x);
+  const double z = InvLn2N * xd;
+  double kd = z + Shift;
+  const uint64_t ki = static_cast<uint64_t>(__double_as_longlong(kd));
+  kd -= Shift;
+  const double r = fma(InvLn2N, xd, -kd);
+  const uint64_t t = T[ki & 31] + (ki << 47);
+  const double s = __longlong_as_double(static_cast<long long>(t));
+  const double p = fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = fma(C2, r, 1.0);
+  y = fma(p, r2, y);
+  y = y * s;
+  return static_cast<float>(y);
+}
+
 // utils::sigmoid<float>, utils.h:20-23: 1 / (1 + std::exp(-x)) with std::exp(float) = expf.
-// glibc's expf evaluates in double and rounds once (<= 0.502 ULP); exp() in double rounded to
-// float reproduces that result except within ~1e-3 ULP of a rounding boundary.
 __device__ __forceinline__ float sigmoid_ref(float x) {
-  const float e = static_cast<float>(exp(static_cast<double>(-x)));
-  return 1.0f / (1.0f + e);
+  return 1.0f / (1.0f + expf_glibc(-x));
 }
 
 // loss(int y, double logit), src/include/eval/loss.h:8-12 (inf/NaN at saturation preserved)

@@ -12,44 +12,81 @@ namespace ftrl_dev {
 constexpr int kGroupThreads = 256;
 constexpr int kSortCap = 16384;  // ints of LDS for the in-workgroup bitonic sort (64 KiB)
 
+// One atomic per wave instead of one per lane: lanes with pred get consecutive slots.
+__device__ __forceinline__ int wave_append_slot(int *counter, bool pred) {
+  const unsigned long long mask = __ballot(pred);
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+  int base = 0;
+  if (pred && lane == leader) base = atomicAdd(counter, __popcll(mask));
+  base = __shfl(base, leader < 0 ? 0 : leader, 64);
+  return base + __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// Same for a per-lane amount: wave-wide exclusive prefix sum, one atomic for the total.
+__device__ __forceinline__ int wave_reserve(int *counter, int amount) {
+  const int lane = threadIdx.x & 63;
+  int incl = amount;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (lane == 63) base = atomicAdd(counter, total);
+  base = __shfl(base, 63, 64);
+  return base + incl - amount;
+}
+
 // Entry p: validate (remove_out_range, ftrl_model.cpp:36-42 / ffm.cpp:30-36), find its row,
 // count its feature, register first-seen features.
 __global__ __launch_bounds__(kGroupThreads) void group_count_kernel(ModelDev m, Rows rows,
                                                                     Scratch s) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= rows.nnz) return;
-  // row_ptr[r] <= p < row_ptr[r+1]  (upper bound - 1; tolerates empty rows)
-  int lo = 0, hi = rows.n_rows;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (rows.row_ptr[mid + 1] <= p) lo = mid + 1; else hi = mid;
+  const bool in = p < rows.nnz;
+  bool valid = false;
+  int i = 0;
+  if (in) {
+    // row_ptr[r] <= p < row_ptr[r+1]  (upper bound - 1; tolerates empty rows)
+    int lo = 0, hi = rows.n_rows;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (rows.row_ptr[mid + 1] <= p) lo = mid + 1; else hi = mid;
+    }
+    s.row_of[p] = lo;
+    i = rows.feat[p];
+    const int f = rows.field ? rows.field[p] : 0;
+    valid = i >= 0 && i < m.n_feats;
+    if (m.type == 2) valid = valid && f >= 0 && f < m.n_fields;
   }
-  s.row_of[p] = lo;
-  const int i = rows.feat[p];
-  const int f = rows.field ? rows.field[p] : 0;
-  bool valid = i >= 0 && i < m.n_feats;
-  if (m.type == 2) valid = valid && f >= 0 && f < m.n_fields;
-  s.efeat[p] = valid ? i : -1;
-  if (!valid) return;
-  if (atomicAdd(&s.cnt[i], 1) == 0) {
-    const int u = atomicAdd(&s.counters[CNT_NUNIQ], 1);
-    s.uniq[u] = i;
-  }
+  if (in) s.efeat[p] = valid ? i : -1;
+  const bool first = valid && atomicAdd(&s.cnt[i], 1) == 0;
+  const int u = wave_append_slot(&s.counters[CNT_NUNIQ], first);
+  if (first) s.uniq[u] = i;
 }
 
 // Distinct feature u: reserve its group in occ, remember where, re-zero its counter (reused as
-// the fill cursor), list it for sorting when it occurs more than once.
+// the fill cursor), and sort it into the lists the later passes walk: "multi" (more than one
+// occurrence: needs ordering), "small" / "big" (which update path owns it).
 __global__ __launch_bounds__(kGroupThreads) void group_alloc_kernel(Scratch s) {
   const int n_uniq = s.counters[CNT_NUNIQ];
-  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_uniq; u += gridDim.x * blockDim.x) {
-    const int i = s.uniq[u];
-    const int c = s.cnt[i];
-    const int start = atomicAdd(&s.counters[CNT_CURSOR], c);
+  const int n_round = (n_uniq + 63) & ~63;  // whole waves stay converged for the wave-wide ops
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_round; u += gridDim.x * blockDim.x) {
+    const bool live = u < n_uniq;
+    const int i = live ? s.uniq[u] : 0;
+    const int c = live ? s.cnt[i] : 0;
+    const int start = wave_reserve(&s.counters[CNT_CURSOR], c);
+    const int im = wave_append_slot(&s.counters[CNT_NMULTI], live && c > 1);
+    const int is = wave_append_slot(&s.counters[CNT_NSMALL], live && c <= kSmallMax);
+    const int ib = wave_append_slot(&s.counters[CNT_NBIG], live && c > kSmallMax);
+    if (!live) continue;
     s.ustart[u] = start;
     s.ucount[u] = c;
     s.fstart[i] = start;
     s.cnt[i] = 0;
-    if (c > 1) s.multi[atomicAdd(&s.counters[CNT_NMULTI], 1)] = u;
+    if (c > 1) s.multi[im] = u;
+    if (c <= kSmallMax) s.small[is] = u; else s.big[ib] = u;
   }
 }
 
@@ -109,6 +146,15 @@ __global__ __launch_bounds__(kGroupThreads) void group_sort_kernel(Scratch s, in
       for (int t = threadIdx.x; t < c; t += blockDim.x) seg[t] = out[t];
     }
     __syncthreads();
+  }
+}
+
+// Groups are final: publish them as {entry, row} pairs so the owners need one load per touch.
+__global__ __launch_bounds__(kGroupThreads) void group_expand_kernel(int nnz_valid_cap, Scratch s) {
+  const int n = s.counters[CNT_CURSOR];  // number of surviving entries
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const int p = s.occ[t];
+    s.occ2[t] = make_int2(p, s.row_of[p]);
   }
 }
 

@@ -9,6 +9,10 @@
 // Numerics: each pair's dot product is a k-long sequential fp32 chain (std::inner_product, init
 // 0.0f), the term is (dot*x1)*x2, and the terms are added to the linear logit in the reference's
 // pair order by one lane, so the logit is the bit pattern the reference computes.
+//
+// Memory: a feature's record is [n row | z row | w row], each row_len floats, so the refresh of
+// one row's nnz features is nnz pairs of contiguous 16-byte-vector streams in and one out; the
+// pair phase re-reads the freshly written w slots (64 B each at k = 16) out of L2.
 #pragma once
 #include "engine_types.h"
 
@@ -17,45 +21,64 @@ namespace ftrl_dev {
 constexpr int kRowThreads = 256;
 constexpr int kTermsCap = 2048;  // pair terms staged in LDS per pass
 
-// Dynamic LDS carve of the row kernels (16-byte aligned base, guide G17).
+// Dynamic LDS carve of the row kernels (16-byte aligned base, guide G17).  All per-entry arrays
+// are indexed by the COMPACT index a of the surviving entries (remove_out_range applied).
 struct RowLds {
-  int *idx;      // [max_row_nnz] positions (relative to the row start) of the surviving entries
-  float *linw;   // [max_row_nnz] their linear weights
-  float *terms;  // [kTermsCap]
+  float *terms;  // [kTermsCap]           (first: keeps 16-byte alignment for b128 reads)
+  int *pos;      // [max_row_nnz] position of entry a inside the row
+  int *field;    // [max_row_nnz]
+  int *feat;     // [max_row_nnz]
+  float *val;    // [max_row_nnz]
+  float *linw;   // [max_row_nnz] linear weight
   int *fcnt;     // [n_fields] surviving entries per field
+  int *ffirst;   // [n_fields] compact index of the first entry of the field, -1 if none
 };
 __host__ __device__ inline size_t row_lds_bytes(int max_row_nnz, int n_fields) {
-  return sizeof(int) * (size_t)max_row_nnz + sizeof(float) * (size_t)max_row_nnz +
-         sizeof(float) * kTermsCap + sizeof(int) * (size_t)(n_fields > 0 ? n_fields : 1) + 64;
+  const size_t M = (size_t)((max_row_nnz + 3) & ~3), Fp = (size_t)((n_fields + 3) & ~3);
+  return sizeof(float) * kTermsCap + 5 * 4 * M + 2 * 4 * (Fp ? Fp : 4);
 }
-__device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz) {
+__device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int n_fields) {
+  const int M = (max_row_nnz + 3) & ~3, Fp = ((n_fields + 3) & ~3) ? ((n_fields + 3) & ~3) : 4;
   RowLds l;
-  l.idx = reinterpret_cast<int *>(base);
-  l.linw = reinterpret_cast<float *>(l.idx + max_row_nnz);
-  l.terms = l.linw + max_row_nnz;
-  l.fcnt = reinterpret_cast<int *>(l.terms + kTermsCap);
+  l.terms = reinterpret_cast<float *>(base);
+  l.pos = reinterpret_cast<int *>(l.terms + kTermsCap);
+  l.field = l.pos + M;
+  l.feat = l.field + M;
+  l.val = reinterpret_cast<float *>(l.feat + M);
+  l.linw = l.val + M;
+  l.fcnt = reinterpret_cast<int *>(l.linw + M);
+  l.ffirst = l.fcnt + Fp;
   return l;
 }
 
-// Compacts the surviving entries of the row (remove_out_range) into lds.idx, in row order.
-// Executed by wave 0; returns the count through *nv_out (LDS).
-__device__ __forceinline__ void compact_row(const ModelDev &m, const Rows &rows, int b, int nnz,
-                                            int *idx, int *nv_out) {
+// Stages the surviving entries of the row (remove_out_range: ftrl_model.cpp:36-42, ffm.cpp:30-36)
+// into LDS, in row order.  Executed by wave 0; the count goes to *nv_out.
+__device__ __forceinline__ void stage_row(const ModelDev &m, const Rows &rows, int b, int nnz,
+                                          RowLds &lds, int *nv_out) {
   if (threadIdx.x < 64) {
     int nv = 0;
     for (int base = 0; base < nnz; base += 64) {
       const int p = base + threadIdx.x;
       bool valid = false;
+      int i = 0, f = 0;
+      float x = 0.0f;
       if (p < nnz) {
-        const int i = rows.feat[b + p];
+        i = rows.feat[b + p];
+        x = rows.val[b + p];
         valid = i >= 0 && i < m.n_feats;
         if (m.type == 2) {
-          const int f = rows.field[b + p];
+          f = rows.field[b + p];
           valid = valid && f >= 0 && f < m.n_fields;
         }
       }
       const unsigned long long mask = __ballot(valid);
-      if (valid) idx[nv + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = p;
+      if (valid) {
+        const int a = nv + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+        lds.pos[a] = p;
+        lds.field[a] = f;
+        lds.feat[a] = i;
+        lds.val[a] = x;
+      }
       nv += __popcll(mask);
     }
     if (threadIdx.x == 0) *nv_out = nv;
@@ -64,31 +87,43 @@ __device__ __forceinline__ void compact_row(const ModelDev &m, const Rows &rows,
 
 // pair number q (reference order: a outer, b inner, a < b) -> (a, b) over nv entries
 __device__ __forceinline__ void unrank_pair(int q, int nv, int &a, int &b) {
-  // rows of the strict upper triangle have nv-1, nv-2, ... entries
   const float fn = 2.0f * nv - 1.0f;
-  int aa = static_cast<int>((fn - sqrtf(fn * fn - 8.0f * q)) * 0.5f);
+  int aa = static_cast<int>((fn - __fsqrt_rn(fn * fn - 8.0f * q)) * 0.5f);
   if (aa < 0) aa = 0;
   if (aa > nv - 2) aa = nv - 2;
-  // first pair of row aa: aa*nv - aa*(aa+1)/2
   while (aa > 0 && aa * nv - aa * (aa + 1) / 2 > q) aa--;
   while ((aa + 1) * nv - (aa + 1) * (aa + 2) / 2 <= q) aa++;
   a = aa;
   b = q - (aa * nv - aa * (aa + 1) / 2) + aa + 1;
 }
 
+// Sequential sum of cnt staged terms into acc, in order (one lane; b128 LDS reads).
+__device__ __forceinline__ float add_terms_in_order(const float *terms, int cnt, float acc) {
+  int j = 0;
+  const float4 *t4 = reinterpret_cast<const float4 *>(terms);
+  for (; j + 4 <= cnt; j += 4) {
+    const float4 t = t4[j >> 2];
+    acc += t.x; acc += t.y; acc += t.z; acc += t.w;
+  }
+  for (; j < cnt; j++) acc += terms[j];
+  return acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // FFM (and LR when row_len == 0): one workgroup per row.
-// TRAIN: refresh linear/bias/latent weights of everything the row touches, build the row's
-// per-field entry chains for the update kernel, write the (partial) logit.
+// TRAIN: refresh linear/bias/latent weights of everything the row touches, publish the row's
+// per-field tables for the update kernel, write the (partial) logit.
 // !TRAIN: logit from the stored weights; out = logit or sigmoid(logit); per-row loss if labelled.
+// VEC4: n_factors is a multiple of 4, so every slot is a whole number of 16-byte vectors.
 // ------------------------------------------------------------------------------------------
-template <bool TRAIN>
+template <bool TRAIN, bool VEC4>
 __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
                                                               int output_prob) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv;
-  RowLds lds = carve_row_lds(smem, max_row_nnz);
+  const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
+  RowLds lds = carve_row_lds(smem, max_row_nnz, F);
   const int r = blockIdx.x;
   const int b = rows.row_ptr[r];
   int nnz = rows.row_ptr[r + 1] - b;
@@ -96,55 +131,93 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     if (threadIdx.x == 0) atomicOr(&s.counters[CNT_ERROR], ERR_ROW_TOO_LONG);
     nnz = max_row_nnz;
   }
-  const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
   const bool is_ffm = m.type == 2;
   const bool lin_owner = m.shard_rank == 0;
 
-  for (int f = threadIdx.x; f < F; f += blockDim.x) lds.fcnt[f] = 0;
-  compact_row(m, rows, b, nnz, lds.idx, &s_nv);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) { lds.fcnt[f] = 0; lds.ffirst[f] = -1; }
+  stage_row(m, rows, b, nnz, lds, &s_nv);
   __syncthreads();
   const int nv = s_nv;
 
   if (is_ffm) {
-    for (int a = threadIdx.x; a < nv; a += blockDim.x)
-      atomicAdd(&lds.fcnt[rows.field[b + lds.idx[a]]], 1);
+    for (int a = threadIdx.x; a < nv; a += blockDim.x) {
+      atomicAdd(&lds.fcnt[lds.field[a]], 1);
+      atomicMin(reinterpret_cast<unsigned *>(&lds.ffirst[lds.field[a]]), static_cast<unsigned>(a));
+    }
     __syncthreads();
   }
 
   if (TRAIN && is_ffm) {
-    // per-field chains of this row's surviving entries, ascending position
+    // Per-field view of this row for the update kernel: rowtab[r][f] = {feat, val bits, entry
+    // index, count} of the only entry with field f (entry index -1: none, -2: several -- then
+    // head/next chains list them in row order).
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
-      int head = -1, prev = -1;
-      if (lds.fcnt[f] > 0)
-        for (int a = 0; a < nv; a++) {
-          const int p = b + lds.idx[a];
-          if (rows.field[p] == f) {
-            if (prev < 0) head = p; else s.next[prev] = p;
-            prev = p;
-          }
+      const int cnt = lds.fcnt[f];
+      int4 t = make_int4(-1, 0, -1, cnt);
+      int head = -1;
+      if (cnt >= 1) {
+        const int a0 = lds.ffirst[f];
+        head = b + lds.pos[a0];
+        t = make_int4(lds.feat[a0], __float_as_int(lds.val[a0]), cnt == 1 ? head : -2, cnt);
+        if (cnt > 1) {
+          int prev = head;
+          for (int a = a0 + 1; a < nv; a++)
+            if (lds.field[a] == f) {
+              s.next[prev] = b + lds.pos[a];
+              prev = b + lds.pos[a];
+            }
+          s.next[prev] = -1;
+        } else {
+          s.next[head] = -1;
         }
-      if (prev >= 0) s.next[prev] = -1;
+      }
       s.head[static_cast<int64_t>(r) * F + f] = head;
+      s.rowtab[static_cast<int64_t>(r) * F + f] = t;
     }
     // lazy refresh of every slot (feature a, partner field fp) that a pair of this row touches:
     // FFM::update_vector_w, ffm.cpp:72-88
-    const int total = nv * RL;
-    for (int t = threadIdx.x; t < total; t += blockDim.x) {
-      const int a = t / RL, e = t - a * RL;
-      const int fp = e / k;
-      const int p = b + lds.idx[a];
-      const int fa = rows.field[p];
-      const bool touched = (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
-      if (touched) {
-        float *row = lat_row(m, rows.feat[p]);
-        row[LAT_W * RL + e] = ftrl_weight(m.h, row[LAT_N * RL + e], row[LAT_Z * RL + e]);
+    if (VEC4) {
+      const int RL4 = RL >> 2, k4 = k >> 2;
+      const float inv_RL4 = 1.0f / static_cast<float>(RL4), inv_k4 = 1.0f / static_cast<float>(k4);
+      const int total = nv * RL4;
+#pragma unroll 4
+      for (int t = threadIdx.x; t < total; t += kRowThreads) {
+        int a = static_cast<int>((t + 0.5f) * inv_RL4);
+        a += (a + 1) * RL4 <= t ? 1 : (a * RL4 > t ? -1 : 0);  // exact for any size
+        const int c4 = t - a * RL4;
+        int fp = static_cast<int>((c4 + 0.5f) * inv_k4);
+        fp += (fp + 1) * k4 <= c4 ? 1 : (fp * k4 > c4 ? -1 : 0);
+        const int fa = lds.field[a];
+        const bool touched = (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
+        if (touched) {
+          float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a]));
+          const float4 n4 = row[LAT_N * RL4 + c4], z4 = row[LAT_Z * RL4 + c4];
+          float4 w4;
+          w4.x = ftrl_weight(m.h, n4.x, z4.x);
+          w4.y = ftrl_weight(m.h, n4.y, z4.y);
+          w4.z = ftrl_weight(m.h, n4.z, z4.z);
+          w4.w = ftrl_weight(m.h, n4.w, z4.w);
+          row[LAT_W * RL4 + c4] = w4;
+        }
+      }
+    } else {
+      const int total = nv * RL;
+      for (int t = threadIdx.x; t < total; t += kRowThreads) {
+        const int a = t / RL, e = t - a * RL;
+        const int fp = e / k;
+        const int fa = lds.field[a];
+        const bool touched = (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
+        if (touched) {
+          float *row = lat_row(m, lds.feat[a]);
+          row[LAT_W * RL + e] = ftrl_weight(m.h, row[LAT_N * RL + e], row[LAT_Z * RL + e]);
+        }
       }
     }
   }
 
   // linear weights of the surviving entries (update_linear_w, ftrl_model.cpp:52-59)
   for (int a = threadIdx.x; a < nv; a += blockDim.x) {
-    const int i = rows.feat[b + lds.idx[a]];
+    const int i = lds.feat[a];
     float lw;
     if (TRAIN) {
       lw = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
@@ -158,45 +231,54 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
 
   // linear logit, sequential in row order (compute_linear_logit, ftrl_model.cpp:44-50)
   float result = 0.0f;
-  if (threadIdx.x == 0) {
-    if (lin_owner) {
-      float bias;
-      if (TRAIN) {
-        bias = ftrl_weight(m.h, m.bias3[1], m.bias3[2]);  // update_bias, ftrl_model.cpp:61-64
-        if (r == 0) m.bias3[0] = bias;
-      } else {
-        bias = m.bias3[0];
-      }
-      result = bias;
-      for (int a = 0; a < nv; a++) result = result + lds.linw[a] * rows.val[b + lds.idx[a]];
+  if (threadIdx.x == 0 && lin_owner) {
+    float bias;
+    if (TRAIN) {
+      bias = ftrl_weight(m.h, m.bias3[1], m.bias3[2]);  // update_bias, ftrl_model.cpp:61-64
+      if (r == 0) m.bias3[0] = bias;
+    } else {
+      bias = m.bias3[0];
     }
+    result = bias;
+    for (int a = 0; a < nv; a++) result = result + lds.linw[a] * lds.val[a];
   }
 
   if (is_ffm && nv > 1) {
     const int n_pairs = nv * (nv - 1) / 2;
     for (int q0 = 0; q0 < n_pairs; q0 += kTermsCap) {
       const int q1 = min(q0 + kTermsCap, n_pairs);
-      for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+      for (int q = q0 + threadIdx.x; q < q1; q += kRowThreads) {
         int a, bb;
         unrank_pair(q, nv, a, bb);
-        const int pa = b + lds.idx[a], pb = b + lds.idx[bb];
-        const int fa = rows.field[pa], fb = rows.field[pb];
+        const int fa = lds.field[a], fb = lds.field[bb];
         float term = 0.0f;
-        bool own = owns_pair(m, fa, fb);
+        const bool own = owns_pair(m, fa, fb);
         if (own) {
-          const float *va = lat_row(m, rows.feat[pa]) + LAT_W * RL + fb * k;
-          const float *vb = lat_row(m, rows.feat[pb]) + LAT_W * RL + fa * k;
+          const float *va = lat_row(m, lds.feat[a]) + LAT_W * RL + fb * k;
+          const float *vb = lat_row(m, lds.feat[bb]) + LAT_W * RL + fa * k;
           float dot = 0.0f;
-          for (int f = 0; f < k; f++) dot = dot + va[f] * vb[f];
-          term = dot * rows.val[pa] * rows.val[pb];
+          if (VEC4) {
+            const float4 *va4 = reinterpret_cast<const float4 *>(va);
+            const float4 *vb4 = reinterpret_cast<const float4 *>(vb);
+            for (int f4 = 0; f4 < (k >> 2); f4++) {
+              const float4 x = va4[f4], y = vb4[f4];
+              dot = dot + x.x * y.x;
+              dot = dot + x.y * y.y;
+              dot = dot + x.z * y.z;
+              dot = dot + x.w * y.w;
+            }
+          } else {
+            for (int f = 0; f < k; f++) dot = dot + va[f] * vb[f];
+          }
+          term = dot * lds.val[a] * lds.val[bb];
         }
-        // non-owned pairs contribute nothing on this shard; mark them so the sum skips them
+        // pairs another shard owns contribute nothing here; tag them so the sum skips them
         lds.terms[q - q0] = own ? term : __int_as_float(0x7fc00001);
       }
       __syncthreads();
       if (threadIdx.x == 0) {
         if (m.n_shards <= 1) {
-          for (int j = 0; j < q1 - q0; j++) result += lds.terms[j];
+          result = add_terms_in_order(lds.terms, q1 - q0, result);
         } else {
           for (int j = 0; j < q1 - q0; j++) {
             const float t = lds.terms[j];
@@ -227,7 +309,7 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
                                                              int output_prob) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv;
-  RowLds lds = carve_row_lds(smem, max_row_nnz);
+  RowLds lds = carve_row_lds(smem, max_row_nnz, 1);
   const int r = blockIdx.x;
   const int b = rows.row_ptr[r];
   int nnz = rows.row_ptr[r + 1] - b;
@@ -236,20 +318,24 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
     nnz = max_row_nnz;
   }
   const int k = m.n_factors;
-  compact_row(m, rows, b, nnz, lds.idx, &s_nv);
+  stage_row(m, rows, b, nnz, lds, &s_nv);
   __syncthreads();
   const int nv = s_nv;
 
   if (TRAIN) {  // FM::update_vector_w, fm.cpp:69-78
     const int total = nv * k;
-    for (int t = threadIdx.x; t < total; t += blockDim.x) {
-      const int a = t / k, e = t - a * k;
-      float *row = lat_row(m, rows.feat[b + lds.idx[a]]);
+    const float inv_k = 1.0f / static_cast<float>(k);
+#pragma unroll 4
+    for (int t = threadIdx.x; t < total; t += kRowThreads) {
+      int a = static_cast<int>((t + 0.5f) * inv_k);
+      a += (a + 1) * k <= t ? 1 : (a * k > t ? -1 : 0);
+      const int e = t - a * k;
+      float *row = lat_row(m, lds.feat[a]);
       row[LAT_W * k + e] = ftrl_weight(m.h, row[LAT_N * k + e], row[LAT_Z * k + e]);
     }
   }
   for (int a = threadIdx.x; a < nv; a += blockDim.x) {
-    const int i = rows.feat[b + lds.idx[a]];
+    const int i = lds.feat[a];
     float lw;
     if (TRAIN) {
       lw = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
@@ -265,8 +351,7 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
   for (int f = threadIdx.x; f < k; f += blockDim.x) {
     float s_vx = 0.0f, sum_sqr = 0.0f;
     for (int a = 0; a < nv; a++) {
-      const int p = b + lds.idx[a];
-      const float vx = lat_row(m, rows.feat[p])[LAT_W * k + f] * rows.val[p];
+      const float vx = lat_row(m, lds.feat[a])[LAT_W * k + f] * lds.val[a];
       s_vx += vx;
       sum_sqr += vx * vx;
     }
@@ -283,8 +368,8 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
       bias = m.bias3[0];
     }
     float result = bias;
-    for (int a = 0; a < nv; a++) result = result + lds.linw[a] * rows.val[b + lds.idx[a]];
-    for (int f = 0; f < k; f++) result += lds.terms[f];
+    for (int a = 0; a < nv; a++) result = result + lds.linw[a] * lds.val[a];
+    result = add_terms_in_order(lds.terms, k, result);
     if (TRAIN) {
       s.logit[r] = result;
     } else {
@@ -320,6 +405,13 @@ __global__ __launch_bounds__(256) void loss_sum_kernel(int n_rows, const double 
     __syncthreads();
   }
   if (threadIdx.x == 0) *out = part[0];
+}
+
+// Evaluates sigmoid_ref on an array (self-test entry point: lets the parity tests compare the
+// device's expf restatement with the host C library on millions of inputs).
+__global__ void sigmoid_eval_kernel(int n, const float *x, float *y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = sigmoid_ref(x[i]);
 }
 
 }  // namespace ftrl_dev

@@ -4,11 +4,18 @@
 //   FFM::update_vector_nz                          src/model/ffm.cpp:90-136  (incl. :118)
 //   FM::update_vector_nz                           src/model/fm.cpp:80-101
 //
-// Every distinct feature of the block has exactly one owner (one wave per 64 latent elements of
-// its record).  The owner keeps (n, z, w) in registers and applies the block's touches to them in
-// row order -- the same sequence of fp32 operations the reference's one-thread loop performs
-// with w and tmp_grad frozen at the block start -- then writes (n, z) back once.  No float
-// atomics, no locks, bit-reproducible.
+// Every distinct feature of the block has exactly one owner.  The owner keeps (n, z, w) in
+// registers and applies the block's touches to them in row order -- the same sequence of fp32
+// operations the reference's one-thread loop performs with w and tmp_grad frozen at the block
+// start -- then writes (n, z) back once.  No float atomics, no locks, bit-reproducible.
+//
+// Two shapes of owner (the grouping pass sorts features into two lists by occurrence count):
+//  * "small" features (<= kSmallMax occurrences, the vast majority): ONE wave owns the whole
+//    record, each lane holding 4 consecutive factors of one slot (16-byte loads of n, z, w and of
+//    each partner slot), all of a record's gathers in flight together -- bandwidth-shaped.
+//  * "hot" features: one wave per 64 elements of the record, touches handled kUnroll at a time
+//    (all of a group's gathers issued before the accumulator chain consumes them) -- keeps the
+//    long sequential chains of a hot feature spread over many waves.
 #pragma once
 #include "engine_types.h"
 
@@ -16,56 +23,209 @@ namespace ftrl_dev {
 
 constexpr int kUpdThreads = 256;
 constexpr int kUpdWaves = kUpdThreads / 64;
+constexpr int kUnroll = 8;
 
-// FFM latent update.  Work item = (distinct feature u, chunk of 64 elements of its row_len).
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_kernel(ModelDev m, Rows rows,
-                                                                 Scratch s) {
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// One touch of slot (own feature, partner field fp) by the pair {own entry, other entry}.
+__device__ __forceinline__ void ffm_touch(const Hyper &h, bool own_first, float tg, float x_own,
+                                          float x_other, float vp, float w, float &n, float &z) {
+  if (own_first) {
+    // own entry is the pair's first: slot (i, field2), ffm.cpp:112-115
+    const float x = x_own * x_other;
+    const float g1 = tg * vp * x;
+    nz_step_latent(h, w, g1, n, z);
+  } else {
+    // own entry is the pair's second: slot (j, field1), ffm.cpp:117-120 with the :118 quirk
+    const float x = x_other * x_own;
+    const float g2 = tg * vp * x;  // tmp_grad * vif1 * x
+    const float g1 = tg * w * x;   // tmp_grad * vif2 * x (the first entry's gradient)
+    nz_step_latent_jside(h, w, g2, g1, n, z);
+  }
+}
+
+// ---- hot features: work item = (feature from the big list, chunk of 64 elements) ----------
+// ALL = true: every distinct feature takes this path (n_factors not a multiple of 4).
+template <bool ALL>
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m, Rows rows,
+                                                                     Scratch s) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
-  const int chunks = (RL + 63) / 64;
+  const unsigned chunks = (RL + 63) / 64;
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * kUpdWaves + (threadIdx.x >> 6);
-  const int n_waves = gridDim.x * kUpdWaves;
-  const int64_t n_items = static_cast<int64_t>(s.counters[CNT_NUNIQ]) * chunks;
-  for (int64_t item = wave; item < n_items; item += n_waves) {
-    const int u = static_cast<int>(item / chunks);
-    const int e = static_cast<int>(item - static_cast<int64_t>(u) * chunks) * 64 + lane;
-    if (e >= RL) continue;
-    const int fp = e / k, kk = e - fp * k;  // this lane's slot: partner field fp, factor kk
-    const int i = s.uniq[u];
-    const int start = s.ustart[u], c = s.ucount[u];
+  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = gridDim.x * kUpdWaves;
+  const unsigned n_feat = ALL ? s.counters[CNT_NUNIQ] : s.counters[CNT_NBIG];
+  const unsigned n_items = n_feat * chunks;  // the host bounds max_batch_nnz * chunks below 2^31
+  const float inv_k = 1.0f / static_cast<float>(k);
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned li = item / chunks;
+    const int u = ALL ? static_cast<int>(li) : wave_uniform(s.big[li]);
+    const int e = static_cast<int>(item - li * chunks) * 64 + lane;
+    const bool active = e < RL;
+    const int ee = active ? e : 0;
+    int fp = static_cast<int>((ee + 0.5f) * inv_k);  // this lane's partner field
+    fp += (fp + 1) * k <= ee ? 1 : (fp * k > ee ? -1 : 0);
+    const int kk = ee - fp * k;  // and factor
+    const int i = wave_uniform(s.uniq[u]);
+    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     float *rec = lat_row(m, i);
-    float n = rec[LAT_N * RL + e], z = rec[LAT_Z * RL + e];
-    const float w = rec[LAT_W * RL + e];
+    float n = rec[LAT_N * RL + ee], z = rec[LAT_Z * RL + ee];
+    const float w = rec[LAT_W * RL + ee];
     bool touched = false;
-    for (int t = 0; t < c; t++) {
-      const int p = s.occ[start + t];  // an entry holding feature i
-      const int r = s.row_of[p];
-      const int fm = rows.field[p];
-      if (!owns_pair(m, fm, fp)) continue;
-      const float tg = s.tg[r];
-      const float xm = rows.val[p];
-      // every other surviving entry q of row r whose field is fp pairs with p through this slot
-      for (int q = s.head[static_cast<int64_t>(r) * F + fp]; q >= 0; q = s.next[q]) {
-        if (q == p) continue;
-        const float vp = lat_row(m, rows.feat[q])[LAT_W * RL + fm * k + kk];  // partner slot w
-        touched = true;
-        if (p < q) {
-          // p is the pair's first entry: slot (i, field2), ffm.cpp:112-115
-          const float x = xm * rows.val[q];
-          const float g1 = tg * vp * x;
-          nz_step_latent(m.h, w, g1, n, z);
-        } else {
-          // p is the pair's second entry: slot (j, field1), ffm.cpp:117-120 with the :118 quirk
-          const float x = rows.val[q] * xm;
-          const float g2 = tg * vp * x;  // tmp_grad * vif1 * x
-          const float g1 = tg * w * x;   // tmp_grad * vif2 * x (the first entry's gradient)
-          nz_step_latent_jside(m.h, w, g2, g1, n, z);
+    for (int t0 = 0; t0 < c; t0 += kUnroll) {
+      int pj[kUnroll], fmj[kUnroll];
+      float tgj[kUnroll], xmj[kUnroll], vpj[kUnroll];
+      int4 rtj[kUnroll];
+#pragma unroll
+      for (int j = 0; j < kUnroll; j++) {
+        const int t = min(t0 + j, c - 1);  // clamp: the tail re-reads the last entry, unused
+        const int2 pr = s.occ2[start + t];
+        pj[j] = pr.x;
+        fmj[j] = rows.field[pr.x];
+        xmj[j] = rows.val[pr.x];
+        tgj[j] = s.tg[pr.y];
+        rtj[j] = s.rowtab[static_cast<int64_t>(pr.y) * F + fp];
+      }
+#pragma unroll
+      for (int j = 0; j < kUnroll; j++) {
+        // partner weight w[feat_q][field_own][kk]; harmless address when there is no partner
+        const int fq = rtj[j].x >= 0 ? rtj[j].x : i;
+        vpj[j] = lat_row(m, fq)[LAT_W * RL + fmj[j] * k + kk];
+      }
+      bool simple[kUnroll], complex_any = false;
+#pragma unroll
+      for (int j = 0; j < kUnroll; j++) {
+        const bool live = t0 + j < c && active && owns_pair(m, fmj[j], fp);
+        simple[j] = live && rtj[j].z >= 0 && rtj[j].z != pj[j];
+        complex_any = complex_any || (live && rtj[j].z == -2);
+      }
+      if (!__any(complex_any)) {
+        // The group's touches, as the reference applies them one after another, but laid out so
+        // the expensive parts are independent: gradients first, then the running n (a chain of
+        // plain adds), then every touch's sigma (sqrt/divide, all independent given the running
+        // n), then the running z (two adds per touch).  Same operations, same operands, same
+        // order per accumulator as ffm_touch -- only the instruction schedule differs.
+        float gj[kUnroll], aj[kUnroll], nb[kUnroll], mj[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; j++) {
+          const bool first = pj[j] < rtj[j].z;
+          const float xo = __int_as_float(rtj[j].y);
+          const float x = first ? xmj[j] * xo : xo * xmj[j];
+          const float g = tgj[j] * vpj[j] * x;  // own slot's gradient (g1 if first, else g2)
+          const float g1 = tgj[j] * w * x;      // j-side only: the first entry's gradient
+          gj[j] = g;
+          aj[j] = first ? g * g : g * g1;       // what the square root sees added to n (:118)
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; j++) {
+          nb[j] = n;
+          if (simple[j]) n = n + gj[j] * gj[j];
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; j++) {
+          const float sg = (sqrtf(nb[j] + aj[j]) - sqrtf(nb[j])) / m.h.alpha;
+          mj[j] = sg * w;
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; j++)
+          if (simple[j]) { z = (z + gj[j]) - mj[j]; touched = true; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kUnroll; j++) {
+          if (t0 + j < c && active && owns_pair(m, fmj[j], fp)) {
+            const int p = pj[j], fm = fmj[j];
+            const int q = rtj[j].z;
+            if (q >= 0) {  // exactly one entry of this row has field fp
+              if (q != p) {
+                ffm_touch(m.h, p < q, tgj[j], xmj[j], __int_as_float(rtj[j].y), vpj[j], w, n, z);
+                touched = true;
+              }
+            } else if (q == -2) {
+              // several entries share field fp (multi-valued field): walk the row's chain in order
+              const int r = s.row_of[p];
+              for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+                if (qq == p) continue;
+                const float vp = lat_row(m, rows.feat[qq])[LAT_W * RL + fm * k + kk];
+                ffm_touch(m.h, p < qq, tgj[j], xmj[j], rows.val[qq], vp, w, n, z);
+                touched = true;
+              }
+            }
+          }
         }
       }
     }
     if (touched) {
-      rec[LAT_N * RL + e] = n;
-      rec[LAT_Z * RL + e] = z;
+      rec[LAT_N * RL + ee] = n;
+      rec[LAT_Z * RL + ee] = z;
+    }
+  }
+}
+
+// ---- small features: one wave per feature, lanes = 4 consecutive factors of a slot ---------
+// Requires n_factors % 4 == 0.  c <= kSmallMax occurrences.  Kept lean in registers: the
+// bandwidth comes from many resident waves, each with its record's loads in flight.
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev m, Rows rows,
+                                                                       Scratch s) {
+  const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
+  const int RL4 = RL >> 2, k4 = k >> 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = gridDim.x * kUpdWaves;
+  const int n_small = s.counters[CNT_NSMALL];
+  const float inv_k4 = 1.0f / static_cast<float>(k4);
+  for (int li = wave; li < n_small; li += n_waves) {
+    const int u = wave_uniform(s.small[li]);
+    const int i = wave_uniform(s.uniq[u]);
+    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i));
+    for (int l0 = 0; l0 < RL4; l0 += 64) {
+      const int l = l0 + lane;
+      if (l >= RL4) continue;
+      int fp = static_cast<int>((l + 0.5f) * inv_k4);  // partner field of this lane's slot
+      fp += (fp + 1) * k4 <= l ? 1 : (fp * k4 > l ? -1 : 0);
+      const int kq = l - fp * k4;  // which 16-byte quarter of the slot
+      float4 n4 = rec4[LAT_N * RL4 + l], z4 = rec4[LAT_Z * RL4 + l];
+      const float4 w4 = rec4[LAT_W * RL4 + l];
+      bool touched = false;
+      for (int j = 0; j < c; j++) {
+        const int2 pr = s.occ2[start + j];  // wave-uniform
+        const int p = pr.x, r = pr.y;
+        const int fm = rows.field[p];
+        if (!owns_pair(m, fm, fp)) continue;
+        const float xm = rows.val[p], tg = s.tg[r];
+        const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
+        const int q = rt.z;
+        if (q >= 0) {
+          if (q != p) {
+            const float4 vp =
+                reinterpret_cast<const float4 *>(lat_row(m, rt.x))[LAT_W * RL4 + fm * k4 + kq];
+            const bool first = p < q;
+            const float xo = __int_as_float(rt.y);
+            ffm_touch(m.h, first, tg, xm, xo, vp.x, w4.x, n4.x, z4.x);
+            ffm_touch(m.h, first, tg, xm, xo, vp.y, w4.y, n4.y, z4.y);
+            ffm_touch(m.h, first, tg, xm, xo, vp.z, w4.z, n4.z, z4.z);
+            ffm_touch(m.h, first, tg, xm, xo, vp.w, w4.w, n4.w, z4.w);
+            touched = true;
+          }
+        } else if (q == -2) {
+          for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+            if (qq == p) continue;
+            const float4 vp = reinterpret_cast<const float4 *>(
+                lat_row(m, rows.feat[qq]))[LAT_W * RL4 + fm * k4 + kq];
+            const bool first = p < qq;
+            const float xo = rows.val[qq];
+            ffm_touch(m.h, first, tg, xm, xo, vp.x, w4.x, n4.x, z4.x);
+            ffm_touch(m.h, first, tg, xm, xo, vp.y, w4.y, n4.y, z4.y);
+            ffm_touch(m.h, first, tg, xm, xo, vp.z, w4.z, n4.z, z4.z);
+            ffm_touch(m.h, first, tg, xm, xo, vp.w, w4.w, n4.w, z4.w);
+            touched = true;
+          }
+        }
+      }
+      if (touched) {
+        rec4[LAT_N * RL4 + l] = n4;
+        rec4[LAT_Z * RL4 + l] = z4;
+      }
     }
   }
 }
@@ -75,58 +235,138 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
   const int k = m.n_factors;
   const int chunks = (k + 63) / 64;
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * kUpdWaves + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const int n_waves = gridDim.x * kUpdWaves;
   const int64_t n_items = static_cast<int64_t>(s.counters[CNT_NUNIQ]) * chunks;
   for (int64_t item = wave; item < n_items; item += n_waves) {
     const int u = static_cast<int>(item / chunks);
     const int e = static_cast<int>(item - static_cast<int64_t>(u) * chunks) * 64 + lane;
     if (e >= k) continue;
-    const int i = s.uniq[u];
-    const int start = s.ustart[u], c = s.ucount[u];
+    const int i = wave_uniform(s.uniq[u]);
+    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     float *rec = lat_row(m, i);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
     const float w = rec[LAT_W * k + e];
-    for (int t = 0; t < c; t++) {  // fm.cpp:84-95
-      const int p = s.occ[start + t];
-      const int r = s.row_of[p];
-      const float x = rows.val[p];
-      const float s_vx = s.svx[static_cast<int64_t>(r) * k + e];
-      const float g = s.tg[r] * (x * s_vx - w * x * x);
-      nz_step_latent(m.h, w, g, n, z);
+    for (int t0 = 0; t0 < c; t0 += kUnroll) {
+      float xj[kUnroll], tgj[kUnroll], sj[kUnroll];
+#pragma unroll
+      for (int j = 0; j < kUnroll; j++) {
+        const int t = min(t0 + j, c - 1);
+        const int2 pr = s.occ2[start + t];
+        xj[j] = rows.val[pr.x];
+        tgj[j] = s.tg[pr.y];
+        sj[j] = s.svx[static_cast<int64_t>(pr.y) * k + e];
+      }
+#pragma unroll
+      for (int j = 0; j < kUnroll; j++) {  // fm.cpp:84-95
+        if (t0 + j >= c) break;
+        const float x = xj[j];
+        const float g = tgj[j] * (x * sj[j] - w * x * x);
+        nz_step_latent(m.h, w, g, n, z);
+      }
     }
     rec[LAT_N * k + e] = n;
     rec[LAT_Z * k + e] = z;
   }
 }
 
-// Linear + bias update.  Thread per distinct feature (update_linear_nz, ftrl_model.cpp:66-77);
-// the very first thread also walks all rows for the bias (update_bias_nz, :79-85).
+// Strictly left-to-right running sum over the 64 lanes: returns S_j = ((carry + a_0) + a_1) ... + a_j
+// in lane j, every addition rounded exactly as a one-lane sequential loop would round it.  Step t
+// finalises lane t (S_t = S_{t-1} + a_t through a whole-wave shift-right-by-one DPP move); lanes
+// already final recompute the same value, so no predication is needed.  Idle lanes pass -0.0f
+// (x + -0.0f == x bit for bit, for every x including both zeros).
+__device__ __forceinline__ float wave_sequential_prefix(float carry, float a) {
+  const int lane = threadIdx.x & 63;
+  float s = lane == 0 ? carry + a : a;
+  const float step = lane == 0 ? -0.0f : a;
+#pragma unroll
+  for (int t = 1; t < 64; t++) {
+    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(
+        __float_as_int(s), __float_as_int(s), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    s = prev + step;
+  }
+  return s;
+}
+
+// The linear/bias accumulator chain over up to 64 gradients held one per lane (lane j = the j-th
+// touch, in order; lanes >= count idle).  Sequential semantics of nz_step_linear, evaluated as:
+// (1) running n by a strictly sequential prefix sum, (2) every touch's z increment in parallel,
+// (3) z by a second sequential prefix -- the same operations on the same values in the same
+// order as the one-thread loop, so bit-identical.
+__device__ __forceinline__ void linear_chain64(const Hyper &h, float w, float g, int count,
+                                               float &n, float &z) {
+  const int lane = threadIdx.x & 63;
+  const bool live = lane < count;
+  const float n_after = wave_sequential_prefix(n, live ? g * g : -0.0f);
+  float n_before = __int_as_float(__builtin_amdgcn_update_dpp(
+      __float_as_int(n), __float_as_int(n_after), 0x138, 0xf, 0xf, false));
+  if (lane == 0) n_before = n;
+  const float sgm = (sqrtf(n_after) - sqrtf(n_before)) / h.alpha;  // n_after = n_before + g*g
+  const float z_run = wave_sequential_prefix(z, live ? g - sgm * w : -0.0f);
+  n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n_after), 63));
+  z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_run), 63));
+}
+
+// Linear update (update_linear_nz, ftrl_model.cpp:66-77).  Small features: one thread each,
+// touches applied one after another; hot features: one wave each, 64 touches per pass.
 __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, Rows rows,
                                                                     Scratch s) {
+  const int n_small = s.counters[CNT_NSMALL], n_big = s.counters[CNT_NBIG];
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n_uniq = s.counters[CNT_NUNIQ];
-  for (int u = gtid; u < n_uniq; u += gridDim.x * blockDim.x) {
+  for (int li = gtid; li < n_small; li += gridDim.x * blockDim.x) {
+    const int u = s.small[li];
     const int i = s.uniq[u];
     const int start = s.ustart[u], c = s.ucount[u];
     float n = m.lin_n[i], z = m.lin_z[i];
     const float w = m.lin_w[i];
     for (int t = 0; t < c; t++) {
-      const int p = s.occ[start + t];
-      nz_step_linear(m.h, w, s.tg[s.row_of[p]] * rows.val[p], n, z);
+      const int2 pr = s.occ2[start + t];
+      nz_step_linear(m.h, w, s.tg[pr.y] * rows.val[pr.x], n, z);
     }
     m.lin_n[i] = n;
     m.lin_z[i] = z;
   }
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = gridDim.x * kUpdWaves;
+  for (int li = wave; li < n_big; li += n_waves) {
+    const int u = wave_uniform(s.big[li]);
+    const int i = wave_uniform(s.uniq[u]);
+    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    float n = m.lin_n[i], z = m.lin_z[i];
+    const float w = m.lin_w[i];
+    for (int t0 = 0; t0 < c; t0 += 64) {
+      const int cnt = min(64, c - t0);
+      float g = 0.0f;
+      if (lane < cnt) {
+        const int2 pr = s.occ2[start + t0 + lane];
+        g = s.tg[pr.y] * rows.val[pr.x];
+      }
+      linear_chain64(m.h, w, g, cnt, n, z);
+    }
+    if (lane == 0) {
+      m.lin_n[i] = n;
+      m.lin_z[i] = z;
+    }
+  }
 }
 
-__global__ void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// Bias update: one wave walks all rows of the block in order (update_bias_nz, :79-85).
+__global__ __launch_bounds__(64) void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
+  const int lane = threadIdx.x & 63;
   float n = m.bias3[1], z = m.bias3[2];
   const float w = m.bias3[0];
-  for (int r = 0; r < n_rows; r++) nz_step_linear(m.h, w, s.tg[r], n, z);
-  m.bias3[1] = n;
-  m.bias3[2] = z;
+  float g_next = lane < n_rows ? s.tg[lane] : 0.0f;
+  for (int r0 = 0; r0 < n_rows; r0 += 64) {
+    const int cnt = min(64, n_rows - r0);
+    const float g = g_next;
+    g_next = (r0 + 64 + lane) < n_rows ? s.tg[r0 + 64 + lane] : 0.0f;  // prefetch the next 64
+    linear_chain64(m.h, w, lane < cnt ? g : 0.0f, cnt, n, z);
+  }
+  if (lane == 0) {
+    m.bias3[1] = n;
+    m.bias3[2] = z;
+  }
 }
 
 }  // namespace ftrl_dev

@@ -64,6 +64,9 @@ ABI = [
     ("ffm_engine_train_forward_device", ctypes.c_int,
      [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [_vp]),
     ("ffm_engine_train_update_device", ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    ("ffm_engine_fill_state", ctypes.c_int,
+     [_vp, ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.c_float]),
+    ("ffm_engine_eval_sigmoid", ctypes.c_int, [_vp, ctypes.c_int32, _f32p, _f32p]),
     ("ffm_engine_sync", ctypes.c_int, [_vp]),
     ("ffm_engine_profile_enable", ctypes.c_int, [_vp, ctypes.c_int32]),
     ("ffm_engine_profile_read", ctypes.c_int,
@@ -228,6 +231,16 @@ class Engine:
         self._check(self.lib.ffm_engine_predict_batch_device(self.h, n_rows, nnz, row_ptr, field,
                                                              feat, val, label, int(output_prob),
                                                              out, loss_sum_out))
+
+    def fill_state(self, seed=7, n_lo=0.05, n_hi=1.0, z_stddev=0.3):
+        """Warm random accumulators drawn on the device (measurement utility)."""
+        self._check(self.lib.ffm_engine_fill_state(self.h, int(seed), n_lo, n_hi, z_stddev))
+
+    def eval_sigmoid(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        self._check(self.lib.ffm_engine_eval_sigmoid(self.h, x.size, _f(x), _f(y)))
+        return y
 
     def sync(self):
         self._check(self.lib.ffm_engine_sync(self.h))

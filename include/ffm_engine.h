@@ -148,6 +148,17 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
 int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *logit_out,
                                    double *loss_sum_out);
 
+/* Measurement utility: overwrite ALL accumulators with a reproducible "warm" state drawn on the
+ * device -- n ~ U[n_lo, n_hi), z ~ N(0, z_stddev) for bias, linear and latent -- so that
+ * benchmarks exercise the full arithmetic (a fresh model has n = z = 0 everywhere, which makes
+ * every weight take the |z| <= l1 early exit).  Not used by training itself. */
+int ffm_engine_fill_state(ffm_engine *e, uint64_t seed, float n_lo, float n_hi, float z_stddev);
+
+/* Self-test utility: y[i] = the device's sigmoid(x[i]) (utils::sigmoid<float>, utils.h:20-23, with
+ * the C library's expf restated on the device); host arrays.  Lets tests compare it with the
+ * host libm on millions of inputs. */
+int ffm_engine_eval_sigmoid(ffm_engine *e, int32_t n, const float *x, float *y);
+
 /* Blocks until everything queued on the engine's stream has finished. */
 int ffm_engine_sync(ffm_engine *e);
 

@@ -101,6 +101,18 @@ __global__ void fill_state_kernel(ModelDev m, uint64_t seed, float n_lo, float n
   }
 }
 
+// Proves div_alpha_fast == IEEE divide for this alpha over every float significand, both signs
+// and two exponents (ftrl_math.h); any mismatch raises *bad.
+__global__ void verify_div_alpha_kernel(Hyper h, int *bad) {
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;  // 2^25 threads
+  const unsigned mant = idx & 0x7fffffu;
+  const unsigned expo = (idx >> 23) & 1u ? 0x3f800000u : 0x40000000u;
+  const unsigned sign = (idx >> 24) & 1u ? 0x80000000u : 0u;
+  const float x = __uint_as_float(sign | expo | mant);
+  const float a = div_alpha_fast(h, x), b = x / h.alpha;
+  if (__float_as_uint(a) != __float_as_uint(b)) atomicOr(bad, 1);
+}
+
 // Copies one component (n, z or w) of features [feat0, feat0+nf) between the interleaved record
 // layout and a dense [feat][row_len] staging buffer (the reference's save order).
 __global__ void lat_component_copy_kernel(float *lat, int row_len, int comp, float *dense,
@@ -276,7 +288,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
               : cfg->model_type == FFM_MODEL_FM ? cfg->n_factors : 0;
   m.n_shards = cfg->n_shards;
   m.shard_rank = cfg->shard_rank;
-  m.h = Hyper{cfg->w_alpha, cfg->w_beta, cfg->w_l1, cfg->w_l2};
+  m.h = Hyper{cfg->w_alpha, cfg->w_beta, cfg->w_l1, cfg->w_l2, 1.0f / cfg->w_alpha, 0};
   if (static_cast<int64_t>(cfg->n_fields) * cfg->n_factors > (1 << 24))
     { delete e; return fail(FFM_E_UNSUPPORTED, "n_fields*n_factors too large"); }
   if (static_cast<int64_t>(cfg->max_batch_nnz) * ((m.row_len + 63) / 64 + 1) >= (1ll << 31))
@@ -346,6 +358,17 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (n_lat) TRY_HIP(hipMemsetAsync(m.lat, 0, n_lat * sizeof(float), e->stream));
   TRY_HIP(hipMemsetAsync(s.cnt, 0, nf * sizeof(int), e->stream));
   TRY_HIP(hipMemsetAsync(s.counters, 0, 8 * sizeof(int), e->stream));
+  if (cfg->w_alpha >= 0x1p-30f && cfg->w_alpha <= 0x1p30f) {
+    // prove the short x/alpha sequence exact for this alpha before any kernel may use it
+    int bad = 0;
+    Hyper probe = m.h;
+    probe.fast_div = 1;
+    hipLaunchKernelGGL(verify_div_alpha_kernel, dim3(1u << 17), dim3(256), 0, e->stream, probe, s.counters);
+    TRY_HIP(hipMemcpyAsync(&bad, s.counters, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    TRY_HIP(hipStreamSynchronize(e->stream));
+    TRY_HIP(hipMemsetAsync(s.counters, 0, 8 * sizeof(int), e->stream));
+    m.h.fast_div = bad ? 0 : 1;
+  }
   if (!(cfg->flags & FFM_FLAG_SKIP_INIT))
     hipLaunchKernelGGL(init_weights_kernel, dim3(2048), dim3(256), 0, e->stream, m, cfg->init_mean,
                        cfg->init_stddev, cfg->seed);

@@ -9,10 +9,85 @@ namespace ftrl_dev {
 
 struct Hyper {
   float alpha, beta, l1, l2;
+  float inv_alpha;  // RN(1/alpha)
+  int fast_div;     // 1 when div_alpha's short sequence was proven exact for this alpha
 };
 
 // utils::sgn, reference src/include/utils/utils.h:15-18: x > 0 ? 1 : -1 (sgn(0) = -1)
 __device__ __forceinline__ float sgn_ref(float x) { return x > 0.0f ? 1.0f : -1.0f; }
+
+// ---- correctly rounded fp32 sqrt and x/alpha in fewer instructions ---------------------------
+// These kernels are VALU-bound (DESIGN.md "Rooflines"): hipcc's IEEE sqrtf/divide expand to ~15
+// instructions each.  Both replacements below return the SAME bits as sqrtf(x) and x / alpha.
+
+// sqrtf(x): the compiler's own algorithm (v_sqrt_f32, then pick among s-1ulp, s, s+1ulp by the
+// sign of two fused residuals) without its denormal pre-scaling, used when every lane of the wave
+// holds 0 or a value in [2^-96, 2^96]; anything else (tiny, huge, negative, NaN) takes sqrtf.
+__device__ __forceinline__ bool sqrt_fast_ok(float x) {
+  return (x == 0.0f) || (x >= 0x1p-96f && x <= 0x1p96f);
+}
+__device__ __forceinline__ float sqrt_fast(float x) {  // requires sqrt_fast_ok(x)
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __int_as_float(__float_as_int(s) - 1);
+  const float su = __int_as_float(__float_as_int(s) + 1);
+  const float ed = fmaf(-sd, s, x);
+  const float eu = fmaf(-su, s, x);
+  float r = ed <= 0.0f ? sd : s;
+  r = eu > 0.0f ? su : r;
+  return x == 0.0f ? x : r;
+}
+__device__ __forceinline__ float sqrt_cr(float x) {
+  if (__all(sqrt_fast_ok(x))) return sqrt_fast(x);
+  return sqrtf(x);
+}
+
+// x / alpha for the engine's constant alpha: q0 = x*r with r = RN(1/alpha), exact residual by
+// FMA, one correction (Markstein).  ffm_engine_create checks this sequence against the IEEE
+// divide for every one of the 2^24 float significands (the rounding of a quotient depends only
+// on significands while nothing under/overflows) and clears fast_div if any differs; at run time
+// it is used when every lane's dividend is +0 or comfortably normal.
+__device__ __forceinline__ bool div_fast_ok(float x) {
+  const float ax = fabsf(x);
+  return (ax >= 0x1p-60f && ax <= 0x1p60f) || __float_as_uint(x) == 0u;
+}
+__device__ __forceinline__ float div_alpha_fast(const Hyper &h, float x) {
+  const float q0 = x * h.inv_alpha;
+  const float rem = fmaf(-q0, h.alpha, x);
+  return fmaf(rem, h.inv_alpha, q0);
+}
+__device__ __forceinline__ float div_alpha(const Hyper &h, float x) {
+  if (h.fast_div && __all(div_fast_ok(x))) return div_alpha_fast(h, x);
+  return x / h.alpha;
+}
+
+// N values at once with ONE wave vote (a vote is a scheduling barrier: hoisting it lets the
+// compiler interleave the N independent sequences).
+template <int N>
+__device__ __forceinline__ void sqrt_cr_n(const float (&x)[N], float (&r)[N]) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < N; i++) ok = ok && sqrt_fast_ok(x[i]);
+  if (__all(ok)) {
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = sqrt_fast(x[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = sqrtf(x[i]);
+  }
+}
+template <int N>
+__device__ __forceinline__ void div_alpha_n(const Hyper &h, const float (&x)[N], float (&r)[N]) {
+  bool ok = h.fast_div != 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) ok = ok && div_fast_ok(x[i]);
+  if (__all(ok)) {
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = div_alpha_fast(h, x[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = x[i] / h.alpha;
+  }
+}
 
 // FtrlModel::maybe_zero_weight, src/include/model/ftrl_model.h:28-33.  The reference promotes the
 // divide to double and narrows the result; with 24-bit operands that double rounding is
@@ -20,15 +95,32 @@ __device__ __forceinline__ float sgn_ref(float x) { return x > 0.0f ? 1.0f : -1.
 __device__ __forceinline__ float ftrl_weight(const Hyper &h, float n, float z) {
   if (fabsf(z) <= h.l1) return 0.0f;
   const float num = z - sgn_ref(z) * h.l1;
-  const float den = h.l2 + (h.beta + sqrtf(n)) / h.alpha;
+  const float den = h.l2 + div_alpha(h, h.beta + sqrt_cr(n));
   return (-num) / den;
+}
+
+// Four weights at once (one float4 of a slot): same arithmetic as ftrl_weight per component.
+__device__ __forceinline__ float4 ftrl_weight4(const Hyper &h, float4 n, float4 z) {
+  const float nn[4] = {n.x, n.y, n.z, n.w}, zz[4] = {z.x, z.y, z.z, z.w};
+  float sq[4], t[4], dv[4], w[4];
+  sqrt_cr_n<4>(nn, sq);
+#pragma unroll
+  for (int i = 0; i < 4; i++) t[i] = h.beta + sq[i];
+  div_alpha_n<4>(h, t, dv);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float num = zz[i] - sgn_ref(zz[i]) * h.l1;
+    const float den = h.l2 + dv[i];
+    w[i] = fabsf(zz[i]) <= h.l1 ? 0.0f : (-num) / den;
+  }
+  return make_float4(w[0], w[1], w[2], w[3]);
 }
 
 // Linear / bias accumulator step, src/model/ftrl_model.cpp:69-74 and :81-84:
 //   s = (sqrtf(n + g*g) - sqrtf(n)) / alpha;  z += g - s*w;  n += g*g
 __device__ __forceinline__ void nz_step_linear(const Hyper &h, float w, float g, float &n,
                                                float &z) {
-  const float s = (sqrtf(n + g * g) - sqrtf(n)) / h.alpha;
+  const float s = div_alpha(h, sqrt_cr(n + g * g) - sqrt_cr(n));
   z = z + (g - s * w);
   n = n + g * g;
 }
@@ -37,7 +129,7 @@ __device__ __forceinline__ void nz_step_linear(const Hyper &h, float w, float g,
 //   s = (sqrtf(n + g*g) - sqrtf(n)) / alpha;  z' = z + g - s*w;  n' = n + g*g
 __device__ __forceinline__ void nz_step_latent(const Hyper &h, float w, float g, float &n,
                                                float &z) {
-  const float s = (sqrtf(n + g * g) - sqrtf(n)) / h.alpha;
+  const float s = div_alpha(h, sqrt_cr(n + g * g) - sqrt_cr(n));
   z = (z + g) - s * w;
   n = n + g * g;
 }
@@ -46,7 +138,7 @@ __device__ __forceinline__ void nz_step_latent(const Hyper &h, float w, float g,
 // n + g2*g1 (product of the two different gradients), which is NaN when that is negative.
 __device__ __forceinline__ void nz_step_latent_jside(const Hyper &h, float w, float g2, float g1,
                                                      float &n, float &z) {
-  const float s = (sqrtf(n + g2 * g1) - sqrtf(n)) / h.alpha;
+  const float s = div_alpha(h, sqrt_cr(n + g2 * g1) - sqrt_cr(n));
   z = (z + g2) - s * w;
   n = n + g2 * g2;
 }

@@ -192,12 +192,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
         if (touched) {
           float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a]));
           const float4 n4 = row[LAT_N * RL4 + c4], z4 = row[LAT_Z * RL4 + c4];
-          float4 w4;
-          w4.x = ftrl_weight(m.h, n4.x, z4.x);
-          w4.y = ftrl_weight(m.h, n4.y, z4.y);
-          w4.z = ftrl_weight(m.h, n4.z, z4.z);
-          w4.w = ftrl_weight(m.h, n4.w, z4.w);
-          row[LAT_W * RL4 + c4] = w4;
+          row[LAT_W * RL4 + c4] = ftrl_weight4(m.h, n4, z4);
         }
       }
     } else {

@@ -44,6 +44,34 @@ __device__ __forceinline__ void ffm_touch(const Hyper &h, bool own_first, float 
   }
 }
 
+// The same touch on the 4 factors a float4 lane owns, votes hoisted (sqrt_cr_n / div_alpha_n).
+__device__ __forceinline__ void ffm_touch4(const Hyper &h, bool own_first, float tg, float x_own,
+                                           float x_other, float4 vp4, float4 w4, float4 &n4,
+                                           float4 &z4) {
+  const float vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w}, w[4] = {w4.x, w4.y, w4.z, w4.w};
+  float n[4] = {n4.x, n4.y, n4.z, n4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w};
+  float g[4], arg[8], sq[8], d[4], sg[4];
+  const float x = own_first ? x_own * x_other : x_other * x_own;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    g[i] = tg * vp[i] * x;              // own slot's gradient
+    const float g1 = tg * w[i] * x;     // second-entry case: the first entry's gradient
+    arg[i] = n[i] + (own_first ? g[i] * g[i] : g[i] * g1);  // ffm.cpp:113 / :118
+    arg[4 + i] = n[i];
+  }
+  sqrt_cr_n<8>(arg, sq);
+#pragma unroll
+  for (int i = 0; i < 4; i++) d[i] = sq[i] - sq[4 + i];
+  div_alpha_n<4>(h, d, sg);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    z[i] = (z[i] + g[i]) - sg[i] * w[i];
+    n[i] = n[i] + g[i] * g[i];
+  }
+  n4 = make_float4(n[0], n[1], n[2], n[3]);
+  z4 = make_float4(z[0], z[1], z[2], z[3]);
+}
+
 // ---- hot features: work item = (feature from the big list, chunk of 64 elements) ----------
 // ALL = true: every distinct feature takes this path (n_factors not a multiple of 4).
 template <bool ALL>
@@ -201,10 +229,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
                 reinterpret_cast<const float4 *>(lat_row(m, rt.x))[LAT_W * RL4 + fm * k4 + kq];
             const bool first = p < q;
             const float xo = __int_as_float(rt.y);
-            ffm_touch(m.h, first, tg, xm, xo, vp.x, w4.x, n4.x, z4.x);
-            ffm_touch(m.h, first, tg, xm, xo, vp.y, w4.y, n4.y, z4.y);
-            ffm_touch(m.h, first, tg, xm, xo, vp.z, w4.z, n4.z, z4.z);
-            ffm_touch(m.h, first, tg, xm, xo, vp.w, w4.w, n4.w, z4.w);
+            ffm_touch4(m.h, first, tg, xm, xo, vp, w4, n4, z4);
             touched = true;
           }
         } else if (q == -2) {
@@ -214,10 +239,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
                 lat_row(m, rows.feat[qq]))[LAT_W * RL4 + fm * k4 + kq];
             const bool first = p < qq;
             const float xo = rows.val[qq];
-            ffm_touch(m.h, first, tg, xm, xo, vp.x, w4.x, n4.x, z4.x);
-            ffm_touch(m.h, first, tg, xm, xo, vp.y, w4.y, n4.y, z4.y);
-            ffm_touch(m.h, first, tg, xm, xo, vp.z, w4.z, n4.z, z4.z);
-            ffm_touch(m.h, first, tg, xm, xo, vp.w, w4.w, n4.w, z4.w);
+            ffm_touch4(m.h, first, tg, xm, xo, vp, w4, n4, z4);
             touched = true;
           }
         }
@@ -301,7 +323,7 @@ __device__ __forceinline__ void linear_chain64(const Hyper &h, float w, float g,
   float n_before = __int_as_float(__builtin_amdgcn_update_dpp(
       __float_as_int(n), __float_as_int(n_after), 0x138, 0xf, 0xf, false));
   if (lane == 0) n_before = n;
-  const float sgm = (sqrtf(n_after) - sqrtf(n_before)) / h.alpha;  // n_after = n_before + g*g
+  const float sgm = div_alpha(h, sqrt_cr(n_after) - sqrt_cr(n_before));  // n_after = n_before + g*g
   const float z_run = wave_sequential_prefix(z, live ? g - sgm * w : -0.0f);
   n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n_after), 63));
   z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_run), 63));

@@ -10,3 +10,8 @@ from .engine import (ABI, FFM, FM, LR, Config, Engine, EngineError, LIB_PATH,  #
 def build(force=False, verbose=False):
     """Compile libffm_engine.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     return _build.build(force=force, verbose=verbose)
+
+
+def build_host(force=False, verbose=False):
+    """Compile the C++ host mirror (host/): the trainer CLI and its test executable."""
+    return _build.build_host(force=force, verbose=verbose)

@@ -38,5 +38,30 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+HOST_SRCS = ["cmd_option.cpp", "parser.cpp", "reader.cpp", "ftrl_model.cpp", "trainer.cpp"]
+MAIN_BIN = os.path.join(HOST, "ftrl_ffm_main")
+TEST_BIN = os.path.join(HOST, "host_tests")
+
+
+def build_host(force=False, verbose=False):
+    """The C++17 host mirror of the reference's trainer (host/) linked against libffm_engine.so:
+    the CLI `ftrl_ffm_main` and the `host_tests` executable."""
+    build(force=False, verbose=verbose)
+    srcs = [os.path.join(HOST, f) for f in HOST_SRCS]
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".h", ".cpp"))] + [LIB]
+    for out, main in ((MAIN_BIN, "main.cpp"), (TEST_BIN, "host_tests.cpp")):
+        if (not force and os.path.exists(out)
+                and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps)):
+            continue
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-o", out,
+               os.path.join(HOST, main)] + srcs + [LIB, "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return MAIN_BIN, TEST_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_host(force="--force" in sys.argv, verbose=True)

@@ -47,7 +47,9 @@ __device__ __forceinline__ float *lat_row(const ModelDev &m, int feat) {
 __device__ __forceinline__ bool owns_pair(const ModelDev &m, int fa, int fb) {
   if (m.n_shards <= 1) return true;
   const int lo = fa < fb ? fa : fb, hi = fa < fb ? fb : fa;
-  return (lo * m.n_fields + hi) % m.n_shards == m.shard_rank;
+  // index of {lo, hi} in the upper triangle (diagonal included), dealt round-robin: balanced
+  const int idx = lo * m.n_fields - lo * (lo - 1) / 2 + (hi - lo);
+  return idx % m.n_shards == m.shard_rank;
 }
 
 // Per-block scratch: the block grouped by feature ("postings"), per-row field chains, outputs.

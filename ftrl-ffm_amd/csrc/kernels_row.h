@@ -180,7 +180,6 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
       const int RL4 = RL >> 2, k4 = k >> 2;
       const float inv_RL4 = 1.0f / static_cast<float>(RL4), inv_k4 = 1.0f / static_cast<float>(k4);
       const int total = nv * RL4;
-#pragma unroll 4
       for (int t = threadIdx.x; t < total; t += kRowThreads) {
         int a = static_cast<int>((t + 0.5f) * inv_RL4);
         a += (a + 1) * RL4 <= t ? 1 : (a * RL4 > t ? -1 : 0);  // exact for any size
@@ -320,7 +319,6 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
   if (TRAIN) {  // FM::update_vector_w, fm.cpp:69-78
     const int total = nv * k;
     const float inv_k = 1.0f / static_cast<float>(k);
-#pragma unroll 4
     for (int t = threadIdx.x; t < total; t += kRowThreads) {
       int a = static_cast<int>((t + 0.5f) * inv_k);
       a += (a + 1) * k <= t ? 1 : (a * k > t ? -1 : 0);

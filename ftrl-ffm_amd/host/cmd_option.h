@@ -1,0 +1,28 @@
+// cmd_option.h -- flags of the trainer.  Names and defaults are the reference's
+// (src/include/utils/cmd_option.h:29-66, src/utils/cmd_option.cpp:61-114); the last block is new.
+#pragma once
+#include <cstdint>
+#include <string>
+
+struct config_options {
+  std::string model_path, train_path, eval_path;
+  std::string model_type = "FFM";
+  std::string file_type;
+  float init_mean = 0.0f, init_stddev = 0.02f;
+  float w_alpha = 1e-4f, w_beta = 1.0f, w_l1 = 0.1f, w_l2 = 5.0f;
+  int thread_num = 1;  // host threads for parsing; the model update itself runs on the GPU
+  int epoch = 1;
+  int n_fields = 8, n_feats = 10000, n_factors = 16;
+  bool cmd = false;
+  bool online = true;
+  // --- new: the mini-batch scheduler that replaces the per-sample thread pool ---
+  int batch_size = 4096;   // --batch_size: rows per block handed to the engine
+  int batch_ramp = 32;     // --batch_ramp: block size <= rows_seen / ramp (0 = off); DESIGN.md
+  uint64_t seed = 42;      // --seed: weight init and the offline shuffle (the reference is unseeded)
+  int device = 0;          // --device: HIP device ordinal
+
+  void parse_option(int argc, char *argv[]);  // throws std::invalid_argument like the reference
+};
+
+std::string detect_file_type(const std::string &file_path);  // cmd_option.cpp:35-59
+extern const char *const cmd_help;

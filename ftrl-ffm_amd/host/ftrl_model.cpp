@@ -1,0 +1,138 @@
+#include "ftrl_model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+namespace ftrl {
+
+static void check(int rc, const char *what) {
+  if (rc != FFM_OK)
+    throw std::runtime_error(std::string(what) + ": " + ffm_engine_last_error());
+}
+
+double loss(int y, double logit) {
+  const double s = 1 / (1 + std::exp(-logit));
+  return -y * std::log(s) - (1 - y) * std::log(1 - s);
+}
+
+FtrlModel::FtrlModel(const config_options &opt, int mt)
+    : model_type(static_cast<ModelType>(mt)),
+      n_feats(opt.n_feats), n_fields(opt.n_fields), n_factors(opt.n_factors) {
+  ffm_engine_config cfg;
+  ffm_engine_default_config(&cfg);
+  cfg.model_type = mt;
+  cfg.n_feats = opt.n_feats;
+  cfg.n_fields = opt.n_fields;
+  cfg.n_factors = opt.n_factors;
+  cfg.w_alpha = opt.w_alpha;
+  cfg.w_beta = opt.w_beta;
+  cfg.w_l1 = opt.w_l1;
+  cfg.w_l2 = opt.w_l2;
+  cfg.init_mean = opt.init_mean;
+  cfg.init_stddev = opt.init_stddev;
+  cfg.seed = opt.seed;
+  cfg.max_batch_rows = std::max(1, opt.batch_size);
+  cfg.max_batch_nnz = cfg.max_batch_rows * 256;
+  cfg.device_id = opt.device;
+  const int rc = ffm_engine_create(&cfg, &eng_);
+  if (rc == FFM_E_INVALID) throw std::invalid_argument(ffm_engine_last_error());
+  check(rc, "ffm_engine_create");
+  row_len_ = ffm_engine_row_len(eng_);
+  lin_w.resize(static_cast<size_t>(n_feats));
+  if (row_len_ > 0)
+    vec_w.assign(static_cast<size_t>(n_feats), std::vector<float>(static_cast<size_t>(row_len_)));
+  pull_weights();
+}
+
+FtrlModel::~FtrlModel() { ffm_engine_destroy(eng_); }
+
+void FtrlModel::remove_out_range(feat_vec &feats) {  // ftrl_model.cpp:36-42
+  feats.erase(std::remove_if(feats.begin(), feats.end(),
+                             [&](const feat &f) {
+                               const int i = std::get<1>(f);
+                               return i < 0 || i >= n_feats;
+                             }),
+              feats.end());
+}
+
+void FFM::remove_out_range(feat_vec &feats) {
+  feats.erase(std::remove_if(feats.begin(), feats.end(),
+                             [&](const feat &f) {
+                               const auto [field, i, v] = f;
+                               (void)v;
+                               return field < 0 || i < 0 || field >= n_fields || i >= n_feats;
+                             }),
+              feats.end());
+}
+
+float FtrlModel::train(feat_vec &features, int label) {
+  remove_out_range(features);
+  one_.clear();
+  one_.push(Sample{features, label});
+  float logit = 0.0f;
+  train_block(one_, &logit);
+  return logit;
+}
+
+float FtrlModel::predict(feat_vec &features, bool output_prob) {
+  remove_out_range(features);
+  one_.clear();
+  one_.push(Sample{features, 0});
+  float out = 0.0f;
+  predict_block(one_, output_prob, &out);
+  return out;
+}
+
+double FtrlModel::train_block(const CsrBlock &blk, float *logit_out) {
+  double loss_sum = 0.0;
+  check(ffm_engine_train_batch(eng_, blk.n_rows(), blk.row_ptr.data(), blk.field.data(),
+                               blk.feat.data(), blk.val.data(), blk.label.data(), logit_out,
+                               &loss_sum),
+        "ffm_engine_train_batch");
+  return loss_sum;
+}
+
+double FtrlModel::predict_block(const CsrBlock &blk, bool output_prob, float *out) {
+  double loss_sum = 0.0;
+  check(ffm_engine_predict_batch(eng_, blk.n_rows(), blk.row_ptr.data(), blk.field.data(),
+                                 blk.feat.data(), blk.val.data(), blk.label.data(),
+                                 output_prob ? 1 : 0, out, &loss_sum),
+        "ffm_engine_predict_batch");
+  return loss_sum;
+}
+
+void FtrlModel::pull_weights() {
+  std::vector<float> flat(static_cast<size_t>(n_feats) * static_cast<size_t>(row_len_));
+  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), flat.empty() ? nullptr : flat.data()),
+        "ffm_engine_get_weights");
+  for (size_t i = 0; i < vec_w.size(); i++)
+    std::copy(flat.begin() + i * row_len_, flat.begin() + (i + 1) * row_len_, vec_w[i].begin());
+}
+
+void FtrlModel::push_weights() {
+  std::vector<float> flat(static_cast<size_t>(n_feats) * static_cast<size_t>(row_len_));
+  for (size_t i = 0; i < vec_w.size(); i++)
+    std::copy(vec_w[i].begin(), vec_w[i].end(), flat.begin() + i * row_len_);
+  check(ffm_engine_set_weights(eng_, &bias, lin_w.data(), flat.empty() ? nullptr : flat.data()),
+        "ffm_engine_set_weights");
+}
+
+bool FtrlModel::has_zero_weights() {  // utils.h:63-76 over lin_w and vec_w
+  pull_weights();
+  if (std::any_of(lin_w.begin(), lin_w.end(), [](float w) { return w == 0.0f; })) return true;
+  for (const auto &v : vec_w)
+    if (std::any_of(v.begin(), v.end(), [](float w) { return w == 0.0f; })) return true;
+  return false;
+}
+
+std::unique_ptr<FtrlModel> make_model(const config_options &opt) {
+  if (opt.model_type == "LR") return std::make_unique<LR>(opt);
+  if (opt.model_type == "FM") return std::make_unique<FM>(opt);
+  if (opt.model_type == "FFM") return std::make_unique<FFM>(opt);
+  std::fprintf(stderr, "Invalid model_type: %s, expect `LR`, `FM` or `FFM`.\n", opt.model_type.c_str());
+  throw std::invalid_argument("invalid model_type");
+}
+
+}  // namespace ftrl

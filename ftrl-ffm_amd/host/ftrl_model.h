@@ -1,0 +1,77 @@
+// ftrl_model.h -- host-side mirror of the reference's model interface
+// (src/include/model/ftrl_model.h:14-51, ffm.h:11-33, fm.h:11-28, lr.h:10-17) over the C ABI of
+// include/ffm_engine.h.  Same class names, same train()/predict() meaning and return values, same
+// public members; the arithmetic happens in HBM behind an ffm_engine handle.
+//
+//   float train(feat_vec&, int)   one reference train(): returns the pre-update logit and erases
+//                                 out-of-range entries from the caller's vector, as the reference.
+//   float predict(feat_vec&, bool)
+//   train_block / predict_block   the same for a block of rows (what the trainers call).
+//
+// bias / lin_w / vec_w are host mirrors of the device weights: call pull_weights() to refresh them
+// after training, push_weights() after editing them (the reference's tests poke them directly).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ffm_engine.h"
+#include "cmd_option.h"
+#include "types.h"
+
+namespace ftrl {
+
+class FtrlModel {
+ public:
+  explicit FtrlModel(const config_options &opt, int model_type);
+  virtual ~FtrlModel();
+  FtrlModel(const FtrlModel &) = delete;
+  FtrlModel &operator=(const FtrlModel &) = delete;
+
+  virtual float train(feat_vec &features, int label);
+  virtual float predict(feat_vec &features, bool output_prob);
+  virtual void remove_out_range(feat_vec &feats);
+
+  // Block entry points used by FtrlOffline / FtrlOnline.  Return sum of loss(y, logit).
+  double train_block(const CsrBlock &blk, float *logit_out = nullptr);
+  double predict_block(const CsrBlock &blk, bool output_prob, float *out = nullptr);
+
+  void pull_weights();  // device -> bias / lin_w / vec_w
+  void push_weights();  // bias / lin_w / vec_w -> device
+  bool has_zero_weights();
+
+  ModelType model_type;
+  float bias = 0.0f;
+  std::vector<float> lin_w;
+  std::vector<std::vector<float>> vec_w;  // [n_feats][row_len]; empty for LR
+
+  ffm_engine *engine() { return eng_; }
+  int64_t row_len() const { return row_len_; }
+
+ protected:
+  int n_feats, n_fields, n_factors;
+  int64_t row_len_ = 0;
+  ffm_engine *eng_ = nullptr;
+  CsrBlock one_;  // scratch for the one-row shims
+};
+
+class LR : public FtrlModel {
+ public:
+  explicit LR(const config_options &opt) : FtrlModel(opt, FFM_MODEL_LR) {}
+};
+class FM : public FtrlModel {
+ public:
+  explicit FM(const config_options &opt) : FtrlModel(opt, FFM_MODEL_FM) {}
+};
+class FFM : public FtrlModel {
+ public:
+  explicit FFM(const config_options &opt) : FtrlModel(opt, FFM_MODEL_FFM) {}
+  void remove_out_range(feat_vec &feats) override;  // also filters the field (ffm.cpp:30-36)
+};
+
+std::unique_ptr<FtrlModel> make_model(const config_options &opt);  // throws std::invalid_argument
+
+// loss(int y, double logit), src/include/eval/loss.h:8-12
+double loss(int y, double logit);
+
+}  // namespace ftrl

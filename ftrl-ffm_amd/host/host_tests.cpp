@@ -1,0 +1,171 @@
+// host_tests.cpp -- the reference's own unit/integration tests for this path, restated against the
+// host mirror (reference tests/test_data.cpp:9-18, tests/test_model.cpp:22-49,
+// tests/test_task.cpp:25-43, tests/test_utils.cpp:40-43), plus flag parsing and parser errors.
+//   host_tests cpu   -> everything that needs no GPU (reader, parsers, flags, loss)
+//   host_tests gpu   -> model shapes, remove_out_range, weight round trip, online/offline tasks
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+
+#include "cmd_option.h"
+#include "ftrl_model.h"
+#include "reader.h"
+#include "trainer.h"
+
+static int g_failed = 0, g_checked = 0;
+#define CHECK(cond)                                                              \
+  do {                                                                           \
+    g_checked++;                                                                 \
+    if (!(cond)) { g_failed++; std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); } \
+  } while (0)
+
+// the 10-row libffm fixture of the reference's tests (tests/common.h:14-24): data, not code
+static const char *kSamples =
+    "0 0:1:1 1:13:1 2:21:1 3:31:1\n1 0:4:1 1:11:1 2:23:1 3:32:1\n1 0:2:1 1:13:1 2:25:1 3:34:1\n"
+    "0 0:1:1 1:14:1 2:21:1 3:32:1\n0 0:2:1 1:15:1 2:22:1 3:34:1\n1 0:4:1 1:11:1 2:21:1 3:35:1\n"
+    "1 0:5:1 1:12:1 2:23:1 3:31:1\n1 0:5:1 1:12:1 2:25:1 3:38:1\n0 0:2:1 1:11:1 2:24:1 3:37:1\n"
+    "1 0:1:1 1:15:1 2:22:1 3:35:1";
+static const char *kPath = "./host_test_file.txt";
+static void write_fixture() { std::ofstream(kPath) << kSamples; }
+
+static void test_reader_and_parsers() {
+  write_fixture();
+  ftrl::Reader reader("libffm");
+  reader.load_from_file(kPath, 4);
+  CHECK(reader.get_size() == 10);
+  CHECK(reader.data[0].y == 0);
+  CHECK(reader.data[0].x[0] == std::make_tuple(0, 1, 1.0f));
+  CHECK(reader.data[0].x[3] == std::make_tuple(3, 31, 1.0f));
+  CHECK(reader.data[9].y == 1 && reader.data[9].x.size() == 4);
+  ftrl::LibsvmParser sp;
+  Sample s;
+  sp.parse("-1 3:0.5 7:0 9:2", s);  // label <= 0 -> 0; zero value dropped; field 0
+  CHECK(s.y == 0 && s.x.size() == 2 && s.x[1] == std::make_tuple(0, 9, 2.0f));
+  sp.parse("  2 5:1  ", s);
+  CHECK(s.y == 1 && s.x.size() == 1);
+  ftrl::FFMParser fp;
+  bool threw = false;
+  try { fp.parse("1 0:5", s); } catch (const std::out_of_range &) { threw = true; }
+  CHECK(threw);  // malformed token -> std::out_of_range (parser.cpp:24-27)
+  threw = false;
+  try { sp.parse("1 12", s); } catch (const std::out_of_range &) { threw = true; }
+  CHECK(threw);
+  CHECK(detect_file_type(kPath) == "libffm");
+  std::remove(kPath);
+}
+
+static void test_flags() {
+  write_fixture();
+  config_options d;
+  CHECK(d.model_type == "FFM" && d.n_fields == 8 && d.n_feats == 10000 && d.n_factors == 16);
+  CHECK(d.w_alpha == 1e-4f && d.w_beta == 1.0f && d.w_l1 == 0.1f && d.w_l2 == 5.0f && d.online);
+  const char *argv[] = {"main", "--train_data", kPath, "--model_type", "ffm", "--n_fields", "4",
+                        "--n_feats", "50", "--n_factors", "4", "--n_epochs", "2", "--online",
+                        "false", "--w_alpha", "0.1", "--batch_size", "8"};
+  config_options o;
+  o.parse_option(19, const_cast<char **>(argv));
+  CHECK(o.model_type == "FFM" && o.file_type == "libffm" && o.n_fields == 4 && o.epoch == 2);
+  CHECK(!o.online && o.w_alpha == 0.1f && o.batch_size == 8);
+  const char *bad[] = {"main", "--epoch", "3"};  // the reference accepts only --n_epochs
+  bool threw = false;
+  try { config_options b; b.parse_option(3, const_cast<char **>(bad)); }
+  catch (const std::invalid_argument &) { threw = true; }
+  CHECK(threw);
+  std::remove(kPath);
+}
+
+static void test_loss_known_answers() {  // tests/test_utils.cpp:40-43
+  CHECK(std::fabs(ftrl::loss(1, 2) - 0.1269) < 1e-4);
+  CHECK(std::fabs(ftrl::loss(0, 1) - 1.3133) < 1e-4);
+  ftrl::BlockScheduler s(256, 32);
+  CHECK(s.next_block_rows() == 1);
+  s.consumed(64);
+  CHECK(s.next_block_rows() == 2);
+  s.consumed(1 << 20);
+  CHECK(s.next_block_rows() == 256);
+}
+
+static config_options small_args(const char *type) {
+  config_options a;
+  a.n_fields = 4; a.n_feats = 50; a.n_factors = 4;
+  a.model_type = type;
+  a.batch_size = 16;
+  return a;
+}
+
+static void test_models_gpu() {  // tests/test_model.cpp:22-49
+  {
+    ftrl::LR model{small_args("LR")};
+    CHECK(model.model_type == ModelType::LR);
+    CHECK(model.lin_w.size() == 50);
+    feat_vec invalid = {{1, -1, 3}, {1, 0, 1}, {1, 100, 0}};
+    model.remove_out_range(invalid);
+    CHECK(invalid.size() == 1);
+  }
+  {
+    ftrl::FM model{small_args("FM")};
+    CHECK(model.model_type == ModelType::FM);
+    CHECK(model.vec_w.size() == 50 && model.vec_w[0].size() == 4);
+  }
+  {
+    ftrl::FFM model{small_args("FFM")};
+    CHECK(model.model_type == ModelType::FFM);
+    CHECK(model.vec_w[0].size() == 16);
+    feat_vec invalid = {{1, -1, 3}, {44, 0, 1}, {1, 100, 0}};
+    model.remove_out_range(invalid);
+    CHECK(invalid.empty());
+    // weights are public, editable, and what predict() uses (save/load round trip analogue)
+    feat_vec sample = {{1, 3, 3}, {1, 0, 1}, {1, 2, 0}, {3, 10, 1}, {12, 4, 0}, {111, 1, 0}, {8, 8, 8}};
+    feat_vec s1 = sample;
+    const float pred = model.predict(s1, false);
+    CHECK(s1.size() == 4);  // out-of-range entries erased from the caller's row, as the reference
+    auto a2 = small_args("FFM");
+    a2.seed = 7;
+    ftrl::FFM other{a2};
+    feat_vec s2 = sample;
+    CHECK(other.predict(s2, false) != pred);
+    other.bias = model.bias; other.lin_w = model.lin_w; other.vec_w = model.vec_w;
+    other.push_weights();
+    feat_vec s3 = sample;
+    CHECK(other.predict(s3, false) == pred);
+    // one train() from a fresh model returns logit 0 after the lazy refresh zeroes what it touches
+    feat_vec row = {{0, 1, 1.0f}, {1, 13, 1.0f}};
+    CHECK(model.train(row, 1) == 0.0f);
+    bool threw = false;
+    auto bad = small_args("XX");
+    try { ftrl::make_model(bad); } catch (const std::invalid_argument &) { threw = true; }
+    CHECK(threw);
+  }
+}
+
+static void test_tasks_gpu() {  // tests/test_task.cpp:25-43
+  for (int online = 0; online < 2; online++) {
+    write_fixture();
+    config_options opt = small_args("FFM");
+    opt.train_path = kPath;
+    opt.eval_path = kPath;
+    opt.epoch = 2;
+    opt.thread_num = 4;
+    opt.file_type = "libffm";
+    opt.online = online != 0;
+    if (online) { ftrl::FtrlOnline t(opt); t.train(); CHECK(t.has_zero_weights()); }
+    else { ftrl::FtrlOffline t(opt); t.train(); CHECK(t.has_zero_weights()); }
+    std::remove(kPath);
+  }
+}
+
+int main(int argc, char **argv) {
+  const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+  test_reader_and_parsers();
+  test_flags();
+  test_loss_known_answers();
+  if (gpu) {
+    test_models_gpu();
+    test_tasks_gpu();
+  }
+  std::printf("%s: %d checks, %d failed\n", gpu ? "host tests (cpu+gpu)" : "host tests (cpu)", g_checked, g_failed);
+  return g_failed ? 1 : 0;
+}

@@ -1,0 +1,145 @@
+#include "trainer.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <random>
+
+namespace ftrl {
+
+using timer = std::chrono::steady_clock;
+static double seconds_since(timer::time_point t0) {
+  return std::chrono::duration<double>(timer::now() - t0).count();
+}
+
+// ---------------- offline: data in memory, seeded shuffle per epoch ----------------
+
+FtrlOffline::FtrlOffline(const config_options &opt)
+    : model_ptr(make_model(opt)), n_epochs(opt.epoch), n_threads(opt.thread_num), seed_(opt.seed),
+      sched_(opt.batch_size, opt.batch_ramp) {
+  train_data_loader = std::make_unique<Reader>(opt.file_type);
+  train_data_loader->load_from_file(opt.train_path, n_threads);
+  if (!opt.eval_path.empty()) {
+    eval_data_loader = std::make_unique<Reader>(opt.file_type);
+    eval_data_loader->load_from_file(opt.eval_path, n_threads);
+  }
+}
+
+void FtrlOffline::train() {
+  for (int i = 1; i <= n_epochs; i++) {
+    const auto t0 = timer::now();
+    const double train_loss = one_epoch(train_data_loader->data, true, true);
+    std::printf("epoch %d train time: %.4lfs, train loss: %.4lf\n", i, seconds_since(t0), train_loss);
+    if (eval_data_loader != nullptr) evaluate(i);
+  }
+}
+
+void FtrlOffline::evaluate(int epoch) {
+  const auto t0 = timer::now();
+  const double eval_loss = one_epoch(eval_data_loader->data, false, false);
+  std::printf("epoch %d eval time: %.4lfs, eval loss: %.4lf\n", epoch, seconds_since(t0), eval_loss);
+}
+
+// One pass over `samples`: training visits them in a seeded shuffle (the reference shuffles from
+// std::random_device, ftrl_offline.cpp:67-71), block by block; evaluation in order.  Returns the
+// mean of loss(y, logit) over all rows, as ftrl_offline.cpp:101-102.
+double FtrlOffline::one_epoch(std::vector<Sample> &samples, bool train, bool /*use_pool*/) {
+  const size_t total = samples.size();
+  if (total == 0) return 0.0;
+  std::vector<int> indices(total);
+  std::iota(indices.begin(), indices.end(), 0);
+  if (train) std::shuffle(indices.begin(), indices.end(), std::mt19937_64{seed_ + (++epoch_no_)});
+  double total_loss = 0.0;
+  CsrBlock blk;
+  size_t pos = 0;
+  while (pos < total) {
+    const size_t rows = std::min<size_t>(train ? sched_.next_block_rows() : sched_.max_block_rows(), total - pos);
+    blk.clear();
+    for (size_t r = 0; r < rows; r++) blk.push(samples[indices[pos + r]]);
+    total_loss += train ? model_ptr->train_block(blk) : model_ptr->predict_block(blk, false);
+    if (train) sched_.consumed(static_cast<int>(rows));
+    pos += rows;
+  }
+  return total_loss / static_cast<double>(total);
+}
+
+// ---------------- online: streaming from the file, file order ----------------
+
+FtrlOnline::FtrlOnline(const config_options &opt)
+    : model_ptr(make_model(opt)), n_epochs(opt.epoch), cmd_(opt.cmd),
+      sched_(opt.batch_size, opt.batch_ramp), parser_(make_parser(opt.file_type)) {
+  if (!cmd_) {
+    train_ifs_.open(opt.train_path, std::ios::in | std::ios::binary);
+    if (!train_ifs_.good()) {
+      std::fprintf(stderr, "open file <%s> error. \n", opt.train_path.c_str());
+      std::exit(EXIT_FAILURE);
+    }
+    if (!opt.eval_path.empty()) {
+      eval_ifs_.open(opt.eval_path, std::ios::in | std::ios::binary);
+      if (!eval_ifs_.good()) {
+        std::fprintf(stderr, "open file <%s> error. \n", opt.eval_path.c_str());
+        std::exit(EXIT_FAILURE);
+      }
+      has_eval_ = true;
+    }
+  }
+}
+
+// Reads the stream to its end, parsing rows into blocks (parse time is inside the timed region,
+// as in the reference's online mode) and feeding them to the engine in file order.
+double FtrlOnline::run_file(std::ifstream &ifs, bool train) {
+  CsrBlock blk;
+  std::string line;
+  Sample sample;
+  double sum = 0.0;
+  unsigned long long rows = 0, line_num = 0;
+  bool more = true;
+  while (more) {
+    const int want = train ? sched_.next_block_rows() : sched_.max_block_rows();
+    blk.clear();
+    while (blk.n_rows() < want) {
+      if (!std::getline(ifs, line)) { more = false; break; }
+      parser_->parse(line, sample);
+      blk.push(sample);
+      if (++line_num % 1000000 == 0) std::printf("%llu lines finished...\n", line_num);
+    }
+    if (blk.n_rows() == 0) break;
+    sum += train ? model_ptr->train_block(blk) : model_ptr->predict_block(blk, false);
+    if (train) sched_.consumed(blk.n_rows());
+    rows += blk.n_rows();
+  }
+  ifs.clear();
+  ifs.seekg(0, std::ios::beg);
+  loss_sum_ = sum;
+  loss_rows_ = rows;
+  return rows ? sum / static_cast<double>(rows) : 0.0;
+}
+
+double FtrlOnline::get_loss() {
+  const double r = loss_rows_ ? loss_sum_ / static_cast<double>(loss_rows_) : 0.0;
+  loss_sum_ = 0.0;
+  loss_rows_ = 0;
+  return r;
+}
+
+void FtrlOnline::train() {
+  if (cmd_) return;  // stdin mode is a TODO stub in the reference too (ftrl_online.cpp:55-57)
+  for (int i = 1; i <= n_epochs; i++) {
+    const auto t0 = timer::now();
+    run_file(train_ifs_, true);
+    const double train_loss = get_loss();
+    std::printf("epoch %d train time: %.4lfs, train loss: %.4lf\n", i, seconds_since(t0), train_loss);
+    if (has_eval_) evaluate(i);
+  }
+}
+
+void FtrlOnline::evaluate(int epoch) {
+  const auto t0 = timer::now();
+  run_file(eval_ifs_, false);
+  const double eval_loss = get_loss();
+  std::printf("epoch %d eval time: %.4lfs, eval loss: %.4lf\n", epoch, seconds_since(t0), eval_loss);
+}
+
+}  // namespace ftrl

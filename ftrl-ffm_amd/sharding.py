@@ -1,0 +1,45 @@
+"""Field-pair sharding of the FFM latent tensor over the GPUs of one node (DESIGN.md "Multi-GPU").
+
+Both latent slots of a pair -- (feature i, field of j) and (feature j, field of i) -- belong to the
+rank that owns the unordered field pair {field_i, field_j}, so forward, gradient and FTRL update of
+a pair are local; the only exchange per block is ONE all-reduce (sum) of n_rows partial logits
+(RCCL over xGMI when the process group is "nccl"; "gloo" in the CPU tests).  Rank 0 also owns the
+bias and the linear terms.  The rule is the same arithmetic as owns_pair() in csrc/engine_types.h.
+"""
+import numpy as np
+
+
+def pair_owner(field_a, field_b, n_fields, n_shards):
+    """Rank owning the unordered field pair (works on ints or numpy arrays)."""
+    lo = np.minimum(field_a, field_b)
+    hi = np.maximum(field_a, field_b)
+    # index of {lo, hi} in the upper triangle (diagonal included), dealt round-robin: balanced
+    return (lo * n_fields - lo * (lo - 1) // 2 + (hi - lo)) % n_shards
+
+
+def owned_pair_counts(n_fields, n_shards):
+    """How many of the n_fields*(n_fields-1)/2 cross-field pairs (+ n_fields same-field pairs)
+    each rank owns: the load balance of the partition."""
+    f = np.arange(n_fields)
+    own = pair_owner(f[:, None], f[None, :], n_fields, n_shards)
+    iu = np.triu_indices(n_fields, 0)
+    return np.bincount(own[iu], minlength=n_shards)
+
+
+class ShardedStep:
+    """One training block on a sharded engine: local forward -> all-reduce -> local update.
+
+    `engine` needs train_forward_device / train_update_device (ftrl_ffm_amd.Engine);
+    `dist` is torch.distributed (initialised) or None for a single shard;
+    `logit` is a torch tensor of n_rows floats on the engine's device that receives the partial
+    and then the summed logits."""
+
+    def __init__(self, engine, dist, logit):
+        self.engine, self.dist, self.logit = engine, dist, logit
+
+    def __call__(self, n_rows, nnz, row_ptr, field, feat, val, label, loss_sum_out=None):
+        ptr = self.logit.data_ptr()
+        self.engine.train_forward_device(n_rows, nnz, row_ptr, field, feat, val, label, ptr)
+        if self.dist is not None and self.dist.get_world_size() > 1:
+            self.dist.all_reduce(self.logit[:n_rows])  # the path's one collective
+        self.engine.train_update_device(ptr, None, loss_sum_out)

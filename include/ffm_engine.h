@@ -66,8 +66,9 @@ typedef struct ffm_engine_config {
   int32_t max_batch_nnz;   /* capacity in entries of one call */
   int32_t device_id;       /* HIP device ordinal */
   /* Field-pair sharding of the latent tensor over the GPUs of a node (FFM; DESIGN.md
-   * "Multi-GPU"): this engine owns the unordered field pairs {f,f'} with
-   * ((min*n_fields+max) % n_shards) == shard_rank, plus bias/linear when shard_rank == 0. */
+   * "Multi-GPU"): this engine owns the unordered field pairs {f,f'} whose index in the
+   * upper triangle (min*n_fields - min*(min-1)/2 + max-min), taken modulo n_shards, equals
+   * shard_rank -- a balanced round-robin deal -- plus bias/linear when shard_rank == 0. */
   int32_t n_shards;        /* 1 */
   int32_t shard_rank;      /* 0 */
   void *stream;            /* hipStream_t to run on; NULL = the engine creates its own */

@@ -278,11 +278,11 @@ def test_field_pair_sharding_two_shards_on_one_gpu():
         e.train_update_device(total.data_ptr())
         e.sync()
     s0, s1 = shards[0].get_state(), shards[1].get_state()
-    # ownership: slot (feature of field f, partner field fp) belongs to ((min*F+max) % 2)
+    # ownership: slot (feature of field f, partner field fp) belongs to the owner of {f, fp}
+    from ftrl_ffm_amd import sharding
     fld = np.arange(nf) // per
     fp = np.arange(F)
-    lo_, hi_ = np.minimum(fld[:, None], fp[None, :]), np.maximum(fld[:, None], fp[None, :])
-    owner = np.repeat(((lo_ * F + hi_) % 2), k, axis=1)
+    owner = np.repeat(sharding.pair_owner(fld[:, None], fp[None, :], F, 2), k, axis=1)
     for key in ("vec_n", "vec_z", "vec_w"):
         merged = np.where(owner == 0, s0[key], s1[key])
         np.testing.assert_allclose(merged, s_ref[key], rtol=2e-4, atol=1e-6, err_msg=key)

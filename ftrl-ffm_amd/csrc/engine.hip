@@ -46,15 +46,16 @@ int fail(int code, const std::string &msg) {
 
 enum KernelId {
   K_GROUP_COUNT, K_GROUP_ALLOC, K_GROUP_SCATTER, K_GROUP_SORT, K_GROUP_EXPAND, K_ROW, K_TMP_GRAD,
-  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_GROUP_CLEANUP,
+  K_HOT_META,
+  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_LATENT_UPDATE_HUGE, K_GROUP_CLEANUP,
   K_PREDICT_ROW,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "group_count_kernel", "group_alloc_kernel", "group_scatter_kernel", "group_sort_kernel",
-    "group_expand_kernel", "row_kernel<train>", "tmp_grad_kernel", "loss_sum_kernel",
+    "group_expand_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
     "linear_update_kernel", "bias_update_kernel", "latent_update_kernel", "latent_update_hot_kernel",
-    "group_cleanup_kernel",
+    "latent_update_huge_kernel", "group_cleanup_kernel",
     "row_kernel<predict>"};
 
 struct ProfRec {
@@ -138,7 +139,8 @@ struct ffm_engine {
   bool own_stream = false;
   hipStream_t aux = nullptr;   // side stream: linear + bias chains beside the latent update
   hipStream_t aux2 = nullptr;  // side stream: hot-feature latent update beside the small-feature one
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  hipStream_t aux3 = nullptr;  // side stream: very-hot-feature latent update
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_join3 = nullptr;
   int max_rows = 0, max_nnz = 0, max_row_nnz = 1024;
   // staging for the host-buffer entry points
   int *d_row_ptr = nullptr, *d_field = nullptr, *d_feat = nullptr, *d_label = nullptr;
@@ -241,6 +243,8 @@ void ffm_engine_destroy(ffm_engine *e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
+  if (e->ev_join3) (void)hipEventDestroy(e->ev_join3);
+  if (e->aux3) (void)hipStreamDestroy(e->aux3);
   if (e->aux) (void)hipStreamDestroy(e->aux);
   if (e->aux2) (void)hipStreamDestroy(e->aux2);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -291,8 +295,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.h = Hyper{cfg->w_alpha, cfg->w_beta, cfg->w_l1, cfg->w_l2, 1.0f / cfg->w_alpha, 0};
   if (static_cast<int64_t>(cfg->n_fields) * cfg->n_factors > (1 << 24))
     { delete e; return fail(FFM_E_UNSUPPORTED, "n_fields*n_factors too large"); }
-  if (static_cast<int64_t>(cfg->max_batch_nnz) * ((m.row_len + 63) / 64 + 1) >= (1ll << 31))
-    { delete e; return fail(FFM_E_UNSUPPORTED, "max_batch_nnz * ceil(row_len/64) must stay below 2^31"); }
+  if (static_cast<int64_t>(cfg->max_batch_nnz) / (kSmallMax + 1) * ((m.row_len + 7) / 8 + 1) >= (1ll << 31))
+    { delete e; return fail(FFM_E_UNSUPPORTED, "max_batch_nnz * row_len too large for 32-bit work-item ids"); }
 
   int rc = FFM_OK;
 #define TRY_ALLOC(call) do { rc = (call); if (rc != FFM_OK) { ffm_engine_destroy(e); return rc; } } while (0)
@@ -308,6 +312,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_HIP(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
   TRY_HIP(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
+  TRY_HIP(hipStreamCreateWithFlags(&e->aux3, hipStreamNonBlocking));
+  TRY_HIP(hipEventCreateWithFlags(&e->ev_join3, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   const size_t nf = static_cast<size_t>(cfg->n_feats);
@@ -329,12 +335,17 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.multi, E));
   TRY_ALLOC(e->alloc(&s.small, E));
   TRY_ALLOC(e->alloc(&s.big, E));
+  TRY_ALLOC(e->alloc(&s.huge, E));
   TRY_ALLOC(e->alloc(&s.counters, 8));
   TRY_ALLOC(e->alloc(&s.cnt, nf));
   TRY_ALLOC(e->alloc(&s.fstart, nf));
   TRY_ALLOC(e->alloc(&s.head, R * static_cast<size_t>(m.n_fields)));
   TRY_ALLOC(e->alloc(&s.next, E));
   TRY_ALLOC(e->alloc(&s.rowtab, R * static_cast<size_t>(m.n_fields)));
+  TRY_ALLOC(e->alloc(&s.occpos, E));
+  const bool ffm_model = m.type == FFM_MODEL_FFM;
+  TRY_ALLOC(e->alloc(&s.haux, ffm_model ? E * static_cast<size_t>(m.n_fields) : 1));
+  TRY_ALLOC(e->alloc(&s.hmeta, ffm_model ? E : 1));
   TRY_ALLOC(e->alloc(&s.logit, R));
   TRY_ALLOC(e->alloc(&s.tg, R));
   TRY_ALLOC(e->alloc(&s.loss, R));
@@ -552,6 +563,8 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->s.tg, e->s.loss, logit_out);
   if (loss_sum_out)
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->s.loss, loss_sum_out);
+  if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0)
+    LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->s);
   const bool lin_owner = e->m.shard_rank == 0;
   // the bias and linear chains are short and serial: run them beside the latent update
   const bool forked = rows.n_rows > 0 && lin_owner && !e->serial;
@@ -571,17 +584,23 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     HIP_TRY(hipEventRecord(e->ev_join, e->aux));
   }
   if (ffm && vec4 && e->serial) {
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel<false>, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
     LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
   } else if (ffm && vec4) {
-    // hot features (long sequential chains) beside the bandwidth-shaped small-feature pass
+    // the three owner shapes touch disjoint features: run them side by side (long sequential
+    // chains of the hot ones beside the bandwidth-shaped small-feature pass)
+    HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
+    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel<false>, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
     LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   } else if (ffm) {
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel<true>, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
   } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
     LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
   }
@@ -731,10 +750,12 @@ int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms
   if (total_ms) *total_ms = ms[best];
   if (kernel_name && kernel_name_cap) {
     std::string name = kKernelNames[best];
-    if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT)
+    if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT ||
+        best == K_LATENT_UPDATE_HUGE)
       name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +
              (best == K_LATENT_UPDATE ? (e->m.type == FFM_MODEL_FM ? "update_kernel" : "update_small_kernel")
               : best == K_LATENT_UPDATE_HOT ? "update_hot_kernel"
+              : best == K_LATENT_UPDATE_HUGE ? "update_huge_kernel"
               : (best == K_ROW ? "row_kernel<train>" : "row_kernel<predict>"));
     std::snprintf(kernel_name, kernel_name_cap, "%s", name.c_str());
   }

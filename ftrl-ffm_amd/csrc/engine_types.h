@@ -63,7 +63,8 @@ struct Scratch {
   int *ucount;    // [nnz] its number of occurrences
   int *multi;     // [nnz] indices into uniq of the features that occur more than once
   int *small;     // [nnz] indices into uniq of the features with <= kSmallMax occurrences
-  int *big;       // [nnz] indices into uniq of the others ("hot" features)
+  int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
+  int *huge;      // [nnz] ... with more ("very hot": present in a large share of the rows)
   int *counters;  // [8]   0 n_uniq, 1 occ cursor, 2 n_multi, 3 error bits
   int *cnt;       // [n_feats] per-feature counter, all zero between blocks
   int *fstart;    // [n_feats] group start per feature (valid for features of the block)
@@ -71,13 +72,23 @@ struct Scratch {
   int *next;      // [nnz] next entry of the same row with the same field, -1 at the end
   int4 *rowtab;   // [n_rows*n_fields] {feat, val bits, entry, count} of the field's entry in the
                   //      row; entry = -1 none, -2 several (then head/next list them)
+  // Hot features (more than kSmallMax occurrences in the block) have their touches' facts laid
+  // out by occurrence position t (= index into occ), so their owners stream them:
+  int *occpos;    // [nnz] entry -> its position t in occ when its feature is hot, else -1
+  int4 *haux;     // [nnz*n_fields] per (occurrence t, partner field): {partner value bits,
+                  //      flags | own field << 8, partner feature id, entry} -- from the row kernel
+  float2 *hmeta;  // [nnz] {tmp_grad, own value} of occurrence t
   float *logit;   // [n_rows] this shard's (partial) logit
   float *tg;      // [n_rows] tmp_grad = sigmoid(logit) - y
   double *loss;   // [n_rows] logloss per row
   float *svx;     // [n_rows*n_factors] FM per-row factor sums (sum_vx, fm.h:24)
 };
 
-enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5 };
+enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5,
+       CNT_NHUGE = 6 };
+constexpr int kHugeMin = 96;  // occurrences per block above which a feature takes the lane-parallel path
+enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
+                                                     // first / several entries share the field
 constexpr int kSmallMax = 4;  // occurrences per block up to which a feature takes the "small" path
 enum { ERR_ROW_TOO_LONG = 1 };
 

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kGroupThreads) void group_count_kernel(ModelDev m, 
     valid = i >= 0 && i < m.n_feats;
     if (m.type == 2) valid = valid && f >= 0 && f < m.n_fields;
   }
-  if (in) s.efeat[p] = valid ? i : -1;
+  if (in) { s.efeat[p] = valid ? i : -1; s.occpos[p] = -1; }
   const bool first = valid && atomicAdd(&s.cnt[i], 1) == 0;
   const int u = wave_append_slot(&s.counters[CNT_NUNIQ], first);
   if (first) s.uniq[u] = i;
@@ -79,14 +79,17 @@ __global__ __launch_bounds__(kGroupThreads) void group_alloc_kernel(Scratch s) {
     const int start = wave_reserve(&s.counters[CNT_CURSOR], c);
     const int im = wave_append_slot(&s.counters[CNT_NMULTI], live && c > 1);
     const int is = wave_append_slot(&s.counters[CNT_NSMALL], live && c <= kSmallMax);
-    const int ib = wave_append_slot(&s.counters[CNT_NBIG], live && c > kSmallMax);
+    const int ib = wave_append_slot(&s.counters[CNT_NBIG], live && c > kSmallMax && c <= kHugeMin);
+    const int ih = wave_append_slot(&s.counters[CNT_NHUGE], live && c > kHugeMin);
     if (!live) continue;
     s.ustart[u] = start;
     s.ucount[u] = c;
     s.fstart[i] = start;
     s.cnt[i] = 0;
     if (c > 1) s.multi[im] = u;
-    if (c <= kSmallMax) s.small[is] = u; else s.big[ib] = u;
+    if (c <= kSmallMax) s.small[is] = u;
+    else if (c <= kHugeMin) s.big[ib] = u;
+    else s.huge[ih] = u;
   }
 }
 
@@ -155,6 +158,19 @@ __global__ __launch_bounds__(kGroupThreads) void group_expand_kernel(int nnz_val
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const int p = s.occ[t];
     s.occ2[t] = make_int2(p, s.row_of[p]);
+    // after the scatter cnt[feature] holds its occurrence count again
+    s.occpos[p] = s.cnt[s.efeat[p]] > kSmallMax ? t : -1;
+  }
+}
+
+// Once tmp_grad is known: per-occurrence facts of the hot features' entries, in occ order, so
+// their owners read them as one contiguous stream.
+__global__ __launch_bounds__(kGroupThreads) void hot_meta_kernel(Rows rows, Scratch s) {
+  const int n = s.counters[CNT_CURSOR];
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const int2 pr = s.occ2[t];
+    if (s.occpos[pr.x] < 0) continue;
+    s.hmeta[t] = make_float2(s.tg[pr.y], rows.val[pr.x]);
   }
 }
 

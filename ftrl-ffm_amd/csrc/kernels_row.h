@@ -30,12 +30,13 @@ struct RowLds {
   int *feat;     // [max_row_nnz]
   float *val;    // [max_row_nnz]
   float *linw;   // [max_row_nnz] linear weight
+  int *opos;     // [max_row_nnz] occurrence position when the entry's feature is hot, else -1
   int *fcnt;     // [n_fields] surviving entries per field
   int *ffirst;   // [n_fields] compact index of the first entry of the field, -1 if none
 };
 __host__ __device__ inline size_t row_lds_bytes(int max_row_nnz, int n_fields) {
   const size_t M = (size_t)((max_row_nnz + 3) & ~3), Fp = (size_t)((n_fields + 3) & ~3);
-  return sizeof(float) * kTermsCap + 5 * 4 * M + 2 * 4 * (Fp ? Fp : 4);
+  return sizeof(float) * kTermsCap + 6 * 4 * M + 2 * 4 * (Fp ? Fp : 4);
 }
 __device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int n_fields) {
   const int M = (max_row_nnz + 3) & ~3, Fp = ((n_fields + 3) & ~3) ? ((n_fields + 3) & ~3) : 4;
@@ -46,7 +47,8 @@ __device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int
   l.feat = l.field + M;
   l.val = reinterpret_cast<float *>(l.feat + M);
   l.linw = l.val + M;
-  l.fcnt = reinterpret_cast<int *>(l.linw + M);
+  l.opos = reinterpret_cast<int *>(l.linw + M);
+  l.fcnt = l.opos + M;
   l.ffirst = l.fcnt + Fp;
   return l;
 }
@@ -148,6 +150,29 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   }
 
   if (TRAIN && is_ffm) {
+    for (int a = threadIdx.x; a < nv; a += blockDim.x) lds.opos[a] = s.occpos[b + lds.pos[a]];
+    __syncthreads();
+    // For entries of hot features: what each partner field contributes to their touches
+    // ({partner value, flags | own field, partner id, entry}), laid out by occurrence position
+    // for the hot update kernel.
+    for (int t = threadIdx.x; t < nv * F; t += blockDim.x) {
+      const int a = t / F, f = t - a * F;
+      const int op = lds.opos[a];
+      if (op < 0) continue;
+      const int cnt = lds.fcnt[f];
+      const int a0 = lds.ffirst[f];
+      int flags = 0, fq = lds.feat[a];  // harmless partner id when there is no plain partner
+      float xo = 0.0f;
+      if (cnt == 1 && a0 != a) {
+        flags = HF_SIMPLE | (a < a0 ? HF_FIRST : 0);
+        xo = lds.val[a0];
+        fq = lds.feat[a0];
+      } else if (cnt > 1) {
+        flags = HF_CHAIN;
+      }
+      s.haux[static_cast<int64_t>(op) * F + f] =
+          make_int4(__float_as_int(xo), flags | (lds.field[a] << 8), fq, b + lds.pos[a]);
+    }
     // Per-field view of this row for the update kernel: rowtab[r][f] = {feat, val bits, entry
     // index, count} of the only entry with field f (entry index -1: none, -2: several -- then
     // head/next chains list them in row order).

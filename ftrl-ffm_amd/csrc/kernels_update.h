@@ -72,9 +72,175 @@ __device__ __forceinline__ void ffm_touch4(const Hyper &h, bool own_first, float
   z4 = make_float4(z[0], z[1], z[2], z[3]);
 }
 
-// ---- hot features: work item = (feature from the big list, chunk of 64 elements) ----------
-// ALL = true: every distinct feature takes this path (n_factors not a multiple of 4).
-template <bool ALL>
+// ---- very hot features (more than kHugeMin occurrences) ----------------------------------
+// A hot feature's touches form one long sequential chain per element.  A wave that walks such a
+// chain one touch at a time runs at the LATENCY of ~100 dependent instructions per touch (measured
+// 0.45 us per touch: a feature present in 1100 rows of the block then costs 0.5 ms on its own).
+// So the chain is laid across lanes instead: a wave owns 8 elements of the record and applies 8
+// consecutive touches per step, lane = (element, touch).  Everything that does not depend on the
+// running accumulators -- gradients, the two square roots, the alpha divide -- is one instruction
+// for all 8 touches at once; the running n and z are strictly left-to-right prefix chains over
+// the 8 touch lanes of each element (7 DPP shift-right-by-one steps: step s finalises lane s, lanes
+// already final recompute the same value), i.e. exactly the additions the one-thread loop performs,
+// in its order.  Touch facts come as contiguous streams laid out by occurrence position (s.haux
+// from the row kernel, s.hmeta), prefetched two steps ahead; partner weights one step ahead.
+constexpr int kHotT = 8;  // touches per step (lanes per element)
+constexpr int kHotE = 8;  // elements per wave
+
+__device__ __forceinline__ float dpp_row_shr1(float keep, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v),
+                                                    0x111 /* row_shr:1 */, 0xf, 0xf, false));
+}
+
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m, Rows rows,
+                                                                      Scratch s) {
+  const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
+  const unsigned groups = (RL + kHotE - 1) / kHotE;
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & (kHotT - 1);  // which of the step's 8 touches
+  const int el = lane >> 3;           // which of the wave's 8 elements
+  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = gridDim.x * kUpdWaves;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * groups;
+  const float inv_k = 1.0f / static_cast<float>(k);
+  const size_t rec_floats = static_cast<size_t>(3) * RL;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned li = item / groups;
+    const int u = wave_uniform(s.huge[li]);
+    const int e = static_cast<int>(item - li * groups) * kHotE + el;
+    const bool active = e < RL;
+    const int ee = active ? e : 0;
+    int fp = static_cast<int>((ee + 0.5f) * inv_k);  // this lane's partner field
+    fp += (fp + 1) * k <= ee ? 1 : (fp * k > ee ? -1 : 0);
+    const int kk = ee - fp * k;  // and factor
+    const int i = wave_uniform(s.uniq[u]);
+    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    float *rec = lat_row(m, i);
+    float nc = rec[LAT_N * RL + ee], zc = rec[LAT_Z * RL + ee];  // running (n, z) of element e
+    const float w = rec[LAT_W * RL + ee];
+    const float *wcol = m.lat + LAT_W * RL + kk;                       // + feat*rec + field*k
+    const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;  // + t*F
+    const float2 *mcol = s.hmeta + start;                              // + t
+    const int steps = (c + kHotT - 1) / kHotT;
+    bool touched = false;
+
+    // pipeline: facts two steps ahead, partner weight one step ahead
+    int4 ax = acol[static_cast<int64_t>(min(tl, c - 1)) * F];
+    float2 mt = mcol[min(tl, c - 1)];
+    int4 axN = acol[static_cast<int64_t>(min(kHotT + tl, c - 1)) * F];
+    float2 mtN = mcol[min(kHotT + tl, c - 1)];
+    float vp = wcol[ax.z * rec_floats + (ax.y >> 8) * k];
+    for (int st = 0; st < steps; st++) {
+      const int t = st * kHotT + tl;
+      const float vpN = wcol[axN.z * rec_floats + (axN.y >> 8) * k];      // weights of step st+1
+      const int tNN = min((st + 2) * kHotT + tl, c - 1);                  // facts of step st+2
+      const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
+      const float2 mtNN = mcol[tNN];
+
+      const int fl = ax.y;
+      const bool live = t < c && active && owns_pair(m, fl >> 8, fp);
+      const bool simple = live & ((fl & HF_SIMPLE) != 0);
+      if (!__any(live & ((fl & HF_CHAIN) != 0))) {
+        const bool first = fl & HF_FIRST;
+        const float xo = __int_as_float(ax.x), tg = mt.x, xm = mt.y;
+        const float x = first ? xm * xo : xo * xm;
+        const float g = tg * vp * x;   // own slot's gradient (g1 if own entry first, else g2)
+        const float g1 = tg * w * x;   // second-entry case: the first entry's gradient
+        const float gg = g * g;
+        const float q = simple ? gg : -0.0f;  // x + -0.0f == x bit for bit: idle touches add nothing
+        // running n: strictly left-to-right prefix over the 8 touch lanes of each element
+        float S = tl == 0 ? nc + q : q;
+#pragma unroll
+        for (int r = 1; r < kHotT; r++) {
+          const float prev = dpp_row_shr1(S, S);
+          S = tl == 0 ? S : prev + q;
+        }
+        const float prevS = dpp_row_shr1(S, S);
+        const float nb = tl == 0 ? nc : prevS;  // n before this touch
+        const float arg[2] = {nb + (first ? gg : g * g1), nb};  // ffm.cpp:113 / :118
+        float sq[2];
+        sqrt_cr_n<2>(arg, sq);
+        const float dd[1] = {simple ? sq[0] - sq[1] : 0.0f};
+        float sg[1];
+        div_alpha_n<1>(m.h, dd, sg);
+        const float mm = sg[0] * w;
+        // running z: z' = (z + g) - sigma*w per live touch, same left-to-right chain
+        float Z = simple ? (zc + g) - mm : zc;  // correct for tl == 0; others fixed up below
+#pragma unroll
+        for (int r = 1; r < kHotT; r++) {
+          const float prev = dpp_row_shr1(Z, Z);
+          const float cand = simple ? (prev + g) - mm : prev;
+          Z = tl == 0 ? Z : cand;
+        }
+        nc = __shfl(S, lane | (kHotT - 1), 64);
+        zc = __shfl(Z, lane | (kHotT - 1), 64);
+        const unsigned long long sm = __ballot(simple);
+        touched = touched | (((sm >> (el * kHotT)) & 0xffull) != 0ull);
+      } else {
+        // a multi-valued field in this step: its 8 touches one after another, every lane of an
+        // element's group applying them to its copy of the running (n, z)
+        for (int tt = 0; tt < kHotT; tt++) {
+          const int src = (lane & ~(kHotT - 1)) | tt;
+          const int flt = __shfl(fl, src, 64);
+          const int pt = __shfl(ax.w, src, 64);
+          const float xot = __shfl(__int_as_float(ax.x), src, 64);
+          const float tgt = __shfl(mt.x, src, 64), xmt = __shfl(mt.y, src, 64);
+          const float vpt = __shfl(vp, src, 64);
+          const int fm = flt >> 8;
+          if (st * kHotT + tt >= c || !active || !owns_pair(m, fm, fp)) continue;
+          if (flt & HF_SIMPLE) {
+            ffm_touch(m.h, flt & HF_FIRST, tgt, xmt, xot, vpt, w, nc, zc);
+            touched = true;
+          } else if (flt & HF_CHAIN) {
+            const int r = s.row_of[pt];
+            for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+              if (qq == pt) continue;
+              const float vq = wcol[rows.feat[qq] * rec_floats + fm * k];
+              ffm_touch(m.h, pt < qq, tgt, xmt, rows.val[qq], vq, w, nc, zc);
+              touched = true;
+            }
+          }
+        }
+      }
+      ax = axN; mt = mtN; vp = vpN;
+      axN = axNN; mtN = mtNN;
+    }
+    if (touched && active && tl == 0) {
+      rec[LAT_N * RL + ee] = nc;
+      rec[LAT_Z * RL + ee] = zc;
+    }
+  }
+}
+
+// ---- hot features, moderate counts: work item = (feature from the big list, 64 elements) ----
+// One wave owns 64 elements and walks the touches kUnroll at a time, software-pipelined three
+// groups deep over the same occurrence-ordered streams (group b applied while group b+1's partner
+// weights and group b+2's facts are in flight).  Per group: gradients, then the running n (plain
+// adds), then every touch's sigma (independent given the running n), then the running z.
+struct HotFacts {  // per-lane facts of a group of touches
+  float xo[kUnroll];
+  int fl[kUnroll];   // flags | own field << 8
+  int fq[kUnroll];   // partner feature id
+};
+
+__device__ __forceinline__ void hot_load_facts(const int4 *acol, int F, int c, int t0,
+                                               HotFacts &f, int (&pe)[kUnroll]) {
+#pragma unroll
+  for (int j = 0; j < kUnroll; j++) {
+    const int4 ax = acol[static_cast<int64_t>(min(t0 + j, c - 1)) * F];  // tail: repeats, unused
+    f.xo[j] = __int_as_float(ax.x);
+    f.fl[j] = ax.y;
+    f.fq[j] = ax.z;
+    pe[j] = ax.w;
+  }
+}
+
+__device__ __forceinline__ void hot_issue_weights(const float *wcol, size_t rec_floats, int k,
+                                                  const HotFacts &f, float (&vp)[kUnroll]) {
+#pragma unroll
+  for (int j = 0; j < kUnroll; j++) vp[j] = wcol[f.fq[j] * rec_floats + (f.fl[j] >> 8) * k];
+}
+
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m, Rows rows,
                                                                      Scratch s) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
@@ -82,12 +248,12 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
   const int lane = threadIdx.x & 63;
   const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const unsigned n_waves = gridDim.x * kUpdWaves;
-  const unsigned n_feat = ALL ? s.counters[CNT_NUNIQ] : s.counters[CNT_NBIG];
-  const unsigned n_items = n_feat * chunks;  // the host bounds max_batch_nnz * chunks below 2^31
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NBIG]) * chunks;
   const float inv_k = 1.0f / static_cast<float>(k);
+  const size_t rec_floats = static_cast<size_t>(3) * RL;
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned li = item / chunks;
-    const int u = ALL ? static_cast<int>(li) : wave_uniform(s.big[li]);
+    const int u = wave_uniform(s.big[li]);
     const int e = static_cast<int>(item - li * chunks) * 64 + lane;
     const bool active = e < RL;
     const int ee = active ? e : 0;
@@ -99,81 +265,83 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     float *rec = lat_row(m, i);
     float n = rec[LAT_N * RL + ee], z = rec[LAT_Z * RL + ee];
     const float w = rec[LAT_W * RL + ee];
+    const float *wcol = m.lat + LAT_W * RL + kk;                          // + feat*rec + field*k
+    const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;     // + t*F
+    const float2 *mcol = s.hmeta + start;                                 // + t
     bool touched = false;
-    for (int t0 = 0; t0 < c; t0 += kUnroll) {
-      int pj[kUnroll], fmj[kUnroll];
-      float tgj[kUnroll], xmj[kUnroll], vpj[kUnroll];
-      int4 rtj[kUnroll];
+    const int nb = (c + kUnroll - 1) / kUnroll;
+
+    HotFacts fA, fB, fC;          // facts of groups b+2, b+1, b
+    int peA[kUnroll], peB[kUnroll], peC[kUnroll];
+    float vpB[kUnroll], vpC[kUnroll];
+    hot_load_facts(acol, F, c, 0, fB, peB);
+    if (nb > 1) hot_load_facts(acol, F, c, kUnroll, fA, peA);
+    hot_issue_weights(wcol, rec_floats, k, fB, vpB);
+    for (int b = 0; b < nb; b++) {
+      const int t0 = b * kUnroll;
+      fC = fB;
+#pragma unroll
+      for (int j = 0; j < kUnroll; j++) { vpC[j] = vpB[j]; peC[j] = peB[j]; }
+      if (b + 1 < nb) {
+        fB = fA;
+#pragma unroll
+        for (int j = 0; j < kUnroll; j++) peB[j] = peA[j];
+        hot_issue_weights(wcol, rec_floats, k, fB, vpB);                  // weights of group b+1
+      }
+      if (b + 2 < nb) hot_load_facts(acol, F, c, t0 + 2 * kUnroll, fA, peA);  // facts of group b+2
+      float tgj[kUnroll], xmj[kUnroll];
 #pragma unroll
       for (int j = 0; j < kUnroll; j++) {
-        const int t = min(t0 + j, c - 1);  // clamp: the tail re-reads the last entry, unused
-        const int2 pr = s.occ2[start + t];
-        pj[j] = pr.x;
-        fmj[j] = rows.field[pr.x];
-        xmj[j] = rows.val[pr.x];
-        tgj[j] = s.tg[pr.y];
-        rtj[j] = s.rowtab[static_cast<int64_t>(pr.y) * F + fp];
+        const float2 mt = mcol[min(t0 + j, c - 1)];  // wave-uniform, contiguous
+        tgj[j] = mt.x;
+        xmj[j] = mt.y;
       }
+      bool simple[kUnroll], any_chain = false;
 #pragma unroll
       for (int j = 0; j < kUnroll; j++) {
-        // partner weight w[feat_q][field_own][kk]; harmless address when there is no partner
-        const int fq = rtj[j].x >= 0 ? rtj[j].x : i;
-        vpj[j] = lat_row(m, fq)[LAT_W * RL + fmj[j] * k + kk];
+        const bool live = t0 + j < c && active && owns_pair(m, fC.fl[j] >> 8, fp);
+        simple[j] = live && (fC.fl[j] & HF_SIMPLE);
+        any_chain = any_chain || (live && (fC.fl[j] & HF_CHAIN));
       }
-      bool simple[kUnroll], complex_any = false;
-#pragma unroll
-      for (int j = 0; j < kUnroll; j++) {
-        const bool live = t0 + j < c && active && owns_pair(m, fmj[j], fp);
-        simple[j] = live && rtj[j].z >= 0 && rtj[j].z != pj[j];
-        complex_any = complex_any || (live && rtj[j].z == -2);
-      }
-      if (!__any(complex_any)) {
-        // The group's touches, as the reference applies them one after another, but laid out so
-        // the expensive parts are independent: gradients first, then the running n (a chain of
-        // plain adds), then every touch's sigma (sqrt/divide, all independent given the running
-        // n), then the running z (two adds per touch).  Same operations, same operands, same
-        // order per accumulator as ffm_touch -- only the instruction schedule differs.
-        float gj[kUnroll], aj[kUnroll], nb[kUnroll], mj[kUnroll];
+      if (!__any(any_chain)) {
+        float gj[kUnroll], aj[kUnroll], nbv[kUnroll], mj[kUnroll];
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {
-          const bool first = pj[j] < rtj[j].z;
-          const float xo = __int_as_float(rtj[j].y);
-          const float x = first ? xmj[j] * xo : xo * xmj[j];
-          const float g = tgj[j] * vpj[j] * x;  // own slot's gradient (g1 if first, else g2)
-          const float g1 = tgj[j] * w * x;      // j-side only: the first entry's gradient
+          const bool first = fC.fl[j] & HF_FIRST;
+          const float x = first ? xmj[j] * fC.xo[j] : fC.xo[j] * xmj[j];
+          const float g = tgj[j] * vpC[j] * x;  // own slot's gradient (g1 if first, else g2)
+          const float g1 = tgj[j] * w * x;      // second-entry case: the first entry's gradient
           gj[j] = g;
           aj[j] = first ? g * g : g * g1;       // what the square root sees added to n (:118)
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {
-          nb[j] = n;
+          nbv[j] = n;
           if (simple[j]) n = n + gj[j] * gj[j];
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {
-          const float sg = (sqrtf(nb[j] + aj[j]) - sqrtf(nb[j])) / m.h.alpha;
+          const float sg = (sqrtf(nbv[j] + aj[j]) - sqrtf(nbv[j])) / m.h.alpha;
           mj[j] = sg * w;
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; j++)
           if (simple[j]) { z = (z + gj[j]) - mj[j]; touched = true; }
       } else {
+        // a multi-valued field somewhere in the group: one touch after another, chains walked
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {
-          if (t0 + j < c && active && owns_pair(m, fmj[j], fp)) {
-            const int p = pj[j], fm = fmj[j];
-            const int q = rtj[j].z;
-            if (q >= 0) {  // exactly one entry of this row has field fp
-              if (q != p) {
-                ffm_touch(m.h, p < q, tgj[j], xmj[j], __int_as_float(rtj[j].y), vpj[j], w, n, z);
-                touched = true;
-              }
-            } else if (q == -2) {
-              // several entries share field fp (multi-valued field): walk the row's chain in order
+          const int fm = fC.fl[j] >> 8;
+          if (t0 + j < c && active && owns_pair(m, fm, fp)) {
+            if (fC.fl[j] & HF_SIMPLE) {
+              ffm_touch(m.h, fC.fl[j] & HF_FIRST, tgj[j], xmj[j], fC.xo[j], vpC[j], w, n, z);
+              touched = true;
+            } else if (fC.fl[j] & HF_CHAIN) {
+              const int p = peC[j];
               const int r = s.row_of[p];
               for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
                 if (qq == p) continue;
-                const float vp = lat_row(m, rows.feat[qq])[LAT_W * RL + fm * k + kk];
+                const float vp = wcol[rows.feat[qq] * rec_floats + fm * k];
                 ffm_touch(m.h, p < qq, tgj[j], xmj[j], rows.val[qq], vp, w, n, z);
                 touched = true;
               }
@@ -182,9 +350,50 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
         }
       }
     }
-    if (touched) {
+    if (touched && active) {  // idle lanes of the last chunk alias element 0: never store
       rec[LAT_N * RL + ee] = n;
       rec[LAT_Z * RL + ee] = z;
+    }
+  }
+}
+
+// n_factors not a multiple of 4: every distinct feature, hot or not, is owned per 64 elements
+// and gathers its inputs in place (no float4 path, no occurrence-ordered streams).
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDev m, Rows rows,
+                                                                         Scratch s) {
+  const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
+  const unsigned chunks = (RL + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = gridDim.x * kUpdWaves;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NUNIQ]) * chunks;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned u = item / chunks;
+    const int e = static_cast<int>(item - u * chunks) * 64 + lane;
+    if (e >= RL) continue;
+    const int fp = e / k, kk = e - fp * k;
+    const int i = s.uniq[u];
+    const int start = s.ustart[u], c = s.ucount[u];
+    float *rec = lat_row(m, i);
+    float n = rec[LAT_N * RL + e], z = rec[LAT_Z * RL + e];
+    const float w = rec[LAT_W * RL + e];
+    bool touched = false;
+    for (int t = 0; t < c; t++) {
+      const int2 pr = s.occ2[start + t];
+      const int p = pr.x, r = pr.y;
+      const int fm = rows.field[p];
+      if (!owns_pair(m, fm, fp)) continue;
+      const float tg = s.tg[r], xm = rows.val[p];
+      for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+        if (qq == p) continue;
+        const float vp = lat_row(m, rows.feat[qq])[LAT_W * RL + fm * k + kk];
+        ffm_touch(m.h, p < qq, tg, xm, rows.val[qq], vp, w, n, z);
+        touched = true;
+      }
+    }
+    if (touched) {
+      rec[LAT_N * RL + e] = n;
+      rec[LAT_Z * RL + e] = z;
     }
   }
 }
@@ -351,8 +560,9 @@ __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, 
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const int n_waves = gridDim.x * kUpdWaves;
-  for (int li = wave; li < n_big; li += n_waves) {
-    const int u = wave_uniform(s.big[li]);
+  const int n_huge = s.counters[CNT_NHUGE];
+  for (int li = wave; li < n_big + n_huge; li += n_waves) {
+    const int u = wave_uniform(li < n_big ? s.big[li] : s.huge[li - n_big]);
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     float n = m.lin_n[i], z = m.lin_z[i];

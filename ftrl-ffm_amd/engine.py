@@ -82,7 +82,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("FFM_ENGINE_LIB") or LIB_PATH  # env: A/B experiments only
     if not os.path.exists(path):
         raise FileNotFoundError(
             "%s not found: build it with `python ftrl-ffm_amd/build.py` (hipcc, gfx950). "

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turns one tools/profile_round.sh capture (gpurun_out/prof_<round>/) into the committed
+evidence under profiles/: the rocprofv3 --kernel-trace --stats table as is, and a per-kernel
+summary of the HBM byte counters.
+
+Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE come from separate --pmc passes and are in KiB; on gfx950 FETCH_SIZE reports HALF of
+the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled for the kernels whose
+reads are such streams (the row kernel and the small-feature update kernel read float4 per lane);
+other access widths are uncalibrated and left as reported.  Values are per launch (steady-state
+launches of the bench, averaged)."""
+import csv
+import json
+import os
+import shutil
+import sys
+
+WIDE_READERS = ("ffm_row_kernel", "ffm_update_small_kernel")
+
+
+def short(name):
+    n = name.replace("void ", "").replace("ftrl_dev::", "").replace("(anonymous namespace)::", "")
+    return n.split("(")[0]
+
+
+def per_kernel(path, counter):
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            out.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+    return {k: sum(v[-5:]) / len(v[-5:]) for k, v in out.items()}
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join("gpurun_out", "prof_" + rnd)
+    os.makedirs("profiles", exist_ok=True)
+    shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"),
+                os.path.join("profiles", rnd + "_bench_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join("profiles", rnd + "_bench.json"))
+    with open(os.path.join(src, "bench.err")) as f:
+        table = [l for l in f.read().splitlines() if "launches=" in l]
+    with open(os.path.join("profiles", rnd + "_bench_hip_event_table.txt"), "w") as f:
+        f.write("\n".join(table) + "\n")
+    stats = {}
+    with open(os.path.join(src, "trace", "bench_kernel_stats.csv")) as f:
+        for r in csv.DictReader(f):
+            stats[short(r["Name"])] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3,
+                                           pct=float(r["Percentage"]))
+    fetch = per_kernel(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"), "FETCH_SIZE")
+    write = per_kernel(os.path.join(src, "pmc_write", "bench_counter_collection.csv"), "WRITE_SIZE")
+    summary = {}
+    for k, st in stats.items():
+        if k not in fetch:
+            continue
+        corr = 2.0 if k.startswith(WIDE_READERS) else 1.0
+        rd, wr = fetch[k] * 1024.0, write.get(k, 0.0) * 1024.0
+        summary[k] = dict(avg_us=round(st["avg_us"], 2), calls=st["calls"], pct=st["pct"],
+                          FETCH_SIZE_KiB=round(fetch[k], 1), WRITE_SIZE_KiB=round(write.get(k, 0.0), 1),
+                          fetch_correction=corr,
+                          hbm_bytes_per_launch=int(rd * corr + wr),
+                          hbm_GBps=round((rd * corr + wr) / (st["avg_us"] * 1e-6) / 1e9, 1))
+    with open(os.path.join("profiles", rnd + "_pmc_hbm_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1, sort_keys=True)
+    for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["avg_us"]):
+        print("%-36s avg %9.1f us  hbm %8.1f MB/launch  %7.1f GB/s" % (
+            k, v["avg_us"], v["hbm_bytes_per_launch"] / 1e6, v["hbm_GBps"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -36,14 +36,27 @@ def algorithmic_bytes_per_row(nnz, k):
     return nnz * (nnz - 1) * k * 20 + nnz * 20 + 20 + (nnz * 12 + 8) + 12
 
 
-def kernel_share_bytes_per_row(kernel, nnz, k):
-    """The same total apportioned to the two big kernels so that the shares add up to it:
-    row kernel = read (n,z) + write w of every touched slot (+ CSR, linear refresh, logit);
-    update kernel = write (n,z) of every touched slot (+ linear/bias accumulators, loss)."""
-    sf = nnz * (nnz - 1) * k
-    if "update" in kernel:
-        return sf * 8 + nnz * 8 + 8 + 8
-    return sf * 12 + nnz * 12 + 12 + (nnz * 12 + 8) + 4
+def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
+    """Algorithmic bytes ONE launch of `kernel` is responsible for, averaged over the bench's
+    blocks.  SURVEY.md 8(d)'s per-row total (20 B per touched slot-factor: read n,z + write w,n,z)
+    is apportioned to the kernels that move those bytes, so the shares add up to it:
+      row kernel           : read (n,z) + write w of every touched slot = 12 B per slot-factor,
+                             + CSR in, linear refresh, logit out
+      update_small/hot/huge: write (n,z) = 8 B per slot-factor of the occurrences each owns
+                             (features with <= 4, 5..96, > 96 occurrences in the block)
+    Under field-pair sharding every rank moves 1/n_shards of the slot-factors."""
+    per_occ = (nnz - 1) * k  # slot-factors one occurrence of a feature touches
+    rows = [len(f) // nnz for f in blocks_feat]
+    if "row_kernel" in kernel:
+        b = [r * (nnz * per_occ * 12 / n_shards + nnz * 12 + 12 + (nnz * 12 + 8) + 4) for r in rows]
+        return float(np.mean(b))
+    shares = []
+    for f in blocks_feat:
+        _, c = np.unique(f, return_counts=True)
+        occ = {"small": c[c <= 4].sum(), "hot": c[(c > 4) & (c <= 96)].sum(), "huge": c[c > 96].sum()}
+        key = "small" if "small" in kernel else "huge" if "huge" in kernel else "hot"
+        shares.append(occ[key] * per_occ * 8 / n_shards)
+    return float(np.mean(shares))
 
 
 def cpu_baseline(args, gen_kwargs):
@@ -148,8 +161,10 @@ def main():
     # identical synthetic blocks on every rank, uploaded once: resident in HBM before timing
     gen = synth.Generator(N_FIELDS, n_feats, **gen_kwargs)
     blocks = []
+    blocks_feat = []
     for _ in range(args.n_blocks):
         b = gen.block(rows)
+        blocks_feat.append(b.feat.copy())
         blocks.append(dict(
             n_rows=b.n_rows, nnz=b.nnz,
             row_ptr=torch.from_numpy(b.row_ptr).cuda(), field=torch.from_numpy(b.field).cuda(),
@@ -223,14 +238,21 @@ def main():
             "step_algorithmic_GBps": round(value * bytes_row / n_gpus / 1e9, 1),
         }
         if kname:
-            share = kernel_share_bytes_per_row(kname, N_FIELDS, N_FACTORS) / max(world, 1)
+            share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, max(world, 1))
             avg_s = kms / 1000.0 / max(klaunches, 1)
-            achieved = share * rows / avg_s / 1e9
+            achieved = share / avg_s / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_summary.json")
+            if os.path.exists(pmc) and world == 1 and not args.n_feats and not args.rows:
+                with open(pmc) as f:  # rocprofv3 --pmc passes of this same command (tools/)
+                    for name, v in json.load(f).items():
+                        if name.split("<")[0] == kname.split("<")[0]:
+                            traffic = v["hbm_bytes_per_launch"]
             out["roofline"] = {
                 "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
-                "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2), "launches": klaunches,
-                "algorithmic_bytes_per_launch": int(share * rows),
+                "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": klaunches,
+                "algorithmic_bytes_per_launch": int(share),
             }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, gen_kwargs)

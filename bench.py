@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-lookahead", action="store_true", help="group each block inline")
     args = ap.parse_args()
 
     import torch
@@ -187,6 +188,11 @@ def main():
             dist.all_reduce(logit)  # the path's one exchange: n_rows partial logits over xGMI
             eng.train_update_device(ptr(logit), None, out_loss)
 
+    def prepare(blk):  # the scheduler's look-ahead: group the next block beside this one's update
+        ptr = lambda t: t.data_ptr()  # noqa: E731
+        eng.prepare_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
+                           ptr(blk["feat"]), ptr(blk["val"]))
+
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
@@ -195,12 +201,16 @@ def main():
 
     for i in range(args.warmup):
         step(i, blocks[i % len(blocks)])
+        if not args.no_lookahead:
+            prepare(blocks[(i + 1) % len(blocks)])
     fence()
     if not args.no_profile:
         eng.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, blocks[(args.warmup + i) % len(blocks)])
+        if not args.no_lookahead and i + 1 < args.steps:
+            prepare(blocks[(args.warmup + i + 1) % len(blocks)])
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -134,7 +134,15 @@ __global__ void lat_component_copy_kernel(float *lat, int row_len, int comp, flo
 struct ffm_engine {
   ffm_engine_config cfg{};
   ModelDev m{};
-  Scratch s{};
+  // Two sets of grouping outputs (ping-pong): block t+1 can be grouped on the prep stream while
+  // block t is still being updated.  Everything the row kernel writes is shared by both sets.
+  Scratch sc[2]{};
+  int cur = 0;                 // set of the block being trained
+  int prepared = -1;           // set holding a grouping made ahead by ffm_engine_prepare_device
+  Rows prepared_rows{};
+  bool set_used[2] = {false, false};
+  hipStream_t prep = nullptr;  // side stream of ffm_engine_prepare_device
+  hipEvent_t ev_grouped[2] = {nullptr, nullptr}, ev_set_free[2] = {nullptr, nullptr};
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t aux = nullptr;   // side stream: linear + bias chains beside the latent update
@@ -146,7 +154,7 @@ struct ffm_engine {
   int *d_row_ptr = nullptr, *d_field = nullptr, *d_feat = nullptr, *d_label = nullptr;
   float *d_val = nullptr, *d_out = nullptr;
   double *d_loss_sum = nullptr;
-  int *d_sort_tmp = nullptr;
+  int *d_sort_tmp[2] = {nullptr, nullptr};
   float *d_stage = nullptr;  // dense staging for get/set
   int64_t stage_floats = 0;
   std::vector<void *> allocs;
@@ -242,6 +250,11 @@ void ffm_engine_destroy(ffm_engine *e) {
   for (void *p : e->allocs) (void)hipFree(p);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  for (int i = 0; i < 2; i++) {
+    if (e->ev_grouped[i]) (void)hipEventDestroy(e->ev_grouped[i]);
+    if (e->ev_set_free[i]) (void)hipEventDestroy(e->ev_set_free[i]);
+  }
+  if (e->prep) (void)hipStreamDestroy(e->prep);
   if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
   if (e->ev_join3) (void)hipEventDestroy(e->ev_join3);
   if (e->aux3) (void)hipStreamDestroy(e->aux3);
@@ -324,7 +337,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&m.lin_w, nf));
   TRY_ALLOC(e->alloc(&m.lat, n_lat));
   const size_t R = static_cast<size_t>(e->max_rows), E = static_cast<size_t>(e->max_nnz);
-  Scratch &s = e->s;
+  Scratch &s = e->sc[0];
   TRY_ALLOC(e->alloc(&s.efeat, E));
   TRY_ALLOC(e->alloc(&s.row_of, E));
   TRY_ALLOC(e->alloc(&s.occ, E));
@@ -350,7 +363,34 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.tg, R));
   TRY_ALLOC(e->alloc(&s.loss, R));
   TRY_ALLOC(e->alloc(&s.svx, R * static_cast<size_t>(m.type == FFM_MODEL_FM ? m.n_factors : 1)));
-  TRY_ALLOC(e->alloc(&e->d_sort_tmp, E));
+  TRY_ALLOC(e->alloc(&e->d_sort_tmp[0], E));
+  {
+    Scratch &t = e->sc[1];
+    t = s;  // shared: head/next/rowtab/haux/hmeta/logit/tg/loss/svx
+    TRY_ALLOC(e->alloc(&t.efeat, E));
+    TRY_ALLOC(e->alloc(&t.row_of, E));
+    TRY_ALLOC(e->alloc(&t.occ, E));
+    TRY_ALLOC(e->alloc(&t.occ2, E));
+    TRY_ALLOC(e->alloc(&t.uniq, E));
+    TRY_ALLOC(e->alloc(&t.ustart, E));
+    TRY_ALLOC(e->alloc(&t.ucount, E));
+    TRY_ALLOC(e->alloc(&t.multi, E));
+    TRY_ALLOC(e->alloc(&t.small, E));
+    TRY_ALLOC(e->alloc(&t.big, E));
+    TRY_ALLOC(e->alloc(&t.huge, E));
+    TRY_ALLOC(e->alloc(&t.counters, 8));
+    TRY_ALLOC(e->alloc(&t.cnt, nf));
+    TRY_ALLOC(e->alloc(&t.fstart, nf));
+    TRY_ALLOC(e->alloc(&t.occpos, E));
+    TRY_ALLOC(e->alloc(&e->d_sort_tmp[1], E));
+    TRY_HIP(hipMemsetAsync(t.cnt, 0, nf * sizeof(int), e->stream));
+    TRY_HIP(hipMemsetAsync(t.counters, 0, 8 * sizeof(int), e->stream));
+  }
+  TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));
+    TRY_HIP(hipEventCreateWithFlags(&e->ev_set_free[i], hipEventDisableTiming));
+  }
   TRY_ALLOC(e->alloc(&e->d_row_ptr, R + 1));
   TRY_ALLOC(e->alloc(&e->d_field, E));
   TRY_ALLOC(e->alloc(&e->d_feat, E));
@@ -513,16 +553,55 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
   const size_t shmem = row_lds_bytes(e->max_row_nnz, e->m.n_fields);
   const int kid = train ? K_ROW : K_PREDICT_ROW;
   if (e->m.type == FFM_MODEL_FM) {
-    if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
-    else LAUNCH(e, kid, fm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, e->max_row_nnz, out, output_prob);
+    if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], e->max_row_nnz, out, output_prob);
+    else LAUNCH(e, kid, fm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], e->max_row_nnz, out, output_prob);
   } else {
     const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
     const int mr = e->max_row_nnz;
-    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, mr, out, output_prob);
-    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, mr, out, output_prob);
-    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, mr, out, output_prob);
-    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->s, mr, out, output_prob);
+    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob);
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob);
   }
+}
+
+static bool same_block(const Rows &a, const Rows &b) {
+  return a.n_rows == b.n_rows && a.nnz == b.nnz && a.row_ptr == b.row_ptr && a.field == b.field &&
+         a.feat == b.feat && a.val == b.val;
+}
+
+// Groups `rows` by feature into scratch set `set` on stream `st`.
+static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st) {
+  Scratch &sc = e->sc[set];
+  HIP_TRY(hipMemsetAsync(sc.counters, 0, 8 * sizeof(int), st));
+  if (rows.nnz > 0) {
+    const int nnz = rows.nnz;
+    LAUNCH_ON(e, st, K_GROUP_COUNT, group_count_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc);
+    LAUNCH_ON(e, st, K_GROUP_ALLOC, group_alloc_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, sc);
+    LAUNCH_ON(e, st, K_GROUP_SCATTER, group_scatter_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, rows, sc);
+    LAUNCH_ON(e, st, K_GROUP_SORT, group_sort_kernel, 1024, kGroupThreads, 0, sc, e->d_sort_tmp[set]);
+    LAUNCH_ON(e, st, K_GROUP_EXPAND, group_expand_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, nnz, sc);
+  }
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
+                              const int32_t *field, const int32_t *feat, const float *val) {
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  if (rc) return rc;
+  if (e->has_pending) return fail(FFM_E_INVALID, "prepare between train_forward and train_update");
+  if (e->prepared >= 0) return fail(FFM_E_INVALID, "a prepared block is already waiting");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  const int set = 1 - e->cur;
+  Rows rows{n_rows, nnz, row_ptr, field, feat, val, nullptr};
+  if (e->set_used[set]) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[set], 0));
+  rc = launch_grouping(e, set, rows, e->prep);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(e->ev_grouped[set], e->prep));
+  e->prepared = set;
+  e->prepared_rows = rows;
+  return FFM_OK;
 }
 
 int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
@@ -536,17 +615,27 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
   e->pending = rows;
   e->has_pending = true;
-  HIP_TRY(hipMemsetAsync(e->s.counters, 0, 8 * sizeof(int), e->stream));
-  if (nnz > 0) {
-    LAUNCH(e, K_GROUP_COUNT, group_count_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, e->s);
-    LAUNCH(e, K_GROUP_ALLOC, group_alloc_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, e->s);
-    LAUNCH(e, K_GROUP_SCATTER, group_scatter_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, rows, e->s);
-    LAUNCH(e, K_GROUP_SORT, group_sort_kernel, 1024, kGroupThreads, 0, e->s, e->d_sort_tmp);
-    LAUNCH(e, K_GROUP_EXPAND, group_expand_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, nnz, e->s);
+  const bool use_prepared = e->prepared >= 0 && same_block(e->prepared_rows, rows);
+  if (e->prepared >= 0 && !use_prepared) {
+    // a grouping made ahead for some other block: undo its counters, then forget it
+    if (e->prepared_rows.nnz > 0)
+      LAUNCH_ON(e, e->prep, K_GROUP_CLEANUP, group_cleanup_kernel, std::min(cdiv(e->prepared_rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, e->sc[e->prepared]);
+    HIP_TRY(hipEventRecord(e->ev_set_free[e->prepared], e->prep));
+    e->prepared = -1;
   }
+  if (use_prepared) {
+    e->cur = e->prepared;
+    e->prepared = -1;
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_grouped[e->cur], 0));
+  } else {
+    if (e->set_used[e->cur]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_set_free[e->cur], 0));
+    rc = launch_grouping(e, e->cur, rows, e->stream);
+    if (rc) return rc;
+  }
+  e->set_used[e->cur] = true;
   launch_row_kernel(e, rows, true, nullptr, 0);
   if (partial_logit && n_rows > 0)
-    HIP_TRY(hipMemcpyAsync(partial_logit, e->s.logit, sizeof(float) * n_rows, hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(partial_logit, e->sc[e->cur].logit, sizeof(float) * n_rows, hipMemcpyDeviceToDevice, e->stream));
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }
@@ -558,55 +647,56 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   const Rows rows = e->pending;
   e->has_pending = false;
-  const float *lg = logit ? logit : e->s.logit;
+  const float *lg = logit ? logit : e->sc[e->cur].logit;
   if (rows.n_rows > 0)
-    LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->s.tg, e->s.loss, logit_out);
+    LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->sc[e->cur].tg, e->sc[e->cur].loss, logit_out);
   if (loss_sum_out)
-    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->s.loss, loss_sum_out);
+    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
   if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0)
-    LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->s);
+    LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
   const bool lin_owner = e->m.shard_rank == 0;
   // the bias and linear chains are short and serial: run them beside the latent update
   const bool forked = rows.n_rows > 0 && lin_owner && !e->serial;
   if (rows.n_rows > 0 && lin_owner && e->serial) {
-    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->s);
+    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
     if (rows.nnz > 0)
-      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, std::min(cdiv(rows.nnz, kUpdThreads), 1024), kUpdThreads, 0, e->m, rows, e->s);
+      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, std::min(cdiv(rows.nnz, kUpdThreads), 1024), kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   }
   const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
   const bool vec4 = e->m.n_factors % 4 == 0;
   if (forked || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
   if (forked) {
     HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->s);
+    LAUNCH_ON(e, e->aux, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
     if (rows.nnz > 0)
-      LAUNCH_ON(e, e->aux, K_LINEAR_UPDATE, linear_update_kernel, std::min(cdiv(rows.nnz, kUpdThreads), 1024), kUpdThreads, 0, e->m, rows, e->s);
+      LAUNCH_ON(e, e->aux, K_LINEAR_UPDATE, linear_update_kernel, std::min(cdiv(rows.nnz, kUpdThreads), 1024), kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     HIP_TRY(hipEventRecord(e->ev_join, e->aux));
   }
   if (ffm && vec4 && e->serial) {
-    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   } else if (ffm && vec4) {
     // the three owner shapes touch disjoint features: run them side by side (long sequential
     // chains of the hot ones beside the bandwidth-shaped small-feature pass)
     HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   } else if (ffm) {
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
-    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->s);
+    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   }
   if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
   if (rows.nnz > 0)
-    LAUNCH(e, K_GROUP_CLEANUP, group_cleanup_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, e->s);
+    LAUNCH(e, K_GROUP_CLEANUP, group_cleanup_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, e->sc[e->cur]);
+  HIP_TRY(hipEventRecord(e->ev_set_free[e->cur], e->stream));
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }
@@ -633,7 +723,7 @@ int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
   launch_row_kernel(e, rows, false, out ? out : e->d_out, output_prob);
   if (loss_sum_out && label)
-    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, n_rows, e->s.loss, loss_sum_out);
+    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out);
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }
@@ -668,7 +758,7 @@ static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, co
 
 static int check_device_errors(ffm_engine *e) {
   int flags = 0;
-  HIP_TRY(hipMemcpyAsync(&flags, e->s.counters + CNT_ERROR, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(&flags, e->sc[e->cur].counters + CNT_ERROR, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (flags & ERR_ROW_TOO_LONG) return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz");
   return FFM_OK;
@@ -698,7 +788,7 @@ int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_p
   int32_t nnz = 0;
   int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
   if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(e->s.counters, 0, 8 * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->sc[e->cur].counters, 0, 8 * sizeof(int), e->stream));
   rc = ffm_engine_predict_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
                                        e->d_feat, e->d_val, label ? e->d_label : nullptr,
                                        output_prob, e->d_out, e->d_loss_sum);

@@ -61,6 +61,8 @@ ABI = [
      [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [_vp, _vp]),
     ("ffm_engine_predict_batch_device", ctypes.c_int,
      [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [ctypes.c_int32, _vp, _vp]),
+    ("ffm_engine_prepare_device", ctypes.c_int,
+     [_vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     ("ffm_engine_train_forward_device", ctypes.c_int,
      [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [_vp]),
     ("ffm_engine_train_update_device", ctypes.c_int, [_vp, _vp, _vp, _vp]),
@@ -218,6 +220,10 @@ class Engine:
                            loss_sum_out=None):
         self._check(self.lib.ffm_engine_train_batch_device(self.h, n_rows, nnz, row_ptr, field, feat,
                                                            val, label, logit_out, loss_sum_out))
+
+    def prepare_device(self, n_rows, nnz, row_ptr, field, feat, val):
+        """Look-ahead: group the next block on a side stream (see include/ffm_engine.h)."""
+        self._check(self.lib.ffm_engine_prepare_device(self.h, n_rows, nnz, row_ptr, field, feat, val))
 
     def train_forward_device(self, n_rows, nnz, row_ptr, field, feat, val, label, partial_logit):
         self._check(self.lib.ffm_engine_train_forward_device(self.h, n_rows, nnz, row_ptr, field,

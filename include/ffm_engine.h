@@ -137,6 +137,15 @@ int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
                                     const int32_t *feat, const float *val, const int32_t *label,
                                     int32_t output_prob, float *out, double *loss_sum_out);
 
+/* Optional look-ahead of the mini-batch scheduler: start grouping the NEXT block by feature (the
+ * integer-only first stage of training) on a side stream while the current block is still being
+ * updated.  The arrays must be complete in device memory when this is called and must be the very
+ * ones passed to the following ffm_engine_train_batch_device / train_forward_device call (same
+ * pointers and sizes); if a different block is trained next the look-ahead is discarded.  At most
+ * one block can be prepared ahead. */
+int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
+                              const int32_t *field, const int32_t *feat, const float *val);
+
 /* Split-phase training for field-pair sharding over several GPUs (n_shards > 1): phase 1 groups
  * the block, refreshes this shard's weights and writes this shard's PARTIAL logits (shard 0 adds
  * bias + linear) to partial_logit[n_rows] (device); the caller sums them across shards (one RCCL

@@ -353,3 +353,45 @@ def test_device_sigmoid_is_the_c_library_sigmoid():
     got = e.eval_sigmoid(x)
     assert_bitwise(got, want, "sigmoid")
     e.close()
+
+
+def test_lookahead_grouping_is_transparent():
+    """ffm_engine_prepare_device groups the next block on a side stream; results must be the bits
+    of the inline path -- also when the prepared block is NOT the one trained next (discarded)."""
+    F, k, per, B = 8, 16, 60, 256
+    nf = F * per
+    blocks = [synth.Generator(F, nf, "zipf", seed=5).block(B) for _ in range(1)][0:1]
+    g = synth.Generator(F, nf, "zipf", seed=5)
+    blocks = [g.block(B) for _ in range(5)]
+    dev = [{k_: torch.from_numpy(getattr(b, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+           for b in blocks]
+    torch.cuda.synchronize()
+
+    def run(mode):
+        e = fa.Engine("FFM", nf, F, k, max_batch_rows=B, seed=3, **STRESS_HP)
+        e.fill_state(seed=9)
+        out = torch.zeros(len(blocks), B, device="cuda")
+        for i, d in enumerate(dev):
+            e.train_batch_device(B, blocks[i].nnz, d["row_ptr"].data_ptr(), d["field"].data_ptr(),
+                                 d["feat"].data_ptr(), d["val"].data_ptr(), d["label"].data_ptr(),
+                                 out[i].data_ptr())
+            nxt = None
+            if mode == "ahead" and i + 1 < len(dev):
+                nxt = i + 1
+            if mode == "wrong" and i + 2 < len(dev):
+                nxt = i + 2  # prepares a block that is not trained next
+            if nxt is not None:
+                dn = dev[nxt]
+                e.prepare_device(B, blocks[nxt].nnz, dn["row_ptr"].data_ptr(), dn["field"].data_ptr(),
+                                 dn["feat"].data_ptr(), dn["val"].data_ptr())
+        e.sync()
+        st = e.get_state()
+        lg = out.cpu().numpy()
+        e.close()
+        return lg, st
+
+    base_l, base_s = run("inline")
+    for mode in ("ahead", "wrong"):
+        lg, st = run(mode)
+        assert_bitwise(lg, base_l, mode + " logits")
+        assert_state_bitwise(st, base_s, mode)

@@ -84,8 +84,9 @@ __device__ __forceinline__ void ffm_touch4(const Hyper &h, bool own_first, float
 // already final recompute the same value), i.e. exactly the additions the one-thread loop performs,
 // in its order.  Touch facts come as contiguous streams laid out by occurrence position (s.haux
 // from the row kernel, s.hmeta), prefetched two steps ahead; partner weights one step ahead.
-constexpr int kHotT = 8;  // touches per step (lanes per element)
-constexpr int kHotE = 8;  // elements per wave
+constexpr int kHotT = 4;             // touches per step (lanes per element)
+constexpr int kHotE = 64 / kHotT;    // elements per wave
+constexpr int kHotTShift = 2;        // log2(kHotT)
 
 __device__ __forceinline__ float dpp_row_shr1(float keep, float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v),
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const unsigned groups = (RL + kHotE - 1) / kHotE;
   const int lane = threadIdx.x & 63;
-  const int tl = lane & (kHotT - 1);  // which of the step's 8 touches
-  const int el = lane >> 3;           // which of the wave's 8 elements
+  const int tl = lane & (kHotT - 1);  // which of the step's touches
+  const int el = lane >> kHotTShift;  // which of the wave's elements
   const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const unsigned n_waves = gridDim.x * kUpdWaves;
   const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * groups;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
         nc = __shfl(S, lane | (kHotT - 1), 64);
         zc = __shfl(Z, lane | (kHotT - 1), 64);
         const unsigned long long sm = __ballot(simple);
-        touched = touched | (((sm >> (el * kHotT)) & 0xffull) != 0ull);
+        touched = touched | (((sm >> (el * kHotT)) & ((1ull << kHotT) - 1ull)) != 0ull);
       } else {
         // a multi-valued field in this step: its 8 touches one after another, every lane of an
         // element's group applying them to its copy of the running (n, z)

@@ -6,11 +6,12 @@
 
 One "step" = one pass of the hot path (group -> lazy refresh + forward -> FTRL update) over one
 block of synthetic libffm rows that is already resident in HBM.  Workload at N = 1: BASELINE.json's
-headline shape, FFM n_fields=39 n_factors=16, block = 8192 rows, Zipf(1.1) ids, the per-GPU slice
-of the 33M-feature config (n_feats = 4.125M, 30.9 GB of (w,n,z)).  N > 1: the latent tensor is
-field-pair sharded over the ranks (n_feats = 4.125M * N, block = 8192 * N rows); every rank sees
-the whole block, computes the partial logits of the field pairs it owns, one RCCL all-reduce sums
+headline configuration itself -- FFM n_fields=39 n_factors=16 n_feats=33M (247 GB of (w,n,z): it
+fits one MI355X), block = 8192 rows, Zipf(1.1) ids.  N > 1: the same 33M-feature tensor is
+field-pair sharded over the ranks and the block grows with N (8192 * N rows); every rank sees the
+whole block, computes the partial logits of the field pairs it owns, one RCCL all-reduce sums
 them, every rank updates its own slots -- per-GPU work is constant, so scaling is "weak".
+(This round every rank keeps full-length records, so capacity, not bandwidth, is replicated.)
 PyTorch is plumbing here (device buffers for the inputs, the process group); every byte of the
 path is moved by the hand-written kernels in ftrl-ffm_amd/csrc behind include/ffm_engine.h.
 """
@@ -26,7 +27,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_FIELDS, N_FACTORS, ROWS_PER_GPU = 39, 16, 8192
-FEATS_PER_GPU = 33_000_000 // 8
+FEATS_C5 = 33_000_000
+# BASELINE.json configs; only c5's single-GPU slice is the bench line, the others are for DESIGN.md
+CONFIGS = {
+    "c5": dict(model="FFM", fields=39, factors=16, rows=8192, feats=FEATS_C5),
+    "c2": dict(model="FFM", fields=8, factors=16, rows=4096, feats=10_000),
+    "c3": dict(model="FFM", fields=39, factors=4, rows=8192, feats=1_000_000),
+    "c4": dict(model="FM", fields=39, factors=64, rows=8192, feats=10_000_000),
+}
 PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
@@ -111,6 +119,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-lookahead", action="store_true", help="group each block inline")
+    ap.add_argument("--config", default="c5", choices=sorted(CONFIGS))
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend (gloo + --same-device: functional dry run of the "
+                         "multi-rank path on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (dry run)")
     args = ap.parse_args()
 
     import torch
@@ -127,22 +140,33 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run (one rank per GPU)" % n_gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     fa.build()
 
-    rows = args.rows or ROWS_PER_GPU * n_gpus
-    n_feats = args.n_feats or FEATS_PER_GPU * n_gpus
+    global N_FIELDS, N_FACTORS
+    cfgw = CONFIGS[args.config]
+    model = cfgw["model"]
+    N_FIELDS, N_FACTORS = cfgw["fields"], cfgw["factors"]
+    rows = args.rows or cfgw["rows"] * n_gpus
+    n_feats = args.n_feats or cfgw["feats"]
     n_feats -= n_feats % N_FIELDS
-    rec_bytes = 3 * N_FIELDS * N_FACTORS * 4
+    rec_bytes = 3 * (N_FIELDS if model == "FFM" else 1) * N_FACTORS * 4
     free_b, _total_b = torch.cuda.mem_get_info()
     reduced = False
-    budget = int(free_b * 0.85) - (2 << 30)
+    budget = int(free_b * 0.9) - (4 << 30)
+    if args.same_device:
+        budget //= max(world, 1)
     if n_feats * rec_bytes > budget:  # this round every shard stores full-length records
         n_feats = budget // rec_bytes
         n_feats -= n_feats % N_FIELDS
@@ -153,9 +177,28 @@ def main():
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    eng = fa.Engine("FFM", n_feats, N_FIELDS, N_FACTORS, max_batch_rows=rows,
-                    max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=world,
-                    shard_rank=rank, stream=stream, seed=42)
+    eng = None
+    while eng is None:  # an allocation that does not fit is retried 10 % smaller, never fatal
+        try:
+            eng = fa.Engine(model, n_feats, N_FIELDS, N_FACTORS, max_batch_rows=rows,
+                            max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=world,
+                            shard_rank=rank, stream=stream, seed=42)
+        except fa.EngineError as err:
+            if err.code != -3 or n_feats < 10 * N_FIELDS:
+                raise
+            n_feats = int(n_feats * 0.9)
+            n_feats -= n_feats % N_FIELDS
+            reduced = True
+    if dist is not None:  # every rank must train the same model shape
+        t = torch.tensor([n_feats], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) != n_feats:
+            n_feats = int(t.item())
+            eng.close()
+            eng = fa.Engine(model, n_feats, N_FIELDS, N_FACTORS, max_batch_rows=rows,
+                            max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=world,
+                            shard_rank=rank, stream=stream, seed=42)
+            reduced = True
     if args.state == "warm":
         eng.fill_state(seed=7, n_lo=0.05, n_hi=1.0, z_stddev=0.3)
 
@@ -165,6 +208,8 @@ def main():
     blocks_feat = []
     for _ in range(args.n_blocks):
         b = gen.block(rows)
+        if model != "FFM":
+            b.field[:] = 0  # libsvm rows
         blocks_feat.append(b.feat.copy())
         blocks.append(dict(
             n_rows=b.n_rows, nnz=b.nnz,
@@ -227,18 +272,23 @@ def main():
     losses = loss_sum[args.warmup:args.warmup + args.steps].cpu().numpy()
     total_rows = rows * args.steps
     value = total_rows / elapsed
-    bytes_row = algorithmic_bytes_per_row(N_FIELDS, N_FACTORS)
+    if model == "FFM":
+        bytes_row = algorithmic_bytes_per_row(N_FIELDS, N_FACTORS)
+    else:  # FM, SURVEY.md 8(d): nnz*k*20 + nnz*20 + 20 + nnz*8 + 8 + 12
+        bytes_row = N_FIELDS * N_FACTORS * 20 + N_FIELDS * 20 + 20 + N_FIELDS * 8 + 8 + 12
 
     if rank == 0:
         out = {
-            "metric": "train samples/sec + logloss, FFM f=39 k=16", "value": round(value, 1),
+            "metric": "train samples/sec + logloss, FFM f=39 k=16" if args.config == "c5" else
+                      "train samples/sec + logloss, " + args.config, "value": round(value, 1),
             "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "FFM n_fields=39 n_factors=16 nnz=39, %s ids, block=%d rows, n_feats=%d "
+                "workload": "%s n_fields=%d n_factors=%d nnz=%d, %s ids, block=%d rows, n_feats=%d "
                             "(%.1f GB of w,n,z per GPU), %s state, reference default hyper-parameters"
-                            % ("Zipf(1.1)" if args.dist == "zipf" else "uniform", rows, n_feats,
+                            % (model, N_FIELDS, N_FACTORS, N_FIELDS,
+                               "Zipf(1.1)" if args.dist == "zipf" else "uniform", rows, n_feats,
                                n_feats * rec_bytes / 1e9, args.state),
                 "rows_per_step": rows, "n_feats": n_feats, "n_feats_reduced_to_fit": reduced,
                 "sharding": "field-pair x%d, one all-reduce of %d partial logits per step"
@@ -247,7 +297,7 @@ def main():
             "train_logloss": round(float(losses.sum() / total_rows), 6),
             "step_algorithmic_GBps": round(value * bytes_row / n_gpus / 1e9, 1),
         }
-        if kname:
+        if kname and model == "FFM":
             share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, max(world, 1))
             avg_s = kms / 1000.0 / max(klaunches, 1)
             achieved = share / avg_s / 1e9
@@ -264,7 +314,7 @@ def main():
                 "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": klaunches,
                 "algorithmic_bytes_per_launch": int(share),
             }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and args.config == "c5":
             out["cpu_baseline"] = cpu_baseline(args, gen_kwargs)
         print(json.dumps(out), flush=True)
         if table:

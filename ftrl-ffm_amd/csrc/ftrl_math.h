@@ -99,20 +99,27 @@ __device__ __forceinline__ float ftrl_weight(const Hyper &h, float n, float z) {
   return (-num) / den;
 }
 
-// Four weights at once (one float4 of a slot): same arithmetic as ftrl_weight per component.
-__device__ __forceinline__ float4 ftrl_weight4(const Hyper &h, float4 n, float4 z) {
-  const float nn[4] = {n.x, n.y, n.z, n.w}, zz[4] = {z.x, z.y, z.z, z.w};
-  float sq[4], t[4], dv[4], w[4];
-  sqrt_cr_n<4>(nn, sq);
+// N weights at once (float4s of slots): same arithmetic as ftrl_weight per component, the square
+// roots and alpha divides each behind one wave vote and interleaved across the N values.
+template <int N>
+__device__ __forceinline__ void ftrl_weight_n(const Hyper &h, const float (&nn)[N],
+                                              const float (&zz)[N], float (&w)[N]) {
+  float sq[N], t[N], dv[N];
+  sqrt_cr_n<N>(nn, sq);
 #pragma unroll
-  for (int i = 0; i < 4; i++) t[i] = h.beta + sq[i];
-  div_alpha_n<4>(h, t, dv);
+  for (int i = 0; i < N; i++) t[i] = h.beta + sq[i];
+  div_alpha_n<N>(h, t, dv);
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < N; i++) {
     const float num = zz[i] - sgn_ref(zz[i]) * h.l1;
     const float den = h.l2 + dv[i];
     w[i] = fabsf(zz[i]) <= h.l1 ? 0.0f : (-num) / den;
   }
+}
+__device__ __forceinline__ float4 ftrl_weight4(const Hyper &h, float4 n, float4 z) {
+  const float nn[4] = {n.x, n.y, n.z, n.w}, zz[4] = {z.x, z.y, z.z, z.w};
+  float w[4];
+  ftrl_weight_n<4>(h, nn, zz, w);
   return make_float4(w[0], w[1], w[2], w[3]);
 }
 

@@ -39,7 +39,8 @@ def build(force=False, verbose=False):
 
 
 HOST = os.path.join(HERE, "host")
-HOST_SRCS = ["cmd_option.cpp", "parser.cpp", "reader.cpp", "ftrl_model.cpp", "trainer.cpp"]
+HOST_SRCS = ["cmd_option.cpp", "parser.cpp", "reader.cpp", "ftrl_model.cpp", "trainer.cpp",
+             "persist.cpp"]
 MAIN_BIN = os.path.join(HOST, "ftrl_ffm_main")
 TEST_BIN = os.path.join(HOST, "host_tests")
 
@@ -55,7 +56,7 @@ def build_host(force=False, verbose=False):
                 and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps)):
             continue
         cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-o", out,
-               os.path.join(HOST, main)] + srcs + [LIB, "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+               os.path.join(HOST, main)] + srcs + [LIB, "-ldl", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

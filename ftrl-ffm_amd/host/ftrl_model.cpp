@@ -1,5 +1,7 @@
 #include "ftrl_model.h"
 
+#include "persist.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -117,6 +119,54 @@ void FtrlModel::push_weights() {
     std::copy(vec_w[i].begin(), vec_w[i].end(), flat.begin() + i * row_len_);
   check(ffm_engine_set_weights(eng_, &bias, lin_w.data(), flat.empty() ? nullptr : flat.data()),
         "ffm_engine_set_weights");
+}
+
+static ModelWeights gather(FtrlModel &m, int64_t row_len) {
+  m.pull_weights();
+  ModelWeights w;
+  w.bias = m.bias;
+  w.lin_w = m.lin_w;
+  w.vec_w.reserve(m.vec_w.size() * static_cast<size_t>(row_len));
+  for (const auto &v : m.vec_w) w.vec_w.insert(w.vec_w.end(), v.begin(), v.end());
+  return w;
+}
+
+static void scatter(FtrlModel &m, const ModelWeights &w, int64_t row_len) {
+  m.bias = w.bias;
+  m.lin_w = w.lin_w;
+  for (size_t i = 0; i < m.vec_w.size(); i++)
+    std::copy(w.vec_w.begin() + i * row_len, w.vec_w.begin() + (i + 1) * row_len, m.vec_w[i].begin());
+  m.push_weights();
+}
+
+void FtrlModel::save_model(const std::string &file_name) {
+  write_text_model(file_name, gather(*this, row_len_), n_feats, static_cast<size_t>(row_len_));
+}
+void FtrlModel::load_model(const std::string &file_name) {
+  scatter(*this, read_text_model(file_name, n_feats, static_cast<size_t>(row_len_)), row_len_);
+}
+void FtrlModel::save_compressed_model(const std::string &file_name, int compress_level) {
+  write_compressed_model(file_name, gather(*this, row_len_), compress_level);
+}
+void FtrlModel::load_compressed_model(const std::string &file_name) {
+  scatter(*this, read_compressed_model(file_name, n_feats, static_cast<size_t>(row_len_)), row_len_);
+}
+
+void FtrlModel::save_state(const std::string &file_name, int compress_level) {
+  const size_t nf = static_cast<size_t>(n_feats), nv = nf * static_cast<size_t>(row_len_);
+  std::vector<float> flat(2 + 2 * nf + 2 * nv);
+  check(ffm_engine_get_state(eng_, &flat[0], &flat[1], &flat[2], &flat[2 + nf],
+                             nv ? &flat[2 + 2 * nf] : nullptr, nv ? &flat[2 + 2 * nf + nv] : nullptr),
+        "ffm_engine_get_state");
+  write_compressed_floats(file_name, flat, compress_level);
+}
+void FtrlModel::load_state(const std::string &file_name) {
+  const size_t nf = static_cast<size_t>(n_feats), nv = nf * static_cast<size_t>(row_len_);
+  const std::vector<float> flat = read_compressed_floats(file_name);
+  if (flat.size() != 2 + 2 * nf + 2 * nv) throw std::runtime_error(file_name + ": wrong shape");
+  check(ffm_engine_set_state(eng_, &flat[0], &flat[1], &flat[2], &flat[2 + nf],
+                             nv ? &flat[2 + 2 * nf] : nullptr, nv ? &flat[2 + 2 * nf + nv] : nullptr),
+        "ffm_engine_set_state");
 }
 
 bool FtrlModel::has_zero_weights() {  // utils.h:63-76 over lin_w and vec_w

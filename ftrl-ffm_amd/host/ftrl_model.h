@@ -36,6 +36,16 @@ class FtrlModel {
   double train_block(const CsrBlock &blk, float *logit_out = nullptr);
   double predict_block(const CsrBlock &blk, bool output_prob, float *out = nullptr);
 
+  // Model files in the reference's formats (ffm.cpp:138-200, lr.cpp:26-39); available for every
+  // model type here (the reference has none for FM).  save_state/load_state add the FTRL
+  // accumulators, which make a checkpoint resumable.
+  void save_model(const std::string &file_name);
+  void load_model(const std::string &file_name);
+  void save_compressed_model(const std::string &file_name, int compress_level);
+  void load_compressed_model(const std::string &file_name);
+  void save_state(const std::string &file_name, int compress_level = 3);
+  void load_state(const std::string &file_name);
+
   void pull_weights();  // device -> bias / lin_w / vec_w
   void push_weights();  // bias / lin_w / vec_w -> device
   bool has_zero_weights();

@@ -12,6 +12,7 @@
 
 #include "cmd_option.h"
 #include "ftrl_model.h"
+#include "persist.h"
 #include "reader.h"
 #include "trainer.h"
 
@@ -141,6 +142,53 @@ static void test_models_gpu() {  // tests/test_model.cpp:22-49
   }
 }
 
+static void test_persistence_gpu() {  // tests/test_model.cpp:51-102
+  feat_vec sample = {{1, 3, 3}, {1, 0, 1}, {1, 2, 0}, {3, 10, 1}, {12, 4, 0}, {111, 1, 0}, {8, 8, 8}};
+  {  // LR save & load compressed
+    ftrl::LR model{small_args("LR")};
+    feat_vec s1 = sample;
+    const float pred = model.predict(s1, false);
+    model.save_compressed_model("lr.zst", 10);
+    auto a2 = small_args("LR");
+    a2.seed = 9;
+    ftrl::LR fresh{a2};
+    feat_vec s2 = sample;
+    CHECK(fresh.predict(s2, false) != pred);
+    fresh.load_compressed_model("lr.zst");
+    feat_vec s3 = sample;
+    CHECK(fresh.predict(s3, false) == pred);
+    std::remove("lr.zst");
+  }
+  {  // FFM save & load, text (approximate) and compressed (exact)
+    ftrl::FFM model{small_args("FFM")};
+    feat_vec s1 = sample;
+    const float pred = model.predict(s1, false);
+    model.save_model("ffm.txt");
+    model.save_compressed_model("ffm.zst", 10);
+    auto a2 = small_args("FFM");
+    a2.seed = 9;
+    ftrl::FFM t{a2}, z{a2};
+    feat_vec s2 = sample;
+    CHECK(t.predict(s2, false) != pred);
+    t.load_model("ffm.txt");
+    feat_vec s3 = sample;
+    CHECK(std::fabs(t.predict(s3, false) - pred) <= 1e-4f * std::fabs(pred) + 1e-7f);
+    z.load_compressed_model("ffm.zst");
+    feat_vec s4 = sample;
+    CHECK(z.predict(s4, false) == pred);
+    // resumable: weights + accumulators restored -> the next train() steps agree exactly
+    feat_vec r1 = {{0, 1, 1.0f}, {1, 13, 1.0f}, {2, 21, 0.5f}}, r2 = r1, r3 = r1, r4 = r1;
+    model.train(r1, 1);
+    model.save_compressed_model("ffm2.zst", 3);
+    model.save_state("ffm2.nz");
+    const float next = model.train(r2, 0);
+    z.load_compressed_model("ffm2.zst");
+    z.load_state("ffm2.nz");
+    CHECK(z.train(r3, 0) == next);
+    std::remove("ffm.txt"); std::remove("ffm.zst"); std::remove("ffm2.zst"); std::remove("ffm2.nz");
+  }
+}
+
 static void test_tasks_gpu() {  // tests/test_task.cpp:25-43
   for (int online = 0; online < 2; online++) {
     write_fixture();
@@ -157,13 +205,29 @@ static void test_tasks_gpu() {  // tests/test_task.cpp:25-43
   }
 }
 
+// host_tests convert <in> <out> <n_feats> <row_len>: re-encode a model file (".zst" = one zstd
+// frame, anything else = text) with the pure file functions; used to cross-check the formats
+// against files written / read by the compiled reference.
+static int convert(int argc, char **argv) {
+  if (argc < 6) return 2;
+  const std::string in = argv[2], out = argv[3];
+  const size_t nf = std::stoul(argv[4]), rl = std::stoul(argv[5]);
+  auto is_zst = [](const std::string &p) { return p.size() > 4 && p.substr(p.size() - 4) == ".zst"; };
+  const ftrl::ModelWeights w = is_zst(in) ? ftrl::read_compressed_model(in, nf, rl)
+                                          : ftrl::read_text_model(in, nf, rl);
+  if (is_zst(out)) ftrl::write_compressed_model(out, w, 3); else ftrl::write_text_model(out, w, nf, rl);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::strcmp(argv[1], "convert") == 0) return convert(argc, argv);
   const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
   test_reader_and_parsers();
   test_flags();
   test_loss_known_answers();
   if (gpu) {
     test_models_gpu();
+    test_persistence_gpu();
     test_tasks_gpu();
   }
   std::printf("%s: %d checks, %d failed\n", gpu ? "host tests (cpu+gpu)" : "host tests (cpu)", g_checked, g_failed);

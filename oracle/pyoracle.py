@@ -128,6 +128,8 @@ def _lib(kind):
         lib.fr_set_state.argtypes = fp7
         lib.fr_remove_out_range.restype = ctypes.c_int
         lib.fr_remove_out_range.argtypes = [vp, ctypes.c_int, _c_i32p, _c_i32p, _c_f32p]
+        lib.fr_save_model.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        lib.fr_load_model.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
         lib.fr_sgn_int.restype = ctypes.c_int
         lib.fr_sgn_int.argtypes = [ctypes.c_int]
     _libs[kind] = (lib, p)

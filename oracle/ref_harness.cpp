@@ -154,6 +154,20 @@ int fr_remove_out_range(void *h, int nnz, const int32_t *field, const int32_t *f
   return static_cast<int>(x.size());
 }
 
+// persistence of the reference itself (src/model/ffm.cpp:138-200), for file-format cross checks
+int fr_save_model(void *h, const char *path, int compressed, int level) {
+  auto *m = static_cast<fr_model *>(h);
+  if (!m->ffm) return -1;
+  if (compressed) m->ffm->save_compressed_model(path, level); else m->ffm->save_model(path);
+  return 0;
+}
+int fr_load_model(void *h, const char *path, int compressed) {
+  auto *m = static_cast<fr_model *>(h);
+  if (!m->ffm) return -1;
+  if (compressed) m->ffm->load_compressed_model(path); else m->ffm->load_model(path);
+  return 0;
+}
+
 // file order, one thread: what FtrlOnline::run_task does (src/task/ftrl_online.cpp:70-80)
 double fr_train_rows(void *h, int n_rows, const int32_t *row_ptr, const int32_t *field,
                      const int32_t *feat, const float *val, const int32_t *label,

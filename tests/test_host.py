@@ -81,3 +81,55 @@ def test_cli_config1_lr_on_libsvm(tmp_path):
     tr = float(re.findall(r"train loss: ([0-9.]+)", out.stdout)[0])
     ev = float(re.findall(r"eval loss: ([0-9.]+)", out.stdout)[0])
     assert abs(tr - 0.6907) < 2e-4 and abs(ev - 0.6893) < 2e-4
+
+
+from oracle import pyoracle  # noqa: E402
+
+needs_ref = pytest.mark.skipif(not pyoracle.have_ref(), reason="oracle/_ref not built here")
+
+
+@needs_ref
+def test_model_files_interoperate_with_the_reference(tmp_path):
+    """Files written by the reference (ffm.cpp:138-180) are read by the host's file functions and
+    vice versa: zstd frames exactly, the text format to its printed precision."""
+    from oracle.pyoracle import CpuModel
+    from util import rand_state
+    pyoracle.build(ref=True)
+    _, test_bin = fa.build_host()
+    nf, F, k = 30, 3, 4
+    rng = np.random.default_rng(3)
+    ref = CpuModel("ref", "FFM", nf, F, k)
+    st = rand_state(rng, ref)
+    ref.set_state(st)
+    zst, txt = str(tmp_path / "ref.zst"), str(tmp_path / "ref.txt")
+    assert ref.lib.fr_save_model(ref.h, zst.encode(), 1, 5) == 0
+    assert ref.lib.fr_save_model(ref.h, txt.encode(), 0, 0) == 0
+    # reference zst -> host -> text and zst again
+    mine_txt, mine_zst = str(tmp_path / "mine.txt"), str(tmp_path / "mine.zst")
+    for src, dst in ((zst, mine_zst), (zst, mine_txt), (txt, str(tmp_path / "from_txt.zst"))):
+        out = subprocess.run([test_bin, "convert", src, dst, str(nf), str(F * k)], cwd=tmp_path,
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+    # host-written zst read back by the reference: exact weights
+    ref2 = CpuModel("ref", "FFM", nf, F, k)
+    assert ref2.lib.fr_load_model(ref2.h, mine_zst.encode(), 1) == 0
+    got = ref2.get_state()
+    for key in ("bias3", "lin_w", "vec_w"):
+        want = st[key].copy()
+        if key == "bias3":
+            assert got[key][0] == want[0]
+        else:
+            assert np.array_equal(got[key], want), key
+    # host-written text read back by the reference: vec_w exactly (9 significant digits), bias and
+    # lin_w to the 6 digits an ostream prints
+    ref3 = CpuModel("ref", "FFM", nf, F, k)
+    assert ref3.lib.fr_load_model(ref3.h, mine_txt.encode(), 0) == 0
+    got = ref3.get_state()
+    assert np.array_equal(got["vec_w"], st["vec_w"])
+    assert np.allclose(got["lin_w"], st["lin_w"], rtol=1e-5)
+    # reference-written text -> host zst -> reference: what the text held, exactly
+    ref4, ref5 = CpuModel("ref", "FFM", nf, F, k), CpuModel("ref", "FFM", nf, F, k)
+    assert ref4.lib.fr_load_model(ref4.h, str(tmp_path / "from_txt.zst").encode(), 1) == 0
+    assert ref5.lib.fr_load_model(ref5.h, txt.encode(), 0) == 0
+    a, b = ref4.get_state(), ref5.get_state()
+    assert np.array_equal(a["vec_w"], b["vec_w"]) and np.array_equal(a["lin_w"], b["lin_w"])

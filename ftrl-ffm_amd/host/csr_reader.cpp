@@ -1,0 +1,170 @@
+#include "csr_reader.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <charconv>
+#include <cstdio>
+#include <cstdlib>
+#include <future>
+#include <iostream>
+#include <stdexcept>
+
+namespace ftrl {
+namespace {
+
+struct Part {
+  std::vector<int32_t> nnz, field, feat, label;
+  std::vector<float> val;
+};
+
+[[noreturn]] void bad_line(const char *b, const char *e) {
+  const std::string line(b, e);
+  std::cout << "wrong input: " << line << std::endl;
+  throw std::out_of_range(line);
+}
+
+inline int to_int(const char *b, const char *e, const char *lb, const char *le) {
+  int v = 0;
+  if (b < e && *b == '+') b++;
+  const auto r = std::from_chars(b, e, v);
+  if (r.ec != std::errc() || r.ptr == b) bad_line(lb, le);
+  return v;
+}
+inline float to_float(const char *b, const char *e, const char *lb, const char *le) {
+  float v = 0.0f;
+  if (b < e && *b == '+') b++;
+  const auto r = std::from_chars(b, e, v);
+  if (r.ec == std::errc::result_out_of_range) return std::strtof(std::string(b, e).c_str(), nullptr);
+  if (r.ec != std::errc() || r.ptr == b) bad_line(lb, le);
+  return v;
+}
+
+void parse_range(const char *p, const char *end, bool has_field, Part &out) {
+  while (p < end) {
+    const char *le = p;
+    while (le < end && *le != '\n') le++;
+    const char *lb = p;
+    const char *q = lb, *stop = le;
+    if (stop > lb && stop[-1] == '\r') stop--;
+    while (q < stop && *q == ' ') q++;
+    if (q < stop) {
+      const char *t = q;
+      while (t < stop && *t != ' ') t++;
+      out.label.push_back(to_int(q, t, lb, le) > 0 ? 1 : 0);
+      int n = 0;
+      q = t;
+      while (true) {
+        while (q < stop && *q == ' ') q++;
+        if (q >= stop) break;
+        t = q;
+        while (t < stop && *t != ' ') t++;
+        const char *c1 = q;
+        while (c1 < t && *c1 != ':') c1++;
+        if (c1 >= t) bad_line(lb, le);
+        int fld = 0, ft;
+        const char *vb;
+        if (has_field) {
+          fld = to_int(q, c1, lb, le);
+          const char *c2 = c1 + 1;
+          while (c2 < t && *c2 != ':') c2++;
+          if (c2 >= t) bad_line(lb, le);
+          ft = to_int(c1 + 1, c2, lb, le);
+          vb = c2 + 1;
+        } else {
+          ft = to_int(q, c1, lb, le);
+          vb = c1 + 1;
+        }
+        if (vb >= t) bad_line(lb, le);
+        const float v = to_float(vb, t, lb, le);
+        if (v != 0.0f) {
+          out.field.push_back(fld);
+          out.feat.push_back(ft);
+          out.val.push_back(v);
+          n++;
+        }
+        q = t;
+      }
+      out.nnz.push_back(n);
+    }
+    p = le + 1;
+  }
+}
+
+}  // namespace
+
+void CsrData::slice(size_t r0, size_t r1, CsrBlock &out) const {
+  out.clear();
+  const int64_t b = row_ptr[r0], e = row_ptr[r1];
+  out.field.assign(field.begin() + b, field.begin() + e);
+  out.feat.assign(feat.begin() + b, feat.begin() + e);
+  out.val.assign(val.begin() + b, val.begin() + e);
+  out.label.assign(label.begin() + r0, label.begin() + r1);
+  out.row_ptr.resize(r1 - r0 + 1);
+  for (size_t r = r0; r <= r1; r++) out.row_ptr[r - r0] = static_cast<int32_t>(row_ptr[r] - b);
+}
+
+void CsrData::gather(const int *idx, size_t n, CsrBlock &out) const {
+  out.clear();
+  for (size_t j = 0; j < n; j++) {
+    const int64_t b = row_ptr[idx[j]], e = row_ptr[idx[j] + 1];
+    out.field.insert(out.field.end(), field.begin() + b, field.begin() + e);
+    out.feat.insert(out.feat.end(), feat.begin() + b, feat.begin() + e);
+    out.val.insert(out.val.end(), val.begin() + b, val.begin() + e);
+    out.row_ptr.push_back(static_cast<int32_t>(out.feat.size()));
+    out.label.push_back(label[idx[j]]);
+  }
+}
+
+CsrData load_csr(const std::string &path, const std::string &file_type, int n_threads) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) {
+    std::cerr << "fail to open " << path << std::endl;
+    std::exit(EXIT_FAILURE);
+  }
+  struct stat st {};
+  fstat(fd, &st);
+  const size_t len = static_cast<size_t>(st.st_size);
+  CsrData out;
+  if (len == 0) { close(fd); return out; }
+  const char *base = static_cast<const char *>(mmap(nullptr, len, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0));
+  if (base == MAP_FAILED) { close(fd); throw std::runtime_error("mmap failed: " + path); }
+  if (n_threads < 1) n_threads = 1;
+  std::vector<size_t> cut(static_cast<size_t>(n_threads) + 1, len);
+  cut[0] = 0;
+  for (int i = 1; i < n_threads; i++) {
+    size_t pos = len / n_threads * i;
+    while (pos < len && base[pos] != '\n') pos++;
+    cut[i] = pos < len ? pos + 1 : len;
+  }
+  const bool has_field = file_type == "libffm";
+  std::vector<Part> parts(n_threads);
+  std::vector<std::future<void>> futs;
+  for (int i = 0; i < n_threads; i++)
+    futs.emplace_back(std::async(std::launch::async, [&, i] {
+      if (cut[i] >= cut[i + 1]) return;
+      const size_t bytes = cut[i + 1] - cut[i];  // a token is >= 4 bytes, a row >= ~8
+      parts[i].feat.reserve(bytes / 6); parts[i].field.reserve(bytes / 6);
+      parts[i].val.reserve(bytes / 6); parts[i].nnz.reserve(bytes / 32); parts[i].label.reserve(bytes / 32);
+      parse_range(base + cut[i], base + cut[i + 1], has_field, parts[i]);
+    }));
+  for (auto &f : futs) f.get();
+  size_t rows = 0, nnz = 0;
+  for (auto &p : parts) { rows += p.nnz.size(); nnz += p.feat.size(); }
+  out.row_ptr.reserve(rows + 1);
+  out.field.reserve(nnz); out.feat.reserve(nnz); out.val.reserve(nnz); out.label.reserve(rows);
+  for (auto &p : parts) {
+    for (int n : p.nnz) out.row_ptr.push_back(out.row_ptr.back() + n);
+    out.field.insert(out.field.end(), p.field.begin(), p.field.end());
+    out.feat.insert(out.feat.end(), p.feat.begin(), p.feat.end());
+    out.val.insert(out.val.end(), p.val.begin(), p.val.end());
+    out.label.insert(out.label.end(), p.label.begin(), p.label.end());
+  }
+  munmap(const_cast<char *>(base), len);
+  close(fd);
+  return out;
+}
+
+}  // namespace ftrl

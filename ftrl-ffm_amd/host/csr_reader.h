@@ -1,0 +1,29 @@
+// csr_reader.h -- the file straight into the engine's CSR wire format: mmap, one byte range per
+// thread cut at line starts (the partitioning of reference src/data/reader.cpp:22-48), numbers
+// parsed in place with std::from_chars -- no per-row std::vector<std::tuple>.  Same acceptance rules
+// as the line parsers (parser.cpp:11-103): label > 0 -> 1, zero values dropped, libsvm field 0,
+// malformed token -> std::out_of_range.  This is what feeds the GPU at millions of rows/s; the
+// Sample-based Reader stays for API parity.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "types.h"
+
+namespace ftrl {
+
+struct CsrData {
+  std::vector<int64_t> row_ptr{0};
+  std::vector<int32_t> field, feat, label;
+  std::vector<float> val;
+  size_t n_rows() const { return row_ptr.size() - 1; }
+  // rows [r0, r1) as one block
+  void slice(size_t r0, size_t r1, CsrBlock &out) const;
+  // rows idx[0..n) (any order) as one block -- the offline trainer's shuffled visit
+  void gather(const int *idx, size_t n, CsrBlock &out) const;
+};
+
+CsrData load_csr(const std::string &path, const std::string &file_type, int n_threads);
+
+}  // namespace ftrl

@@ -3,6 +3,7 @@
 // tests/test_task.cpp:25-43, tests/test_utils.cpp:40-43), plus flag parsing and parser errors.
 //   host_tests cpu   -> everything that needs no GPU (reader, parsers, flags, loss)
 //   host_tests gpu   -> model shapes, remove_out_range, weight round trip, online/offline tasks
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -11,6 +12,7 @@
 #include <string>
 
 #include "cmd_option.h"
+#include "csr_reader.h"
 #include "ftrl_model.h"
 #include "persist.h"
 #include "reader.h"
@@ -55,6 +57,55 @@ static void test_reader_and_parsers() {
   try { sp.parse("1 12", s); } catch (const std::out_of_range &) { threw = true; }
   CHECK(threw);
   CHECK(detect_file_type(kPath) == "libffm");
+  std::remove(kPath);
+}
+
+static void test_csr_reader_matches_line_parsers() {
+  // a ragged libffm file: zero values, spaces, negative label, multi-valued fields
+  std::string text;
+  unsigned s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+  for (int r = 0; r < 5000; r++) {
+    text += std::to_string(static_cast<int>(rnd() % 3) - 1);
+    const int nnz = rnd() % 12;
+    for (int j = 0; j < nnz; j++) {
+      char tok[64];
+      const int v = rnd() % 5;
+      std::snprintf(tok, sizeof tok, " %u:%u:%s", rnd() % 8, rnd() % 10000,
+                    v == 0 ? "0" : v == 1 ? "1" : v == 2 ? "0.6182" : v == 3 ? "2.5e-3" : "17");
+      text += tok;
+      if (rnd() % 7 == 0) text += " ";
+    }
+    text += "\n";
+  }
+  { std::ofstream(kPath) << text; }
+  ftrl::Reader reader("libffm");
+  reader.load_from_file(kPath, 3);
+  for (int threads : {1, 4}) {
+    const ftrl::CsrData d = ftrl::load_csr(kPath, "libffm", threads);
+    CHECK(d.n_rows() == reader.get_size());
+    bool same = d.n_rows() == reader.get_size();
+    for (size_t r = 0; same && r < d.n_rows(); r++) {
+      const auto &x = reader.data[r].x;
+      same = same && d.label[r] == reader.data[r].y &&
+             static_cast<size_t>(d.row_ptr[r + 1] - d.row_ptr[r]) == x.size();
+      for (size_t j = 0; same && j < x.size(); j++) {
+        const int64_t p = d.row_ptr[r] + static_cast<int64_t>(j);
+        same = d.field[p] == std::get<0>(x[j]) && d.feat[p] == std::get<1>(x[j]) &&
+               d.val[p] == std::get<2>(x[j]);
+      }
+    }
+    CHECK(same);
+    CsrBlock b1, b2;
+    d.slice(10, 20, b1);
+    const int idx[3] = {19, 10, 4000};
+    d.gather(idx, 3, b2);
+    CHECK(b1.n_rows() == 10 && b2.n_rows() == 3 && b2.label[1] == d.label[10]);
+  }
+  bool threw = false;
+  { std::ofstream(kPath) << "1 0:5:1\n0 3:7\n"; }
+  try { ftrl::load_csr(kPath, "libffm", 1); } catch (const std::out_of_range &) { threw = true; }
+  CHECK(threw);
   std::remove(kPath);
 }
 
@@ -219,10 +270,28 @@ static int convert(int argc, char **argv) {
   return 0;
 }
 
+// host_tests ingest <file> <libffm|libsvm> <threads>: rows/s of the two readers
+static int ingest(int argc, char **argv) {
+  if (argc < 5) return 2;
+  const int threads = std::stoi(argv[4]);
+  auto t0 = std::chrono::steady_clock::now();
+  const ftrl::CsrData d = ftrl::load_csr(argv[2], argv[3], threads);
+  const double s1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  t0 = std::chrono::steady_clock::now();
+  ftrl::Reader reader(argv[3]);
+  reader.load_from_file(argv[2], threads);
+  const double s2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("rows %zu  csr_reader %.0f rows/s  sample_reader %.0f rows/s  (threads %d)\n",
+              d.n_rows(), d.n_rows() / s1, reader.get_size() / s2, threads);
+  return d.n_rows() == reader.get_size() ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && std::strcmp(argv[1], "convert") == 0) return convert(argc, argv);
+  if (argc > 1 && std::strcmp(argv[1], "ingest") == 0) return ingest(argc, argv);
   const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
   test_reader_and_parsers();
+  test_csr_reader_matches_line_parsers();
   test_flags();
   test_loss_known_answers();
   if (gpu) {

@@ -19,26 +19,57 @@ static double seconds_since(timer::time_point t0) {
 FtrlOffline::FtrlOffline(const config_options &opt)
     : model_ptr(make_model(opt)), n_epochs(opt.epoch), n_threads(opt.thread_num), seed_(opt.seed),
       sched_(opt.batch_size, opt.batch_ramp) {
+  // the files go straight into CSR (csr_reader.h); the Sample-based readers exist for callers
+  // that use one_epoch(std::vector<Sample>&, ...) as the reference's tests do
   train_data_loader = std::make_unique<Reader>(opt.file_type);
-  train_data_loader->load_from_file(opt.train_path, n_threads);
+  std::printf("Loading data from file: %s\n", opt.train_path.c_str());
+  const auto t0 = timer::now();
+  train_csr_ = load_csr(opt.train_path, opt.file_type, n_threads);
+  std::printf("Total number of samples loaded: %zu\nparsing data time: %.4lfs\n",
+              train_csr_.n_rows(), seconds_since(t0));
   if (!opt.eval_path.empty()) {
     eval_data_loader = std::make_unique<Reader>(opt.file_type);
-    eval_data_loader->load_from_file(opt.eval_path, n_threads);
+    eval_csr_ = load_csr(opt.eval_path, opt.file_type, n_threads);
+    has_eval_ = true;
   }
+}
+
+// One pass over a CSR file image: training visits the rows in a seeded shuffle, block by block;
+// evaluation in file order.  Mean of loss(y, logit) over all rows.
+double FtrlOffline::csr_epoch(const CsrData &d, bool train) {
+  const size_t total = d.n_rows();
+  if (total == 0) return 0.0;
+  std::vector<int> indices;
+  if (train) {
+    indices.resize(total);
+    std::iota(indices.begin(), indices.end(), 0);
+    std::shuffle(indices.begin(), indices.end(), std::mt19937_64{seed_ + (++epoch_no_)});
+  }
+  double total_loss = 0.0;
+  CsrBlock blk;
+  size_t pos = 0;
+  while (pos < total) {
+    const size_t rows = std::min<size_t>(train ? sched_.next_block_rows() : sched_.max_block_rows(), total - pos);
+    if (train) d.gather(indices.data() + pos, rows, blk); else d.slice(pos, pos + rows, blk);
+    total_loss += train ? model_ptr->train_block(blk) : model_ptr->predict_block(blk, false);
+    if (train) sched_.consumed(static_cast<int>(rows));
+    pos += rows;
+  }
+  return total_loss / static_cast<double>(total);
 }
 
 void FtrlOffline::train() {
   for (int i = 1; i <= n_epochs; i++) {
     const auto t0 = timer::now();
-    const double train_loss = one_epoch(train_data_loader->data, true, true);
+    const double train_loss = csr_epoch(train_csr_, true);
     std::printf("epoch %d train time: %.4lfs, train loss: %.4lf\n", i, seconds_since(t0), train_loss);
-    if (eval_data_loader != nullptr) evaluate(i);
+    if (has_eval_) evaluate(i);
   }
 }
 
 void FtrlOffline::evaluate(int epoch) {
   const auto t0 = timer::now();
-  const double eval_loss = one_epoch(eval_data_loader->data, false, false);
+  const double eval_loss = csr_epoch(eval_csr_, false);
   std::printf("epoch %d eval time: %.4lfs, eval loss: %.4lf\n", epoch, seconds_since(t0), eval_loss);
 }
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "ftrl_model.h"
+#include "csr_reader.h"
 #include "reader.h"
 
 namespace ftrl {
@@ -53,7 +54,11 @@ class FtrlOffline {
   uint64_t seed_;
   int epoch_no_ = 0;
   BlockScheduler sched_;
-  std::unique_ptr<Reader> train_data_loader, eval_data_loader;
+  std::unique_ptr<Reader> train_data_loader, eval_data_loader;  // API parity (data stays empty
+                                                                // unless load_samples() is called)
+  CsrData train_csr_, eval_csr_;                                // what train()/evaluate() walk
+  bool has_eval_ = false;
+  double csr_epoch(const CsrData &d, bool train);
 };
 
 class FtrlOnline {

@@ -164,6 +164,7 @@ struct ffm_engine {
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // profiling
   bool prof_on = false;
+  int prof_only = -1;  // >= 0: record only this kernel id (ffm_engine_profile_focus)
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> event_pool;
 
@@ -191,13 +192,15 @@ struct ffm_engine {
     return e;
   }
   void prof_begin(int kid, hipStream_t st) {
-    if (!prof_on) return;
+    prof_skip = !prof_on || (prof_only >= 0 && kid != prof_only);
+    if (prof_skip) return;
     ProfRec r{kid, get_event(), get_event()};
     (void)hipEventRecord(r.e0, st);
     prof.push_back(r);
   }
+  bool prof_skip = true;
   void prof_end(hipStream_t st) {
-    if (!prof_on) return;
+    if (prof_skip) return;
     (void)hipEventRecord(prof.back().e1, st);
   }
 };
@@ -807,16 +810,33 @@ int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_p
 int ffm_engine_profile_enable(ffm_engine *e, int32_t on) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipDeviceSynchronize());
   for (auto &r : e->prof) { e->event_pool.push_back(r.e0); e->event_pool.push_back(r.e1); }
   e->prof.clear();
   e->prof_on = on != 0;
+  e->prof_only = -1;
+  return FFM_OK;
+}
+
+static int profile_totals(ffm_engine *e, double *ms, int *n);
+
+int ffm_engine_profile_focus(ffm_engine *e) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  double ms[K_COUNT];
+  int n[K_COUNT];
+  int rc = profile_totals(e, ms, n);
+  if (rc) return rc;
+  int best = 0;
+  for (int k = 1; k < K_COUNT; k++) if (ms[k] > ms[best]) best = k;
+  for (auto &r : e->prof) { e->event_pool.push_back(r.e0); e->event_pool.push_back(r.e1); }
+  e->prof.clear();
+  e->prof_only = best;
   return FFM_OK;
 }
 
 static int profile_totals(ffm_engine *e, double *ms, int *n) {
   HIP_TRY(hipSetDevice(e->cfg.device_id));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipDeviceSynchronize());
   for (int k = 0; k < K_COUNT; k++) { ms[k] = 0.0; n[k] = 0; }
   for (auto &r : e->prof) {
     float t = 0.0f;

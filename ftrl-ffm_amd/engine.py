@@ -73,6 +73,7 @@ ABI = [
     ("ffm_engine_profile_enable", ctypes.c_int, [_vp, ctypes.c_int32]),
     ("ffm_engine_profile_read", ctypes.c_int,
      [_vp, _i32p, _f64p, ctypes.c_char_p, ctypes.c_size_t]),
+    ("ffm_engine_profile_focus", ctypes.c_int, [_vp]),
     ("ffm_engine_profile_dump", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
 ]
 
@@ -254,6 +255,10 @@ class Engine:
     # ---- kernel timing (HIP events on the engine's stream) ----
     def profile_enable(self, on=True):
         self._check(self.lib.ffm_engine_profile_enable(self.h, int(on)))
+
+    def profile_focus(self):
+        """Keep timing only the kernel that dominated so far (cheap enough for timed regions)."""
+        self._check(self.lib.ffm_engine_profile_focus(self.h))
 
     def profile_read(self):
         n = ctypes.c_int32(0)

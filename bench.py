@@ -332,7 +332,7 @@ def main():
                         "latent_update_huge_kernel": "ffm_update_huge_kernel"}.get(nm)
                 if not full:
                     continue
-                us = float(parts[-1].split("=")[1])
+                us = float(parts[-1])
                 sh = kernel_share_bytes(full, blocks_feat, N_FIELDS, N_FACTORS, max(world, 1))
                 others.append({"kernel": full, "avg_launch_us": us,
                                "algorithmic_bytes_per_launch": int(sh),

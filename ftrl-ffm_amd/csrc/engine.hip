@@ -24,6 +24,7 @@
 #include "kernels_group.h"
 #include "kernels_row.h"
 #include "kernels_update.h"
+#include "kernels_fused.h"
 
 using namespace ftrl_dev;
 
@@ -48,7 +49,7 @@ enum KernelId {
   K_GROUP_COUNT, K_GROUP_ALLOC, K_GROUP_SCATTER, K_GROUP_SORT, K_GROUP_EXPAND, K_ROW, K_TMP_GRAD,
   K_HOT_META,
   K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_LATENT_UPDATE_HUGE, K_GROUP_CLEANUP,
-  K_PREDICT_ROW,
+  K_PREDICT_ROW, K_FUSED_ROW, K_ROW_SHAPE,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
@@ -56,7 +57,7 @@ const char *kKernelNames[K_COUNT] = {
     "group_expand_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
     "linear_update_kernel", "bias_update_kernel", "latent_update_kernel", "latent_update_hot_kernel",
     "latent_update_huge_kernel", "group_cleanup_kernel",
-    "row_kernel<predict>"};
+    "row_kernel<predict>", "fused_row_kernel", "row_shape_kernel"};
 
 struct ProfRec {
   int kid;
@@ -161,6 +162,10 @@ struct ffm_engine {
   // split-phase bookkeeping
   Rows pending{};
   bool has_pending = false;
+  // fused row path (kernels_fused.h): statically possible / asked for by the current call /
+  // in use for the pending block (the block itself may still veto it on the device: CNT_NOFUSE)
+  bool fuse_ok = false, fuse_request = false, fuse_cur = false;
+  int fuse_threads = 0, fuse_max_nv = 0;
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // profiling
   bool prof_on = false;
@@ -299,6 +304,16 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   e->max_nnz = cfg->max_batch_nnz;
   if (cfg->reserved[0] > 0) e->max_row_nnz = cfg->reserved[0];
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
+  {
+    const char *fe = std::getenv("FFM_ENGINE_FUSE");
+    const int k = cfg->n_factors;
+    e->fuse_ok = cfg->model_type == FFM_MODEL_FFM && cfg->n_shards == 1 && cfg->n_fields <= 64 &&
+                 (k == 4 || k == 8 || k == 16) &&
+                 ((fe && fe[0] == '1') || (cfg->flags & FFM_FLAG_FUSE));
+    e->fuse_max_nv = std::min(kFusedMaxNv, e->max_row_nnz);
+    const int pairs = e->fuse_max_nv * (e->fuse_max_nv - 1) / 2;
+    e->fuse_threads = std::max(64, (pairs + 63) / 64 * 64);
+  }
   ModelDev &m = e->m;
   m.type = cfg->model_type;
   m.n_feats = cfg->n_feats;
@@ -350,9 +365,10 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.ucount, E));
   TRY_ALLOC(e->alloc(&s.multi, E));
   TRY_ALLOC(e->alloc(&s.small, E));
+  TRY_ALLOC(e->alloc(&s.few, E));
   TRY_ALLOC(e->alloc(&s.big, E));
   TRY_ALLOC(e->alloc(&s.huge, E));
-  TRY_ALLOC(e->alloc(&s.counters, 8));
+  TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
   TRY_ALLOC(e->alloc(&s.cnt, nf));
   TRY_ALLOC(e->alloc(&s.fstart, nf));
   TRY_ALLOC(e->alloc(&s.head, R * static_cast<size_t>(m.n_fields)));
@@ -362,6 +378,12 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   const bool ffm_model = m.type == FFM_MODEL_FFM;
   TRY_ALLOC(e->alloc(&s.haux, ffm_model ? E * static_cast<size_t>(m.n_fields) : 1));
   TRY_ALLOC(e->alloc(&s.hmeta, ffm_model ? E : 1));
+  {
+    const size_t n_ps = e->fuse_ok ? E * static_cast<size_t>(m.row_len) : 1;
+    TRY_ALLOC(e->alloc(&s.pstream, n_ps));
+    // slots no pair touches are never written but are read (and ignored) by the stream readers
+    TRY_HIP(hipMemsetAsync(s.pstream, 0, n_ps * sizeof(float), e->stream));
+  }
   TRY_ALLOC(e->alloc(&s.logit, R));
   TRY_ALLOC(e->alloc(&s.tg, R));
   TRY_ALLOC(e->alloc(&s.loss, R));
@@ -379,15 +401,16 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.ucount, E));
     TRY_ALLOC(e->alloc(&t.multi, E));
     TRY_ALLOC(e->alloc(&t.small, E));
+    TRY_ALLOC(e->alloc(&t.few, E));
     TRY_ALLOC(e->alloc(&t.big, E));
     TRY_ALLOC(e->alloc(&t.huge, E));
-    TRY_ALLOC(e->alloc(&t.counters, 8));
+    TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
     TRY_ALLOC(e->alloc(&t.cnt, nf));
     TRY_ALLOC(e->alloc(&t.fstart, nf));
     TRY_ALLOC(e->alloc(&t.occpos, E));
     TRY_ALLOC(e->alloc(&e->d_sort_tmp[1], E));
     TRY_HIP(hipMemsetAsync(t.cnt, 0, nf * sizeof(int), e->stream));
-    TRY_HIP(hipMemsetAsync(t.counters, 0, 8 * sizeof(int), e->stream));
+    TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
   TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++) {
@@ -411,7 +434,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_HIP(hipMemsetAsync(m.lin_w, 0, nf * sizeof(float), e->stream));
   if (n_lat) TRY_HIP(hipMemsetAsync(m.lat, 0, n_lat * sizeof(float), e->stream));
   TRY_HIP(hipMemsetAsync(s.cnt, 0, nf * sizeof(int), e->stream));
-  TRY_HIP(hipMemsetAsync(s.counters, 0, 8 * sizeof(int), e->stream));
+  TRY_HIP(hipMemsetAsync(s.counters, 0, kNumCounters * sizeof(int), e->stream));
   if (cfg->w_alpha >= 0x1p-30f && cfg->w_alpha <= 0x1p30f) {
     // prove the short x/alpha sequence exact for this alpha before any kernel may use it
     int bad = 0;
@@ -420,7 +443,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     hipLaunchKernelGGL(verify_div_alpha_kernel, dim3(1u << 17), dim3(256), 0, e->stream, probe, s.counters);
     TRY_HIP(hipMemcpyAsync(&bad, s.counters, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     TRY_HIP(hipStreamSynchronize(e->stream));
-    TRY_HIP(hipMemsetAsync(s.counters, 0, 8 * sizeof(int), e->stream));
+    TRY_HIP(hipMemsetAsync(s.counters, 0, kNumCounters * sizeof(int), e->stream));
     m.h.fast_div = bad ? 0 : 1;
   }
   if (!(cfg->flags & FFM_FLAG_SKIP_INIT))
@@ -561,10 +584,18 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
   } else {
     const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
     const int mr = e->max_row_nnz;
-    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob);
-    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob);
-    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob);
-    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob);
+    const int fuse = train && e->fuse_cur ? 1 : 0;
+    if (fuse) {
+      // both are launched; CNT_NOFUSE (row_shape_kernel) decides on the device which one works
+      const int T = e->fuse_threads;
+      if (e->m.n_factors == 16) LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<4>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
+      else if (e->m.n_factors == 8) LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<2>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
+      else LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<1>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
+    }
+    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse);
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0);
   }
 }
 
@@ -576,9 +607,11 @@ static bool same_block(const Rows &a, const Rows &b) {
 // Groups `rows` by feature into scratch set `set` on stream `st`.
 static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st) {
   Scratch &sc = e->sc[set];
-  HIP_TRY(hipMemsetAsync(sc.counters, 0, 8 * sizeof(int), st));
+  HIP_TRY(hipMemsetAsync(sc.counters, 0, kNumCounters * sizeof(int), st));
   if (rows.nnz > 0) {
     const int nnz = rows.nnz;
+    if (e->fuse_ok && rows.n_rows > 0)
+      LAUNCH_ON(e, st, K_ROW_SHAPE, row_shape_kernel, cdiv(rows.n_rows, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->fuse_max_nv);
     LAUNCH_ON(e, st, K_GROUP_COUNT, group_count_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc);
     LAUNCH_ON(e, st, K_GROUP_ALLOC, group_alloc_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, sc);
     LAUNCH_ON(e, st, K_GROUP_SCATTER, group_scatter_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, rows, sc);
@@ -618,6 +651,8 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
   e->pending = rows;
   e->has_pending = true;
+  e->fuse_cur = e->fuse_ok && e->fuse_request;  // only train_batch_device asks: it owns tmp_grad
+  e->fuse_request = false;
   const bool use_prepared = e->prepared >= 0 && same_block(e->prepared_rows, rows);
   if (e->prepared >= 0 && !use_prepared) {
     // a grouping made ahead for some other block: undo its counters, then forget it
@@ -667,6 +702,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   }
   const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
   const bool vec4 = e->m.n_factors % 4 == 0;
+  const int fuse = e->fuse_cur && !logit ? 1 : 0;
   if (forked || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
   if (forked) {
     HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
@@ -676,19 +712,19 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     HIP_TRY(hipEventRecord(e->ev_join, e->aux));
   }
   if (ffm && vec4 && e->serial) {
-    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
   } else if (ffm && vec4) {
     // the three owner shapes touch disjoint features: run them side by side (long sequential
     // chains of the hot ones beside the bandwidth-shaped small-feature pass)
     HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
     HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   } else if (ffm) {
@@ -710,7 +746,9 @@ int ffm_engine_train_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
                                   float *logit_out, double *loss_sum_out) {
   if (e && e->m.n_shards > 1)
     return fail(FFM_E_INVALID, "sharded engines train with train_forward + all-reduce + train_update");
+  if (e) e->fuse_request = true;
   int rc = ffm_engine_train_forward_device(e, n_rows, nnz, row_ptr, field, feat, val, label, nullptr);
+  if (e) e->fuse_request = false;
   if (rc) return rc;
   return ffm_engine_train_update_device(e, nullptr, logit_out, loss_sum_out);
 }
@@ -791,7 +829,7 @@ int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_p
   int32_t nnz = 0;
   int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
   if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(e->sc[e->cur].counters, 0, 8 * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->sc[e->cur].counters, 0, kNumCounters * sizeof(int), e->stream));
   rc = ffm_engine_predict_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
                                        e->d_feat, e->d_val, label ? e->d_label : nullptr,
                                        output_prob, e->d_out, e->d_loss_sum);
@@ -860,7 +898,8 @@ int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms
   if (total_ms) *total_ms = ms[best];
   if (kernel_name && kernel_name_cap) {
     std::string name = kKernelNames[best];
-    if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT ||
+    if (best == K_FUSED_ROW) name = "ffm_fused_row_kernel";
+    else if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT ||
         best == K_LATENT_UPDATE_HUGE)
       name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +
              (best == K_LATENT_UPDATE ? (e->m.type == FFM_MODEL_FM ? "update_kernel" : "update_small_kernel")

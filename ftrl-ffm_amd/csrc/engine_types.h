@@ -63,9 +63,11 @@ struct Scratch {
   int *ucount;    // [nnz] its number of occurrences
   int *multi;     // [nnz] indices into uniq of the features that occur more than once
   int *small;     // [nnz] indices into uniq of the features with <= kSmallMax occurrences
+  int *few;       // [nnz] ... with 2..kSmallMax occurrences (the small list minus the features
+                  //      that occur once, which the fused row kernel updates itself)
   int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
   int *huge;      // [nnz] ... with more ("very hot": present in a large share of the rows)
-  int *counters;  // [8]   0 n_uniq, 1 occ cursor, 2 n_multi, 3 error bits
+  int *counters;  // [kNumCounters] CNT_* below
   int *cnt;       // [n_feats] per-feature counter, all zero between blocks
   int *fstart;    // [n_feats] group start per feature (valid for features of the block)
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
@@ -74,10 +76,13 @@ struct Scratch {
                   //      row; entry = -1 none, -2 several (then head/next list them)
   // Hot features (more than kSmallMax occurrences in the block) have their touches' facts laid
   // out by occurrence position t (= index into occ), so their owners stream them:
-  int *occpos;    // [nnz] entry -> its position t in occ when its feature is hot, else -1
+  int *occpos;    // [nnz] entry -> its position t in occ when its feature is hot, else
+                  //      OCC_FEW (2..kSmallMax occurrences) or OCC_ONCE (this entry only)
   int4 *haux;     // [nnz*n_fields] per (occurrence t, partner field): {partner value bits,
                   //      flags | own field << 8, partner feature id, entry} -- from the row kernel
   float2 *hmeta;  // [nnz] {tmp_grad, own value} of occurrence t
+  float *pstream; // [nnz*row_len] fused path: partner weights of hot occurrence t, laid out like
+                  //      the own record ([partner field][factor]) -- from the fused row kernel
   float *logit;   // [n_rows] this shard's (partial) logit
   float *tg;      // [n_rows] tmp_grad = sigmoid(logit) - y
   double *loss;   // [n_rows] logloss per row
@@ -85,7 +90,9 @@ struct Scratch {
 };
 
 enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5,
-       CNT_NHUGE = 6 };
+       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NOFUSE = 8 };
+constexpr int kNumCounters = 16;
+enum { OCC_FEW = -1, OCC_ONCE = -2 };
 constexpr int kHugeMin = 96;  // occurrences per block above which a feature takes the lane-parallel path
 enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
                                                      // first / several entries share the field

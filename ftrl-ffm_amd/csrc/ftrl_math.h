@@ -156,8 +156,9 @@ __device__ __forceinline__ void nz_step_latent_jside(const Hyper &h, float w, fl
 // device exp would differ from the reference in those.  This is that algorithm, with the fused
 // multiply-adds x86-64 glibc's FMA build performs; checked on the host against glibc 2.35 expf on
 // all 2^32 float inputs (tests/test_expf_port.py keeps the same statement in C under test).
-__device__ __forceinline__ float expf_glibc(float x) {
-  const uint64_t T[32] = {
+// 2^(i/32) for i = 0..31, bits of the double with the exponent's low bits folded in (glibc's
+// __exp2f_data.tab).  Callers on a latency-critical path stage it in LDS and pass that copy.
+static __device__ const uint64_t kExpTab[32] = {
       0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
       0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
       0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
@@ -166,6 +167,9 @@ __device__ __forceinline__ float expf_glibc(float x) {
       0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
       0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
       0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+template <typename TabPtr>
+__device__ __forceinline__ float expf_glibc_tab(float x, TabPtr T) {
   const uint32_t ix = __float_as_uint(x);
   const uint32_t abstop = (ix >> 20) & 0x7ff;
   if (abstop >= 0x42b) {  // |x| >= 88 or NaN
@@ -194,9 +198,15 @@ __device__ __forceinline__ float expf_glibc(float x) {
   return static_cast<float>(y);
 }
 
+__device__ __forceinline__ float expf_glibc(float x) { return expf_glibc_tab(x, kExpTab); }
+
 // utils::sigmoid<float>, utils.h:20-23: 1 / (1 + std::exp(-x)) with std::exp(float) = expf.
 __device__ __forceinline__ float sigmoid_ref(float x) {
   return 1.0f / (1.0f + expf_glibc(-x));
+}
+template <typename TabPtr>
+__device__ __forceinline__ float sigmoid_ref_tab(float x, TabPtr T) {
+  return 1.0f / (1.0f + expf_glibc_tab(-x, T));
 }
 
 // loss(int y, double logit), src/include/eval/loss.h:8-12 (inf/NaN at saturation preserved)

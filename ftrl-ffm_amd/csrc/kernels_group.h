@@ -39,6 +39,26 @@ __device__ __forceinline__ int wave_reserve(int *counter, int amount) {
   return base + incl - amount;
 }
 
+// Can the fused row kernel (kernels_fused.h) take this block?  It needs every row to hold at most
+// max_nv surviving entries and at most one per field; any row that does not raises CNT_NOFUSE and
+// the block goes down the general path.  One thread per row.
+__global__ __launch_bounds__(kGroupThreads) void row_shape_kernel(ModelDev m, Rows rows, Scratch s,
+                                                                  int max_nv) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows.n_rows) return;
+  const int b = rows.row_ptr[r], e = rows.row_ptr[r + 1];
+  unsigned long long seen = 0ull;
+  int nv = 0;
+  bool bad = false;
+  for (int p = b; p < e && !bad; p++) {
+    const int i = rows.feat[p], f = rows.field[p];
+    if (i < 0 || i >= m.n_feats || f < 0 || f >= m.n_fields) continue;  // remove_out_range
+    bad = ((seen >> f) & 1ull) != 0ull || ++nv > max_nv;
+    seen |= 1ull << f;
+  }
+  if (bad) atomicOr(&s.counters[CNT_NOFUSE], 1);
+}
+
 // Entry p: validate (remove_out_range, ftrl_model.cpp:36-42 / ffm.cpp:30-36), find its row,
 // count its feature, register first-seen features.
 __global__ __launch_bounds__(kGroupThreads) void group_count_kernel(ModelDev m, Rows rows,
@@ -81,12 +101,14 @@ __global__ __launch_bounds__(kGroupThreads) void group_alloc_kernel(Scratch s) {
     const int is = wave_append_slot(&s.counters[CNT_NSMALL], live && c <= kSmallMax);
     const int ib = wave_append_slot(&s.counters[CNT_NBIG], live && c > kSmallMax && c <= kHugeMin);
     const int ih = wave_append_slot(&s.counters[CNT_NHUGE], live && c > kHugeMin);
+    const int iw = wave_append_slot(&s.counters[CNT_NFEW], live && c > 1 && c <= kSmallMax);
     if (!live) continue;
     s.ustart[u] = start;
     s.ucount[u] = c;
     s.fstart[i] = start;
     s.cnt[i] = 0;
     if (c > 1) s.multi[im] = u;
+    if (c > 1 && c <= kSmallMax) s.few[iw] = u;
     if (c <= kSmallMax) s.small[is] = u;
     else if (c <= kHugeMin) s.big[ib] = u;
     else s.huge[ih] = u;
@@ -159,7 +181,8 @@ __global__ __launch_bounds__(kGroupThreads) void group_expand_kernel(int nnz_val
     const int p = s.occ[t];
     s.occ2[t] = make_int2(p, s.row_of[p]);
     // after the scatter cnt[feature] holds its occurrence count again
-    s.occpos[p] = s.cnt[s.efeat[p]] > kSmallMax ? t : -1;
+    const int c = s.cnt[s.efeat[p]];
+    s.occpos[p] = c > kSmallMax ? t : (c == 1 ? OCC_ONCE : OCC_FEW);
   }
 }
 

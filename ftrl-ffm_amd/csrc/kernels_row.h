@@ -111,6 +111,61 @@ __device__ __forceinline__ float add_terms_in_order(const float *terms, int cnt,
   return acc;
 }
 
+// TRAIN, FFM: loads the entries' occurrence classes and publishes the row's per-field tables for
+// the feature-major update kernels.  Called by every thread of the workgroup (has barriers).
+__device__ __forceinline__ void publish_row_tables(const Rows &rows, const Scratch &s, RowLds &lds,
+                                                   int r, int b, int nv, int F) {
+  for (int a = threadIdx.x; a < nv; a += blockDim.x) lds.opos[a] = s.occpos[b + lds.pos[a]];
+  __syncthreads();
+  // For entries of hot features: what each partner field contributes to their touches
+  // ({partner value, flags | own field, partner id, entry}), laid out by occurrence position
+  // for the hot update kernel.
+  for (int t = threadIdx.x; t < nv * F; t += blockDim.x) {
+    const int a = t / F, f = t - a * F;
+    const int op = lds.opos[a];
+    if (op < 0) continue;
+    const int cnt = lds.fcnt[f];
+    const int a0 = lds.ffirst[f];
+    int flags = 0, fq = lds.feat[a];  // harmless partner id when there is no plain partner
+    float xo = 0.0f;
+    if (cnt == 1 && a0 != a) {
+      flags = HF_SIMPLE | (a < a0 ? HF_FIRST : 0);
+      xo = lds.val[a0];
+      fq = lds.feat[a0];
+    } else if (cnt > 1) {
+      flags = HF_CHAIN;
+    }
+    s.haux[static_cast<int64_t>(op) * F + f] =
+        make_int4(__float_as_int(xo), flags | (lds.field[a] << 8), fq, b + lds.pos[a]);
+  }
+  // Per-field view of this row for the update kernel: rowtab[r][f] = {feat, val bits, entry
+  // index, count} of the only entry with field f (entry index -1: none, -2: several -- then
+  // head/next chains list them in row order).
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    const int cnt = lds.fcnt[f];
+    int4 t = make_int4(-1, 0, -1, cnt);
+    int head = -1;
+    if (cnt >= 1) {
+      const int a0 = lds.ffirst[f];
+      head = b + lds.pos[a0];
+      t = make_int4(lds.feat[a0], __float_as_int(lds.val[a0]), cnt == 1 ? head : -2, cnt);
+      if (cnt > 1) {
+        int prev = head;
+        for (int a = a0 + 1; a < nv; a++)
+          if (lds.field[a] == f) {
+            s.next[prev] = b + lds.pos[a];
+            prev = b + lds.pos[a];
+          }
+        s.next[prev] = -1;
+      } else {
+        s.next[head] = -1;
+      }
+    }
+    s.head[static_cast<int64_t>(r) * F + f] = head;
+    s.rowtab[static_cast<int64_t>(r) * F + f] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // FFM (and LR when row_len == 0): one workgroup per row.
 // TRAIN: refresh linear/bias/latent weights of everything the row touches, publish the row's
@@ -121,9 +176,10 @@ __device__ __forceinline__ float add_terms_in_order(const float *terms, int cnt,
 template <bool TRAIN, bool VEC4>
 __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
-                                                              int output_prob) {
+                                                              int output_prob, int fuse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv;
+  if (TRAIN && fuse && !s.counters[CNT_NOFUSE]) return;  // kernels_fused.h took this block
   const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
   RowLds lds = carve_row_lds(smem, max_row_nnz, F);
   const int r = blockIdx.x;
@@ -150,55 +206,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   }
 
   if (TRAIN && is_ffm) {
-    for (int a = threadIdx.x; a < nv; a += blockDim.x) lds.opos[a] = s.occpos[b + lds.pos[a]];
-    __syncthreads();
-    // For entries of hot features: what each partner field contributes to their touches
-    // ({partner value, flags | own field, partner id, entry}), laid out by occurrence position
-    // for the hot update kernel.
-    for (int t = threadIdx.x; t < nv * F; t += blockDim.x) {
-      const int a = t / F, f = t - a * F;
-      const int op = lds.opos[a];
-      if (op < 0) continue;
-      const int cnt = lds.fcnt[f];
-      const int a0 = lds.ffirst[f];
-      int flags = 0, fq = lds.feat[a];  // harmless partner id when there is no plain partner
-      float xo = 0.0f;
-      if (cnt == 1 && a0 != a) {
-        flags = HF_SIMPLE | (a < a0 ? HF_FIRST : 0);
-        xo = lds.val[a0];
-        fq = lds.feat[a0];
-      } else if (cnt > 1) {
-        flags = HF_CHAIN;
-      }
-      s.haux[static_cast<int64_t>(op) * F + f] =
-          make_int4(__float_as_int(xo), flags | (lds.field[a] << 8), fq, b + lds.pos[a]);
-    }
-    // Per-field view of this row for the update kernel: rowtab[r][f] = {feat, val bits, entry
-    // index, count} of the only entry with field f (entry index -1: none, -2: several -- then
-    // head/next chains list them in row order).
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-      const int cnt = lds.fcnt[f];
-      int4 t = make_int4(-1, 0, -1, cnt);
-      int head = -1;
-      if (cnt >= 1) {
-        const int a0 = lds.ffirst[f];
-        head = b + lds.pos[a0];
-        t = make_int4(lds.feat[a0], __float_as_int(lds.val[a0]), cnt == 1 ? head : -2, cnt);
-        if (cnt > 1) {
-          int prev = head;
-          for (int a = a0 + 1; a < nv; a++)
-            if (lds.field[a] == f) {
-              s.next[prev] = b + lds.pos[a];
-              prev = b + lds.pos[a];
-            }
-          s.next[prev] = -1;
-        } else {
-          s.next[head] = -1;
-        }
-      }
-      s.head[static_cast<int64_t>(r) * F + f] = head;
-      s.rowtab[static_cast<int64_t>(r) * F + f] = t;
-    }
+    publish_row_tables(rows, s, lds, r, b, nv, F);
     // lazy refresh of every slot (feature a, partner field fp) that a pair of this row touches:
     // FFM::update_vector_w, ffm.cpp:72-88
     if (VEC4) {

@@ -44,30 +44,38 @@ __device__ __forceinline__ void ffm_touch(const Hyper &h, bool own_first, float 
   }
 }
 
-// The same touch on the 4 factors a float4 lane owns, votes hoisted (sqrt_cr_n / div_alpha_n).
+// The same touch on N factors of one slot held by one lane, votes hoisted (sqrt_cr_n /
+// div_alpha_n): one wave vote per stage instead of one per factor.
+template <int N>
+__device__ __forceinline__ void ffm_touch_n(const Hyper &h, bool own_first, float tg, float x_own,
+                                            float x_other, const float (&vp)[N],
+                                            const float (&w)[N], float (&n)[N], float (&z)[N]) {
+  float g[N], arg[2 * N], sq[2 * N], d[N], sg[N];
+  const float x = own_first ? x_own * x_other : x_other * x_own;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    g[i] = tg * vp[i] * x;              // own slot's gradient
+    const float g1 = tg * w[i] * x;     // second-entry case: the first entry's gradient
+    arg[i] = n[i] + (own_first ? g[i] * g[i] : g[i] * g1);  // ffm.cpp:113 / :118
+    arg[N + i] = n[i];
+  }
+  sqrt_cr_n<2 * N>(arg, sq);
+#pragma unroll
+  for (int i = 0; i < N; i++) d[i] = sq[i] - sq[N + i];
+  div_alpha_n<N>(h, d, sg);
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    z[i] = (z[i] + g[i]) - sg[i] * w[i];
+    n[i] = n[i] + g[i] * g[i];
+  }
+}
+
 __device__ __forceinline__ void ffm_touch4(const Hyper &h, bool own_first, float tg, float x_own,
                                            float x_other, float4 vp4, float4 w4, float4 &n4,
                                            float4 &z4) {
   const float vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w}, w[4] = {w4.x, w4.y, w4.z, w4.w};
   float n[4] = {n4.x, n4.y, n4.z, n4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w};
-  float g[4], arg[8], sq[8], d[4], sg[4];
-  const float x = own_first ? x_own * x_other : x_other * x_own;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    g[i] = tg * vp[i] * x;              // own slot's gradient
-    const float g1 = tg * w[i] * x;     // second-entry case: the first entry's gradient
-    arg[i] = n[i] + (own_first ? g[i] * g[i] : g[i] * g1);  // ffm.cpp:113 / :118
-    arg[4 + i] = n[i];
-  }
-  sqrt_cr_n<8>(arg, sq);
-#pragma unroll
-  for (int i = 0; i < 4; i++) d[i] = sq[i] - sq[4 + i];
-  div_alpha_n<4>(h, d, sg);
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    z[i] = (z[i] + g[i]) - sg[i] * w[i];
-    n[i] = n[i] + g[i] * g[i];
-  }
+  ffm_touch_n<4>(h, own_first, tg, x_own, x_other, vp, w, n, z);
   n4 = make_float4(n[0], n[1], n[2], n[3]);
   z4 = make_float4(z[0], z[1], z[2], z[3]);
 }
@@ -94,8 +102,11 @@ __device__ __forceinline__ float dpp_row_shr1(float keep, float v) {
 }
 
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m, Rows rows,
-                                                                      Scratch s) {
+                                                                      Scratch s, int fuse) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
+  // fused blocks: partner weights come as a stream by occurrence position (s.pstream) instead
+  // of being gathered from the partners' records
+  const bool stream = fuse && !s.counters[CNT_NOFUSE];
   const unsigned groups = (RL + kHotE - 1) / kHotE;
   const int lane = threadIdx.x & 63;
   const int tl = lane & (kHotT - 1);  // which of the step's touches
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
     const float *wcol = m.lat + LAT_W * RL + kk;                       // + feat*rec + field*k
     const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;  // + t*F
     const float2 *mcol = s.hmeta + start;                              // + t
+    const float *pcol = s.pstream + static_cast<int64_t>(start) * RL + ee;  // + t*RL
     const int steps = (c + kHotT - 1) / kHotT;
     bool touched = false;
 
@@ -130,10 +142,12 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
     float2 mt = mcol[min(tl, c - 1)];
     int4 axN = acol[static_cast<int64_t>(min(kHotT + tl, c - 1)) * F];
     float2 mtN = mcol[min(kHotT + tl, c - 1)];
-    float vp = wcol[ax.z * rec_floats + (ax.y >> 8) * k];
+    float vp = stream ? pcol[static_cast<int64_t>(min(tl, c - 1)) * RL]
+                      : wcol[ax.z * rec_floats + (ax.y >> 8) * k];
     for (int st = 0; st < steps; st++) {
       const int t = st * kHotT + tl;
-      const float vpN = wcol[axN.z * rec_floats + (axN.y >> 8) * k];      // weights of step st+1
+      const float vpN = stream ? pcol[static_cast<int64_t>(min(t + kHotT, c - 1)) * RL]
+                               : wcol[axN.z * rec_floats + (axN.y >> 8) * k];  // weights of step st+1
       const int tNN = min((st + 2) * kHotT + tl, c - 1);                  // facts of step st+2
       const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
       const float2 mtNN = mcol[tNN];
@@ -241,10 +255,17 @@ __device__ __forceinline__ void hot_issue_weights(const float *wcol, size_t rec_
 #pragma unroll
   for (int j = 0; j < kUnroll; j++) vp[j] = wcol[f.fq[j] * rec_floats + (f.fl[j] >> 8) * k];
 }
+// fused blocks: the same weights from the occurrence-ordered stream (touches t0 .. t0+kUnroll-1)
+__device__ __forceinline__ void hot_stream_weights(const float *pcol, int RL, int c, int t0,
+                                                   float (&vp)[kUnroll]) {
+#pragma unroll
+  for (int j = 0; j < kUnroll; j++) vp[j] = pcol[static_cast<int64_t>(min(t0 + j, c - 1)) * RL];
+}
 
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m, Rows rows,
-                                                                     Scratch s) {
+                                                                     Scratch s, int fuse) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
+  const bool stream = fuse && !s.counters[CNT_NOFUSE];
   const unsigned chunks = (RL + 63) / 64;
   const int lane = threadIdx.x & 63;
   const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
@@ -269,6 +290,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     const float *wcol = m.lat + LAT_W * RL + kk;                          // + feat*rec + field*k
     const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;     // + t*F
     const float2 *mcol = s.hmeta + start;                                 // + t
+    const float *pcol = s.pstream + static_cast<int64_t>(start) * RL + ee;  // + t*RL
     bool touched = false;
     const int nb = (c + kUnroll - 1) / kUnroll;
 
@@ -277,7 +299,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     float vpB[kUnroll], vpC[kUnroll];
     hot_load_facts(acol, F, c, 0, fB, peB);
     if (nb > 1) hot_load_facts(acol, F, c, kUnroll, fA, peA);
-    hot_issue_weights(wcol, rec_floats, k, fB, vpB);
+    if (stream) hot_stream_weights(pcol, RL, c, 0, vpB);
+    else hot_issue_weights(wcol, rec_floats, k, fB, vpB);
     for (int b = 0; b < nb; b++) {
       const int t0 = b * kUnroll;
       fC = fB;
@@ -287,7 +310,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
         fB = fA;
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) peB[j] = peA[j];
-        hot_issue_weights(wcol, rec_floats, k, fB, vpB);                  // weights of group b+1
+        if (stream) hot_stream_weights(pcol, RL, c, t0 + kUnroll, vpB);   // weights of group b+1
+        else hot_issue_weights(wcol, rec_floats, k, fB, vpB);
       }
       if (b + 2 < nb) hot_load_facts(acol, F, c, t0 + 2 * kUnroll, fA, peA);  // facts of group b+2
       float tgj[kUnroll], xmj[kUnroll];
@@ -403,16 +427,19 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
 // Requires n_factors % 4 == 0.  c <= kSmallMax occurrences.  Kept lean in registers: the
 // bandwidth comes from many resident waves, each with its record's loads in flight.
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev m, Rows rows,
-                                                                       Scratch s) {
+                                                                       Scratch s, int fuse) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int RL4 = RL >> 2, k4 = k >> 2;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const int n_waves = gridDim.x * kUpdWaves;
-  const int n_small = s.counters[CNT_NSMALL];
+  // fused blocks: the features that occur once were updated by the fused row kernel already
+  const bool fused = fuse && !s.counters[CNT_NOFUSE];
+  const int *list = fused ? s.few : s.small;
+  const int n_small = s.counters[fused ? CNT_NFEW : CNT_NSMALL];
   const float inv_k4 = 1.0f / static_cast<float>(k4);
   for (int li = wave; li < n_small; li += n_waves) {
-    const int u = wave_uniform(s.small[li]);
+    const int u = wave_uniform(list[li]);
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i));

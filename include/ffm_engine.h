@@ -77,7 +77,12 @@ typedef struct ffm_engine_config {
 } ffm_engine_config;
 
 enum {
-  FFM_FLAG_SKIP_INIT = 1 /* leave w zeroed; the caller will ffm_engine_set_weights */
+  FFM_FLAG_SKIP_INIT = 1, /* leave w zeroed; the caller will ffm_engine_set_weights */
+  FFM_FLAG_FUSE = 2       /* take the fused row kernel (csrc/kernels_fused.h: one pass per row over
+                           * (n,z,w), features that occur once in the block finished in registers)
+                           * for the blocks it can handle.  Same bits as the general kernels;
+                           * slower than them on gfx950 at n_fields=39, so off by
+                           * default.  Env FFM_ENGINE_FUSE=1 sets it for every engine. */
 };
 
 void ffm_engine_default_config(ffm_engine_config *cfg);

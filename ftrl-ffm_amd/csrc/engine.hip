@@ -49,7 +49,7 @@ enum KernelId {
   K_GROUP_COUNT, K_GROUP_ALLOC, K_GROUP_SCATTER, K_GROUP_SORT, K_GROUP_EXPAND, K_ROW, K_TMP_GRAD,
   K_HOT_META,
   K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_LATENT_UPDATE_HUGE, K_GROUP_CLEANUP,
-  K_PREDICT_ROW, K_FUSED_ROW, K_ROW_SHAPE,
+  K_PREDICT_ROW, K_FUSED_ROW, K_REFRESH,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
@@ -57,7 +57,7 @@ const char *kKernelNames[K_COUNT] = {
     "group_expand_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
     "linear_update_kernel", "bias_update_kernel", "latent_update_kernel", "latent_update_hot_kernel",
     "latent_update_huge_kernel", "group_cleanup_kernel",
-    "row_kernel<predict>", "fused_row_kernel", "row_shape_kernel"};
+    "row_kernel<predict>", "fused_row_kernel", "refresh_kernel"};
 
 struct ProfRec {
   int kid;
@@ -144,10 +144,14 @@ struct ffm_engine {
   bool set_used[2] = {false, false};
   hipStream_t prep = nullptr;  // side stream of ffm_engine_prepare_device
   hipEvent_t ev_grouped[2] = {nullptr, nullptr}, ev_set_free[2] = {nullptr, nullptr};
+  hipEvent_t ev_rows_done = nullptr;  // row phase of the most recently enqueued training block
+  bool rows_done_recorded = false;
+  bool prep_after_rows = false;  // FFM_PREP_AFTER_ROWS=1: group beside the update phase only
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t aux = nullptr;   // side stream: linear + bias chains beside the latent update
-  hipStream_t aux2 = nullptr;  // side stream: hot-feature latent update beside the small-feature one
+  // Streams: the runtime multiplexes streams onto few hardware queues (4 by default), and two
+  // streams on one queue run one after the other -- so no more than stream + 2 side + prep here.
+  hipStream_t aux2 = nullptr;  // side stream: hot-feature latent update (or the bias + linear chains)
   hipStream_t aux3 = nullptr;  // side stream: very-hot-feature latent update
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_join3 = nullptr;
   int max_rows = 0, max_nnz = 0, max_row_nnz = 1024;
@@ -165,7 +169,14 @@ struct ffm_engine {
   // fused row path (kernels_fused.h): statically possible / asked for by the current call /
   // in use for the pending block (the block itself may still veto it on the device: CNT_NOFUSE)
   bool fuse_ok = false, fuse_request = false, fuse_cur = false;
+  // the block's lazy refresh as one pass over its distinct features (ffm_refresh_kernel) instead
+  // of per occurrence inside the row kernel; FFM_ENGINE_ROW_REFRESH=1 keeps it in the row kernel
+  bool pre_refresh = false;
+  unsigned long long *d_ownmask = nullptr;
   int fuse_threads = 0, fuse_max_nv = 0;
+  // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
+  // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
+  int grid_small = 768, grid_hot = 2048, grid_huge = 2048;
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // profiling
   bool prof_on = false;
@@ -262,11 +273,11 @@ void ffm_engine_destroy(ffm_engine *e) {
     if (e->ev_grouped[i]) (void)hipEventDestroy(e->ev_grouped[i]);
     if (e->ev_set_free[i]) (void)hipEventDestroy(e->ev_set_free[i]);
   }
+  if (e->ev_rows_done) (void)hipEventDestroy(e->ev_rows_done);
   if (e->prep) (void)hipStreamDestroy(e->prep);
   if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
   if (e->ev_join3) (void)hipEventDestroy(e->ev_join3);
   if (e->aux3) (void)hipStreamDestroy(e->aux3);
-  if (e->aux) (void)hipStreamDestroy(e->aux);
   if (e->aux2) (void)hipStreamDestroy(e->aux2);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -304,12 +315,21 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   e->max_nnz = cfg->max_batch_nnz;
   if (cfg->reserved[0] > 0) e->max_row_nnz = cfg->reserved[0];
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
+  if (const char *sv = std::getenv("FFM_PREP_AFTER_ROWS")) e->prep_after_rows = sv[0] == '1';
+  if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
   {
     const char *fe = std::getenv("FFM_ENGINE_FUSE");
     const int k = cfg->n_factors;
     e->fuse_ok = cfg->model_type == FFM_MODEL_FFM && cfg->n_shards == 1 && cfg->n_fields <= 64 &&
                  (k == 4 || k == 8 || k == 16) &&
                  ((fe && fe[0] == '1') || (cfg->flags & FFM_FLAG_FUSE));
+    const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
+    const int64_t per = cfg->n_factors % 4 == 0 ? static_cast<int64_t>(cfg->n_fields) * cfg->n_factors / 4
+                                                : static_cast<int64_t>(cfg->n_fields) * cfg->n_factors;
+    e->pre_refresh = cfg->model_type == FFM_MODEL_FFM && cfg->n_fields <= 64 &&
+                     static_cast<int64_t>(e->max_nnz) * per < (1ll << 31) && !(rr && rr[0] == '1');
     e->fuse_max_nv = std::min(kFusedMaxNv, e->max_row_nnz);
     const int pairs = e->fuse_max_nv * (e->fuse_max_nv - 1) / 2;
     e->fuse_threads = std::max(64, (pairs + 63) / 64 * 64);
@@ -340,7 +360,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
   }
-  TRY_HIP(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
   TRY_HIP(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
   TRY_HIP(hipStreamCreateWithFlags(&e->aux3, hipStreamNonBlocking));
@@ -376,6 +395,21 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.rowtab, R * static_cast<size_t>(m.n_fields)));
   TRY_ALLOC(e->alloc(&s.occpos, E));
   const bool ffm_model = m.type == FFM_MODEL_FFM;
+  const bool masks = ffm_model && m.n_fields <= 64;
+  if (masks) {
+    TRY_ALLOC(e->alloc(&s.rowmask, 2 * R));
+    TRY_ALLOC(e->alloc(&s.gmask, E));
+    std::vector<unsigned long long> own(m.n_fields, 0ull);
+    for (int fa = 0; fa < m.n_fields; fa++)
+      for (int fb = 0; fb < m.n_fields; fb++) {
+        const int lo = std::min(fa, fb), hi = std::max(fa, fb);
+        const int idx = lo * m.n_fields - lo * (lo - 1) / 2 + (hi - lo);  // as owns_pair()
+        if (m.n_shards <= 1 || idx % m.n_shards == m.shard_rank) own[fa] |= 1ull << fb;
+      }
+    TRY_ALLOC(e->alloc(&e->d_ownmask, static_cast<size_t>(m.n_fields)));
+    TRY_HIP(hipMemcpy(e->d_ownmask, own.data(), own.size() * sizeof(own[0]), hipMemcpyHostToDevice));
+    m.ownmask = e->d_ownmask;
+  }
   TRY_ALLOC(e->alloc(&s.haux, ffm_model ? E * static_cast<size_t>(m.n_fields) : 1));
   TRY_ALLOC(e->alloc(&s.hmeta, ffm_model ? E : 1));
   {
@@ -408,11 +442,16 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.cnt, nf));
     TRY_ALLOC(e->alloc(&t.fstart, nf));
     TRY_ALLOC(e->alloc(&t.occpos, E));
+    if (masks) {
+      TRY_ALLOC(e->alloc(&t.rowmask, 2 * R));
+      TRY_ALLOC(e->alloc(&t.gmask, E));
+    }
     TRY_ALLOC(e->alloc(&e->d_sort_tmp[1], E));
     TRY_HIP(hipMemsetAsync(t.cnt, 0, nf * sizeof(int), e->stream));
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
   TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
+  TRY_HIP(hipEventCreateWithFlags(&e->ev_rows_done, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) {
     TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&e->ev_set_free[i], hipEventDisableTiming));
@@ -585,6 +624,14 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
     const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
     const int mr = e->max_row_nnz;
     const int fuse = train && e->fuse_cur ? 1 : 0;
+    const int refreshed = train && e->pre_refresh ? 1 : 0;
+    if (refreshed && rows.nnz > 0) {
+      const int per = vec4 ? e->m.row_len / 4 : e->m.row_len;
+      const int64_t items = static_cast<int64_t>(std::min(rows.nnz, e->max_nnz)) * per;
+      const int grid = static_cast<int>(std::min<int64_t>((items + 255) / 256, 8192));
+      if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], fuse);
+      else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], fuse);
+    }
     if (fuse) {
       // both are launched; CNT_NOFUSE (row_shape_kernel) decides on the device which one works
       const int T = e->fuse_threads;
@@ -592,10 +639,10 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
       else if (e->m.n_factors == 8) LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<2>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
       else LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<1>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
     }
-    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse);
-    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse);
-    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0);
-    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0);
+    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed);
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0);
   }
 }
 
@@ -610,11 +657,11 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
   HIP_TRY(hipMemsetAsync(sc.counters, 0, kNumCounters * sizeof(int), st));
   if (rows.nnz > 0) {
     const int nnz = rows.nnz;
-    if (e->fuse_ok && rows.n_rows > 0)
-      LAUNCH_ON(e, st, K_ROW_SHAPE, row_shape_kernel, cdiv(rows.n_rows, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->fuse_max_nv);
-    LAUNCH_ON(e, st, K_GROUP_COUNT, group_count_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc);
+    if (sc.rowmask)
+      HIP_TRY(hipMemsetAsync(sc.rowmask, 0, sizeof(unsigned long long) * 2 * rows.n_rows, st));
+    LAUNCH_ON(e, st, K_GROUP_COUNT, group_count_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->fuse_max_nv);
     LAUNCH_ON(e, st, K_GROUP_ALLOC, group_alloc_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, sc);
-    LAUNCH_ON(e, st, K_GROUP_SCATTER, group_scatter_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, rows, sc);
+    LAUNCH_ON(e, st, K_GROUP_SCATTER, group_scatter_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, rows, sc, e->m.ownmask);
     LAUNCH_ON(e, st, K_GROUP_SORT, group_sort_kernel, 1024, kGroupThreads, 0, sc, e->d_sort_tmp[set]);
     LAUNCH_ON(e, st, K_GROUP_EXPAND, group_expand_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, nnz, sc);
   }
@@ -632,6 +679,9 @@ int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const 
   const int set = 1 - e->cur;
   Rows rows{n_rows, nnz, row_ptr, field, feat, val, nullptr};
   if (e->set_used[set]) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[set], 0));
+  // Optionally group beside the UPDATE phase of the block enqueued last instead of beside its
+  // refresh + row phase (measured: the grouping's atomics slow whichever phase they share).
+  if (e->prep_after_rows && e->rows_done_recorded) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_rows_done, 0));
   rc = launch_grouping(e, set, rows, e->prep);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(e->ev_grouped[set], e->prep));
@@ -672,6 +722,8 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   }
   e->set_used[e->cur] = true;
   launch_row_kernel(e, rows, true, nullptr, 0);
+  HIP_TRY(hipEventRecord(e->ev_rows_done, e->stream));
+  e->rows_done_recorded = true;
   if (partial_logit && n_rows > 0)
     HIP_TRY(hipMemcpyAsync(partial_logit, e->sc[e->cur].logit, sizeof(float) * n_rows, hipMemcpyDeviceToDevice, e->stream));
   HIP_TRY(hipGetLastError());
@@ -688,43 +740,47 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   const float *lg = logit ? logit : e->sc[e->cur].logit;
   if (rows.n_rows > 0)
     LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->sc[e->cur].tg, e->sc[e->cur].loss, logit_out);
-  if (loss_sum_out)
-    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
   if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0)
     LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
   const bool lin_owner = e->m.shard_rank == 0;
-  // the bias and linear chains are short and serial: run them beside the latent update
-  const bool forked = rows.n_rows > 0 && lin_owner && !e->serial;
-  if (rows.n_rows > 0 && lin_owner && e->serial) {
-    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
-    if (rows.nnz > 0)
-      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, std::min(cdiv(rows.nnz, kUpdThreads), 1024), kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-  }
   const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
   const bool vec4 = e->m.n_factors % 4 == 0;
   const int fuse = e->fuse_cur && !logit ? 1 : 0;
+  const int lin_blocks = rows.nnz > 0 ? std::min(cdiv(rows.nnz, kUpdThreads), 1024) : 0;
+  // The bias and linear chains are short and serial: they run beside the latent update -- inside
+  // the hot-feature launch when there is one (side_blocks), else on the side stream.
+  const bool side_in_hot = ffm && vec4 && lin_owner && rows.n_rows > 0;
+  const int side_blocks = side_in_hot ? 1 + lin_blocks : 0;
+  const bool forked = rows.n_rows > 0 && lin_owner && !e->serial && !side_in_hot;
+  if (rows.n_rows > 0 && lin_owner && e->serial && !side_in_hot) {
+    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
+    if (rows.nnz > 0)
+      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+  }
   if (forked || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
   if (forked) {
-    HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
+    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
+    LAUNCH_ON(e, e->aux2, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
     if (rows.nnz > 0)
-      LAUNCH_ON(e, e->aux, K_LINEAR_UPDATE, linear_update_kernel, std::min(cdiv(rows.nnz, kUpdThreads), 1024), kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-    HIP_TRY(hipEventRecord(e->ev_join, e->aux));
+      LAUNCH_ON(e, e->aux2, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    HIP_TRY(hipEventRecord(e->ev_join, e->aux2));
   }
   if (ffm && vec4 && e->serial) {
-    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse, side_blocks);
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
   } else if (ffm && vec4) {
     // the three owner shapes touch disjoint features: run them side by side (long sequential
     // chains of the hot ones beside the bandwidth-shaped small-feature pass)
     HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
     HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse, side_blocks);
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    if (loss_sum_out)
+      LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   } else if (ffm) {
@@ -732,6 +788,8 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
     LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   }
+  if (loss_sum_out && !(ffm && vec4 && !e->serial))
+    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
   if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
   if (rows.nnz > 0)
     LAUNCH(e, K_GROUP_CLEANUP, group_cleanup_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, e->sc[e->cur]);

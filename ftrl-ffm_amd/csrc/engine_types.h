@@ -34,6 +34,9 @@ struct ModelDev {
   float *bias3;
   float *lin_n, *lin_z, *lin_w;
   float *lat;
+  // ownmask[fa] = bit fp set when this shard owns the field pair {fa, fp} (all ones when the
+  // model is not sharded); n_fields <= 64 only, else null
+  const unsigned long long *ownmask;
 };
 
 enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };
@@ -76,6 +79,12 @@ struct Scratch {
                   //      row; entry = -1 none, -2 several (then head/next list them)
   // Hot features (more than kSmallMax occurrences in the block) have their touches' facts laid
   // out by occurrence position t (= index into occ), so their owners stream them:
+  // Which slots of a feature's record does the block touch?  Slot (feature of entry p, field fp)
+  // is touched when p's row holds another entry of field fp (ffm.cpp:72-88 refreshes exactly
+  // those).  n_fields <= 64 only.
+  unsigned long long *rowmask;  // [2*n_rows] per row: fields with >= 1 / >= 2 surviving entries
+  unsigned long long *gmask;    // [nnz] per distinct feature, at index ustart[u]: bit fp set when
+                                //      some row of the block touches slot fp of the feature
   int *occpos;    // [nnz] entry -> its position t in occ when its feature is hot, else
                   //      OCC_FEW (2..kSmallMax occurrences) or OCC_ONCE (this entry only)
   int4 *haux;     // [nnz*n_fields] per (occurrence t, partner field): {partner value bits,
@@ -93,7 +102,10 @@ enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL 
        CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NOFUSE = 8 };
 constexpr int kNumCounters = 16;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
-constexpr int kHugeMin = 96;  // occurrences per block above which a feature takes the lane-parallel path
+#ifndef FFM_HUGE_MIN
+#define FFM_HUGE_MIN 96
+#endif
+constexpr int kHugeMin = FFM_HUGE_MIN;  // occurrences per block above which a feature takes the lane-parallel path
 enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
                                                      // first / several entries share the field
 constexpr int kSmallMax = 4;  // occurrences per block up to which a feature takes the "small" path

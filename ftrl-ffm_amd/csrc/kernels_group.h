@@ -39,30 +39,13 @@ __device__ __forceinline__ int wave_reserve(int *counter, int amount) {
   return base + incl - amount;
 }
 
-// Can the fused row kernel (kernels_fused.h) take this block?  It needs every row to hold at most
-// max_nv surviving entries and at most one per field; any row that does not raises CNT_NOFUSE and
-// the block goes down the general path.  One thread per row.
-__global__ __launch_bounds__(kGroupThreads) void row_shape_kernel(ModelDev m, Rows rows, Scratch s,
-                                                                  int max_nv) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows.n_rows) return;
-  const int b = rows.row_ptr[r], e = rows.row_ptr[r + 1];
-  unsigned long long seen = 0ull;
-  int nv = 0;
-  bool bad = false;
-  for (int p = b; p < e && !bad; p++) {
-    const int i = rows.feat[p], f = rows.field[p];
-    if (i < 0 || i >= m.n_feats || f < 0 || f >= m.n_fields) continue;  // remove_out_range
-    bad = ((seen >> f) & 1ull) != 0ull || ++nv > max_nv;
-    seen |= 1ull << f;
-  }
-  if (bad) atomicOr(&s.counters[CNT_NOFUSE], 1);
-}
-
 // Entry p: validate (remove_out_range, ftrl_model.cpp:36-42 / ffm.cpp:30-36), find its row,
-// count its feature, register first-seen features.
+// count its feature, register first-seen features.  FFM with n_fields <= 64 also collects, per
+// row, the fields present once / more than once (s.rowmask: what group_scatter_kernel turns into
+// the touched-slot masks) and decides whether the fused row kernel may take the block: it needs
+// every row to hold at most max_nv entries and at most one per field, else CNT_NOFUSE.
 __global__ __launch_bounds__(kGroupThreads) void group_count_kernel(ModelDev m, Rows rows,
-                                                                    Scratch s) {
+                                                                    Scratch s, int max_nv) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = p < rows.nnz;
   bool valid = false;
@@ -79,6 +62,16 @@ __global__ __launch_bounds__(kGroupThreads) void group_count_kernel(ModelDev m, 
     const int f = rows.field ? rows.field[p] : 0;
     valid = i >= 0 && i < m.n_feats;
     if (m.type == 2) valid = valid && f >= 0 && f < m.n_fields;
+    if (s.rowmask && valid) {
+      const unsigned long long bit = 1ull << f;
+      const unsigned long long before = atomicOr(&s.rowmask[2 * lo], bit);
+      if (before & bit) {
+        atomicOr(&s.rowmask[2 * lo + 1], bit);
+        atomicOr(&s.counters[CNT_NOFUSE], 1);
+      }
+      if (p == rows.row_ptr[lo] && rows.row_ptr[lo + 1] - p > max_nv)
+        atomicOr(&s.counters[CNT_NOFUSE], 1);
+    }
   }
   if (in) { s.efeat[p] = valid ? i : -1; s.occpos[p] = -1; }
   const bool first = valid && atomicAdd(&s.cnt[i], 1) == 0;
@@ -105,6 +98,7 @@ __global__ __launch_bounds__(kGroupThreads) void group_alloc_kernel(Scratch s) {
     if (!live) continue;
     s.ustart[u] = start;
     s.ucount[u] = c;
+    if (s.gmask) s.gmask[start] = 0ull;
     s.fstart[i] = start;
     s.cnt[i] = 0;
     if (c > 1) s.multi[im] = u;
@@ -115,12 +109,23 @@ __global__ __launch_bounds__(kGroupThreads) void group_alloc_kernel(Scratch s) {
   }
 }
 
-__global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(Rows rows, Scratch s) {
+__global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(
+    Rows rows, Scratch s, const unsigned long long *ownmask) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= rows.nnz) return;
   const int i = s.efeat[p];
   if (i < 0) return;
-  s.occ[s.fstart[i] + atomicAdd(&s.cnt[i], 1)] = p;
+  const int start = s.fstart[i];
+  s.occ[start + atomicAdd(&s.cnt[i], 1)] = p;
+  if (s.gmask) {
+    // slots of feature i that p's row touches: slot fp is touched when the row holds ANOTHER
+    // entry of field fp (FFM::update_vector_w refreshes exactly those, ffm.cpp:72-88), within the
+    // field pairs this shard owns
+    const int r = s.row_of[p], f = rows.field[p];
+    const unsigned long long once = s.rowmask[2 * r], twice = s.rowmask[2 * r + 1];
+    const unsigned long long self = 1ull << f;
+    atomicOr(&s.gmask[start], ((once & ~self) | (twice & self)) & ownmask[f]);
+  }
 }
 
 // Groups with more than one entry: sort ascending by entry index (= row order, then position in

@@ -176,7 +176,8 @@ __device__ __forceinline__ void publish_row_tables(const Rows &rows, const Scrat
 template <bool TRAIN, bool VEC4>
 __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
-                                                              int output_prob, int fuse) {
+                                                              int output_prob, int fuse,
+                                                              int refreshed) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv;
   if (TRAIN && fuse && !s.counters[CNT_NOFUSE]) return;  // kernels_fused.h took this block
@@ -208,8 +209,9 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   if (TRAIN && is_ffm) {
     publish_row_tables(rows, s, lds, r, b, nv, F);
     // lazy refresh of every slot (feature a, partner field fp) that a pair of this row touches:
-    // FFM::update_vector_w, ffm.cpp:72-88
-    if (VEC4) {
+    // FFM::update_vector_w, ffm.cpp:72-88 -- unless ffm_refresh_kernel did it for the whole block
+    if (refreshed) {
+    } else if (VEC4) {
       const int RL4 = RL >> 2, k4 = k >> 2;
       const float inv_RL4 = 1.0f / static_cast<float>(RL4), inv_k4 = 1.0f / static_cast<float>(k4);
       const int total = nv * RL4;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   for (int a = threadIdx.x; a < nv; a += blockDim.x) {
     const int i = lds.feat[a];
     float lw;
-    if (TRAIN) {
+    if (TRAIN && !refreshed) {
       lw = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
       if (lin_owner) m.lin_w[i] = lw;
     } else {
@@ -323,6 +325,48 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     } else {
       out[r] = output_prob ? sigmoid_ref(result) : result;
       if (rows.label) s.loss[r] = logloss_ref(rows.label[r], result);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Lazy weight refresh of a whole block, once per DISTINCT feature instead of once per occurrence:
+// with (n, z) frozen at the block start every occurrence of a feature computes the same w, so the
+// block's refresh (FFM::update_vector_w ffm.cpp:72-88, update_linear_w ftrl_model.cpp:52-59) is
+// one elementwise pass over the records of the block's distinct features -- the slots some row of
+// the block touches (s.gmask, from the grouping) -- and the row kernel is left with the forward.
+// Work item = (distinct feature u, 16-byte vector l of its record); VEC4 as in the row kernel.
+// ------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s, int fuse) {
+  if (fuse && !s.counters[CNT_NOFUSE]) return;  // kernels_fused.h refreshes its own block
+  const int n_uniq = s.counters[CNT_NUNIQ];
+  const int k = m.n_factors, RL = m.row_len;
+  const int per = VEC4 ? (RL >> 2) : RL;       // items per record
+  const int kv = VEC4 ? (k >> 2) : k;          // items per slot
+  const float inv_kv = 1.0f / static_cast<float>(kv);
+  const double inv_per = 1.0 / static_cast<double>(per);
+  const unsigned total = static_cast<unsigned>(n_uniq) * static_cast<unsigned>(per);  // < 2^31 (engine)
+  const unsigned stride = gridDim.x * blockDim.x;
+  const bool lin_owner = m.shard_rank == 0;
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    // u = t / per through the double reciprocal (exact after one correction for t < 2^31)
+    int u = static_cast<int>((static_cast<double>(t) + 0.5) * inv_per);
+    u += static_cast<unsigned>(u + 1) * per <= t ? 1 : (static_cast<unsigned>(u) * per > t ? -1 : 0);
+    const int l = static_cast<int>(t - static_cast<unsigned>(u) * per);
+    int fp = static_cast<int>((l + 0.5f) * inv_kv);
+    fp += (fp + 1) * kv <= l ? 1 : (fp * kv > l ? -1 : 0);
+    const int i = s.uniq[u];
+    const unsigned long long mask = s.gmask[s.ustart[u]];
+    if (l == 0 && lin_owner) m.lin_w[i] = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
+    if (!((mask >> fp) & 1ull)) continue;
+    if (VEC4) {
+      float4 *row = reinterpret_cast<float4 *>(lat_row(m, i));
+      const float4 n4 = row[LAT_N * per + l], z4 = row[LAT_Z * per + l];
+      row[LAT_W * per + l] = ftrl_weight4(m.h, n4, z4);
+    } else {
+      float *row = lat_row(m, i);
+      row[LAT_W * RL + l] = ftrl_weight(m.h, row[LAT_N * RL + l], row[LAT_Z * RL + l]);
     }
   }
 }

@@ -227,6 +227,113 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
   }
 }
 
+// Strictly left-to-right running sum over the 64 lanes: returns S_j = ((carry + a_0) + a_1) ... + a_j
+// in lane j, every addition rounded exactly as a one-lane sequential loop would round it.  Step t
+// finalises lane t (S_t = S_{t-1} + a_t through a whole-wave shift-right-by-one DPP move); lanes
+// already final recompute the same value, so no predication is needed.  Idle lanes pass -0.0f
+// (x + -0.0f == x bit for bit, for every x including both zeros).
+__device__ __forceinline__ float wave_sequential_prefix(float carry, float a) {
+  const int lane = threadIdx.x & 63;
+  float s = lane == 0 ? carry + a : a;
+  const float step = lane == 0 ? -0.0f : a;
+#pragma unroll
+  for (int t = 1; t < 64; t++) {
+    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(
+        __float_as_int(s), __float_as_int(s), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    s = prev + step;
+  }
+  return s;
+}
+
+// The linear/bias accumulator chain over up to 64 gradients held one per lane (lane j = the j-th
+// touch, in order; lanes >= count idle).  Sequential semantics of nz_step_linear, evaluated as:
+// (1) running n by a strictly sequential prefix sum, (2) every touch's z increment in parallel,
+// (3) z by a second sequential prefix -- the same operations on the same values in the same
+// order as the one-thread loop, so bit-identical.
+__device__ __forceinline__ void linear_chain64(const Hyper &h, float w, float g, int count,
+                                               float &n, float &z) {
+  const int lane = threadIdx.x & 63;
+  const bool live = lane < count;
+  const float n_after = wave_sequential_prefix(n, live ? g * g : -0.0f);
+  float n_before = __int_as_float(__builtin_amdgcn_update_dpp(
+      __float_as_int(n), __float_as_int(n_after), 0x138, 0xf, 0xf, false));
+  if (lane == 0) n_before = n;
+  const float sgm = div_alpha(h, sqrt_cr(n_after) - sqrt_cr(n_before));  // n_after = n_before + g*g
+  const float z_run = wave_sequential_prefix(z, live ? g - sgm * w : -0.0f);
+  n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n_after), 63));
+  z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_run), 63));
+}
+
+// Linear update (update_linear_nz, ftrl_model.cpp:66-77).  Small features: one thread each,
+// touches applied one after another; hot features: one wave each, 64 touches per pass.
+__device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows &rows,
+                                                   const Scratch &s, int block, int n_blocks) {
+  const int n_small = s.counters[CNT_NSMALL], n_big = s.counters[CNT_NBIG];
+  const int gtid = block * blockDim.x + threadIdx.x;
+  for (int li = gtid; li < n_small; li += n_blocks * blockDim.x) {
+    const int u = s.small[li];
+    const int i = s.uniq[u];
+    const int start = s.ustart[u], c = s.ucount[u];
+    float n = m.lin_n[i], z = m.lin_z[i];
+    const float w = m.lin_w[i];
+    for (int t = 0; t < c; t++) {
+      const int2 pr = s.occ2[start + t];
+      nz_step_linear(m.h, w, s.tg[pr.y] * rows.val[pr.x], n, z);
+    }
+    m.lin_n[i] = n;
+    m.lin_z[i] = z;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = block * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = n_blocks * kUpdWaves;
+  const int n_huge = s.counters[CNT_NHUGE];
+  for (int li = wave; li < n_big + n_huge; li += n_waves) {
+    const int u = wave_uniform(li < n_big ? s.big[li] : s.huge[li - n_big]);
+    const int i = wave_uniform(s.uniq[u]);
+    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    float n = m.lin_n[i], z = m.lin_z[i];
+    const float w = m.lin_w[i];
+    for (int t0 = 0; t0 < c; t0 += 64) {
+      const int cnt = min(64, c - t0);
+      float g = 0.0f;
+      if (lane < cnt) {
+        const int2 pr = s.occ2[start + t0 + lane];
+        g = s.tg[pr.y] * rows.val[pr.x];
+      }
+      linear_chain64(m.h, w, g, cnt, n, z);
+    }
+    if (lane == 0) {
+      m.lin_n[i] = n;
+      m.lin_z[i] = z;
+    }
+  }
+}
+__global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, Rows rows,
+                                                                    Scratch s) {
+  linear_update_body(m, rows, s, blockIdx.x, gridDim.x);
+}
+
+// Bias update: one wave walks all rows of the block in order (update_bias_nz, :79-85).
+__device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, const Scratch &s) {
+  const int lane = threadIdx.x & 63;
+  float n = m.bias3[1], z = m.bias3[2];
+  const float w = m.bias3[0];
+  float g_next = lane < n_rows ? s.tg[lane] : 0.0f;
+  for (int r0 = 0; r0 < n_rows; r0 += 64) {
+    const int cnt = min(64, n_rows - r0);
+    const float g = g_next;
+    g_next = (r0 + 64 + lane) < n_rows ? s.tg[r0 + 64 + lane] : 0.0f;  // prefetch the next 64
+    linear_chain64(m.h, w, lane < cnt ? g : 0.0f, cnt, n, z);
+  }
+  if (lane == 0) {
+    m.bias3[1] = n;
+    m.bias3[2] = z;
+  }
+}
+__global__ __launch_bounds__(64) void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
+  bias_update_body(m, n_rows, s);
+}
+
 // ---- hot features, moderate counts: work item = (feature from the big list, 64 elements) ----
 // One wave owns 64 elements and walks the touches kUnroll at a time, software-pipelined three
 // groups deep over the same occurrence-ordered streams (group b applied while group b+1's partner
@@ -262,14 +369,26 @@ __device__ __forceinline__ void hot_stream_weights(const float *pcol, int RL, in
   for (int j = 0; j < kUnroll; j++) vp[j] = pcol[static_cast<int64_t>(min(t0 + j, c - 1)) * RL];
 }
 
+// side_blocks > 0: the first workgroups of the launch carry the block's two short serial jobs --
+// workgroup 0 the bias chain, workgroups 1..side_blocks-1 the linear update -- so that they run
+// beside the latent chains without a stream (and a hardware queue) of their own.
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m, Rows rows,
-                                                                     Scratch s, int fuse) {
+                                                                     Scratch s, int fuse,
+                                                                     int side_blocks) {
+  if (static_cast<int>(blockIdx.x) < side_blocks) {
+    if (blockIdx.x == 0) {
+      if (threadIdx.x < 64) bias_update_body(m, rows.n_rows, s);
+    } else {
+      linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1);
+    }
+    return;
+  }
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const bool stream = fuse && !s.counters[CNT_NOFUSE];
   const unsigned chunks = (RL + 63) / 64;
   const int lane = threadIdx.x & 63;
-  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const unsigned n_waves = gridDim.x * kUpdWaves;
+  const unsigned wave = (blockIdx.x - side_blocks) * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = (gridDim.x - side_blocks) * kUpdWaves;
   const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NBIG]) * chunks;
   const float inv_k = 1.0f / static_cast<float>(k);
   const size_t rec_floats = static_cast<size_t>(3) * RL;
@@ -526,106 +645,6 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     }
     rec[LAT_N * k + e] = n;
     rec[LAT_Z * k + e] = z;
-  }
-}
-
-// Strictly left-to-right running sum over the 64 lanes: returns S_j = ((carry + a_0) + a_1) ... + a_j
-// in lane j, every addition rounded exactly as a one-lane sequential loop would round it.  Step t
-// finalises lane t (S_t = S_{t-1} + a_t through a whole-wave shift-right-by-one DPP move); lanes
-// already final recompute the same value, so no predication is needed.  Idle lanes pass -0.0f
-// (x + -0.0f == x bit for bit, for every x including both zeros).
-__device__ __forceinline__ float wave_sequential_prefix(float carry, float a) {
-  const int lane = threadIdx.x & 63;
-  float s = lane == 0 ? carry + a : a;
-  const float step = lane == 0 ? -0.0f : a;
-#pragma unroll
-  for (int t = 1; t < 64; t++) {
-    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(
-        __float_as_int(s), __float_as_int(s), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-    s = prev + step;
-  }
-  return s;
-}
-
-// The linear/bias accumulator chain over up to 64 gradients held one per lane (lane j = the j-th
-// touch, in order; lanes >= count idle).  Sequential semantics of nz_step_linear, evaluated as:
-// (1) running n by a strictly sequential prefix sum, (2) every touch's z increment in parallel,
-// (3) z by a second sequential prefix -- the same operations on the same values in the same
-// order as the one-thread loop, so bit-identical.
-__device__ __forceinline__ void linear_chain64(const Hyper &h, float w, float g, int count,
-                                               float &n, float &z) {
-  const int lane = threadIdx.x & 63;
-  const bool live = lane < count;
-  const float n_after = wave_sequential_prefix(n, live ? g * g : -0.0f);
-  float n_before = __int_as_float(__builtin_amdgcn_update_dpp(
-      __float_as_int(n), __float_as_int(n_after), 0x138, 0xf, 0xf, false));
-  if (lane == 0) n_before = n;
-  const float sgm = div_alpha(h, sqrt_cr(n_after) - sqrt_cr(n_before));  // n_after = n_before + g*g
-  const float z_run = wave_sequential_prefix(z, live ? g - sgm * w : -0.0f);
-  n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n_after), 63));
-  z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_run), 63));
-}
-
-// Linear update (update_linear_nz, ftrl_model.cpp:66-77).  Small features: one thread each,
-// touches applied one after another; hot features: one wave each, 64 touches per pass.
-__global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, Rows rows,
-                                                                    Scratch s) {
-  const int n_small = s.counters[CNT_NSMALL], n_big = s.counters[CNT_NBIG];
-  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int li = gtid; li < n_small; li += gridDim.x * blockDim.x) {
-    const int u = s.small[li];
-    const int i = s.uniq[u];
-    const int start = s.ustart[u], c = s.ucount[u];
-    float n = m.lin_n[i], z = m.lin_z[i];
-    const float w = m.lin_w[i];
-    for (int t = 0; t < c; t++) {
-      const int2 pr = s.occ2[start + t];
-      nz_step_linear(m.h, w, s.tg[pr.y] * rows.val[pr.x], n, z);
-    }
-    m.lin_n[i] = n;
-    m.lin_z[i] = z;
-  }
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const int n_waves = gridDim.x * kUpdWaves;
-  const int n_huge = s.counters[CNT_NHUGE];
-  for (int li = wave; li < n_big + n_huge; li += n_waves) {
-    const int u = wave_uniform(li < n_big ? s.big[li] : s.huge[li - n_big]);
-    const int i = wave_uniform(s.uniq[u]);
-    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
-    float n = m.lin_n[i], z = m.lin_z[i];
-    const float w = m.lin_w[i];
-    for (int t0 = 0; t0 < c; t0 += 64) {
-      const int cnt = min(64, c - t0);
-      float g = 0.0f;
-      if (lane < cnt) {
-        const int2 pr = s.occ2[start + t0 + lane];
-        g = s.tg[pr.y] * rows.val[pr.x];
-      }
-      linear_chain64(m.h, w, g, cnt, n, z);
-    }
-    if (lane == 0) {
-      m.lin_n[i] = n;
-      m.lin_z[i] = z;
-    }
-  }
-}
-
-// Bias update: one wave walks all rows of the block in order (update_bias_nz, :79-85).
-__global__ __launch_bounds__(64) void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
-  const int lane = threadIdx.x & 63;
-  float n = m.bias3[1], z = m.bias3[2];
-  const float w = m.bias3[0];
-  float g_next = lane < n_rows ? s.tg[lane] : 0.0f;
-  for (int r0 = 0; r0 < n_rows; r0 += 64) {
-    const int cnt = min(64, n_rows - r0);
-    const float g = g_next;
-    g_next = (r0 + 64 + lane) < n_rows ? s.tg[r0 + 64 + lane] : 0.0f;  // prefetch the next 64
-    linear_chain64(m.h, w, lane < cnt ? g : 0.0f, cnt, n, z);
-  }
-  if (lane == 0) {
-    m.bias3[1] = n;
-    m.bias3[2] = z;
   }
 }
 

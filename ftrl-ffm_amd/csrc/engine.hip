@@ -2,14 +2,19 @@
 // per-block scratch, and schedules the gfx950 kernels of one block of rows on one HIP stream.
 //
 // Pipeline of one training block (DESIGN.md "Pipeline"):
-//   group_count -> group_alloc -> group_scatter -> group_sort      (kernels_group.h)
+//   group_keys -> radix sort (rocPRIM) -> group_finish              (kernels_group.h)
+//   ffm_refresh           lazy refresh, once per distinct feature   (kernels_row.h)
 //   {ffm,fm}_row<TRAIN>   lazy refresh + forward -> logit           (kernels_row.h)
 //   [cross-shard sum of the logits when n_shards > 1 -- done by the caller, RCCL]
 //   tmp_grad -> loss_sum
 //   linear_update, bias_update, {ffm,fm}_update                     (kernels_update.h)
-//   group_cleanup
 // There is no CPU fallback anywhere in this library.
 #include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -27,6 +32,11 @@
 #include "kernels_fused.h"
 
 using namespace ftrl_dev;
+
+// The grouping's sort: always the Onesweep radix sort (a few passes over the key bits), never
+// rocPRIM's merge-sort variant (about twenty small launches at this size).
+using GroupSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                  rocprim::default_config, 0>;
 
 namespace {
 
@@ -46,17 +56,16 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 enum KernelId {
-  K_GROUP_COUNT, K_GROUP_ALLOC, K_GROUP_SCATTER, K_GROUP_SORT, K_GROUP_EXPAND, K_ROW, K_TMP_GRAD,
+  K_GROUP_KEYS, K_GROUP_SORT, K_GROUP_FINISH, K_ROW, K_TMP_GRAD,
   K_HOT_META,
-  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_LATENT_UPDATE_HUGE, K_GROUP_CLEANUP,
+  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_LATENT_UPDATE_HUGE,
   K_PREDICT_ROW, K_FUSED_ROW, K_REFRESH,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
-    "group_count_kernel", "group_alloc_kernel", "group_scatter_kernel", "group_sort_kernel",
-    "group_expand_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
+    "group_keys_kernel", "group_radix_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
     "linear_update_kernel", "bias_update_kernel", "latent_update_kernel", "latent_update_hot_kernel",
-    "latent_update_huge_kernel", "group_cleanup_kernel",
+    "latent_update_huge_kernel",
     "row_kernel<predict>", "fused_row_kernel", "refresh_kernel"};
 
 struct ProfRec {
@@ -159,7 +168,9 @@ struct ffm_engine {
   int *d_row_ptr = nullptr, *d_field = nullptr, *d_feat = nullptr, *d_label = nullptr;
   float *d_val = nullptr, *d_out = nullptr;
   double *d_loss_sum = nullptr;
-  int *d_sort_tmp[2] = {nullptr, nullptr};
+  void *d_sort_tmp[2] = {nullptr, nullptr};  // rocPRIM radix sort workspace per scratch set
+  size_t sort_tmp_bytes = 0;
+  unsigned sort_bits = 32;
   float *d_stage = nullptr;  // dense staging for get/set
   int64_t stage_floats = 0;
   std::vector<void *> allocs;
@@ -375,21 +386,19 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&m.lat, n_lat));
   const size_t R = static_cast<size_t>(e->max_rows), E = static_cast<size_t>(e->max_nnz);
   Scratch &s = e->sc[0];
-  TRY_ALLOC(e->alloc(&s.efeat, E));
+  TRY_ALLOC(e->alloc(&s.key, E));
+  TRY_ALLOC(e->alloc(&s.skey, E));
   TRY_ALLOC(e->alloc(&s.row_of, E));
   TRY_ALLOC(e->alloc(&s.occ, E));
   TRY_ALLOC(e->alloc(&s.occ2, E));
   TRY_ALLOC(e->alloc(&s.uniq, E));
   TRY_ALLOC(e->alloc(&s.ustart, E));
   TRY_ALLOC(e->alloc(&s.ucount, E));
-  TRY_ALLOC(e->alloc(&s.multi, E));
   TRY_ALLOC(e->alloc(&s.small, E));
   TRY_ALLOC(e->alloc(&s.few, E));
   TRY_ALLOC(e->alloc(&s.big, E));
   TRY_ALLOC(e->alloc(&s.huge, E));
   TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
-  TRY_ALLOC(e->alloc(&s.cnt, nf));
-  TRY_ALLOC(e->alloc(&s.fstart, nf));
   TRY_ALLOC(e->alloc(&s.head, R * static_cast<size_t>(m.n_fields)));
   TRY_ALLOC(e->alloc(&s.next, E));
   TRY_ALLOC(e->alloc(&s.rowtab, R * static_cast<size_t>(m.n_fields)));
@@ -422,32 +431,41 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.tg, R));
   TRY_ALLOC(e->alloc(&s.loss, R));
   TRY_ALLOC(e->alloc(&s.svx, R * static_cast<size_t>(m.type == FFM_MODEL_FM ? m.n_factors : 1)));
-  TRY_ALLOC(e->alloc(&e->d_sort_tmp[0], E));
+  {
+    // stable LSD radix sort of (feature id, entry) pairs: key bits = those of the sentinel n_feats
+    e->sort_bits = 1;
+    while (e->sort_bits < 32 && (static_cast<uint64_t>(cfg->n_feats) >> e->sort_bits) != 0) e->sort_bits++;
+    TRY_HIP(rocprim::radix_sort_pairs<GroupSortConfig>(nullptr, e->sort_tmp_bytes, s.key, s.skey,
+                                      rocprim::counting_iterator<int>(0), s.occ, E, 0u, e->sort_bits,
+                                      e->stream));
+    unsigned char *tmp = nullptr;
+    TRY_ALLOC(e->alloc(&tmp, e->sort_tmp_bytes));
+    e->d_sort_tmp[0] = tmp;
+  }
   {
     Scratch &t = e->sc[1];
     t = s;  // shared: head/next/rowtab/haux/hmeta/logit/tg/loss/svx
-    TRY_ALLOC(e->alloc(&t.efeat, E));
+    TRY_ALLOC(e->alloc(&t.key, E));
+    TRY_ALLOC(e->alloc(&t.skey, E));
     TRY_ALLOC(e->alloc(&t.row_of, E));
     TRY_ALLOC(e->alloc(&t.occ, E));
     TRY_ALLOC(e->alloc(&t.occ2, E));
     TRY_ALLOC(e->alloc(&t.uniq, E));
     TRY_ALLOC(e->alloc(&t.ustart, E));
     TRY_ALLOC(e->alloc(&t.ucount, E));
-    TRY_ALLOC(e->alloc(&t.multi, E));
     TRY_ALLOC(e->alloc(&t.small, E));
     TRY_ALLOC(e->alloc(&t.few, E));
     TRY_ALLOC(e->alloc(&t.big, E));
     TRY_ALLOC(e->alloc(&t.huge, E));
     TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
-    TRY_ALLOC(e->alloc(&t.cnt, nf));
-    TRY_ALLOC(e->alloc(&t.fstart, nf));
     TRY_ALLOC(e->alloc(&t.occpos, E));
     if (masks) {
       TRY_ALLOC(e->alloc(&t.rowmask, 2 * R));
       TRY_ALLOC(e->alloc(&t.gmask, E));
     }
-    TRY_ALLOC(e->alloc(&e->d_sort_tmp[1], E));
-    TRY_HIP(hipMemsetAsync(t.cnt, 0, nf * sizeof(int), e->stream));
+    unsigned char *tmp = nullptr;
+    TRY_ALLOC(e->alloc(&tmp, e->sort_tmp_bytes));
+    e->d_sort_tmp[1] = tmp;
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
   TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
@@ -472,7 +490,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_HIP(hipMemsetAsync(m.lin_z, 0, nf * sizeof(float), e->stream));
   TRY_HIP(hipMemsetAsync(m.lin_w, 0, nf * sizeof(float), e->stream));
   if (n_lat) TRY_HIP(hipMemsetAsync(m.lat, 0, n_lat * sizeof(float), e->stream));
-  TRY_HIP(hipMemsetAsync(s.cnt, 0, nf * sizeof(int), e->stream));
   TRY_HIP(hipMemsetAsync(s.counters, 0, kNumCounters * sizeof(int), e->stream));
   if (cfg->w_alpha >= 0x1p-30f && cfg->w_alpha <= 0x1p30f) {
     // prove the short x/alpha sequence exact for this alpha before any kernel may use it
@@ -659,11 +676,14 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
     const int nnz = rows.nnz;
     if (sc.rowmask)
       HIP_TRY(hipMemsetAsync(sc.rowmask, 0, sizeof(unsigned long long) * 2 * rows.n_rows, st));
-    LAUNCH_ON(e, st, K_GROUP_COUNT, group_count_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->fuse_max_nv);
-    LAUNCH_ON(e, st, K_GROUP_ALLOC, group_alloc_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, sc);
-    LAUNCH_ON(e, st, K_GROUP_SCATTER, group_scatter_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, rows, sc, e->m.ownmask);
-    LAUNCH_ON(e, st, K_GROUP_SORT, group_sort_kernel, 1024, kGroupThreads, 0, sc, e->d_sort_tmp[set]);
-    LAUNCH_ON(e, st, K_GROUP_EXPAND, group_expand_kernel, std::min(cdiv(nnz, kGroupThreads), 1024), kGroupThreads, 0, nnz, sc);
+    LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->fuse_max_nv);
+    e->prof_begin(K_GROUP_SORT, st);
+    size_t bytes = e->sort_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
+                                      rocprim::counting_iterator<int>(0), sc.occ,
+                                      static_cast<size_t>(nnz), 0u, e->sort_bits, st));
+    e->prof_end(st);
+    LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, e->m, rows, sc);
   }
   HIP_TRY(hipGetLastError());
   return FFM_OK;
@@ -705,9 +725,7 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   e->fuse_request = false;
   const bool use_prepared = e->prepared >= 0 && same_block(e->prepared_rows, rows);
   if (e->prepared >= 0 && !use_prepared) {
-    // a grouping made ahead for some other block: undo its counters, then forget it
-    if (e->prepared_rows.nnz > 0)
-      LAUNCH_ON(e, e->prep, K_GROUP_CLEANUP, group_cleanup_kernel, std::min(cdiv(e->prepared_rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, e->sc[e->prepared]);
+    // a grouping made ahead for some other block: forget it
     HIP_TRY(hipEventRecord(e->ev_set_free[e->prepared], e->prep));
     e->prepared = -1;
   }
@@ -791,8 +809,6 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   if (loss_sum_out && !(ffm && vec4 && !e->serial))
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
   if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
-  if (rows.nnz > 0)
-    LAUNCH(e, K_GROUP_CLEANUP, group_cleanup_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, e->sc[e->cur]);
   HIP_TRY(hipEventRecord(e->ev_set_free[e->cur], e->stream));
   HIP_TRY(hipGetLastError());
   return FFM_OK;

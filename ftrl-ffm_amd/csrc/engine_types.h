@@ -57,22 +57,20 @@ __device__ __forceinline__ bool owns_pair(const ModelDev &m, int fa, int fb) {
 
 // Per-block scratch: the block grouped by feature ("postings"), per-row field chains, outputs.
 struct Scratch {
-  int *efeat;     // [nnz] validated feature id, -1 for entries remove_out_range would erase
+  unsigned *key;  // [nnz] sort key per entry: feature id, n_feats for entries remove_out_range erases
+  unsigned *skey; // [nnz] the keys sorted ascending (s.occ holds the entries in the same order)
   int *row_of;    // [nnz] row of each entry
   int *occ;       // [nnz] entry indices grouped by feature; ascending inside a group
   int2 *occ2;     // [nnz] the same groups as {entry, row of the entry}
   int *uniq;      // [nnz] distinct features of the block (arbitrary order)
   int *ustart;    // [nnz] start of each distinct feature's group in occ
   int *ucount;    // [nnz] its number of occurrences
-  int *multi;     // [nnz] indices into uniq of the features that occur more than once
   int *small;     // [nnz] indices into uniq of the features with <= kSmallMax occurrences
   int *few;       // [nnz] ... with 2..kSmallMax occurrences (the small list minus the features
                   //      that occur once, which the fused row kernel updates itself)
   int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
   int *huge;      // [nnz] ... with more ("very hot": present in a large share of the rows)
   int *counters;  // [kNumCounters] CNT_* below
-  int *cnt;       // [n_feats] per-feature counter, all zero between blocks
-  int *fstart;    // [n_feats] group start per feature (valid for features of the block)
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
   int *next;      // [nnz] next entry of the same row with the same field, -1 at the end
   int4 *rowtab;   // [n_rows*n_fields] {feat, val bits, entry, count} of the field's entry in the

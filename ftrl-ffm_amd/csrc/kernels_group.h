@@ -1,5 +1,8 @@
 // kernels_group.h -- groups one block of rows by feature ("postings"): the mini-batch scheduler's
-// device half.  Replaces the per-feature std::mutex / std::shared_mutex arbitration of the
+// device half.  Three steps: group_keys_kernel (one sort key per entry) -> a stable LSD radix sort
+// of (feature id, entry index) pairs (rocPRIM device primitive) -> group_finish_kernel (group
+// boundaries, owner lists, touched-slot masks).  No per-feature arrays and no same-address atomic
+// chains: a feature present in a thousand rows costs what a thousand distinct features cost.  Replaces the per-feature std::mutex / std::shared_mutex arbitration of the
 // reference (src/include/model/ftrl_model.h:49, ffm.h:32): instead of N threads racing for a
 // feature's lock, every distinct feature of the block gets ONE owner that applies all of the
 // block's touches to it in row order (kernels_update.h).  Integer work only; results are
@@ -10,7 +13,7 @@
 namespace ftrl_dev {
 
 constexpr int kGroupThreads = 256;
-constexpr int kSortCap = 16384;  // ints of LDS for the in-workgroup bitonic sort (64 KiB)
+constexpr int kFinishThreads = 1024;  // group_finish_kernel: one atomic per list per workgroup
 
 // One atomic per wave instead of one per lane: lanes with pred get consecutive slots.
 __device__ __forceinline__ int wave_append_slot(int *counter, bool pred) {
@@ -39,155 +42,180 @@ __device__ __forceinline__ int wave_reserve(int *counter, int amount) {
   return base + incl - amount;
 }
 
-// Entry p: validate (remove_out_range, ftrl_model.cpp:36-42 / ffm.cpp:30-36), find its row,
-// count its feature, register first-seen features.  FFM with n_fields <= 64 also collects, per
-// row, the fields present once / more than once (s.rowmask: what group_scatter_kernel turns into
-// the touched-slot masks) and decides whether the fused row kernel may take the block: it needs
-// every row to hold at most max_nv entries and at most one per field, else CNT_NOFUSE.
-__global__ __launch_bounds__(kGroupThreads) void group_count_kernel(ModelDev m, Rows rows,
-                                                                    Scratch s, int max_nv) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in = p < rows.nnz;
-  bool valid = false;
-  int i = 0;
+// Entry p: validate (remove_out_range, ftrl_model.cpp:36-42 / ffm.cpp:30-36), find its row, emit
+// its sort key (the feature id; n_feats for erased entries, which therefore sort last).  FFM with
+// n_fields <= 64 also collects, per row, the fields present once / more than once (s.rowmask: what
+// group_finish_kernel turns into the touched-slot masks) and decides whether the fused row kernel
+// may take the block: it needs every row to hold at most max_nv entries and at most one per
+// field, else CNT_NOFUSE.
+__global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, Rows rows, Scratch s,
+                                                                   int max_nv) {
+  const int pp = blockIdx.x * blockDim.x + threadIdx.x;  // the grid covers whole waves
+  const bool in = pp < rows.nnz;
+  const int p = in ? pp : rows.nnz - 1;  // idle lanes of the last wave shadow the last entry
+  // row_ptr[r] <= p < row_ptr[r+1]  (upper bound - 1; tolerates empty rows)
+  int lo = 0, hi = rows.n_rows;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (rows.row_ptr[mid + 1] <= p) lo = mid + 1; else hi = mid;
+  }
+  const int i = rows.feat[p];
+  const int f = rows.field ? rows.field[p] : 0;
+  bool valid = i >= 0 && i < m.n_feats;
+  if (m.type == 2) valid = valid && f >= 0 && f < m.n_fields;
   if (in) {
-    // row_ptr[r] <= p < row_ptr[r+1]  (upper bound - 1; tolerates empty rows)
-    int lo = 0, hi = rows.n_rows;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (rows.row_ptr[mid + 1] <= p) lo = mid + 1; else hi = mid;
-    }
     s.row_of[p] = lo;
-    i = rows.feat[p];
-    const int f = rows.field ? rows.field[p] : 0;
-    valid = i >= 0 && i < m.n_feats;
-    if (m.type == 2) valid = valid && f >= 0 && f < m.n_fields;
-    if (s.rowmask && valid) {
-      const unsigned long long bit = 1ull << f;
-      const unsigned long long before = atomicOr(&s.rowmask[2 * lo], bit);
-      if (before & bit) {
-        atomicOr(&s.rowmask[2 * lo + 1], bit);
+    s.key[p] = valid ? static_cast<unsigned>(i) : static_cast<unsigned>(m.n_feats);
+    s.occpos[p] = OCC_FEW;
+    if (s.gmask) s.gmask[p] = 0ull;
+  }
+  valid = valid && in;
+  if (s.rowmask) {
+    // fields present once / more than once per row: combined over the lanes of the wave that
+    // share the row (entries of a row are consecutive), then one atomic per row piece
+    const int lane = threadIdx.x & 63;
+    unsigned long long once = valid ? 1ull << f : 0ull, twice = 0ull;
+    const int prev_row = __shfl_up(lo, 1, 64);
+    const unsigned long long starts = __ballot(lane == 0 || prev_row != lo);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const int seg0 = 63 - __clzll(static_cast<long long>(starts & upto));  // first lane of my row piece
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long o = __shfl_up(once, d, 64), w = __shfl_up(twice, d, 64);
+      if (lane - d >= seg0) {
+        twice |= w | (o & once);
+        once |= o;
+      }
+    }
+    const int next_row = __shfl_down(lo, 1, 64);
+    if (in && (lane == 63 || next_row != lo || pp == rows.nnz - 1)) {  // last lane of the piece
+      if (once) {
+        const unsigned long long before = atomicOr(&s.rowmask[2 * lo], once);
+        twice |= before & once;
+      }
+      if (twice) {
+        atomicOr(&s.rowmask[2 * lo + 1], twice);
         atomicOr(&s.counters[CNT_NOFUSE], 1);
       }
-      if (p == rows.row_ptr[lo] && rows.row_ptr[lo + 1] - p > max_nv)
-        atomicOr(&s.counters[CNT_NOFUSE], 1);
     }
+    if (in && p == rows.row_ptr[lo] && rows.row_ptr[lo + 1] - p > max_nv)
+      atomicOr(&s.counters[CNT_NOFUSE], 1);
   }
-  if (in) { s.efeat[p] = valid ? i : -1; s.occpos[p] = -1; }
-  const bool first = valid && atomicAdd(&s.cnt[i], 1) == 0;
-  const int u = wave_append_slot(&s.counters[CNT_NUNIQ], first);
-  if (first) s.uniq[u] = i;
 }
 
-// Distinct feature u: reserve its group in occ, remember where, re-zero its counter (reused as
-// the fill cursor), and sort it into the lists the later passes walk: "multi" (more than one
-// occurrence: needs ordering), "small" / "big" (which update path owns it).
-__global__ __launch_bounds__(kGroupThreads) void group_alloc_kernel(Scratch s) {
-  const int n_uniq = s.counters[CNT_NUNIQ];
-  const int n_round = (n_uniq + 63) & ~63;  // whole waves stay converged for the wave-wide ops
-  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_round; u += gridDim.x * blockDim.x) {
-    const bool live = u < n_uniq;
-    const int i = live ? s.uniq[u] : 0;
-    const int c = live ? s.cnt[i] : 0;
-    const int start = wave_reserve(&s.counters[CNT_CURSOR], c);
-    const int im = wave_append_slot(&s.counters[CNT_NMULTI], live && c > 1);
-    const int is = wave_append_slot(&s.counters[CNT_NSMALL], live && c <= kSmallMax);
-    const int ib = wave_append_slot(&s.counters[CNT_NBIG], live && c > kSmallMax && c <= kHugeMin);
-    const int ih = wave_append_slot(&s.counters[CNT_NHUGE], live && c > kHugeMin);
-    const int iw = wave_append_slot(&s.counters[CNT_NFEW], live && c > 1 && c <= kSmallMax);
-    if (!live) continue;
-    s.ustart[u] = start;
+// first index in skey[0, n) whose key is >= k (strict = false) or > k (strict = true)
+__device__ __forceinline__ int sorted_bound(const unsigned *skey, int n, unsigned k, bool strict) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const unsigned v = skey[mid];
+    if (strict ? v <= k : v < k) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Sorted position t (s.skey ascending, s.occ = the entries in that order; equal keys keep their
+// entry order, i.e. row order then position in the row -- the order the reference's one-thread
+// loop would touch them in).  Finds t's group [lower, upper): from the group heads inside the wave
+// when the group starts / ends there, by binary search when it crosses the wave.  Group heads
+// register the distinct feature (uniq / ustart / ucount) and sort it into the owner lists; every
+// position publishes {entry, row}, its entry's occurrence class, and ORs its touched-slot mask
+// into the group's (one atomic per group piece per wave).
+__global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m, Rows rows,
+                                                                     Scratch s) {
+  const int nnz = rows.nnz;
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // the grid covers whole waves
+  const bool in = t < nnz;
+  const unsigned sentinel = static_cast<unsigned>(m.n_feats);
+  const unsigned K = in ? s.skey[t] : sentinel;
+  const bool valid = in && K < sentinel;
+  const unsigned Kprev = (in && t > 0) ? s.skey[t - 1] : 0xffffffffu;
+  const unsigned Knext = (t + 1 < nnz) ? s.skey[t + 1] : 0xffffffffu;
+  const bool head = valid && (t == 0 || Kprev != K);
+  const bool last = valid && Knext != K;
+  if (last && Knext >= sentinel) s.counters[CNT_CURSOR] = t + 1;  // number of surviving entries
+  // group bounds
+  const unsigned long long heads = __ballot(head), lasts = __ballot(last);
+  const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);  // lanes 0..lane
+  const unsigned long long from = ~0ull << lane;                                   // lanes lane..63
+  const unsigned long long hb = heads & upto, lb = lasts & from;
+  const int hl = hb ? 63 - __clzll(static_cast<long long>(hb)) : -1;   // my group's head lane
+  const int ll = lb ? __ffsll(static_cast<long long>(lb)) - 1 : -1;     // my group's last lane
+  // a group that crosses the wave's edges: lane 0 / lane 63 search its bound for the whole piece
+  int lower0 = 0, upper63 = 0;
+  if (lane == 0 && valid && !head) lower0 = sorted_bound(s.skey, nnz, K, false);
+  if (lane == 63 && valid && !last) upper63 = sorted_bound(s.skey, nnz, K, true);
+  lower0 = __shfl(lower0, 0, 64);
+  upper63 = __shfl(upper63, 63, 64);
+  int lower = 0, upper = 0;
+  if (valid) {
+    lower = hl >= 0 ? t - (lane - hl) : lower0;
+    upper = ll >= 0 ? t + (ll - lane) + 1 : upper63;
+  }
+  const int c = upper - lower;
+  int p = 0;
+  if (valid) {
+    p = s.occ[t];
+    s.occ2[t] = make_int2(p, s.row_of[p]);
+    s.occpos[p] = c > kSmallMax ? t : (c == 1 ? OCC_ONCE : OCC_FEW);
+  }
+  // distinct features and their owner lists: slots handed out per workgroup (one atomic per
+  // list per workgroup -- per-wave atomics on five shared counters would be a serial chain)
+  __shared__ int wave_cnt[kFinishThreads / 64][5];
+  __shared__ int wave_base[kFinishThreads / 64][5];
+  const int wv = threadIdx.x >> 6;
+  const bool pred[5] = {head, head && c <= kSmallMax, head && c > 1 && c <= kSmallMax,
+                        head && c > kSmallMax && c <= kHugeMin, head && c > kHugeMin};
+  const int which[5] = {CNT_NUNIQ, CNT_NSMALL, CNT_NFEW, CNT_NBIG, CNT_NHUGE};
+  unsigned long long pm[5];
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    pm[q] = __ballot(pred[q]);
+    if (lane == 0) wave_cnt[wv][q] = __popcll(pm[q]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const int q = threadIdx.x;
+    int total = 0;
+    for (int w = 0; w < kFinishThreads / 64; w++) { wave_base[w][q] = total; total += wave_cnt[w][q]; }
+    const int base = total ? atomicAdd(&s.counters[which[q]], total) : 0;
+    for (int w = 0; w < kFinishThreads / 64; w++) wave_base[w][q] += base;
+  }
+  __syncthreads();
+  int slot[5];
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int q = 0; q < 5; q++) slot[q] = wave_base[wv][q] + __popcll(pm[q] & below);
+  const int u = slot[0], is = slot[1], iw = slot[2], ib = slot[3], ih = slot[4];
+  if (head) {
+    s.uniq[u] = static_cast<int>(K);
+    s.ustart[u] = t;
     s.ucount[u] = c;
-    if (s.gmask) s.gmask[start] = 0ull;
-    s.fstart[i] = start;
-    s.cnt[i] = 0;
-    if (c > 1) s.multi[im] = u;
     if (c > 1 && c <= kSmallMax) s.few[iw] = u;
     if (c <= kSmallMax) s.small[is] = u;
     else if (c <= kHugeMin) s.big[ib] = u;
     else s.huge[ih] = u;
   }
-}
-
-__global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(
-    Rows rows, Scratch s, const unsigned long long *ownmask) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= rows.nnz) return;
-  const int i = s.efeat[p];
-  if (i < 0) return;
-  const int start = s.fstart[i];
-  s.occ[start + atomicAdd(&s.cnt[i], 1)] = p;
+  // slots of the feature that p's row touches: slot fp is touched when the row holds ANOTHER
+  // entry of field fp (FFM::update_vector_w refreshes exactly those, ffm.cpp:72-88), within the
+  // field pairs this shard owns; OR-ed over the group
   if (s.gmask) {
-    // slots of feature i that p's row touches: slot fp is touched when the row holds ANOTHER
-    // entry of field fp (FFM::update_vector_w refreshes exactly those, ffm.cpp:72-88), within the
-    // field pairs this shard owns
-    const int r = s.row_of[p], f = rows.field[p];
-    const unsigned long long once = s.rowmask[2 * r], twice = s.rowmask[2 * r + 1];
-    const unsigned long long self = 1ull << f;
-    atomicOr(&s.gmask[start], ((once & ~self) | (twice & self)) & ownmask[f]);
-  }
-}
-
-// Groups with more than one entry: sort ascending by entry index (= row order, then position in
-// the row), so the owner applies touches in the order the reference's single-thread loop would.
-__global__ __launch_bounds__(kGroupThreads) void group_sort_kernel(Scratch s, int *tmp) {
-  __shared__ int keys[kSortCap];
-  const int n_multi = s.counters[CNT_NMULTI];
-  for (int mi = blockIdx.x; mi < n_multi; mi += gridDim.x) {
-    const int u = s.multi[mi];
-    const int start = s.ustart[u], c = s.ucount[u];
-    int *seg = s.occ + start;
-    if (c <= 64) {
-      // rank sort inside one wave: entries are distinct
-      if (threadIdx.x < 64) {
-        const int mine = threadIdx.x < c ? seg[threadIdx.x] : 0x7fffffff;
-        int rank = 0;
-        for (int j = 0; j < c; j++) rank += (__shfl(mine, j, 64) < mine) ? 1 : 0;
-        if (threadIdx.x < c) seg[rank] = mine;  // all lanes loaded before any lane stores
-      }
-    } else if (c <= kSortCap) {
-      int n2 = 128;
-      while (n2 < c) n2 <<= 1;
-      for (int t = threadIdx.x; t < n2; t += blockDim.x) keys[t] = t < c ? seg[t] : 0x7fffffff;
-      __syncthreads();
-      for (int size = 2; size <= n2; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-          for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
-            const int lo = (t / stride) * (stride << 1) + (t % stride);
-            const int hi = lo + stride;
-            const bool up = ((lo & size) == 0);
-            const int a = keys[lo], b = keys[hi];
-            if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-          }
-          __syncthreads();
-        }
-      for (int t = threadIdx.x; t < c; t += blockDim.x) seg[t] = keys[t];
-    } else {
-      // longer than the LDS buffer (a feature present far more often than once per row):
-      // O(c^2) rank sort through a global temporary
-      int *out = tmp + start;
-      for (int t = threadIdx.x; t < c; t += blockDim.x) {
-        const int mine = seg[t];
-        int rank = 0;
-        for (int j = 0; j < c; j++) rank += (seg[j] < mine) ? 1 : 0;
-        out[rank] = mine;
-      }
-      __syncthreads();
-      for (int t = threadIdx.x; t < c; t += blockDim.x) seg[t] = out[t];
+    unsigned long long tm = 0ull;
+    if (valid) {
+      const int r = s.row_of[p], f = rows.field[p];
+      const unsigned long long once = s.rowmask[2 * r], twice = s.rowmask[2 * r + 1];
+      const unsigned long long self = 1ull << f;
+      tm = ((once & ~self) | (twice & self)) & m.ownmask[f];
     }
-    __syncthreads();
-  }
-}
-
-// Groups are final: publish them as {entry, row} pairs so the owners need one load per touch.
-__global__ __launch_bounds__(kGroupThreads) void group_expand_kernel(int nnz_valid_cap, Scratch s) {
-  const int n = s.counters[CNT_CURSOR];  // number of surviving entries
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-    const int p = s.occ[t];
-    s.occ2[t] = make_int2(p, s.row_of[p]);
-    // after the scatter cnt[feature] holds its occurrence count again
-    const int c = s.cnt[s.efeat[p]];
-    s.occpos[p] = c > kSmallMax ? t : (c == 1 ? OCC_ONCE : OCC_FEW);
+    const int seg0 = hl >= 0 ? hl : 0;  // first lane of my group's piece in this wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long v = __shfl_up(tm, d, 64);
+      if (lane - d >= seg0) tm |= v;
+    }
+    const bool piece_end = valid && (last || lane == 63 || t == nnz - 1);
+    if (piece_end) atomicOr(&s.gmask[lower], tm);
   }
 }
 
@@ -200,13 +228,6 @@ __global__ __launch_bounds__(kGroupThreads) void hot_meta_kernel(Rows rows, Scra
     if (s.occpos[pr.x] < 0) continue;
     s.hmeta[t] = make_float2(s.tg[pr.y], rows.val[pr.x]);
   }
-}
-
-// Leave cnt[] all zero for the next block.
-__global__ __launch_bounds__(kGroupThreads) void group_cleanup_kernel(Scratch s) {
-  const int n_uniq = s.counters[CNT_NUNIQ];
-  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_uniq; u += gridDim.x * blockDim.x)
-    s.cnt[s.uniq[u]] = 0;
 }
 
 }  // namespace ftrl_dev

@@ -180,6 +180,10 @@ struct ffm_engine {
   // fused row path (kernels_fused.h): statically possible / asked for by the current call /
   // in use for the pending block (the block itself may still veto it on the device: CNT_NOFUSE)
   bool fuse_ok = false, fuse_request = false, fuse_cur = false;
+  // train_batch_device on one shard: the row kernel has the whole logit, so it also produces
+  // tmp_grad, the row losses and the hot occurrences' facts (no tmp_grad / hot_meta passes)
+  bool own_tg_cur = false;
+  float *own_logit_out = nullptr;
   // the block's lazy refresh as one pass over its distinct features (ffm_refresh_kernel) instead
   // of per occurrence inside the row kernel; FFM_ENGINE_ROW_REFRESH=1 keeps it in the row kernel
   bool pre_refresh = false;
@@ -468,6 +472,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     e->d_sort_tmp[1] = tmp;
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
+  // (a high-priority queue for the look-ahead grouping was tried: the whole step got 45% slower)
   TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_rows_done, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) {
@@ -630,7 +635,7 @@ static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *r
 }
 
 
-static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float *out, int output_prob) {
+static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float *out, int output_prob, int own_tg = 0) {
   if (rows.n_rows == 0) return;
   const size_t shmem = row_lds_bytes(e->max_row_nnz, e->m.n_fields);
   const int kid = train ? K_ROW : K_PREDICT_ROW;
@@ -656,10 +661,10 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
       else if (e->m.n_factors == 8) LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<2>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
       else LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<1>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
     }
-    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed);
-    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed);
-    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0);
-    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0);
+    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed, own_tg);
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed, own_tg);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
   }
 }
 
@@ -722,6 +727,7 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   e->pending = rows;
   e->has_pending = true;
   e->fuse_cur = e->fuse_ok && e->fuse_request;  // only train_batch_device asks: it owns tmp_grad
+  e->own_tg_cur = e->fuse_request && e->m.n_shards == 1 && e->m.type != FFM_MODEL_FM && !e->fuse_cur;
   e->fuse_request = false;
   const bool use_prepared = e->prepared >= 0 && same_block(e->prepared_rows, rows);
   if (e->prepared >= 0 && !use_prepared) {
@@ -739,7 +745,7 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
     if (rc) return rc;
   }
   e->set_used[e->cur] = true;
-  launch_row_kernel(e, rows, true, nullptr, 0);
+  launch_row_kernel(e, rows, true, e->own_tg_cur ? e->own_logit_out : nullptr, 0, e->own_tg_cur ? 1 : 0);
   HIP_TRY(hipEventRecord(e->ev_rows_done, e->stream));
   e->rows_done_recorded = true;
   if (partial_logit && n_rows > 0)
@@ -756,9 +762,10 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   const Rows rows = e->pending;
   e->has_pending = false;
   const float *lg = logit ? logit : e->sc[e->cur].logit;
-  if (rows.n_rows > 0)
+  const bool own_tg = e->own_tg_cur && !logit;
+  if (rows.n_rows > 0 && !own_tg)
     LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->sc[e->cur].tg, e->sc[e->cur].loss, logit_out);
-  if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0)
+  if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0 && !own_tg)
     LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
   const bool lin_owner = e->m.shard_rank == 0;
   const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
@@ -820,7 +827,7 @@ int ffm_engine_train_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
                                   float *logit_out, double *loss_sum_out) {
   if (e && e->m.n_shards > 1)
     return fail(FFM_E_INVALID, "sharded engines train with train_forward + all-reduce + train_update");
-  if (e) e->fuse_request = true;
+  if (e) { e->fuse_request = true; e->own_logit_out = logit_out; }
   int rc = ffm_engine_train_forward_device(e, n_rows, nnz, row_ptr, field, feat, val, label, nullptr);
   if (e) e->fuse_request = false;
   if (rc) return rc;

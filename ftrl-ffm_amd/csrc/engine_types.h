@@ -106,7 +106,10 @@ enum { OCC_FEW = -1, OCC_ONCE = -2 };
 constexpr int kHugeMin = FFM_HUGE_MIN;  // occurrences per block above which a feature takes the lane-parallel path
 enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
                                                      // first / several entries share the field
-constexpr int kSmallMax = 4;  // occurrences per block up to which a feature takes the "small" path
+#ifndef FFM_SMALL_MAX
+#define FFM_SMALL_MAX 4
+#endif
+constexpr int kSmallMax = FFM_SMALL_MAX;  // occurrences per block up to which a feature takes the "small" path
 enum { ERR_ROW_TOO_LONG = 1 };
 
 }  // namespace ftrl_dev

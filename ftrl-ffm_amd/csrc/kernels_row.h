@@ -166,6 +166,34 @@ __device__ __forceinline__ void publish_row_tables(const Rows &rows, const Scrat
   }
 }
 
+// The same sum by one whole wave: lane 0's acc + terms[0] + terms[1] + ... strictly in order, one
+// dependent add after another, but with the terms staged in registers (kTermsPerLane consecutive
+// terms per lane) and fed to the chain by v_readlane instead of one LDS round trip per four terms.
+// Terms carrying the "not this shard's pair" tag are replaced by -0.0f (x + -0.0f == x bit for
+// bit).  Every lane returns the sum.
+constexpr int kTermsPerLane = 12;
+__device__ __forceinline__ float wave_add_terms_in_order(const float *terms, int cnt, float acc0) {
+  const int lane = threadIdx.x & 63;
+  float acc = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(acc0)));
+  for (int base = 0; base < cnt; base += 64 * kTermsPerLane) {
+    float tl[kTermsPerLane];
+#pragma unroll
+    for (int j = 0; j < kTermsPerLane; j++) {
+      const int q = base + lane * kTermsPerLane + j;
+      const float t = q < cnt ? terms[q] : -0.0f;
+      tl[j] = __float_as_int(t) == 0x7fc00001 ? -0.0f : t;
+    }
+    const int left = cnt - base;
+    const int lanes_used = left >= 64 * kTermsPerLane ? 64 : (left + kTermsPerLane - 1) / kTermsPerLane;
+    for (int l = 0; l < lanes_used; l++) {
+#pragma unroll
+      for (int j = 0; j < kTermsPerLane; j++)
+        acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tl[j]), l));
+    }
+  }
+  return acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // FFM (and LR when row_len == 0): one workgroup per row.
 // TRAIN: refresh linear/bias/latent weights of everything the row touches, publish the row's
@@ -177,9 +205,10 @@ template <bool TRAIN, bool VEC4>
 __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
                                                               int output_prob, int fuse,
-                                                              int refreshed) {
+                                                              int refreshed, int own_tg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv;
+  __shared__ float s_tg;
   if (TRAIN && fuse && !s.counters[CNT_NOFUSE]) return;  // kernels_fused.h took this block
   const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
   RowLds lds = carve_row_lds(smem, max_row_nnz, F);
@@ -289,12 +318,25 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
           if (VEC4) {
             const float4 *va4 = reinterpret_cast<const float4 *>(va);
             const float4 *vb4 = reinterpret_cast<const float4 *>(vb);
-            for (int f4 = 0; f4 < (k >> 2); f4++) {
-              const float4 x = va4[f4], y = vb4[f4];
-              dot = dot + x.x * y.x;
-              dot = dot + x.y * y.y;
-              dot = dot + x.z * y.z;
-              dot = dot + x.w * y.w;
+            if (k == 16) {  // the common slot size: both slots' eight vectors in flight together
+              float4 x[4], y[4];
+#pragma unroll
+              for (int f4 = 0; f4 < 4; f4++) { x[f4] = va4[f4]; y[f4] = vb4[f4]; }
+#pragma unroll
+              for (int f4 = 0; f4 < 4; f4++) {
+                dot = dot + x[f4].x * y[f4].x;
+                dot = dot + x[f4].y * y[f4].y;
+                dot = dot + x[f4].z * y[f4].z;
+                dot = dot + x[f4].w * y[f4].w;
+              }
+            } else {
+              for (int f4 = 0; f4 < (k >> 2); f4++) {
+                const float4 x = va4[f4], y = vb4[f4];
+                dot = dot + x.x * y.x;
+                dot = dot + x.y * y.y;
+                dot = dot + x.z * y.z;
+                dot = dot + x.w * y.w;
+              }
             }
           } else {
             for (int f = 0; f < k; f++) dot = dot + va[f] * vb[f];
@@ -305,16 +347,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
         lds.terms[q - q0] = own ? term : __int_as_float(0x7fc00001);
       }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        if (m.n_shards <= 1) {
-          result = add_terms_in_order(lds.terms, q1 - q0, result);
-        } else {
-          for (int j = 0; j < q1 - q0; j++) {
-            const float t = lds.terms[j];
-            if (__float_as_int(t) != 0x7fc00001) result += t;
-          }
-        }
-      }
+      if (threadIdx.x < 64) result = wave_add_terms_in_order(lds.terms, q1 - q0, result);
       __syncthreads();
     }
   }
@@ -322,9 +355,28 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   if (threadIdx.x == 0) {
     if (TRAIN) {
       s.logit[r] = result;
+      if (own_tg) {
+        // the whole logit is here (one shard): tmp_grad = sigmoid(logit) - y (ffm.cpp:44) and the
+        // row's logloss (ftrl_offline.cpp:80) without a pass of their own
+        const int y = rows.label[r];
+        const float tg = sigmoid_ref(result) - static_cast<float>(y);
+        s.tg[r] = tg;
+        s.loss[r] = logloss_ref(y, result);
+        if (out) out[r] = result;
+        s_tg = tg;
+      }
     } else {
       out[r] = output_prob ? sigmoid_ref(result) : result;
       if (rows.label) s.loss[r] = logloss_ref(rows.label[r], result);
+    }
+  }
+  if (TRAIN && own_tg && is_ffm) {
+    // {tmp_grad, own value} of this row's hot entries, by occurrence position, for their owners
+    __syncthreads();
+    const float tg = s_tg;
+    for (int a = threadIdx.x; a < nv; a += blockDim.x) {
+      const int op = lds.opos[a];
+      if (op >= 0) s.hmeta[op] = make_float2(tg, lds.val[a]);
     }
   }
 }

@@ -377,6 +377,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
                                                                      int side_blocks) {
   if (static_cast<int>(blockIdx.x) < side_blocks) {
     if (blockIdx.x == 0) {
+      // one wave, 8192 dependent touches: let it win the issue arbitration on its SIMD
+      __builtin_amdgcn_s_setprio(3);
       if (threadIdx.x < 64) bias_update_body(m, rows.n_rows, s);
     } else {
       linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1);

@@ -248,20 +248,27 @@ def main():
     # region then carries HIP events only around that dominant kernel
     if not args.no_profile:
         eng.profile_enable(True)
-    for i in range(args.warmup):
-        step(i, blocks[i % len(blocks)])
-        if not args.no_lookahead:
-            prepare(blocks[(i + 1) % len(blocks)])
+    DEPTH = 2  # blocks grouped ahead (ffm_engine_prepare_device): two hide the grouping completely
+
+    def run(first, count):
+        """`count` steps starting at global step `first`; every grouping of these steps -- ahead or
+        inline -- is issued inside the call, none for later steps."""
+        ahead = 0  # blocks currently prepared ahead
+        for i in range(count):
+            step(first + i, blocks[(first + i) % len(blocks)])
+            ahead = max(ahead - 1, 0)
+            while not args.no_lookahead and ahead < DEPTH and i + ahead + 1 < count:
+                prepare(blocks[(first + i + ahead + 1) % len(blocks)])
+                ahead += 1
+
+    run(0, args.warmup)
     fence()
     table = ""
     if not args.no_profile:
         table = eng.profile_dump()
         eng.profile_focus()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, blocks[(args.warmup + i) % len(blocks)])
-        if not args.no_lookahead and i + 1 < args.steps:
-            prepare(blocks[(args.warmup + i + 1) % len(blocks)])
+    run(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -144,15 +144,21 @@ __global__ void lat_component_copy_kernel(float *lat, int row_len, int comp, flo
 struct ffm_engine {
   ffm_engine_config cfg{};
   ModelDev m{};
-  // Two sets of grouping outputs (ping-pong): block t+1 can be grouped on the prep stream while
-  // block t is still being updated.  Everything the row kernel writes is shared by both sets.
-  Scratch sc[2]{};
+  // kSets sets of grouping outputs, used in rotation: block t+1 is grouped on the prep stream into
+  // the set block t-2 used, so it never waits for block t-1 or t to retire (with two sets the
+  // grouping could only start when the previous block ended, and then sat starved of wave slots
+  // behind that block's persistent update kernels).  What the row kernel writes is shared.
+  static constexpr int kSets = 3;
+  Scratch sc[kSets]{};
   int cur = 0;                 // set of the block being trained
-  int prepared = -1;           // set holding a grouping made ahead by ffm_engine_prepare_device
-  Rows prepared_rows{};
-  bool set_used[2] = {false, false};
+  // groupings made ahead by ffm_engine_prepare_device, oldest first (at most kSets - 1)
+  int n_prepared = 0;
+  int prepared_set[kSets] = {};
+  Rows prepared_rows[kSets] = {};
+  int last_set = 0;            // set handed out most recently (to a prepare or to a training block)
+  bool set_used[kSets] = {};
   hipStream_t prep = nullptr;  // side stream of ffm_engine_prepare_device
-  hipEvent_t ev_grouped[2] = {nullptr, nullptr}, ev_set_free[2] = {nullptr, nullptr};
+  hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
   hipEvent_t ev_rows_done = nullptr;  // row phase of the most recently enqueued training block
   bool rows_done_recorded = false;
   bool prep_after_rows = false;  // FFM_PREP_AFTER_ROWS=1: group beside the update phase only
@@ -168,7 +174,7 @@ struct ffm_engine {
   int *d_row_ptr = nullptr, *d_field = nullptr, *d_feat = nullptr, *d_label = nullptr;
   float *d_val = nullptr, *d_out = nullptr;
   double *d_loss_sum = nullptr;
-  void *d_sort_tmp[2] = {nullptr, nullptr};  // rocPRIM radix sort workspace per scratch set
+  void *d_sort_tmp[kSets] = {};  // rocPRIM radix sort workspace per scratch set
   size_t sort_tmp_bytes = 0;
   unsigned sort_bits = 32;
   float *d_stage = nullptr;  // dense staging for get/set
@@ -284,7 +290,7 @@ void ffm_engine_destroy(ffm_engine *e) {
   for (void *p : e->allocs) (void)hipFree(p);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < ffm_engine::kSets; i++) {
     if (e->ev_grouped[i]) (void)hipEventDestroy(e->ev_grouped[i]);
     if (e->ev_set_free[i]) (void)hipEventDestroy(e->ev_set_free[i]);
   }
@@ -446,8 +452,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&tmp, e->sort_tmp_bytes));
     e->d_sort_tmp[0] = tmp;
   }
-  {
-    Scratch &t = e->sc[1];
+  for (int si = 1; si < ffm_engine::kSets; si++) {
+    Scratch &t = e->sc[si];
     t = s;  // shared: head/next/rowtab/haux/hmeta/logit/tg/loss/svx
     TRY_ALLOC(e->alloc(&t.key, E));
     TRY_ALLOC(e->alloc(&t.skey, E));
@@ -469,13 +475,13 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     }
     unsigned char *tmp = nullptr;
     TRY_ALLOC(e->alloc(&tmp, e->sort_tmp_bytes));
-    e->d_sort_tmp[1] = tmp;
+    e->d_sort_tmp[si] = tmp;
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
   // (a high-priority queue for the look-ahead grouping was tried: the whole step got 45% slower)
   TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_rows_done, hipEventDisableTiming));
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < ffm_engine::kSets; i++) {
     TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&e->ev_set_free[i], hipEventDisableTiming));
   }
@@ -699,9 +705,9 @@ int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const 
   int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
   if (rc) return rc;
   if (e->has_pending) return fail(FFM_E_INVALID, "prepare between train_forward and train_update");
-  if (e->prepared >= 0) return fail(FFM_E_INVALID, "a prepared block is already waiting");
+  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "two prepared blocks are already waiting");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
-  const int set = 1 - e->cur;
+  const int set = (e->last_set + 1) % ffm_engine::kSets;
   Rows rows{n_rows, nnz, row_ptr, field, feat, val, nullptr};
   if (e->set_used[set]) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[set], 0));
   // Optionally group beside the UPDATE phase of the block enqueued last instead of beside its
@@ -710,8 +716,10 @@ int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const 
   rc = launch_grouping(e, set, rows, e->prep);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(e->ev_grouped[set], e->prep));
-  e->prepared = set;
-  e->prepared_rows = rows;
+  e->last_set = set;
+  e->prepared_set[e->n_prepared] = set;
+  e->prepared_rows[e->n_prepared] = rows;
+  e->n_prepared++;
   return FFM_OK;
 }
 
@@ -729,17 +737,23 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   e->fuse_cur = e->fuse_ok && e->fuse_request;  // only train_batch_device asks: it owns tmp_grad
   e->own_tg_cur = e->fuse_request && e->m.n_shards == 1 && e->m.type != FFM_MODEL_FM && !e->fuse_cur;
   e->fuse_request = false;
-  const bool use_prepared = e->prepared >= 0 && same_block(e->prepared_rows, rows);
-  if (e->prepared >= 0 && !use_prepared) {
-    // a grouping made ahead for some other block: forget it
-    HIP_TRY(hipEventRecord(e->ev_set_free[e->prepared], e->prep));
-    e->prepared = -1;
+  const bool use_prepared = e->n_prepared > 0 && same_block(e->prepared_rows[0], rows);
+  if (e->n_prepared > 0 && !use_prepared) {
+    // groupings made ahead for some other block: forget them all
+    for (int i = 0; i < e->n_prepared; i++) HIP_TRY(hipEventRecord(e->ev_set_free[e->prepared_set[i]], e->prep));
+    e->n_prepared = 0;
   }
   if (use_prepared) {
-    e->cur = e->prepared;
-    e->prepared = -1;
+    e->cur = e->prepared_set[0];
+    for (int i = 1; i < e->n_prepared; i++) {
+      e->prepared_set[i - 1] = e->prepared_set[i];
+      e->prepared_rows[i - 1] = e->prepared_rows[i];
+    }
+    e->n_prepared--;
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_grouped[e->cur], 0));
   } else {
+    e->cur = (e->last_set + 1) % ffm_engine::kSets;
+    e->last_set = e->cur;
     if (e->set_used[e->cur]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_set_free[e->cur], 0));
     rc = launch_grouping(e, e->cur, rows, e->stream);
     if (rc) return rc;

@@ -146,8 +146,11 @@ int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
  * integer-only first stage of training) on a side stream while the current block is still being
  * updated.  The arrays must be complete in device memory when this is called and must be the very
  * ones passed to the following ffm_engine_train_batch_device / train_forward_device call (same
- * pointers and sizes); if a different block is trained next the look-ahead is discarded.  At most
- * one block can be prepared ahead. */
+ * pointers and sizes); if a different block is trained next the look-ahead is discarded.  Up to
+ * two blocks can be prepared ahead; they are consumed in the order they were prepared.  (Two ahead
+ * is what hides the grouping completely: the grouping of block t+2 then runs beside block t's
+ * refresh and row phases and is long finished when block t+1 ends.)  FFM_E_CAPACITY when two
+ * prepared blocks are already waiting. */
 int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
                               const int32_t *field, const int32_t *feat, const float *val);
 

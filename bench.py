@@ -48,16 +48,21 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
     """Algorithmic bytes ONE launch of `kernel` is responsible for, averaged over the bench's
     blocks.  SURVEY.md 8(d)'s per-row total (20 B per touched slot-factor: read n,z + write w,n,z)
     is apportioned to the kernels that move those bytes, so the shares add up to it:
-      row kernel           : read (n,z) + write w of every touched slot = 12 B per slot-factor,
-                             + CSR in, linear refresh, logit out
+      refresh kernel       : read (n,z) + write w = 12 B per touched slot-factor of the block's
+                             DISTINCT features (with (n,z) frozen over the block every occurrence
+                             would compute the same w, so once per distinct feature is all the
+                             block algorithm needs; the per-row figure of 8(d) counts it per
+                             occurrence, and step_algorithmic_GBps keeps that accounting)
+      row kernel           : CSR in, linear weights, logit / tmp_grad / loss out
       update_small/hot/huge: write (n,z) = 8 B per slot-factor of the occurrences each owns
                              (features with <= 4, 5..96, > 96 occurrences in the block)
     Under field-pair sharding every rank moves 1/n_shards of the slot-factors."""
     per_occ = (nnz - 1) * k  # slot-factors one occurrence of a feature touches
     rows = [len(f) // nnz for f in blocks_feat]
+    if "refresh" in kernel:
+        return float(np.mean([len(np.unique(f)) * per_occ * 12 / n_shards for f in blocks_feat]))
     if "row_kernel" in kernel:
-        b = [r * (nnz * per_occ * 12 / n_shards + nnz * 12 + 12 + (nnz * 12 + 8) + 4) for r in rows]
-        return float(np.mean(b))
+        return float(np.mean([r * (nnz * 12 + 12 + (nnz * 12 + 8) + 4 + 16) for r in rows]))
     shares = []
     for f in blocks_feat:
         _, c = np.unique(f, return_counts=True)
@@ -325,8 +330,9 @@ def main():
                 "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": klaunches,
                 "algorithmic_bytes_per_launch": int(share),
                 "note": "the three update kernels (small/hot/huge) run side by side on separate "
-                        "streams, so a kernel's span includes waiting for CUs; warm-up spans of "
-                        "all kernels are in other_kernels",
+                        "streams, so a kernel's span includes waiting for CUs; they are bound by "
+                        "VALU issue and dependent-load latency, not HBM (DESIGN.md); warm-up "
+                        "spans of all kernels are in other_kernels",
             }
             # the other big kernels, from the fully timed warm-up launches (same accounting)
             others = []
@@ -334,6 +340,7 @@ def main():
                 parts = line.split()
                 nm = parts[0]
                 full = {"row_kernel<train>": "ffm_row_kernel<train>",
+                        "refresh_kernel": "ffm_refresh_kernel",
                         "latent_update_kernel": "ffm_update_small_kernel",
                         "latent_update_hot_kernel": "ffm_update_hot_kernel",
                         "latent_update_huge_kernel": "ffm_update_huge_kernel"}.get(nm)

@@ -953,14 +953,24 @@ int ffm_engine_profile_enable(ffm_engine *e, int32_t on) {
 
 static int profile_totals(ffm_engine *e, double *ms, int *n);
 
+// The kernel with the largest total time among those on the step's critical path.  The look-ahead
+// grouping is left out: it runs beside the step on its own queue, and its "time" is mostly waiting.
+static int dominant_kernel(const double *ms) {
+  int best = K_ROW;
+  for (int k = 0; k < K_COUNT; k++) {
+    if (k == K_GROUP_KEYS || k == K_GROUP_SORT || k == K_GROUP_FINISH) continue;
+    if (ms[k] > ms[best]) best = k;
+  }
+  return best;
+}
+
 int ffm_engine_profile_focus(ffm_engine *e) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
   double ms[K_COUNT];
   int n[K_COUNT];
   int rc = profile_totals(e, ms, n);
   if (rc) return rc;
-  int best = 0;
-  for (int k = 1; k < K_COUNT; k++) if (ms[k] > ms[best]) best = k;
+  const int best = dominant_kernel(ms);
   for (auto &r : e->prof) { e->event_pool.push_back(r.e0); e->event_pool.push_back(r.e1); }
   e->prof.clear();
   e->prof_only = best;
@@ -987,13 +997,13 @@ int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms
   int n[K_COUNT];
   int rc = profile_totals(e, ms, n);
   if (rc) return rc;
-  int best = 0;
-  for (int k = 1; k < K_COUNT; k++) if (ms[k] > ms[best]) best = k;
+  const int best = dominant_kernel(ms);
   if (n_launches) *n_launches = n[best];
   if (total_ms) *total_ms = ms[best];
   if (kernel_name && kernel_name_cap) {
     std::string name = kKernelNames[best];
     if (best == K_FUSED_ROW) name = "ffm_fused_row_kernel";
+    else if (best == K_REFRESH) name = "ffm_refresh_kernel";
     else if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT ||
         best == K_LATENT_UPDATE_HUGE)
       name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +

@@ -129,6 +129,11 @@ def main():
                     help="process-group backend (gloo + --same-device: functional dry run of the "
                          "multi-rank path on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (dry run)")
+    ap.add_argument("--emulate-shards", type=int, default=0,
+                    help="tuning aid on one GPU: run ONE rank's share of an N-GPU field-pair-sharded "
+                         "job (N x rows per step, 1/N of the field pairs, no all-reduce) and print "
+                         "what the N-GPU job's rate would be if the exchange were free")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -163,7 +168,8 @@ def main():
     cfgw = CONFIGS[args.config]
     model = cfgw["model"]
     N_FIELDS, N_FACTORS = cfgw["fields"], cfgw["factors"]
-    rows = args.rows or cfgw["rows"] * n_gpus
+    emu = args.emulate_shards if world == 1 else 0
+    rows = args.rows or cfgw["rows"] * (emu or n_gpus)
     n_feats = args.n_feats or cfgw["feats"]
     n_feats -= n_feats % N_FIELDS
     rec_bytes = 3 * (N_FIELDS if model == "FFM" else 1) * N_FACTORS * 4
@@ -186,8 +192,9 @@ def main():
     while eng is None:  # an allocation that does not fit is retried 10 % smaller, never fatal
         try:
             eng = fa.Engine(model, n_feats, N_FIELDS, N_FACTORS, max_batch_rows=rows,
-                            max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=world,
-                            shard_rank=rank, stream=stream, seed=42)
+                            max_batch_nnz=rows * N_FIELDS, device_id=local_rank,
+                            n_shards=emu or world, shard_rank=args.emulate_rank if emu else rank,
+                            stream=stream, seed=42)
         except fa.EngineError as err:
             if err.code != -3 or n_feats < 10 * N_FIELDS:
                 raise
@@ -227,7 +234,7 @@ def main():
     def step(i, blk):
         ptr = lambda t: t.data_ptr()  # noqa: E731
         out_loss = loss_sum.data_ptr() + 8 * i
-        if world == 1:
+        if world == 1 and not emu:
             eng.train_batch_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
                                    ptr(blk["feat"]), ptr(blk["val"]), ptr(blk["label"]),
                                    ptr(logit), out_loss)
@@ -235,7 +242,8 @@ def main():
             eng.train_forward_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]),
                                      ptr(blk["field"]), ptr(blk["feat"]), ptr(blk["val"]),
                                      ptr(blk["label"]), ptr(logit))
-            dist.all_reduce(logit)  # the path's one exchange: n_rows partial logits over xGMI
+            if dist is not None:
+                dist.all_reduce(logit)  # the path's one exchange: n_rows partial logits over xGMI
             eng.train_update_device(ptr(logit), None, out_loss)
 
     def prepare(blk):  # the scheduler's look-ahead: group the next block beside this one's update
@@ -310,11 +318,14 @@ def main():
                 "sharding": "field-pair x%d, one all-reduce of %d partial logits per step"
                             % (world, rows) if world > 1 else "none",
             },
+            **({"emulated": "one rank's compute of a %d-GPU job on one GPU, no exchange; `value` is "
+                            "what the %d-GPU job would reach if the all-reduce were free (tuning "
+                            "aid, not a result)" % (emu, emu)} if emu else {}),
             "train_logloss": round(float(losses.sum() / total_rows), 6),
             "step_algorithmic_GBps": round(value * bytes_row / n_gpus / 1e9, 1),
         }
         if kname and model == "FFM":
-            share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, max(world, 1))
+            share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, max(emu or world, 1))
             avg_s = kms / 1000.0 / max(klaunches, 1)
             achieved = share / avg_s / 1e9
             traffic = None
@@ -347,7 +358,7 @@ def main():
                 if not full:
                     continue
                 us = float(parts[-1])
-                sh = kernel_share_bytes(full, blocks_feat, N_FIELDS, N_FACTORS, max(world, 1))
+                sh = kernel_share_bytes(full, blocks_feat, N_FIELDS, N_FACTORS, max(emu or world, 1))
                 others.append({"kernel": full, "avg_launch_us": us,
                                "algorithmic_bytes_per_launch": int(sh),
                                "achieved": round(sh / (us * 1e-6) / 1e9, 1),

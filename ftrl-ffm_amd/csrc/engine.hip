@@ -198,6 +198,7 @@ struct ffm_engine {
   // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
   // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
   int grid_small = 768, grid_hot = 2048, grid_huge = 2048;
+  int row_threads = kRowThreads;  // workgroup size of the FFM row kernel (FFM_ROW_THREADS)
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // profiling
   bool prof_on = false;
@@ -322,6 +323,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     return fail(FFM_E_INVALID, "invalid n_shards / shard_rank");
   if (cfg->n_shards > 1 && cfg->model_type != FFM_MODEL_FFM)
     return fail(FFM_E_UNSUPPORTED, "field-pair sharding applies to FFM only");
+  if (cfg->n_shards > 1 && cfg->n_fields > 64)
+    return fail(FFM_E_UNSUPPORTED, "field-pair sharding supports up to 64 fields");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return fail(FFM_E_DEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -337,6 +340,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (cfg->reserved[0] > 0) e->max_row_nnz = cfg->reserved[0];
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_PREP_AFTER_ROWS")) e->prep_after_rows = sv[0] == '1';
+  // (128-thread row workgroups for sharded engines, 1/n_shards of the pairs per row, measured
+  // slower: the per-row tables are throughput work too)
+  if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::min(kRowThreads, std::max(64, std::atoi(sv) / 64 * 64));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
@@ -404,6 +410,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.uniq, E));
   TRY_ALLOC(e->alloc(&s.ustart, E));
   TRY_ALLOC(e->alloc(&s.ucount, E));
+  TRY_ALLOC(e->alloc(&s.ufield, E));
   TRY_ALLOC(e->alloc(&s.small, E));
   TRY_ALLOC(e->alloc(&s.few, E));
   TRY_ALLOC(e->alloc(&s.big, E));
@@ -428,6 +435,22 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&e->d_ownmask, static_cast<size_t>(m.n_fields)));
     TRY_HIP(hipMemcpy(e->d_ownmask, own.data(), own.size() * sizeof(own[0]), hipMemcpyHostToDevice));
     m.ownmask = e->d_ownmask;
+    if (m.n_shards > 1) {
+      // the same ownership as lists: the partner fields this shard owns for each own field
+      const int F = m.n_fields;
+      std::vector<int> cnt(F, 0), fp(static_cast<size_t>(F) * F, 0);
+      for (int fa = 0; fa < F; fa++)
+        for (int fb = 0; fb < F; fb++)
+          if ((own[fa] >> fb) & 1ull) fp[static_cast<size_t>(fa) * F + cnt[fa]++] = fb;
+      m.own_max = *std::max_element(cnt.begin(), cnt.end());
+      int *d_cnt = nullptr, *d_fp = nullptr;
+      TRY_ALLOC(e->alloc(&d_cnt, cnt.size()));
+      TRY_ALLOC(e->alloc(&d_fp, fp.size()));
+      TRY_HIP(hipMemcpy(d_cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+      TRY_HIP(hipMemcpy(d_fp, fp.data(), fp.size() * sizeof(int), hipMemcpyHostToDevice));
+      m.own_cnt = d_cnt;
+      m.own_fp = d_fp;
+    }
   }
   TRY_ALLOC(e->alloc(&s.haux, ffm_model ? E * static_cast<size_t>(m.n_fields) : 1));
   TRY_ALLOC(e->alloc(&s.hmeta, ffm_model ? E : 1));
@@ -463,6 +486,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.uniq, E));
     TRY_ALLOC(e->alloc(&t.ustart, E));
     TRY_ALLOC(e->alloc(&t.ucount, E));
+    TRY_ALLOC(e->alloc(&t.ufield, E));
     TRY_ALLOC(e->alloc(&t.small, E));
     TRY_ALLOC(e->alloc(&t.few, E));
     TRY_ALLOC(e->alloc(&t.big, E));
@@ -667,10 +691,10 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
       else if (e->m.n_factors == 8) LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<2>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
       else LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<1>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
     }
-    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed, own_tg);
-    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed, own_tg);
-    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
-    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
+    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed, own_tg);
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed, own_tg);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
   }
 }
 

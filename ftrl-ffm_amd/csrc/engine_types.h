@@ -37,6 +37,12 @@ struct ModelDev {
   // ownmask[fa] = bit fp set when this shard owns the field pair {fa, fp} (all ones when the
   // model is not sharded); n_fields <= 64 only, else null
   const unsigned long long *ownmask;
+  // Sharded engines walk a record through the partner fields this shard owns for the feature's
+  // own field fa: own_fp[fa*n_fields + j], j < own_cnt[fa] <= own_max (ascending).  Null when
+  // n_shards == 1.
+  const int *own_cnt;
+  const int *own_fp;
+  int own_max;
 };
 
 enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };
@@ -55,6 +61,22 @@ __device__ __forceinline__ bool owns_pair(const ModelDev &m, int fa, int fb) {
   return idx % m.n_shards == m.shard_rank;
 }
 
+// A record's elements as the feature-major kernels walk them, in units of `unit` floats per slot
+// (n_factors, n_factors/4 for 16-byte vectors, ...).  One shard: all n_fields slots, in place.
+// Sharded: only the slots whose field pair this shard owns -- 1/n_shards of the record -- so the
+// work per occurrence shrinks with the number of shards instead of leaving lanes idle.
+__device__ __forceinline__ int record_span(const ModelDev &m, int unit) {
+  return (m.n_shards > 1 ? m.own_max : m.n_fields) * unit;
+}
+// index into the record of walk position ec of a feature whose field is fa; -1 past its last slot
+__device__ __forceinline__ int record_index(const ModelDev &m, int fa, int ec, int unit) {
+  if (m.n_shards <= 1) return ec < m.n_fields * unit ? ec : -1;
+  int c = static_cast<int>((ec + 0.5f) / static_cast<float>(unit));
+  c += (c + 1) * unit <= ec ? 1 : (c * unit > ec ? -1 : 0);
+  if (c >= m.own_cnt[fa]) return -1;
+  return m.own_fp[fa * m.n_fields + c] * unit + (ec - c * unit);
+}
+
 // Per-block scratch: the block grouped by feature ("postings"), per-row field chains, outputs.
 struct Scratch {
   unsigned *key;  // [nnz] sort key per entry: feature id, n_feats for entries remove_out_range erases
@@ -65,6 +87,7 @@ struct Scratch {
   int *uniq;      // [nnz] distinct features of the block (arbitrary order)
   int *ustart;    // [nnz] start of each distinct feature's group in occ
   int *ucount;    // [nnz] its number of occurrences
+  int *ufield;    // [nnz] the field its first occurrence carries (FFM)
   int *small;     // [nnz] indices into uniq of the features with <= kSmallMax occurrences
   int *few;       // [nnz] ... with 2..kSmallMax occurrences (the small list minus the features
                   //      that occur once, which the fused row kernel updates itself)

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kFusedThreads) void ffm_fused_row_kernel(ModelDev m
     atomicMin(reinterpret_cast<unsigned *>(&lds.ffirst[lds.field[t]]), static_cast<unsigned>(t));
   }
   __syncthreads();
-  publish_row_tables(rows, s, lds, r, b, nv, F);
+  publish_row_tables(m, rows, s, lds, r, b, nv, F);
 
   // linear weights of the surviving entries (update_linear_w, ftrl_model.cpp:52-59)
   for (int t = tid; t < nv; t += blockDim.x) {

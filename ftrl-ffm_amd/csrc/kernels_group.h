@@ -192,6 +192,7 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
     s.uniq[u] = static_cast<int>(K);
     s.ustart[u] = t;
     s.ucount[u] = c;
+    if (rows.field) s.ufield[u] = rows.field[p];
     if (c > 1 && c <= kSmallMax) s.few[iw] = u;
     if (c <= kSmallMax) s.small[is] = u;
     else if (c <= kHugeMin) s.big[ib] = u;

@@ -113,8 +113,9 @@ __device__ __forceinline__ float add_terms_in_order(const float *terms, int cnt,
 
 // TRAIN, FFM: loads the entries' occurrence classes and publishes the row's per-field tables for
 // the feature-major update kernels.  Called by every thread of the workgroup (has barriers).
-__device__ __forceinline__ void publish_row_tables(const Rows &rows, const Scratch &s, RowLds &lds,
-                                                   int r, int b, int nv, int F) {
+__device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows &rows,
+                                                   const Scratch &s, RowLds &lds, int r, int b,
+                                                   int nv, int F) {
   for (int a = threadIdx.x; a < nv; a += blockDim.x) lds.opos[a] = s.occpos[b + lds.pos[a]];
   __syncthreads();
   // For entries of hot features: what each partner field contributes to their touches
@@ -123,7 +124,7 @@ __device__ __forceinline__ void publish_row_tables(const Rows &rows, const Scrat
   for (int t = threadIdx.x; t < nv * F; t += blockDim.x) {
     const int a = t / F, f = t - a * F;
     const int op = lds.opos[a];
-    if (op < 0) continue;
+    if (op < 0 || !owns_pair(m, lds.field[a], f)) continue;  // facts this shard's owners will read
     const int cnt = lds.fcnt[f];
     const int a0 = lds.ffirst[f];
     int flags = 0, fq = lds.feat[a];  // harmless partner id when there is no plain partner
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   }
 
   if (TRAIN && is_ffm) {
-    publish_row_tables(rows, s, lds, r, b, nv, F);
+    publish_row_tables(m, rows, s, lds, r, b, nv, F);
     // lazy refresh of every slot (feature a, partner field fp) that a pair of this row touches:
     // FFM::update_vector_w, ffm.cpp:72-88 -- unless ffm_refresh_kernel did it for the whole block
     if (refreshed) {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
       const int RL4 = RL >> 2, k4 = k >> 2;
       const float inv_RL4 = 1.0f / static_cast<float>(RL4), inv_k4 = 1.0f / static_cast<float>(k4);
       const int total = nv * RL4;
-      for (int t = threadIdx.x; t < total; t += kRowThreads) {
+      for (int t = threadIdx.x; t < total; t += blockDim.x) {
         int a = static_cast<int>((t + 0.5f) * inv_RL4);
         a += (a + 1) * RL4 <= t ? 1 : (a * RL4 > t ? -1 : 0);  // exact for any size
         const int c4 = t - a * RL4;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
       }
     } else {
       const int total = nv * RL;
-      for (int t = threadIdx.x; t < total; t += kRowThreads) {
+      for (int t = threadIdx.x; t < total; t += blockDim.x) {
         const int a = t / RL, e = t - a * RL;
         const int fp = e / k;
         const int fa = lds.field[a];
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     const int n_pairs = nv * (nv - 1) / 2;
     for (int q0 = 0; q0 < n_pairs; q0 += kTermsCap) {
       const int q1 = min(q0 + kTermsCap, n_pairs);
-      for (int q = q0 + threadIdx.x; q < q1; q += kRowThreads) {
+      for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
         int a, bb;
         unrank_pair(q, nv, a, bb);
         const int fa = lds.field[a], fb = lds.field[bb];
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s,
   if (fuse && !s.counters[CNT_NOFUSE]) return;  // kernels_fused.h refreshes its own block
   const int n_uniq = s.counters[CNT_NUNIQ];
   const int k = m.n_factors, RL = m.row_len;
-  const int per = VEC4 ? (RL >> 2) : RL;       // items per record
   const int kv = VEC4 ? (k >> 2) : k;          // items per slot
+  const int per = record_span(m, kv);          // items walked per record
   const float inv_kv = 1.0f / static_cast<float>(kv);
   const double inv_per = 1.0 / static_cast<double>(per);
   const unsigned total = static_cast<unsigned>(n_uniq) * static_cast<unsigned>(per);  // < 2^31 (engine)
@@ -405,17 +406,23 @@ __global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s,
     // u = t / per through the double reciprocal (exact after one correction for t < 2^31)
     int u = static_cast<int>((static_cast<double>(t) + 0.5) * inv_per);
     u += static_cast<unsigned>(u + 1) * per <= t ? 1 : (static_cast<unsigned>(u) * per > t ? -1 : 0);
-    const int l = static_cast<int>(t - static_cast<unsigned>(u) * per);
+    const int lc = static_cast<int>(t - static_cast<unsigned>(u) * per);
+    if (lc == 0 && lin_owner) {
+      const int i0 = s.uniq[u];
+      m.lin_w[i0] = ftrl_weight(m.h, m.lin_n[i0], m.lin_z[i0]);
+    }
+    const int l = record_index(m, s.ufield[u], lc, kv);
+    if (l < 0) continue;
     int fp = static_cast<int>((l + 0.5f) * inv_kv);
     fp += (fp + 1) * kv <= l ? 1 : (fp * kv > l ? -1 : 0);
     const int i = s.uniq[u];
     const unsigned long long mask = s.gmask[s.ustart[u]];
-    if (l == 0 && lin_owner) m.lin_w[i] = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
     if (!((mask >> fp) & 1ull)) continue;
     if (VEC4) {
+      const int RL4 = RL >> 2;
       float4 *row = reinterpret_cast<float4 *>(lat_row(m, i));
-      const float4 n4 = row[LAT_N * per + l], z4 = row[LAT_Z * per + l];
-      row[LAT_W * per + l] = ftrl_weight4(m.h, n4, z4);
+      const float4 n4 = row[LAT_N * RL4 + l], z4 = row[LAT_Z * RL4 + l];
+      row[LAT_W * RL4 + l] = ftrl_weight4(m.h, n4, z4);
     } else {
       float *row = lat_row(m, i);
       row[LAT_W * RL + l] = ftrl_weight(m.h, row[LAT_N * RL + l], row[LAT_Z * RL + l]);

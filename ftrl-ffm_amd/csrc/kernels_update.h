@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
   // fused blocks: partner weights come as a stream by occurrence position (s.pstream) instead
   // of being gathered from the partners' records
   const bool stream = fuse && !s.counters[CNT_NOFUSE];
-  const unsigned groups = (RL + kHotE - 1) / kHotE;
+  const unsigned groups = (record_span(m, k) + kHotE - 1) / kHotE;
   const int lane = threadIdx.x & 63;
   const int tl = lane & (kHotT - 1);  // which of the step's touches
   const int el = lane >> kHotTShift;  // which of the wave's elements
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned li = item / groups;
     const int u = wave_uniform(s.huge[li]);
-    const int e = static_cast<int>(item - li * groups) * kHotE + el;
-    const bool active = e < RL;
+    const int e = record_index(m, wave_uniform(s.ufield[u]), static_cast<int>(item - li * groups) * kHotE + el, k);
+    const bool active = e >= 0;
     const int ee = active ? e : 0;
     int fp = static_cast<int>((ee + 0.5f) * inv_k);  // this lane's partner field
     fp += (fp + 1) * k <= ee ? 1 : (fp * k > ee ? -1 : 0);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
   }
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const bool stream = fuse && !s.counters[CNT_NOFUSE];
-  const unsigned chunks = (RL + 63) / 64;
+  const unsigned chunks = (record_span(m, k) + 63) / 64;
   const int lane = threadIdx.x & 63;
   const unsigned wave = (blockIdx.x - side_blocks) * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const unsigned n_waves = (gridDim.x - side_blocks) * kUpdWaves;
@@ -397,8 +397,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned li = item / chunks;
     const int u = wave_uniform(s.big[li]);
-    const int e = static_cast<int>(item - li * chunks) * 64 + lane;
-    const bool active = e < RL;
+    const int e = record_index(m, wave_uniform(s.ufield[u]), static_cast<int>(item - li * chunks) * 64 + lane, k);
+    const bool active = e >= 0;
     const int ee = active ? e : 0;
     int fp = static_cast<int>((ee + 0.5f) * inv_k);  // this lane's partner field
     fp += (fp + 1) * k <= ee ? 1 : (fp * k > ee ? -1 : 0);
@@ -559,14 +559,16 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
   const int *list = fused ? s.few : s.small;
   const int n_small = s.counters[fused ? CNT_NFEW : CNT_NSMALL];
   const float inv_k4 = 1.0f / static_cast<float>(k4);
+  const int span4 = record_span(m, k4);
   for (int li = wave; li < n_small; li += n_waves) {
     const int u = wave_uniform(list[li]);
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i));
-    for (int l0 = 0; l0 < RL4; l0 += 64) {
-      const int l = l0 + lane;
-      if (l >= RL4) continue;
+    const int fa = wave_uniform(s.ufield[u]);
+    for (int l0 = 0; l0 < span4; l0 += 64) {
+      const int l = record_index(m, fa, l0 + lane, k4);
+      if (l < 0) continue;
       int fp = static_cast<int>((l + 0.5f) * inv_k4);  // partner field of this lane's slot
       fp += (fp + 1) * k4 <= l ? 1 : (fp * k4 > l ? -1 : 0);
       const int kq = l - fp * k4;  // which 16-byte quarter of the slot

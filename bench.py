@@ -340,6 +340,10 @@ def main():
                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
                 "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": klaunches,
                 "algorithmic_bytes_per_launch": int(share),
+                # the whole step against the same roof: SURVEY.md 8(d)'s bytes per row x rows/s
+                "whole_step": {"achieved": out["step_algorithmic_GBps"],
+                               "frac": round(out["step_algorithmic_GBps"] / PEAK_HBM_GBPS, 4),
+                               "bytes_per_row": int(bytes_row)},
                 "note": "the three update kernels (small/hot/huge) run side by side on separate "
                         "streams, so a kernel's span includes waiting for CUs; they are bound by "
                         "VALU issue and dependent-load latency, not HBM (DESIGN.md); warm-up "

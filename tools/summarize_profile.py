@@ -6,8 +6,9 @@ summary of the HBM byte counters.
 Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE come from separate --pmc passes and are in KiB; on gfx950 FETCH_SIZE reports HALF of
 the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled for the kernels whose
-reads are such streams (the row kernel and the small-feature update kernel read float4 per lane);
-other access widths are uncalibrated and left as reported.  Values are per launch (steady-state
+reads are such streams (the refresh kernel and the small-feature update kernel stream whole
+records as float4 per lane); other access patterns (the row kernel's 64-byte slot gathers, the
+chain kernels' 4-byte gathers) are uncalibrated and left as reported.  Values are per launch (steady-state
 launches of the bench, averaged)."""
 import csv
 import json
@@ -15,7 +16,7 @@ import os
 import shutil
 import sys
 
-WIDE_READERS = ("ffm_row_kernel", "ffm_update_small_kernel")
+WIDE_READERS = ("ffm_refresh_kernel", "ffm_update_small_kernel")
 
 
 def short(name):

@@ -109,7 +109,8 @@ struct Scratch {
   int *occpos;    // [nnz] entry -> its position t in occ when its feature is hot, else
                   //      OCC_FEW (2..kSmallMax occurrences) or OCC_ONCE (this entry only)
   int4 *haux;     // [nnz*n_fields] per (occurrence t, partner field): {partner value bits,
-                  //      flags | own field << 8, partner feature id, entry} -- from the row kernel
+                  //      flags | own field << 8, offset (in floats, 64 bits: lo, hi) of the
+                  //      partner's weights for this touch inside lat} -- from the row kernel
   float2 *hmeta;  // [nnz] {tmp_grad, own value} of occurrence t
   float *pstream; // [nnz*row_len] fused path: partner weights of hot occurrence t, laid out like
                   //      the own record ([partner field][factor]) -- from the fused row kernel

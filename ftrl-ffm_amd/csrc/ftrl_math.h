@@ -60,6 +60,13 @@ __device__ __forceinline__ float div_alpha(const Hyper &h, float x) {
   return x / h.alpha;
 }
 
+// One test for a sqrt operand of the accumulator chains: x in [2^-70, 2^96] (false for 0, negative,
+// NaN, inf).  Inside it sqrt_fast(x) is exact, and the difference of two such square roots is +0
+// or has magnitude in [2^-58, 2^48] -- inside div_alpha_fast's proven range.
+__device__ __forceinline__ bool chain_operand_ok(float x) {
+  return __builtin_amdgcn_fmed3f(x, 0x1p-70f, 0x1p96f) == x;
+}
+
 // N values at once with ONE wave vote (a vote is a scheduling barrier: hoisting it lets the
 // compiler interleave the N independent sequences).
 template <int N>

@@ -119,7 +119,7 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
   for (int a = threadIdx.x; a < nv; a += blockDim.x) lds.opos[a] = s.occpos[b + lds.pos[a]];
   __syncthreads();
   // For entries of hot features: what each partner field contributes to their touches
-  // ({partner value, flags | own field, partner id, entry}), laid out by occurrence position
+  // ({partner value, flags | own field, offset of the partner's weights lo, hi}), laid out by occurrence position
   // for the hot update kernel.
   for (int t = threadIdx.x; t < nv * F; t += blockDim.x) {
     const int a = t / F, f = t - a * F;
@@ -127,7 +127,7 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
     if (op < 0 || !owns_pair(m, lds.field[a], f)) continue;  // facts this shard's owners will read
     const int cnt = lds.fcnt[f];
     const int a0 = lds.ffirst[f];
-    int flags = 0, fq = lds.feat[a];  // harmless partner id when there is no plain partner
+    int flags = 0, fq = lds.feat[a];  // harmless partner when there is no plain partner
     float xo = 0.0f;
     if (cnt == 1 && a0 != a) {
       flags = HF_SIMPLE | (a < a0 ? HF_FIRST : 0);
@@ -136,8 +136,13 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
     } else if (cnt > 1) {
       flags = HF_CHAIN;
     }
+    // where the partner's weights for this touch start inside m.lat (floats): its record, the w
+    // row, the slot of the own entry's field -- the owners add their factor index and load
+    const int64_t woff = static_cast<int64_t>(fq) * 3 * m.row_len + LAT_W * m.row_len +
+                         lds.field[a] * m.n_factors;
     s.haux[static_cast<int64_t>(op) * F + f] =
-        make_int4(__float_as_int(xo), flags | (lds.field[a] << 8), fq, b + lds.pos[a]);
+        make_int4(__float_as_int(xo), flags | (lds.field[a] << 8), static_cast<int>(woff & 0xffffffff),
+                  static_cast<int>(woff >> 32));
   }
   // Per-field view of this row for the update kernel: rowtab[r][f] = {feat, val bits, entry
   // index, count} of the only entry with field f (entry index -1: none, -2: several -- then

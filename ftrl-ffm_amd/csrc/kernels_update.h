@@ -27,6 +27,11 @@ constexpr int kUnroll = 8;
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// the 64-bit float offset a haux entry carries in its .z (lo) and .w (hi)
+__device__ __forceinline__ int64_t haux_offset(int lo, int hi) {
+  return (static_cast<int64_t>(hi) << 32) | static_cast<unsigned>(lo);
+}
+
 // One touch of slot (own feature, partner field fp) by the pair {own entry, other entry}.
 __device__ __forceinline__ void ffm_touch(const Hyper &h, bool own_first, float tg, float x_own,
                                           float x_other, float vp, float w, float &n, float &z) {
@@ -96,6 +101,17 @@ constexpr int kHotT = 4;             // touches per step (lanes per element)
 constexpr int kHotE = 64 / kHotT;    // elements per wave
 constexpr int kHotTShift = 2;        // log2(kHotT)
 
+// quad (4 consecutive lanes) moves: every lane gets its left neighbour's value, lane 0 its own;
+// every lane gets lane 3's value
+__device__ __forceinline__ float quad_left(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x90 /* quad_perm:[0,0,1,2] */,
+                                                    0xf, 0xf, false));
+}
+__device__ __forceinline__ float quad_last(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xff /* quad_perm:[3,3,3,3] */,
+                                                    0xf, 0xf, false));
+}
+
 __device__ __forceinline__ float dpp_row_shr1(float keep, float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v),
                                                     0x111 /* row_shr:1 */, 0xf, 0xf, false));
@@ -143,11 +159,11 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
     int4 axN = acol[static_cast<int64_t>(min(kHotT + tl, c - 1)) * F];
     float2 mtN = mcol[min(kHotT + tl, c - 1)];
     float vp = stream ? pcol[static_cast<int64_t>(min(tl, c - 1)) * RL]
-                      : wcol[ax.z * rec_floats + (ax.y >> 8) * k];
+                      : m.lat[haux_offset(ax.z, ax.w) + kk];
     for (int st = 0; st < steps; st++) {
       const int t = st * kHotT + tl;
       const float vpN = stream ? pcol[static_cast<int64_t>(min(t + kHotT, c - 1)) * RL]
-                               : wcol[axN.z * rec_floats + (axN.y >> 8) * k];  // weights of step st+1
+                               : m.lat[haux_offset(axN.z, axN.w) + kk];  // weights of step st+1
       const int tNN = min((st + 2) * kHotT + tl, c - 1);                  // facts of step st+2
       const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
       const float2 mtNN = mcol[tNN];
@@ -157,47 +173,52 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
       const bool simple = live & ((fl & HF_SIMPLE) != 0);
       if (!__any(live & ((fl & HF_CHAIN) != 0))) {
         const bool first = fl & HF_FIRST;
-        const float xo = __int_as_float(ax.x), tg = mt.x, xm = mt.y;
-        const float x = first ? xm * xo : xo * xm;
+        const float tg = mt.x;
+        const float x = mt.y * __int_as_float(ax.x);  // x_own*x_other or x_other*x_own: same product
         const float g = tg * vp * x;   // own slot's gradient (g1 if own entry first, else g2)
         const float g1 = tg * w * x;   // second-entry case: the first entry's gradient
         const float gg = g * g;
-        const float q = simple ? gg : -0.0f;  // x + -0.0f == x bit for bit: idle touches add nothing
-        // running n: strictly left-to-right prefix over the 8 touch lanes of each element
-        float S = tl == 0 ? nc + q : q;
+        // Running n and z are strictly left-to-right chains over the quad's four touch lanes.  One
+        // chain step is "take the left neighbour's value, apply my touch": a quad-permuted add in
+        // which lane 0 re-reads ITSELF and applies nothing (+ -0.0f, - +0.0f leave every float,
+        // either zero included, bit for bit), so no lane needs masking; lanes already final
+        // recompute the same value.  Idle touches apply nothing either.
+        const bool l0 = tl == 0;
+        const float q = simple ? gg : -0.0f;
+        const float qc = l0 ? -0.0f : q;
+        float S = nc + q;  // lane 0: n after its touch
 #pragma unroll
-        for (int r = 1; r < kHotT; r++) {
-          const float prev = dpp_row_shr1(S, S);
-          S = tl == 0 ? S : prev + q;
+        for (int r = 1; r < kHotT; r++) S = quad_left(S) + qc;
+        const float left = quad_left(S);
+        const float nb = l0 ? nc : left;  // n before this touch
+        nc = quad_last(S);
+        const float arg0 = nb + (first ? gg : g * g1);  // ffm.cpp:113 / :118
+        // both square roots and the alpha divide in their short exact forms when every lane's
+        // operands are comfortably normal (ftrl_math.h: chain_operand_ok), else IEEE
+        float sg;
+        if (__all(m.h.fast_div && chain_operand_ok(arg0) && chain_operand_ok(nb))) {
+          const float d = sqrt_fast(arg0) - sqrt_fast(nb);
+          sg = div_alpha_fast(m.h, simple ? d : 0.0f);
+        } else {
+          const float d = sqrtf(arg0) - sqrtf(nb);
+          sg = (simple ? d : 0.0f) / m.h.alpha;
         }
-        const float prevS = dpp_row_shr1(S, S);
-        const float nb = tl == 0 ? nc : prevS;  // n before this touch
-        const float arg[2] = {nb + (first ? gg : g * g1), nb};  // ffm.cpp:113 / :118
-        float sq[2];
-        sqrt_cr_n<2>(arg, sq);
-        const float dd[1] = {simple ? sq[0] - sq[1] : 0.0f};
-        float sg[1];
-        div_alpha_n<1>(m.h, dd, sg);
-        const float mm = sg[0] * w;
-        // running z: z' = (z + g) - sigma*w per live touch, same left-to-right chain
-        float Z = simple ? (zc + g) - mm : zc;  // correct for tl == 0; others fixed up below
+        const float mm = sg * w;
+        // running z: z' = (z + g) - sigma*w per live touch
+        const float ga = simple ? g : -0.0f, ms = simple ? mm : 0.0f;
+        const float gc = l0 ? -0.0f : ga, mc = l0 ? 0.0f : ms;
+        float Z = (zc + ga) - ms;  // lane 0: z after its touch
 #pragma unroll
-        for (int r = 1; r < kHotT; r++) {
-          const float prev = dpp_row_shr1(Z, Z);
-          const float cand = simple ? (prev + g) - mm : prev;
-          Z = tl == 0 ? Z : cand;
-        }
-        nc = __shfl(S, lane | (kHotT - 1), 64);
-        zc = __shfl(Z, lane | (kHotT - 1), 64);
-        const unsigned long long sm = __ballot(simple);
-        touched = touched | (((sm >> (el * kHotT)) & ((1ull << kHotT) - 1ull)) != 0ull);
+        for (int r = 1; r < kHotT; r++) Z = (quad_left(Z) + gc) - mc;
+        zc = quad_last(Z);
+        touched = touched | simple;
       } else {
         // a multi-valued field in this step: its 8 touches one after another, every lane of an
         // element's group applying them to its copy of the running (n, z)
         for (int tt = 0; tt < kHotT; tt++) {
           const int src = (lane & ~(kHotT - 1)) | tt;
           const int flt = __shfl(fl, src, 64);
-          const int pt = __shfl(ax.w, src, 64);
+          const int pt = s.occ2[start + min(st * kHotT + tt, c - 1)].x;  // the touch's own entry
           const float xot = __shfl(__int_as_float(ax.x), src, 64);
           const float tgt = __shfl(mt.x, src, 64), xmt = __shfl(mt.y, src, 64);
           const float vpt = __shfl(vp, src, 64);
@@ -220,7 +241,9 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
       ax = axN; mt = mtN; vp = vpN;
       axN = axNN; mtN = mtNN;
     }
-    if (touched && active && tl == 0) {
+    // any of the element's four touch lanes touched it?
+    const unsigned long long tm = __ballot(touched);
+    if (((tm >> (el * kHotT)) & ((1ull << kHotT) - 1ull)) != 0ull && active && tl == 0) {
       rec[LAT_N * RL + ee] = nc;
       rec[LAT_Z * RL + ee] = zc;
     }
@@ -342,7 +365,7 @@ __global__ __launch_bounds__(64) void bias_update_kernel(ModelDev m, int n_rows,
 struct HotFacts {  // per-lane facts of a group of touches
   float xo[kUnroll];
   int fl[kUnroll];   // flags | own field << 8
-  int fq[kUnroll];   // partner feature id
+  int fq[kUnroll];   // offset of the partner's weights inside lat, low word (high word: pe[])
 };
 
 __device__ __forceinline__ void hot_load_facts(const int4 *acol, int F, int c, int t0,
@@ -353,14 +376,14 @@ __device__ __forceinline__ void hot_load_facts(const int4 *acol, int F, int c, i
     f.xo[j] = __int_as_float(ax.x);
     f.fl[j] = ax.y;
     f.fq[j] = ax.z;
-    pe[j] = ax.w;
+    pe[j] = ax.w;  // with fq: the 64-bit offset of the partner's weights
   }
 }
 
-__device__ __forceinline__ void hot_issue_weights(const float *wcol, size_t rec_floats, int k,
-                                                  const HotFacts &f, float (&vp)[kUnroll]) {
+__device__ __forceinline__ void hot_issue_weights(const float *wcol, const HotFacts &f,
+                                                  const int (&pe)[kUnroll], float (&vp)[kUnroll]) {
 #pragma unroll
-  for (int j = 0; j < kUnroll; j++) vp[j] = wcol[f.fq[j] * rec_floats + (f.fl[j] >> 8) * k];
+  for (int j = 0; j < kUnroll; j++) vp[j] = wcol[haux_offset(f.fq[j], pe[j])];
 }
 // fused blocks: the same weights from the occurrence-ordered stream (touches t0 .. t0+kUnroll-1)
 __device__ __forceinline__ void hot_stream_weights(const float *pcol, int RL, int c, int t0,
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     hot_load_facts(acol, F, c, 0, fB, peB);
     if (nb > 1) hot_load_facts(acol, F, c, kUnroll, fA, peA);
     if (stream) hot_stream_weights(pcol, RL, c, 0, vpB);
-    else hot_issue_weights(wcol, rec_floats, k, fB, vpB);
+    else hot_issue_weights(m.lat + kk, fB, peB, vpB);
     for (int b = 0; b < nb; b++) {
       const int t0 = b * kUnroll;
       fC = fB;
@@ -432,7 +455,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) peB[j] = peA[j];
         if (stream) hot_stream_weights(pcol, RL, c, t0 + kUnroll, vpB);   // weights of group b+1
-        else hot_issue_weights(wcol, rec_floats, k, fB, vpB);
+        else hot_issue_weights(m.lat + kk, fB, peB, vpB);
       }
       if (b + 2 < nb) hot_load_facts(acol, F, c, t0 + 2 * kUnroll, fA, peA);  // facts of group b+2
       float tgj[kUnroll], xmj[kUnroll];
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
               ffm_touch(m.h, fC.fl[j] & HF_FIRST, tgj[j], xmj[j], fC.xo[j], vpC[j], w, n, z);
               touched = true;
             } else if (fC.fl[j] & HF_CHAIN) {
-              const int p = peC[j];
+              const int p = s.occ2[start + t0 + j].x;  // the touch's own entry
               const int r = s.row_of[p];
               for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
                 if (qq == p) continue;

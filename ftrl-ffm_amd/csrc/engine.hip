@@ -59,14 +59,14 @@ enum KernelId {
   K_GROUP_KEYS, K_GROUP_SORT, K_GROUP_FINISH, K_ROW, K_TMP_GRAD,
   K_HOT_META,
   K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_LATENT_UPDATE_HUGE,
-  K_PREDICT_ROW, K_FUSED_ROW, K_REFRESH,
+  K_PREDICT_ROW, K_FUSED_ROW, K_REFRESH, K_LATENT_UPDATE_SINGLE,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "group_keys_kernel", "group_radix_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
     "linear_update_kernel", "bias_update_kernel", "latent_update_kernel", "latent_update_hot_kernel",
     "latent_update_huge_kernel",
-    "row_kernel<predict>", "fused_row_kernel", "refresh_kernel"};
+    "row_kernel<predict>", "fused_row_kernel", "refresh_kernel", "latent_update_single_kernel"};
 
 struct ProfRec {
   int kid;
@@ -197,7 +197,8 @@ struct ffm_engine {
   int fuse_threads = 0, fuse_max_nv = 0;
   // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
   // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
-  int grid_small = 768, grid_hot = 2048, grid_huge = 2048;
+  int grid_small = 768, grid_hot = 2048, grid_huge = 2048, grid_single = 768;
+  bool single_kernel = true;  // FFM_SINGLE_KERNEL=0: once-only features through the small kernel
   int row_threads = kRowThreads;  // workgroup size of the FFM row kernel (FFM_ROW_THREADS)
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // profiling
@@ -343,6 +344,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   // (128-thread row workgroups for sharded engines, 1/n_shards of the pairs per row, measured
   // slower: the per-row tables are throughput work too)
   if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::min(kRowThreads, std::max(64, std::atoi(sv) / 64 * 64));
+  if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
+  if (const char *sv = std::getenv("FFM_GRID_SINGLE")) e->grid_single = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
@@ -413,6 +416,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.ufield, E));
   TRY_ALLOC(e->alloc(&s.small, E));
   TRY_ALLOC(e->alloc(&s.few, E));
+  TRY_ALLOC(e->alloc(&s.sdesc, E));
   TRY_ALLOC(e->alloc(&s.big, E));
   TRY_ALLOC(e->alloc(&s.huge, E));
   TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
@@ -489,6 +493,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.ufield, E));
     TRY_ALLOC(e->alloc(&t.small, E));
     TRY_ALLOC(e->alloc(&t.few, E));
+    TRY_ALLOC(e->alloc(&t.sdesc, E));
     TRY_ALLOC(e->alloc(&t.big, E));
     TRY_ALLOC(e->alloc(&t.huge, E));
     TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
@@ -828,10 +833,16 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       LAUNCH_ON(e, e->aux2, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     HIP_TRY(hipEventRecord(e->ev_join, e->aux2));
   }
+  // small features on the main stream: the once-only ones through their descriptor kernel
+  auto launch_small = [&]() {
+    const bool single = e->single_kernel && !fuse;
+    if (single) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse, single ? 1 : 0);
+  };
   if (ffm && vec4 && e->serial) {
     LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
     LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse, side_blocks);
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    launch_small();
   } else if (ffm && vec4) {
     // the three owner shapes touch disjoint features: run them side by side (long sequential
     // chains of the hot ones beside the bandwidth-shaped small-feature pass)
@@ -841,7 +852,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
     LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse, side_blocks);
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    launch_small();
     if (loss_sum_out)
       LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
@@ -1028,6 +1039,7 @@ int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms
     std::string name = kKernelNames[best];
     if (best == K_FUSED_ROW) name = "ffm_fused_row_kernel";
     else if (best == K_REFRESH) name = "ffm_refresh_kernel";
+    else if (best == K_LATENT_UPDATE_SINGLE) name = "ffm_update_single_kernel";
     else if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT ||
         best == K_LATENT_UPDATE_HUGE)
       name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +

@@ -89,6 +89,7 @@ struct Scratch {
   int *ucount;    // [nnz] its number of occurrences
   int *ufield;    // [nnz] the field its first occurrence carries (FFM)
   int *small;     // [nnz] indices into uniq of the features with <= kSmallMax occurrences
+  int4 *sdesc;    // [nnz] one descriptor per feature that occurs once: {feature, entry, row, field}
   int *few;       // [nnz] ... with 2..kSmallMax occurrences (the small list minus the features
                   //      that occur once, which the fused row kernel updates itself)
   int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
@@ -121,7 +122,7 @@ struct Scratch {
 };
 
 enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5,
-       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NOFUSE = 8 };
+       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NOFUSE = 8, CNT_NSINGLE = 9 };
 constexpr int kNumCounters = 16;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 #ifndef FFM_HUGE_MIN

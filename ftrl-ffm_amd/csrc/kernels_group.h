@@ -162,20 +162,21 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
   }
   // distinct features and their owner lists: slots handed out per workgroup (one atomic per
   // list per workgroup -- per-wave atomics on five shared counters would be a serial chain)
-  __shared__ int wave_cnt[kFinishThreads / 64][5];
-  __shared__ int wave_base[kFinishThreads / 64][5];
+  __shared__ int wave_cnt[kFinishThreads / 64][6];
+  __shared__ int wave_base[kFinishThreads / 64][6];
   const int wv = threadIdx.x >> 6;
-  const bool pred[5] = {head, head && c <= kSmallMax, head && c > 1 && c <= kSmallMax,
-                        head && c > kSmallMax && c <= kHugeMin, head && c > kHugeMin};
-  const int which[5] = {CNT_NUNIQ, CNT_NSMALL, CNT_NFEW, CNT_NBIG, CNT_NHUGE};
-  unsigned long long pm[5];
+  const bool pred[6] = {head, head && c <= kSmallMax, head && c > 1 && c <= kSmallMax,
+                        head && c > kSmallMax && c <= kHugeMin, head && c > kHugeMin,
+                        head && c == 1};
+  const int which[6] = {CNT_NUNIQ, CNT_NSMALL, CNT_NFEW, CNT_NBIG, CNT_NHUGE, CNT_NSINGLE};
+  unsigned long long pm[6];
 #pragma unroll
-  for (int q = 0; q < 5; q++) {
+  for (int q = 0; q < 6; q++) {
     pm[q] = __ballot(pred[q]);
     if (lane == 0) wave_cnt[wv][q] = __popcll(pm[q]);
   }
   __syncthreads();
-  if (threadIdx.x < 5) {
+  if (threadIdx.x < 6) {
     const int q = threadIdx.x;
     int total = 0;
     for (int w = 0; w < kFinishThreads / 64; w++) { wave_base[w][q] = total; total += wave_cnt[w][q]; }
@@ -183,16 +184,18 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
     for (int w = 0; w < kFinishThreads / 64; w++) wave_base[w][q] += base;
   }
   __syncthreads();
-  int slot[5];
+  int slot[6];
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int q = 0; q < 5; q++) slot[q] = wave_base[wv][q] + __popcll(pm[q] & below);
+  for (int q = 0; q < 6; q++) slot[q] = wave_base[wv][q] + __popcll(pm[q] & below);
   const int u = slot[0], is = slot[1], iw = slot[2], ib = slot[3], ih = slot[4];
   if (head) {
     s.uniq[u] = static_cast<int>(K);
     s.ustart[u] = t;
     s.ucount[u] = c;
-    if (rows.field) s.ufield[u] = rows.field[p];
+    const int fld = rows.field ? rows.field[p] : 0;
+    s.ufield[u] = fld;
+    if (c == 1) s.sdesc[slot[5]] = make_int4(static_cast<int>(K), p, s.row_of[p], fld);
     if (c > 1 && c <= kSmallMax) s.few[iw] = u;
     if (c <= kSmallMax) s.small[is] = u;
     else if (c <= kHugeMin) s.big[ib] = u;

@@ -23,7 +23,8 @@ namespace ftrl_dev {
 
 constexpr int kUpdThreads = 256;
 constexpr int kUpdWaves = kUpdThreads / 64;
-constexpr int kUnroll = 8;
+constexpr int kUnroll = 4;    // touches per group in the hot kernel (8: more registers, measured slower)
+constexpr int kFmUnroll = 8;  // touches per prefetch group in the FM update kernel
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -64,10 +65,26 @@ __device__ __forceinline__ void ffm_touch_n(const Hyper &h, bool own_first, floa
     arg[i] = n[i] + (own_first ? g[i] * g[i] : g[i] * g1);  // ffm.cpp:113 / :118
     arg[N + i] = n[i];
   }
-  sqrt_cr_n<2 * N>(arg, sq);
+  // both square roots and the alpha divide in their short exact forms when every operand of the
+  // wave is comfortably normal (one vote; ftrl_math.h: chain_operand_ok), else IEEE
+  bool ok = h.fast_div != 0;
 #pragma unroll
-  for (int i = 0; i < N; i++) d[i] = sq[i] - sq[N + i];
-  div_alpha_n<N>(h, d, sg);
+  for (int i = 0; i < 2 * N; i++) ok = ok && chain_operand_ok(arg[i]);
+  if (__all(ok)) {
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) sq[i] = sqrt_fast(arg[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) d[i] = sq[i] - sq[N + i];
+#pragma unroll
+    for (int i = 0; i < N; i++) sg[i] = div_alpha_fast(h, d[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) sq[i] = sqrtf(arg[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) d[i] = sq[i] - sq[N + i];
+#pragma unroll
+    for (int i = 0; i < N; i++) sg[i] = d[i] / h.alpha;
+  }
 #pragma unroll
   for (int i = 0; i < N; i++) {
     z[i] = (z[i] + g[i]) - sg[i] * w[i];
@@ -570,15 +587,18 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
 // ---- small features: one wave per feature, lanes = 4 consecutive factors of a slot ---------
 // Requires n_factors % 4 == 0.  c <= kSmallMax occurrences.  Kept lean in registers: the
 // bandwidth comes from many resident waves, each with its record's loads in flight.
+// few_only: the features that occur once are somebody else's (ffm_update_single_kernel, or the
+// fused row kernel when `fuse` and the block allowed it)
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev m, Rows rows,
-                                                                       Scratch s, int fuse) {
+                                                                       Scratch s, int fuse,
+                                                                       int few_only) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int RL4 = RL >> 2, k4 = k >> 2;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const int n_waves = gridDim.x * kUpdWaves;
   // fused blocks: the features that occur once were updated by the fused row kernel already
-  const bool fused = fuse && !s.counters[CNT_NOFUSE];
+  const bool fused = few_only || (fuse && !s.counters[CNT_NOFUSE]);
   const int *list = fused ? s.few : s.small;
   const int n_small = s.counters[fused ? CNT_NFEW : CNT_NSMALL];
   const float inv_k4 = 1.0f / static_cast<float>(k4);
@@ -635,6 +655,84 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
   }
 }
 
+// ---- features that occur ONCE in the block (most of the distinct features) ----------------------
+// One wave per feature, driven by a 16-byte descriptor {feature, entry, row, field} the grouping
+// wrote for it, so the dependent-load chain is three deep instead of six (descriptor -> record
+// vectors + the row's per-field table -> partner weights): each lane takes up to kSingleTrips
+// 16-byte vectors of the record and has all their loads in flight together.
+constexpr int kSingleTrips = 3;
+
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev m, Rows rows,
+                                                                        Scratch s) {
+  const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
+  const int RL4 = RL >> 2, k4 = k >> 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = gridDim.x * kUpdWaves;
+  const int n_single = s.counters[CNT_NSINGLE];
+  const float inv_k4 = 1.0f / static_cast<float>(k4);
+  const int span4 = record_span(m, k4);
+  for (int li = wave; li < n_single; li += n_waves) {
+    const int4 d = s.sdesc[li];
+    const int i = wave_uniform(d.x), p = wave_uniform(d.y), r = wave_uniform(d.z);
+    const int fa = wave_uniform(d.w);
+    const float xm = rows.val[p], tg = s.tg[r];
+    float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i));
+    const int4 *rtab = s.rowtab + static_cast<int64_t>(r) * F;
+    for (int l0 = 0; l0 < span4; l0 += 64 * kSingleTrips) {
+      int l[kSingleTrips], fp[kSingleTrips];
+      float4 n4[kSingleTrips], z4[kSingleTrips], w4[kSingleTrips], vp[kSingleTrips];
+      int4 rt[kSingleTrips];
+#pragma unroll
+      for (int t = 0; t < kSingleTrips; t++) {
+        const int lc = l0 + t * 64 + lane;
+        l[t] = lc < span4 ? record_index(m, fa, lc, k4) : -1;
+        const int ll = l[t] < 0 ? 0 : l[t];
+        int f = static_cast<int>((ll + 0.5f) * inv_k4);  // partner field of this vector's slot
+        f += (f + 1) * k4 <= ll ? 1 : (f * k4 > ll ? -1 : 0);
+        fp[t] = f;
+        if (l[t] >= 0) {
+          n4[t] = rec4[LAT_N * RL4 + ll];
+          z4[t] = rec4[LAT_Z * RL4 + ll];
+          w4[t] = rec4[LAT_W * RL4 + ll];
+          rt[t] = rtab[f];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < kSingleTrips; t++) {
+        if (l[t] >= 0 && rt[t].z >= 0 && rt[t].z != p)
+          vp[t] = reinterpret_cast<const float4 *>(lat_row(m, rt[t].x))[LAT_W * RL4 + fa * k4 +
+                                                                       (l[t] - fp[t] * k4)];
+      }
+#pragma unroll
+      for (int t = 0; t < kSingleTrips; t++) {
+        if (l[t] < 0) continue;
+        const int q = rt[t].z;
+        bool touched = false;
+        if (q >= 0) {
+          if (q != p) {
+            ffm_touch4(m.h, p < q, tg, xm, __int_as_float(rt[t].y), vp[t], w4[t], n4[t], z4[t]);
+            touched = true;
+          }
+        } else if (q == -2) {  // several entries of that field in the row: walk them in row order
+          const int kq = l[t] - fp[t] * k4;
+          for (int qq = s.head[static_cast<int64_t>(r) * F + fp[t]]; qq >= 0; qq = s.next[qq]) {
+            if (qq == p) continue;
+            const float4 vq = reinterpret_cast<const float4 *>(
+                lat_row(m, rows.feat[qq]))[LAT_W * RL4 + fa * k4 + kq];
+            ffm_touch4(m.h, p < qq, tg, xm, rows.val[qq], vq, w4[t], n4[t], z4[t]);
+            touched = true;
+          }
+        }
+        if (touched) {
+          rec4[LAT_N * RL4 + l[t]] = n4[t];
+          rec4[LAT_Z * RL4 + l[t]] = z4[t];
+        }
+      }
+    }
+  }
+}
+
 // FM latent update.  Work item = (distinct feature u, chunk of 64 factors).
 __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s) {
   const int k = m.n_factors;
@@ -652,10 +750,10 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     float *rec = lat_row(m, i);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
     const float w = rec[LAT_W * k + e];
-    for (int t0 = 0; t0 < c; t0 += kUnroll) {
-      float xj[kUnroll], tgj[kUnroll], sj[kUnroll];
+    for (int t0 = 0; t0 < c; t0 += kFmUnroll) {
+      float xj[kFmUnroll], tgj[kFmUnroll], sj[kFmUnroll];
 #pragma unroll
-      for (int j = 0; j < kUnroll; j++) {
+      for (int j = 0; j < kFmUnroll; j++) {
         const int t = min(t0 + j, c - 1);
         const int2 pr = s.occ2[start + t];
         xj[j] = rows.val[pr.x];
@@ -663,7 +761,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
         sj[j] = s.svx[static_cast<int64_t>(pr.y) * k + e];
       }
 #pragma unroll
-      for (int j = 0; j < kUnroll; j++) {  // fm.cpp:84-95
+      for (int j = 0; j < kFmUnroll; j++) {  // fm.cpp:84-95
         if (t0 + j >= c) break;
         const float x = xj[j];
         const float g = tgj[j] * (x * sj[j] - w * x * x);

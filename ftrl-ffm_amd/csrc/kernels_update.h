@@ -505,10 +505,22 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
           nbv[j] = n;
           if (simple[j]) n = n + gj[j] * gj[j];
         }
+        // the group's square roots and alpha divides in their short exact forms when every
+        // operand of the wave is comfortably normal (one vote; ftrl_math.h), else IEEE
+        float arg[kUnroll];
+        bool ok = m.h.fast_div != 0;
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {
-          const float sg = (sqrtf(nbv[j] + aj[j]) - sqrtf(nbv[j])) / m.h.alpha;
-          mj[j] = sg * w;
+          arg[j] = nbv[j] + aj[j];
+          ok = ok && chain_operand_ok(arg[j]) && chain_operand_ok(nbv[j]);
+        }
+        if (__all(ok)) {
+#pragma unroll
+          for (int j = 0; j < kUnroll; j++)
+            mj[j] = div_alpha_fast(m.h, sqrt_fast(arg[j]) - sqrt_fast(nbv[j])) * w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < kUnroll; j++) mj[j] = ((sqrtf(arg[j]) - sqrtf(nbv[j])) / m.h.alpha) * w;
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; j++)

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv;
   __shared__ float s_tg;
+  __shared__ uint64_t s_tab[32];  // expf's table, staged so the row's last step waits on no load
   if (TRAIN && fuse && !s.counters[CNT_NOFUSE]) return;  // kernels_fused.h took this block
+  if (TRAIN && own_tg && threadIdx.x < 32) s_tab[threadIdx.x] = kExpTab[threadIdx.x];
   const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
   RowLds lds = carve_row_lds(smem, max_row_nnz, F);
   const int r = blockIdx.x;
@@ -233,6 +235,21 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   __syncthreads();
   const int nv = s_nv;
 
+  // linear weights of the surviving entries (update_linear_w, ftrl_model.cpp:52-59).  The first
+  // blockDim.x of them are fetched now into a register each, so that the loads fly while the row's
+  // tables are built, and parked in LDS afterwards.
+  auto linear_weight = [&](int i) {
+    float lw;
+    if (TRAIN && !refreshed) {
+      lw = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
+      if (lin_owner) m.lin_w[i] = lw;
+    } else {
+      lw = m.lin_w[i];
+    }
+    return lw;
+  };
+  float lw_early = 0.0f;
+  if (static_cast<int>(threadIdx.x) < nv) lw_early = linear_weight(lds.feat[threadIdx.x]);
   if (is_ffm) {
     for (int a = threadIdx.x; a < nv; a += blockDim.x) {
       atomicAdd(&lds.fcnt[lds.field[a]], 1);
@@ -279,18 +296,8 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     }
   }
 
-  // linear weights of the surviving entries (update_linear_w, ftrl_model.cpp:52-59)
-  for (int a = threadIdx.x; a < nv; a += blockDim.x) {
-    const int i = lds.feat[a];
-    float lw;
-    if (TRAIN && !refreshed) {
-      lw = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
-      if (lin_owner) m.lin_w[i] = lw;
-    } else {
-      lw = m.lin_w[i];
-    }
-    lds.linw[a] = lw;
-  }
+  if (static_cast<int>(threadIdx.x) < nv) lds.linw[threadIdx.x] = lw_early;
+  for (int a = threadIdx.x + blockDim.x; a < nv; a += blockDim.x) lds.linw[a] = linear_weight(lds.feat[a]);
   __syncthreads();  // this row's refreshed weights are now readable by the whole workgroup
 
   // linear logit, sequential in row order (compute_linear_logit, ftrl_model.cpp:44-50)
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
         // the whole logit is here (one shard): tmp_grad = sigmoid(logit) - y (ffm.cpp:44) and the
         // row's logloss (ftrl_offline.cpp:80) without a pass of their own
         const int y = rows.label[r];
-        const float tg = sigmoid_ref(result) - static_cast<float>(y);
+        const float tg = sigmoid_ref_tab(result, s_tab) - static_cast<float>(y);
         s.tg[r] = tg;
         s.loss[r] = logloss_ref(y, result);
         if (out) out[r] = result;

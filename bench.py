@@ -194,7 +194,7 @@ def main():
             eng = fa.Engine(model, n_feats, N_FIELDS, N_FACTORS, max_batch_rows=rows,
                             max_batch_nnz=rows * N_FIELDS, device_id=local_rank,
                             n_shards=emu or world, shard_rank=args.emulate_rank if emu else rank,
-                            stream=stream, seed=42)
+                            stream=stream, seed=42, max_row_nnz=N_FIELDS)
         except fa.EngineError as err:
             if err.code != -3 or n_feats < 10 * N_FIELDS:
                 raise
@@ -209,7 +209,7 @@ def main():
             eng.close()
             eng = fa.Engine(model, n_feats, N_FIELDS, N_FACTORS, max_batch_rows=rows,
                             max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=world,
-                            shard_rank=rank, stream=stream, seed=42)
+                            shard_rank=rank, stream=stream, seed=42, max_row_nnz=N_FIELDS)
             reduced = True
     if args.state == "warm":
         eng.fill_state(seed=7, n_lo=0.05, n_hi=1.0, z_stddev=0.3)

@@ -170,6 +170,9 @@ struct ffm_engine {
   hipStream_t aux3 = nullptr;  // side stream: very-hot-feature latent update
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_join3 = nullptr;
   int max_rows = 0, max_nnz = 0, max_row_nnz = 1024;
+  // longest row of the block being staged from host memory (known there; 0 = unknown: device
+  // callers).  The row kernels size their LDS by it, which decides how many rows a CU holds.
+  int staged_row_cap = 0;
   // staging for the host-buffer entry points
   int *d_row_ptr = nullptr, *d_field = nullptr, *d_feat = nullptr, *d_label = nullptr;
   float *d_val = nullptr, *d_out = nullptr;
@@ -341,8 +344,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (cfg->reserved[0] > 0) e->max_row_nnz = cfg->reserved[0];
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_PREP_AFTER_ROWS")) e->prep_after_rows = sv[0] == '1';
-  // (128-thread row workgroups for sharded engines, 1/n_shards of the pairs per row, measured
-  // slower: the per-row tables are throughput work too)
+  // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
+  // workgroups measured the same as 256)
   if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::min(kRowThreads, std::max(64, std::atoi(sv) / 64 * 64));
   if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_GRID_SINGLE")) e->grid_single = std::max(1, std::atoi(sv));
@@ -671,15 +674,17 @@ static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *r
 
 
 static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float *out, int output_prob, int own_tg = 0) {
+  const int row_cap = e->staged_row_cap > 0 ? e->staged_row_cap : e->max_row_nnz;
+  e->staged_row_cap = 0;
   if (rows.n_rows == 0) return;
-  const size_t shmem = row_lds_bytes(e->max_row_nnz, e->m.n_fields);
+  const size_t shmem = row_lds_bytes(row_cap, e->m.n_fields);
   const int kid = train ? K_ROW : K_PREDICT_ROW;
   if (e->m.type == FFM_MODEL_FM) {
-    if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], e->max_row_nnz, out, output_prob);
-    else LAUNCH(e, kid, fm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], e->max_row_nnz, out, output_prob);
+    if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], row_cap, out, output_prob);
+    else LAUNCH(e, kid, fm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], row_cap, out, output_prob);
   } else {
     const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
-    const int mr = e->max_row_nnz;
+    const int mr = row_cap;
     const int fuse = train && e->fuse_cur ? 1 : 0;
     const int refreshed = train && e->pre_refresh ? 1 : 0;
     if (refreshed && rows.nnz > 0) {
@@ -911,9 +916,13 @@ static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, co
   const int32_t nnz = row_ptr[n_rows];
   int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
   if (rc) return rc;
-  for (int r = 0; r < n_rows; r++)
+  int longest = 1;
+  for (int r = 0; r < n_rows; r++) {
     if (row_ptr[r + 1] - row_ptr[r] > e->max_row_nnz)
       return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz");
+    longest = std::max(longest, row_ptr[r + 1] - row_ptr[r]);
+  }
+  e->staged_row_cap = longest;
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   HIP_TRY(hipMemcpyAsync(e->d_row_ptr, row_ptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice, e->stream));
   if (nnz > 0) {

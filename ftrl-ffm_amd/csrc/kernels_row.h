@@ -121,10 +121,7 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
   // For entries of hot features: what each partner field contributes to their touches
   // ({partner value, flags | own field, offset of the partner's weights lo, hi}), laid out by occurrence position
   // for the hot update kernel.
-  for (int t = threadIdx.x; t < nv * F; t += blockDim.x) {
-    const int a = t / F, f = t - a * F;
-    const int op = lds.opos[a];
-    if (op < 0 || !owns_pair(m, lds.field[a], f)) continue;  // facts this shard's owners will read
+  auto emit_facts = [&](int a, int f, int op) {
     const int cnt = lds.fcnt[f];
     const int a0 = lds.ffirst[f];
     int flags = 0, fq = lds.feat[a];  // harmless partner when there is no plain partner
@@ -143,6 +140,24 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
     s.haux[static_cast<int64_t>(op) * F + f] =
         make_int4(__float_as_int(xo), flags | (lds.field[a] << 8), static_cast<int>(woff & 0xffffffff),
                   static_cast<int>(woff >> 32));
+  };
+  if (m.n_shards > 1) {
+    // only the partner fields this shard owns for the entry's field (m.own_fp): 1/n_shards of them
+    const int om = m.own_max;
+    for (int t = threadIdx.x; t < nv * om; t += blockDim.x) {
+      const int a = t / om, j = t - a * om;
+      const int op = lds.opos[a];
+      const int fa = lds.field[a];
+      if (op < 0 || j >= m.own_cnt[fa]) continue;
+      emit_facts(a, m.own_fp[fa * F + j], op);
+    }
+  } else {
+    for (int t = threadIdx.x; t < nv * F; t += blockDim.x) {
+      const int a = t / F, f = t - a * F;
+      const int op = lds.opos[a];
+      if (op < 0) continue;
+      emit_facts(a, f, op);
+    }
   }
   // Per-field view of this row for the update kernel: rowtab[r][f] = {feat, val bits, entry
   // index, count} of the only entry with field f (entry index -1: none, -2: several -- then
@@ -314,7 +329,54 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     for (int a = 0; a < nv; a++) result = result + lds.linw[a] * lds.val[a];
   }
 
-  if (is_ffm && nv > 1) {
+  // A shard owns 1/n_shards of the field pairs: walk (entry a, owned partner field of a's field)
+  // instead of testing all nv(nv-1)/2 pairs -- when no field holds two entries in this row.  The
+  // shard's terms are then summed in that walk's order (fixed, so deterministic; the cross-shard
+  // sum reorders the pairs anyway).
+  bool shard_walk = false;
+  if (is_ffm && m.n_shards > 1 && nv > 1) {
+    bool multi = false;
+    for (int f = 0; f < F; f++) multi = multi || lds.fcnt[f] > 1;
+    shard_walk = !multi;
+  }
+  if (shard_walk) {
+    const int om = m.own_max, items = nv * om;
+    for (int q0 = 0; q0 < items; q0 += kTermsCap) {
+      const int q1 = min(q0 + kTermsCap, items);
+      for (int t = q0 + threadIdx.x; t < q1; t += blockDim.x) {
+        const int a = t / om, j = t - a * om;
+        const int fa = lds.field[a];
+        float term = __int_as_float(0x7fc00001);  // "no pair here"
+        if (j < m.own_cnt[fa]) {
+          const int fb = m.own_fp[fa * F + j];
+          const int bb = lds.ffirst[fb];
+          if (lds.fcnt[fb] == 1 && bb > a) {
+            const float *va = lat_row(m, lds.feat[a]) + LAT_W * RL + fb * k;
+            const float *vb = lat_row(m, lds.feat[bb]) + LAT_W * RL + fa * k;
+            float dot = 0.0f;
+            if (VEC4) {
+              const float4 *va4 = reinterpret_cast<const float4 *>(va);
+              const float4 *vb4 = reinterpret_cast<const float4 *>(vb);
+              for (int f4 = 0; f4 < (k >> 2); f4++) {
+                const float4 x = va4[f4], y = vb4[f4];
+                dot = dot + x.x * y.x;
+                dot = dot + x.y * y.y;
+                dot = dot + x.z * y.z;
+                dot = dot + x.w * y.w;
+              }
+            } else {
+              for (int f = 0; f < k; f++) dot = dot + va[f] * vb[f];
+            }
+            term = dot * lds.val[a] * lds.val[bb];
+          }
+        }
+        lds.terms[t - q0] = term;
+      }
+      __syncthreads();
+      if (threadIdx.x < 64) result = wave_add_terms_in_order(lds.terms, q1 - q0, result);
+      __syncthreads();
+    }
+  } else if (is_ffm && nv > 1) {
     const int n_pairs = nv * (nv - 1) / 2;
     for (int q0 = 0; q0 < n_pairs; q0 += kTermsCap) {
       const int q1 = min(q0 + kTermsCap, n_pairs);

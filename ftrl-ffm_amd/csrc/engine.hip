@@ -357,7 +357,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     const int k = cfg->n_factors;
     e->fuse_ok = cfg->model_type == FFM_MODEL_FFM && cfg->n_shards == 1 && cfg->n_fields <= 64 &&
                  (k == 4 || k == 8 || k == 16) &&
-                 ((fe && fe[0] == '1') || (cfg->flags & FFM_FLAG_FUSE));
+                 ((fe && fe[0] == '1') || (cfg->flags & FFM_FLAG_FUSE)) &&
+                 !(cfg->flags & FFM_FLAG_LEARN);  // the fused kernel implements the reference rule only
     const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
     const int64_t per = cfg->n_factors % 4 == 0 ? static_cast<int64_t>(cfg->n_fields) * cfg->n_factors / 4
                                                 : static_cast<int64_t>(cfg->n_fields) * cfg->n_factors;
@@ -376,7 +377,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
               : cfg->model_type == FFM_MODEL_FM ? cfg->n_factors : 0;
   m.n_shards = cfg->n_shards;
   m.shard_rank = cfg->shard_rank;
-  m.h = Hyper{cfg->w_alpha, cfg->w_beta, cfg->w_l1, cfg->w_l2, 1.0f / cfg->w_alpha, 0};
+  m.h = Hyper{cfg->w_alpha, cfg->w_beta, cfg->w_l1, cfg->w_l2, 1.0f / cfg->w_alpha, 0,
+              (cfg->flags & FFM_FLAG_LEARN) ? 1 : 0};
   if (static_cast<int64_t>(cfg->n_fields) * cfg->n_factors > (1 << 24))
     { delete e; return fail(FFM_E_UNSUPPORTED, "n_fields*n_factors too large"); }
   if (static_cast<int64_t>(cfg->max_batch_nnz) / (kSmallMax + 1) * ((m.row_len + 7) / 8 + 1) >= (1ll << 31))

@@ -11,6 +11,7 @@ struct Hyper {
   float alpha, beta, l1, l2;
   float inv_alpha;  // RN(1/alpha)
   int fast_div;     // 1 when div_alpha's short sequence was proven exact for this alpha
+  int learn;        // FFM_FLAG_LEARN: opt-in variant (keep w until n > 0; g2*g2 at ffm.cpp:118)
 };
 
 // utils::sgn, reference src/include/utils/utils.h:15-18: x > 0 ? 1 : -1 (sgn(0) = -1)
@@ -123,11 +124,28 @@ __device__ __forceinline__ void ftrl_weight_n(const Hyper &h, const float (&nn)[
     w[i] = fabsf(zz[i]) <= h.l1 ? 0.0f : (-num) / den;
   }
 }
+// Latent refresh rule: W(n, z), except that the learning variant keeps the stored weight of a slot
+// that has not seen a gradient yet (n == 0).
+__device__ __forceinline__ float latent_weight(const Hyper &h, float n, float z, float w_old) {
+  const float w = ftrl_weight(h, n, z);
+  return (h.learn && !(n > 0.0f)) ? w_old : w;
+}
 __device__ __forceinline__ float4 ftrl_weight4(const Hyper &h, float4 n, float4 z) {
   const float nn[4] = {n.x, n.y, n.z, n.w}, zz[4] = {z.x, z.y, z.z, z.w};
   float w[4];
   ftrl_weight_n<4>(h, nn, zz, w);
   return make_float4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ float4 latent_weight4(const Hyper &h, float4 n, float4 z, float4 w_old) {
+  float4 w = ftrl_weight4(h, n, z);
+  if (h.learn) {
+    w.x = n.x > 0.0f ? w.x : w_old.x;
+    w.y = n.y > 0.0f ? w.y : w_old.y;
+    w.z = n.z > 0.0f ? w.z : w_old.z;
+    w.w = n.w > 0.0f ? w.w : w_old.w;
+  }
+  return w;
 }
 
 // Linear / bias accumulator step, src/model/ftrl_model.cpp:69-74 and :81-84:
@@ -152,7 +170,7 @@ __device__ __forceinline__ void nz_step_latent(const Hyper &h, float w, float g,
 // n + g2*g1 (product of the two different gradients), which is NaN when that is negative.
 __device__ __forceinline__ void nz_step_latent_jside(const Hyper &h, float w, float g2, float g1,
                                                      float &n, float &z) {
-  const float s = div_alpha(h, sqrt_cr(n + g2 * g1) - sqrt_cr(n));
+  const float s = div_alpha(h, sqrt_cr(n + (h.learn ? g2 * g2 : g2 * g1)) - sqrt_cr(n));
   z = (z + g2) - s * w;
   n = n + g2 * g2;
 }

@@ -293,7 +293,8 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
         if (touched) {
           float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a]));
           const float4 n4 = row[LAT_N * RL4 + c4], z4 = row[LAT_Z * RL4 + c4];
-          row[LAT_W * RL4 + c4] = ftrl_weight4(m.h, n4, z4);
+          const float4 w4 = m.h.learn ? row[LAT_W * RL4 + c4] : n4;
+          row[LAT_W * RL4 + c4] = latent_weight4(m.h, n4, z4, w4);
         }
       }
     } else {
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
         const bool touched = (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
         if (touched) {
           float *row = lat_row(m, lds.feat[a]);
-          row[LAT_W * RL + e] = ftrl_weight(m.h, row[LAT_N * RL + e], row[LAT_Z * RL + e]);
+          row[LAT_W * RL + e] = latent_weight(m.h, row[LAT_N * RL + e], row[LAT_Z * RL + e],
+                                             m.h.learn ? row[LAT_W * RL + e] : 0.0f);
         }
       }
     }
@@ -496,10 +498,12 @@ __global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s,
       const int RL4 = RL >> 2;
       float4 *row = reinterpret_cast<float4 *>(lat_row(m, i));
       const float4 n4 = row[LAT_N * RL4 + l], z4 = row[LAT_Z * RL4 + l];
-      row[LAT_W * RL4 + l] = ftrl_weight4(m.h, n4, z4);
+      const float4 w4 = m.h.learn ? row[LAT_W * RL4 + l] : n4;
+      row[LAT_W * RL4 + l] = latent_weight4(m.h, n4, z4, w4);
     } else {
       float *row = lat_row(m, i);
-      row[LAT_W * RL + l] = ftrl_weight(m.h, row[LAT_N * RL + l], row[LAT_Z * RL + l]);
+      row[LAT_W * RL + l] = latent_weight(m.h, row[LAT_N * RL + l], row[LAT_Z * RL + l],
+                                         m.h.learn ? row[LAT_W * RL + l] : 0.0f);
     }
   }
 }
@@ -534,7 +538,8 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
       a += (a + 1) * k <= t ? 1 : (a * k > t ? -1 : 0);
       const int e = t - a * k;
       float *row = lat_row(m, lds.feat[a]);
-      row[LAT_W * k + e] = ftrl_weight(m.h, row[LAT_N * k + e], row[LAT_Z * k + e]);
+      row[LAT_W * k + e] = latent_weight(m.h, row[LAT_N * k + e], row[LAT_Z * k + e],
+                                        m.h.learn ? row[LAT_W * k + e] : 0.0f);
     }
   }
   for (int a = threadIdx.x; a < nv; a += blockDim.x) {

@@ -62,7 +62,7 @@ __device__ __forceinline__ void ffm_touch_n(const Hyper &h, bool own_first, floa
   for (int i = 0; i < N; i++) {
     g[i] = tg * vp[i] * x;              // own slot's gradient
     const float g1 = tg * w[i] * x;     // second-entry case: the first entry's gradient
-    arg[i] = n[i] + (own_first ? g[i] * g[i] : g[i] * g1);  // ffm.cpp:113 / :118
+    arg[i] = n[i] + ((own_first || h.learn) ? g[i] * g[i] : g[i] * g1);  // ffm.cpp:113 / :118
     arg[N + i] = n[i];
   }
   // both square roots and the alpha divide in their short exact forms when every operand of the
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
         const float left = quad_left(S);
         const float nb = l0 ? nc : left;  // n before this touch
         nc = quad_last(S);
-        const float arg0 = nb + (first ? gg : g * g1);  // ffm.cpp:113 / :118
+        const float arg0 = nb + ((first || m.h.learn) ? gg : g * g1);  // ffm.cpp:113 / :118
         // both square roots and the alpha divide in their short exact forms when every lane's
         // operands are comfortably normal (ftrl_math.h: chain_operand_ok), else IEEE
         float sg;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
           const float g = tgj[j] * vpC[j] * x;  // own slot's gradient (g1 if first, else g2)
           const float g1 = tgj[j] * w * x;      // second-entry case: the first entry's gradient
           gj[j] = g;
-          aj[j] = first ? g * g : g * g1;       // what the square root sees added to n (:118)
+          aj[j] = (first || m.h.learn) ? g * g : g * g1;  // what the square root sees added to n (:118)
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {

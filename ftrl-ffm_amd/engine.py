@@ -14,6 +14,7 @@ LR, FM, FFM = 0, 1, 2
 MODEL_TYPES = {"LR": LR, "FM": FM, "FFM": FFM}
 FLAG_SKIP_INIT = 1
 FLAG_FUSE = 2
+FLAG_LEARN = 4
 
 _i32p = ctypes.POINTER(ctypes.c_int32)
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -117,7 +118,7 @@ class Engine:
     def __init__(self, model_type="FFM", n_feats=10000, n_fields=8, n_factors=16, w_alpha=1e-4,
                  w_beta=1.0, w_l1=0.1, w_l2=5.0, init_mean=0.0, init_stddev=0.02, seed=42,
                  max_batch_rows=8192, max_batch_nnz=None, device_id=0, n_shards=1, shard_rank=0,
-                 stream=None, skip_init=False, max_row_nnz=0, fuse=False):
+                 stream=None, skip_init=False, max_row_nnz=0, fuse=False, learn=False):
         self.lib = load_library()
         cfg = Config()
         self.lib.ffm_engine_default_config(ctypes.byref(cfg))
@@ -129,7 +130,7 @@ class Engine:
         cfg.max_batch_nnz = int(max_batch_nnz if max_batch_nnz else max_batch_rows * 64)
         cfg.device_id, cfg.n_shards, cfg.shard_rank = int(device_id), int(n_shards), int(shard_rank)
         cfg.stream = stream
-        cfg.flags = (FLAG_SKIP_INIT if skip_init else 0) | (FLAG_FUSE if fuse else 0)
+        cfg.flags = (FLAG_SKIP_INIT if skip_init else 0) | (FLAG_FUSE if fuse else 0) | (FLAG_LEARN if learn else 0)
         cfg.reserved[0] = int(max_row_nnz)
         self.cfg = cfg
         self.h = _vp()

@@ -30,7 +30,9 @@ const char *const cmd_help =
     "--batch_size <rows>: rows per block sent to the GPU\tdefault:4096\n"
     "--batch_ramp <r>: block size grows as rows_seen/r (0 disables)\tdefault:32\n"
     "--seed <seed>: seed of the weight init and the offline shuffle\tdefault:42\n"
-    "--device <id>: HIP device ordinal\tdefault:0\n";
+    "--device <id>: HIP device ordinal\tdefault:0\n"
+    "--learn <bool>: keep initial latent weights until their first gradient and use g2*g2 at\n"
+    "                ffm.cpp:118, so FM/FFM factors train (NOT the reference's results)\tdefault:false\n";
 
 static bool assign_bool(std::string arg) {
   std::transform(arg.begin(), arg.end(), arg.begin(), [](unsigned char c) { return std::tolower(c); });
@@ -85,6 +87,7 @@ void config_options::parse_option(int argc, char *argv[]) {
     else if (k == "--batch_ramp") batch_ramp = std::stoi(v);
     else if (k == "--seed") seed = std::stoull(v);
     else if (k == "--device") device = std::stoi(v);
+    else if (k == "--learn") learn = assign_bool(v);
     else throw std::invalid_argument("unknown argument: " + k + "\n");
   }
   file_type = detect_file_type(train_path);

@@ -20,6 +20,7 @@ struct config_options {
   int batch_ramp = 32;     // --batch_ramp: block size <= rows_seen / ramp (0 = off); DESIGN.md
   uint64_t seed = 42;      // --seed: weight init and the offline shuffle (the reference is unseeded)
   int device = 0;          // --device: HIP device ordinal
+  bool learn = false;      // --learn: FFM_FLAG_LEARN, the opt-in variant in which the factors train
 
   void parse_option(int argc, char *argv[]);  // throws std::invalid_argument like the reference
 };

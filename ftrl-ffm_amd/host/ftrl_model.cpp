@@ -38,6 +38,7 @@ FtrlModel::FtrlModel(const config_options &opt, int mt)
   cfg.max_batch_rows = std::max(1, opt.batch_size);
   cfg.max_batch_nnz = cfg.max_batch_rows * 256;
   cfg.device_id = opt.device;
+  if (opt.learn) cfg.flags |= FFM_FLAG_LEARN;
   const int rc = ffm_engine_create(&cfg, &eng_);
   if (rc == FFM_E_INVALID) throw std::invalid_argument(ffm_engine_last_error());
   check(rc, "ffm_engine_create");

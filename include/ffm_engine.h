@@ -78,6 +78,12 @@ typedef struct ffm_engine_config {
 
 enum {
   FFM_FLAG_SKIP_INIT = 1, /* leave w zeroed; the caller will ffm_engine_set_weights */
+  FFM_FLAG_LEARN = 4,     /* opt-in "learning" variant, NOT the reference's arithmetic (SURVEY.md
+                           * 8(f) rank 4): (1) the lazy refresh keeps a latent slot's initial
+                           * weight until its first gradient (n > 0) instead of overwriting it
+                           * with W(0,0) = 0 (ffm.cpp:72-88, fm.cpp:69-78), (2) ffm.cpp:118 uses
+                           * g2*g2 instead of g2*g1 -- so that FM / FFM factors actually train.
+                           * Off: the reference bit for bit. */
   FFM_FLAG_FUSE = 2       /* take the fused row kernel (csrc/kernels_fused.h: one pass per row over
                            * (n,z,w), features that occur once in the block finished in registers)
                            * for the blocks it can handle.  Same bits as the general kernels;

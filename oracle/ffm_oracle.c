@@ -23,6 +23,7 @@ struct fo_model {
   float *sum_vx;                /* fm.h:24 */
   pthread_mutex_t *locks;       /* ftrl_model.h:49, ffm.h:32 (threaded baseline only) */
   pthread_mutex_t bias_lock;    /* ftrl_model.h:50 */
+  int learn;                    /* fo_set_variant: SURVEY.md 8(f) rank 4, NOT reference behaviour */
 };
 
 fo_model *fo_create(int model_type, int n_feats, int n_fields, int n_factors, float w_alpha,
@@ -66,6 +67,15 @@ void fo_destroy(fo_model *m) {
   free(m);
 }
 
+/* Opt-in variant that lets the latent factors train (off = the reference, bit for bit):
+ * (1) the lazy refresh keeps a slot's initial weight until its first gradient (n > 0), instead of
+ *     overwriting it with W(0, 0) = 0 (ffm.cpp:72-88, fm.cpp:69-78);
+ * (2) the second slot's step size uses g2*g2, not g2*g1 (ffm.cpp:118). */
+void fo_set_variant(fo_model *m, int learn) { m->learn = learn != 0; }
+
+/* latent refresh under the variant rule */
+static inline float mzw_latent(const fo_model *m, float n, float z, float w_old);
+
 float *fo_bias3(fo_model *m) { return m->bias3; }
 float *fo_lin_w(fo_model *m) { return m->lin_w; }
 float *fo_lin_n(fo_model *m) { return m->lin_n; }
@@ -96,6 +106,11 @@ static inline float mzw(const fo_model *m, float n, float z) {
   return (float)(-1.0 * (double)num / (double)den);
 }
 float fo_maybe_zero_weight(const fo_model *m, float n, float z) { return mzw(m, n, z); }
+
+static inline float mzw_latent(const fo_model *m, float n, float z, float w_old) {
+  if (m->learn && !(n > 0.0f)) return w_old;
+  return mzw(m, n, z);
+}
 
 /* ftrl_model.cpp:36-42 (feat only) and ffm.cpp:30-36 (field too) */
 static inline int in_range(const fo_model *m, int field, int feat) {
@@ -173,9 +188,9 @@ static void ffm_update_vector_w(fo_model *m, const rowview *rv) {
       const int field2 = RV_FIELD(rv, b), j = RV_FEAT(rv, b);
       for (int f = 0; f < k; f++) {
         const int64_t f1 = i * L + (int64_t)field2 * k + f;
-        m->vec_w[f1] = mzw(m, m->vec_n[f1], m->vec_z[f1]);
+        m->vec_w[f1] = mzw_latent(m, m->vec_n[f1], m->vec_z[f1], m->vec_w[f1]);
         const int64_t f2 = j * L + (int64_t)field1 * k + f;
-        m->vec_w[f2] = mzw(m, m->vec_n[f2], m->vec_z[f2]);
+        m->vec_w[f2] = mzw_latent(m, m->vec_n[f2], m->vec_z[f2], m->vec_w[f2]);
       }
     }
 }
@@ -211,7 +226,8 @@ static inline void ffm_pair_step(const fo_model *m, float tmp_grad, float x, flo
   const float zi1 = v_zif1 + v_gif1 - v_sif1 * vif1;
   const float ni1 = v_nif1 + v_gif1 * v_gif1;
   const float v_gif2 = tmp_grad * vif1 * x;
-  const float v_sif2 = (sqrtf(v_nif2 + v_gif2 * v_gif1) - sqrtf(v_nif2)) / m->w_alpha;
+  const float v_sif2 =
+      (sqrtf(v_nif2 + (m->learn ? v_gif2 * v_gif2 : v_gif2 * v_gif1)) - sqrtf(v_nif2)) / m->w_alpha;
   const float zi2 = v_zif2 + v_gif2 - v_sif2 * vif2;
   const float ni2 = v_nif2 + v_gif2 * v_gif2;
   *z1 = zi1; *n1 = ni1; *z2 = zi2; *n2 = ni2;
@@ -253,7 +269,8 @@ static void fm_update_vector_w(fo_model *m, const rowview *rv) {
   const int k = m->n_factors;
   for (int a = 0; a < rv->n; a++) {
     const int64_t o = (int64_t)RV_FEAT(rv, a) * k;
-    for (int f = 0; f < k; f++) m->vec_w[o + f] = mzw(m, m->vec_n[o + f], m->vec_z[o + f]);
+    for (int f = 0; f < k; f++)
+      m->vec_w[o + f] = mzw_latent(m, m->vec_n[o + f], m->vec_z[o + f], m->vec_w[o + f]);
   }
 }
 
@@ -467,9 +484,9 @@ static float train_locked(fo_model *m, int nnz, const int32_t *field, const int3
         lock2(m, i, j);
         for (int f = 0; f < k; f++) {
           const int64_t f1 = i * L + (int64_t)field2 * k + f;
-          m->vec_w[f1] = mzw(m, m->vec_n[f1], m->vec_z[f1]);
+          m->vec_w[f1] = mzw_latent(m, m->vec_n[f1], m->vec_z[f1], m->vec_w[f1]);
           const int64_t f2 = j * L + (int64_t)field1 * k + f;
-          m->vec_w[f2] = mzw(m, m->vec_n[f2], m->vec_z[f2]);
+          m->vec_w[f2] = mzw_latent(m, m->vec_n[f2], m->vec_z[f2], m->vec_w[f2]);
         }
         unlock2(m, i, j);
       }
@@ -480,7 +497,7 @@ static float train_locked(fo_model *m, int nnz, const int32_t *field, const int3
       pthread_mutex_lock(&m->locks[i]);
       for (int f = 0; f < k; f++) {
         const int64_t o = (int64_t)i * k + f;
-        m->vec_w[o] = mzw(m, m->vec_n[o], m->vec_z[o]);
+        m->vec_w[o] = mzw_latent(m, m->vec_n[o], m->vec_z[o], m->vec_w[o]);
       }
       pthread_mutex_unlock(&m->locks[i]);
     }

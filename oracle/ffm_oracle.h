@@ -33,6 +33,11 @@ fo_model *fo_create(int model_type, int n_feats, int n_fields, int n_factors, fl
                     float w_beta, float w_l1, float w_l2);
 void fo_destroy(fo_model *m);
 
+/* Opt-in "learning" variant (NOT the reference's behaviour, so not pinned
+ * by it): keep a latent slot's initial weight until its first gradient, and use g2*g2 at
+ * ffm.cpp:118.  learn = 0 (default) is the reference bit for bit. */
+void fo_set_variant(fo_model *m, int learn);
+
 /* Raw state access (row-major [feat][row_len], the reference's save order ffm.cpp:138-146). */
 float *fo_bias3(fo_model *m); /* {bias, bias_n, bias_z} */
 float *fo_lin_w(fo_model *m);

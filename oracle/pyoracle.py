@@ -91,6 +91,8 @@ def _lib(kind):
     f.restype = vp
     f.argtypes = [ctypes.c_int] * 4 + [ctypes.c_float] * 4
     getattr(lib, p + "destroy").argtypes = [vp]
+    if kind == "oracle":
+        lib.fo_set_variant.argtypes = [vp, ctypes.c_int]
     getattr(lib, p + "row_len").restype = ctypes.c_int64
     getattr(lib, p + "row_len").argtypes = [vp]
     for name in ("train", "predict"):
@@ -143,7 +145,8 @@ class CpuModel:
     """One LR/FM/FFM model on the CPU: ``kind="oracle"`` (restatement) or ``"ref"`` (reference)."""
 
     def __init__(self, kind, model_type, n_feats, n_fields=1, n_factors=1, w_alpha=1e-4,
-                 w_beta=1.0, w_l1=0.1, w_l2=5.0):
+                 w_beta=1.0, w_l1=0.1, w_l2=5.0, learn=False):
+        """learn=True: the opt-in "learning" variant (oracle only; not the reference's behaviour)."""
         self.kind = kind
         self.lib, self.p = _lib(kind)
         self.model_type = MODEL_TYPES[model_type] if isinstance(model_type, str) else model_type
@@ -151,6 +154,10 @@ class CpuModel:
         self.h = getattr(self.lib, self.p + "create")(self.model_type, n_feats, n_fields, n_factors,
                                                       w_alpha, w_beta, w_l1, w_l2)
         self.row_len = int(getattr(self.lib, self.p + "row_len")(self.h))
+        if learn:
+            if kind != "oracle":
+                raise ValueError("the learning variant exists in the oracle only")
+            self.lib.fo_set_variant(self.h, 1)
         if kind == "ref":  # the reference ctor leaves random weights behind: start from zeros
             self.set_state(self.zero_state())
 

@@ -400,3 +400,40 @@ def test_lookahead_grouping_is_transparent():
         lg, st = run(mode)
         assert_bitwise(lg, base_l, mode + " logits")
         assert_state_bitwise(st, base_s, mode)
+
+
+@pytest.mark.parametrize("mt,F,k,per", [("FFM", 8, 16, 40), ("FFM", 5, 3, 20), ("FM", 1, 7, 100)])
+@pytest.mark.parametrize("B", [1, 64])
+def test_learning_variant_matches_its_oracle(mt, F, k, per, B):
+    """FFM_FLAG_LEARN (not the reference's arithmetic): the device against the
+    oracle's restatement of the same two rule changes, bit for bit, on a state where half of the
+    slots have not seen a gradient yet (n = 0: the refresh must keep their weights)."""
+    rng = np.random.default_rng(21)
+    nf = F * per if mt == "FFM" else per
+    o = CpuModel("oracle", mt, nf, F, k, learn=True, **STRESS_HP)
+    st = rand_state(rng, o)
+    fresh = rng.random(st["vec_n"].shape) < 0.5
+    st["vec_n"][fresh] = 0.0
+    st["vec_z"][fresh] = 0.0
+    st["vec_n"][~fresh] += np.float32(0.05)
+    o.set_state(st)
+    e = fa.Engine(mt, nf, F, k, skip_init=True, max_batch_rows=256, learn=True, **STRESS_HP)
+    e.set_state(st)
+    blk = synth.Generator(F if mt == "FFM" else 13, nf, "zipf", seed=4).block(256)
+    if mt != "FFM":
+        blk.field[:] = 0
+    n = 256 if B > 1 else 32
+    for r0 in range(0, n, B):
+        sub = blk.rows(r0, min(r0 + B, n))
+        lo, so = o.train_batch(sub)
+        lg, sg = e.train_batch(sub)
+        assert_bitwise(lg, lo, "logits block at %d" % r0)
+        assert loss_close(sg, so)
+    assert_state_bitwise(e.get_state(), o.get_state(), "%s learn B=%d" % (mt, B))
+    # and it is not the reference rule: the reference-mode oracle ends elsewhere
+    ref = CpuModel("oracle", mt, nf, F, k, **STRESS_HP)
+    ref.set_state(st)
+    for r0 in range(0, n, B):
+        ref.train_batch(blk.rows(r0, min(r0 + B, n)))
+    assert not np.array_equal(ref.get_state()["vec_w"], o.get_state()["vec_w"])
+    e.close()

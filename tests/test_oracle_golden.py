@@ -13,6 +13,7 @@ import pytest
 
 from oracle import pyoracle
 from oracle.pyoracle import CpuModel, Csr
+from ftrl_ffm_amd import synth
 from util import (DEFAULT_HP, GOLDEN, STRESS_HP, assert_bitwise, assert_state_bitwise,
                   bundled_rows, golden_cases, load_case, make_cpu, rand_state)
 
@@ -159,3 +160,39 @@ def test_remove_out_range_rule():
     import os
     z = np.load(os.path.join(GOLDEN, "g8_remove_out_range_counts.npz"))
     assert int(z["lr_keeps"]) == 1 and int(z["ffm_keeps"]) == 0
+
+
+def test_learning_variant_is_opt_in_and_lets_factors_train():
+    """SURVEY.md 8(f) rank 4.  learn=False is the reference bit for bit (all tests above); learn=True
+    (1) keeps a latent slot's initial weight until its first gradient and (2) uses g2*g2 at
+    ffm.cpp:118 -- so from a fresh model (n = z = 0, random w) the factors move instead of being
+    zeroed by the first refresh (the reference's dead latents)."""
+    rng = np.random.default_rng(11)
+    F, k, per = 4, 4, 10
+    nf = F * per
+    blk = synth.Generator(F, nf, "zipf", seed=5).block(64)
+    outs = {}
+    for learn in (False, True):
+        m = CpuModel("oracle", "FFM", nf, F, k, learn=learn)
+        st = m.zero_state()
+        st["vec_w"][...] = np.random.default_rng(1).normal(0, 0.02, st["vec_w"].shape).astype(np.float32)
+        m.set_state(st)
+        w0 = st["vec_w"].copy()
+        m.train_rows(blk)
+        outs[learn] = (m.get_state(), w0)
+    ref_state, w0 = outs[False]
+    lrn_state, _ = outs[True]
+    touched = ref_state["vec_w"] != w0          # slots some pair of the block refreshed
+    assert touched.any()
+    # the reference zeroes every touched slot at its first refresh (W(0,0) = 0); with w = 0 the
+    # gradients are 0, so n and z never move: the latents are dead
+    assert np.all(ref_state["vec_w"][touched] == 0.0)
+    assert np.all(ref_state["vec_n"] == 0.0) and np.all(ref_state["vec_z"] == 0.0)
+    # the variant keeps the initial weight for the first forward, accumulates n, z and trains w
+    assert np.mean(lrn_state["vec_n"][touched] > 0.0) > 0.9
+    assert np.count_nonzero(lrn_state["vec_w"][touched] != w0[touched]) > 0
+    # untouched slots keep their initial weights in both
+    assert_bitwise(ref_state["vec_w"][~touched], w0[~touched])
+    assert_bitwise(lrn_state["vec_w"][~touched], w0[~touched])
+    # and the variant never produces the :118 NaN from a fresh model
+    assert np.isfinite(lrn_state["vec_z"]).all()

@@ -201,6 +201,8 @@ struct ffm_engine {
   // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
   // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
   int grid_small = 768, grid_hot = 2048, grid_huge = 2048, grid_single = 768;
+  // FFM_WAIT_GROUPING=1: hold the update kernels until the look-ahead grouping in flight is done
+  bool wait_grouping = false;
   bool single_kernel = true;  // FFM_SINGLE_KERNEL=0: once-only features through the small kernel
   int row_threads = kRowThreads;  // workgroup size of the FFM row kernel (FFM_ROW_THREADS)
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
@@ -347,6 +349,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
   if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::min(kRowThreads, std::max(64, std::atoi(sv) / 64 * 64));
+  if (const char *sv = std::getenv("FFM_WAIT_GROUPING")) e->wait_grouping = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_GRID_SINGLE")) e->grid_single = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
@@ -832,6 +835,11 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     if (rows.nnz > 0)
       LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   }
+  // The update kernels are persistent and fill the chip: a look-ahead grouping still in flight on
+  // the prep queue makes little progress beside them.  Optionally let it finish first (measured
+  // the same either way once the grouping's workgroups were small enough to find wave slots).
+  if (e->n_prepared > 0 && !e->serial && e->wait_grouping)
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_grouped[e->prepared_set[0]], 0));
   if (forked || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
   if (forked) {
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));

@@ -13,7 +13,12 @@
 namespace ftrl_dev {
 
 constexpr int kGroupThreads = 256;
-constexpr int kFinishThreads = 1024;  // group_finish_kernel: one atomic per list per workgroup
+#ifndef FFM_FINISH_THREADS
+#define FFM_FINISH_THREADS 256
+#endif
+// group_finish_kernel: one atomic per list per workgroup.  (1024-thread workgroups need 16 free
+// wave slots on one CU at once: beside the persistent update kernels they waited for that.)
+constexpr int kFinishThreads = FFM_FINISH_THREADS;
 
 // One atomic per wave instead of one per lane: lanes with pred get consecutive slots.
 __device__ __forceinline__ int wave_append_slot(int *counter, bool pred) {

@@ -376,19 +376,23 @@ def test_lookahead_grouping_is_transparent():
         e = fa.Engine("FFM", nf, F, k, max_batch_rows=B, seed=3, **STRESS_HP)
         e.fill_state(seed=9)
         out = torch.zeros(len(blocks), B, device="cuda")
+        prepared_upto = [0]
         for i, d in enumerate(dev):
             e.train_batch_device(B, blocks[i].nnz, d["row_ptr"].data_ptr(), d["field"].data_ptr(),
                                  d["feat"].data_ptr(), d["val"].data_ptr(), d["label"].data_ptr(),
                                  out[i].data_ptr())
-            nxt = None
+            nxt = []
             if mode == "ahead" and i + 1 < len(dev):
-                nxt = i + 1
+                nxt = [i + 1]
+            if mode == "ahead2":  # two blocks ahead, as bench.py does
+                nxt = [j for j in (i + 1, i + 2) if j < len(dev) and j > prepared_upto[0]]
             if mode == "wrong" and i + 2 < len(dev):
-                nxt = i + 2  # prepares a block that is not trained next
-            if nxt is not None:
-                dn = dev[nxt]
-                e.prepare_device(B, blocks[nxt].nnz, dn["row_ptr"].data_ptr(), dn["field"].data_ptr(),
+                nxt = [i + 2]  # prepares a block that is not trained next
+            for j in nxt:
+                dn = dev[j]
+                e.prepare_device(B, blocks[j].nnz, dn["row_ptr"].data_ptr(), dn["field"].data_ptr(),
                                  dn["feat"].data_ptr(), dn["val"].data_ptr())
+                prepared_upto[0] = max(prepared_upto[0], j)
         e.sync()
         st = e.get_state()
         lg = out.cpu().numpy()
@@ -396,10 +400,22 @@ def test_lookahead_grouping_is_transparent():
         return lg, st
 
     base_l, base_s = run("inline")
-    for mode in ("ahead", "wrong"):
+    for mode in ("ahead", "ahead2", "wrong"):
         lg, st = run(mode)
         assert_bitwise(lg, base_l, mode + " logits")
         assert_state_bitwise(st, base_s, mode)
+    # at most two prepared blocks may wait
+    e = fa.Engine("FFM", nf, F, k, max_batch_rows=B, seed=3, **STRESS_HP)
+    for j in range(2):
+        dn = dev[j]
+        e.prepare_device(B, blocks[j].nnz, dn["row_ptr"].data_ptr(), dn["field"].data_ptr(),
+                         dn["feat"].data_ptr(), dn["val"].data_ptr())
+    with pytest.raises(fa.EngineError) as err:
+        dn = dev[2]
+        e.prepare_device(B, blocks[2].nnz, dn["row_ptr"].data_ptr(), dn["field"].data_ptr(),
+                         dn["feat"].data_ptr(), dn["val"].data_ptr())
+    assert err.value.code == -4  # FFM_E_CAPACITY
+    e.close()
 
 
 @pytest.mark.parametrize("mt,F,k,per", [("FFM", 8, 16, 40), ("FFM", 5, 3, 20), ("FM", 1, 7, 100)])

@@ -904,12 +904,31 @@ int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
                                     int32_t output_prob, float *out, double *loss_sum_out) {
   int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
   if (rc) return rc;
-  if (e->m.n_shards > 1) return fail(FFM_E_UNSUPPORTED, "predict on a sharded engine is not implemented");
+  if (e->m.n_shards > 1 && (label || output_prob || loss_sum_out))
+    return fail(FFM_E_INVALID, "a sharded engine predicts partial logits only (label = NULL, output_prob = 0, "
+                               "no loss): sum them across shards, then ffm_engine_predict_finish_device");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
   launch_row_kernel(e, rows, false, out ? out : e->d_out, output_prob);
   if (loss_sum_out && label)
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out);
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+int ffm_engine_predict_finish_device(ffm_engine *e, int32_t n_rows, const float *logit,
+                                     const int32_t *label, int32_t output_prob, float *out,
+                                     double *loss_sum_out) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (n_rows < 0 || n_rows > e->max_rows) return fail(FFM_E_CAPACITY, "n_rows out of range");
+  if (n_rows > 0 && !logit) return fail(FFM_E_INVALID, "null logit array");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if (n_rows > 0)
+    LAUNCH(e, K_TMP_GRAD, predict_finish_kernel, cdiv(n_rows, 256), 256, 0, n_rows, logit, label, output_prob, out, e->sc[e->cur].loss);
+  if (loss_sum_out) {
+    if (label) LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out);
+    else HIP_TRY(hipMemsetAsync(loss_sum_out, 0, sizeof(double), e->stream));
+  }
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }

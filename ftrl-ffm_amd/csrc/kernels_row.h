@@ -600,6 +600,17 @@ __global__ void tmp_grad_kernel(int n_rows, const float *logit, const int *label
   if (logit_out) logit_out[r] = lg;
 }
 
+// Second half of predict() for logits that were summed outside (sharded engines): the value
+// predict returns (ffm.cpp:51-55) and the row's logloss (eval/loss.h:8-12).
+__global__ void predict_finish_kernel(int n_rows, const float *logit, const int *label,
+                                      int output_prob, float *out, double *loss) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const float lg = logit[r];
+  if (label) loss[r] = logloss_ref(label[r], lg);
+  if (out) out[r] = output_prob ? sigmoid_ref(lg) : lg;
+}
+
 // Deterministic sum of the per-row losses (fixed order: 256 strided partials, then a tree).
 __global__ __launch_bounds__(256) void loss_sum_kernel(int n_rows, const double *loss,
                                                        double *out) {

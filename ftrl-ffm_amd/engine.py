@@ -63,6 +63,8 @@ ABI = [
      [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [_vp, _vp]),
     ("ffm_engine_predict_batch_device", ctypes.c_int,
      [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [ctypes.c_int32, _vp, _vp]),
+    ("ffm_engine_predict_finish_device", ctypes.c_int,
+     [_vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     ("ffm_engine_prepare_device", ctypes.c_int,
      [_vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     ("ffm_engine_train_forward_device", ctypes.c_int,
@@ -240,6 +242,11 @@ class Engine:
         self._check(self.lib.ffm_engine_predict_batch_device(self.h, n_rows, nnz, row_ptr, field,
                                                              feat, val, label, int(output_prob),
                                                              out, loss_sum_out))
+
+    def predict_finish_device(self, n_rows, logit, label, output_prob, out, loss_sum_out=None):
+        """Second phase of a sharded predict: full logits (summed across shards) -> out / loss."""
+        self._check(self.lib.ffm_engine_predict_finish_device(self.h, n_rows, logit, label,
+                                                              int(output_prob), out, loss_sum_out))
 
     def fill_state(self, seed=7, n_lo=0.05, n_hi=1.0, z_stddev=0.3):
         """Warm random accumulators drawn on the device (measurement utility)."""

@@ -43,3 +43,13 @@ class ShardedStep:
         if self.dist is not None and self.dist.get_world_size() > 1:
             self.dist.all_reduce(self.logit[:n_rows])  # the path's one collective
         self.engine.train_update_device(ptr, None, loss_sum_out)
+
+    def predict(self, n_rows, nnz, row_ptr, field, feat, val, label=None, output_prob=False,
+                out=None, loss_sum_out=None):
+        """predict() on the sharded model: partial logits -> all-reduce -> value / logloss."""
+        ptr = self.logit.data_ptr()
+        self.engine.predict_batch_device(n_rows, nnz, row_ptr, field, feat, val, None, False, ptr)
+        if self.dist is not None and self.dist.get_world_size() > 1:
+            self.dist.all_reduce(self.logit[:n_rows])
+        self.engine.predict_finish_device(n_rows, ptr, label, output_prob, out if out else ptr,
+                                          loss_sum_out)

@@ -148,6 +148,17 @@ int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
                                     const int32_t *feat, const float *val, const int32_t *label,
                                     int32_t output_prob, float *out, double *loss_sum_out);
 
+/* Prediction on a sharded engine (n_shards > 1), split like training: phase 1 is
+ * ffm_engine_predict_batch_device with label = NULL, output_prob = 0, loss_sum_out = NULL -- `out`
+ * then receives this shard's PARTIAL logits (shard 0 adds bias + linear); the caller sums them
+ * across shards (the same all-reduce as in training); phase 2 turns the full logits into what
+ * predict() returns: out[i] = logit or sigmoid(logit) (ffm.cpp:51-55), and the sum of
+ * loss(y, logit) (eval/loss.h:8-12) when label is given.  Device pointers; `out` may alias
+ * `logit`.  Works on unsharded engines too. */
+int ffm_engine_predict_finish_device(ffm_engine *e, int32_t n_rows, const float *logit,
+                                     const int32_t *label, int32_t output_prob, float *out,
+                                     double *loss_sum_out);
+
 /* Optional look-ahead of the mini-batch scheduler: start grouping the NEXT block by feature (the
  * integer-only first stage of training) on a side stream while the current block is still being
  * updated.  The arrays must be complete in device memory when this is called and must be the very

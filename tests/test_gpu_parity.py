@@ -293,6 +293,28 @@ def test_field_pair_sharding_two_shards_on_one_gpu():
         np.testing.assert_allclose(merged, s_ref[key], rtol=2e-4, atol=1e-6, err_msg=key)
     for key in ("lin_n", "lin_z", "lin_w", "bias3"):
         np.testing.assert_allclose(s0[key], s_ref[key], rtol=2e-4, atol=1e-6, err_msg=key)
+    # predict on the shards: partial logits summed, then finished by any shard
+    pl_ref, ploss_ref = ref.predict_batch(blk)
+    pp_ref, _ = ref.predict_batch(blk, output_prob=True)
+    pparts = [torch.zeros(B, device="cuda") for _ in range(2)]
+    for r, e in enumerate(shards):
+        e.predict_batch_device(B, blk.nnz, dev["row_ptr"].data_ptr(), dev["field"].data_ptr(),
+                               dev["feat"].data_ptr(), dev["val"].data_ptr(), None, False,
+                               pparts[r].data_ptr())
+        e.sync()
+    ptotal = pparts[0] + pparts[1]
+    out = torch.zeros(B, device="cuda")
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda")
+    shards[1].predict_finish_device(B, ptotal.data_ptr(), dev["label"].data_ptr(), True,
+                                    out.data_ptr(), loss.data_ptr())
+    shards[1].sync()
+    np.testing.assert_allclose(ptotal.cpu().numpy(), pl_ref, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), pp_ref, rtol=2e-4, atol=1e-6)
+    assert abs(float(loss.item()) - ploss_ref) <= 1e-4 * max(1.0, abs(ploss_ref))
+    with pytest.raises(fa.EngineError):  # a shard cannot produce probabilities or losses itself
+        shards[0].predict_batch_device(B, blk.nnz, dev["row_ptr"].data_ptr(), dev["field"].data_ptr(),
+                                       dev["feat"].data_ptr(), dev["val"].data_ptr(),
+                                       dev["label"].data_ptr(), True, out.data_ptr())
     for e in shards + [ref]:
         e.close()
 

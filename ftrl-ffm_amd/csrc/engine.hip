@@ -177,6 +177,22 @@ struct ffm_engine {
   int *d_row_ptr = nullptr, *d_field = nullptr, *d_feat = nullptr, *d_label = nullptr;
   float *d_val = nullptr, *d_out = nullptr;
   double *d_loss_sum = nullptr;
+  // pipelined host-buffer training (ffm_engine_train_batch_async): kSlots staging slots, each a
+  // pinned host image and device arrays of one block; block t is copied + grouped on the prep
+  // stream while block t-1 trains on the main stream and the caller builds block t+1
+  static constexpr int kSlots = 3;
+  struct Slot {
+    char *pinned = nullptr;
+    int *row_ptr = nullptr, *field = nullptr, *feat = nullptr, *label = nullptr;
+    float *val = nullptr;
+    hipEvent_t ev_copied = nullptr, ev_trained = nullptr;
+    bool used = false;
+    int n_rows = 0, nnz = 0, row_cap = 0;
+    bool has_field = false;
+  } slots[kSlots];
+  bool slots_ready = false;
+  int slot_next = 0, slot_pending = -1;
+  double *d_loss_acc = nullptr;  // [1] sum of the async blocks' losses since the last flush
   void *d_sort_tmp[kSets] = {};  // rocPRIM radix sort workspace per scratch set
   size_t sort_tmp_bytes = 0;
   unsigned sort_bits = 32;
@@ -294,6 +310,11 @@ void ffm_engine_destroy(ffm_engine *e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &r : e->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
+  for (auto &sl : e->slots) {
+    if (sl.pinned) (void)hipHostFree(sl.pinned);
+    if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
+    if (sl.ev_trained) (void)hipEventDestroy(sl.ev_trained);
+  }
   for (void *p : e->allocs) (void)hipFree(p);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -933,8 +954,10 @@ int ffm_engine_predict_finish_device(ffm_engine *e, int32_t n_rows, const float 
   return FFM_OK;
 }
 
-static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, const int32_t *field,
-                       const int32_t *feat, const float *val, const int32_t *label, int32_t *nnz_out) {
+// Checks one block of host arrays; returns its nnz and its longest row.
+static int validate_host_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                               const int32_t *field, const int32_t *feat, const float *val,
+                               int32_t *nnz_out, int *longest_out) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
   if (n_rows < 0) return fail(FFM_E_INVALID, "negative n_rows");
   if (!row_ptr) return fail(FFM_E_INVALID, "null row_ptr");
@@ -951,6 +974,17 @@ static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, co
       return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz");
     longest = std::max(longest, row_ptr[r + 1] - row_ptr[r]);
   }
+  *nnz_out = nnz;
+  *longest_out = longest;
+  return FFM_OK;
+}
+
+static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, const int32_t *field,
+                       const int32_t *feat, const float *val, const int32_t *label, int32_t *nnz_out) {
+  int32_t nnz = 0;
+  int longest = 1;
+  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
+  if (rc) return rc;
   e->staged_row_cap = longest;
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   HIP_TRY(hipMemcpyAsync(e->d_row_ptr, row_ptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice, e->stream));
@@ -1008,6 +1042,105 @@ int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_p
     if (label) HIP_TRY(hipMemcpyAsync(loss_sum_out, e->d_loss_sum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
     else *loss_sum_out = 0.0;
   }
+  return check_device_errors(e);
+}
+
+// ---- pipelined host-buffer training ---------------------------------------------------------
+
+__global__ void loss_accumulate_kernel(double *acc, const double *one) { *acc += *one; }
+
+static int slots_init(ffm_engine *e) {
+  if (e->slots_ready) return FFM_OK;
+  const size_t R = static_cast<size_t>(e->max_rows), E = static_cast<size_t>(e->max_nnz);
+  const size_t bytes = 4 * (R + 1) + 4 * E * 3 + 4 * R;
+  for (auto &sl : e->slots) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.pinned), bytes, hipHostMallocDefault));
+    int rc;
+    if ((rc = e->alloc(&sl.row_ptr, R + 1)) || (rc = e->alloc(&sl.field, E)) || (rc = e->alloc(&sl.feat, E)) ||
+        (rc = e->alloc(&sl.val, E)) || (rc = e->alloc(&sl.label, R)))
+      return rc;
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev_trained, hipEventDisableTiming));
+  }
+  int rc = e->alloc(&e->d_loss_acc, 1);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(e->d_loss_acc, 0, sizeof(double), e->stream));
+  e->slots_ready = true;
+  return FFM_OK;
+}
+
+static int train_pending_slot(ffm_engine *e) {
+  if (e->slot_pending < 0) return FFM_OK;
+  ffm_engine::Slot &sl = e->slots[e->slot_pending];
+  e->slot_pending = -1;
+  e->staged_row_cap = sl.row_cap;
+  int rc = ffm_engine_train_batch_device(e, sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr,
+                                         sl.feat, sl.val, sl.label, nullptr, e->d_loss_sum);
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
+  HIP_TRY(hipEventRecord(sl.ev_trained, e->stream));
+  return FFM_OK;
+}
+
+int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                 const int32_t *field, const int32_t *feat, const float *val,
+                                 const int32_t *label) {
+  int32_t nnz = 0;
+  int longest = 1;
+  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
+  if (rc) return rc;
+  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
+  if (e->m.n_shards > 1) return fail(FFM_E_INVALID, "sharded engines train with train_forward + all-reduce + train_update");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if ((rc = slots_init(e))) return rc;
+  ffm_engine::Slot &sl = e->slots[e->slot_next];
+  const int this_slot = e->slot_next;
+  e->slot_next = (e->slot_next + 1) % ffm_engine::kSlots;
+  if (sl.used) {
+    HIP_TRY(hipEventSynchronize(sl.ev_copied));                   // its pinned image is free again
+    HIP_TRY(hipStreamWaitEvent(e->prep, sl.ev_trained, 0));      // and nothing reads its device arrays
+  }
+  // host arrays -> pinned image (the caller may reuse its buffers on return) -> device, prep stream
+  const size_t R1 = static_cast<size_t>(n_rows) + 1, E = static_cast<size_t>(nnz);
+  char *p = sl.pinned;
+  auto put = [&](const void *src, size_t bytes, void *dst) -> hipError_t {
+    if (!bytes) return hipSuccess;
+    std::memcpy(p, src, bytes);
+    hipError_t err = hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, e->prep);
+    p += (bytes + 15) & ~static_cast<size_t>(15);
+    return err;
+  };
+  HIP_TRY(put(row_ptr, 4 * R1, sl.row_ptr));
+  if (field) HIP_TRY(put(field, 4 * E, sl.field));
+  HIP_TRY(put(feat, 4 * E, sl.feat));
+  HIP_TRY(put(val, 4 * E, sl.val));
+  HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
+  HIP_TRY(hipEventRecord(sl.ev_copied, e->prep));
+  sl.used = true;
+  sl.n_rows = n_rows;
+  sl.nnz = nnz;
+  sl.row_cap = longest;
+  sl.has_field = field != nullptr;
+  // group it ahead on the prep stream, then train the block staged by the previous call
+  rc = ffm_engine_prepare_device(e, n_rows, nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr, sl.feat, sl.val);
+  if (rc) return rc;
+  rc = train_pending_slot(e);
+  e->slot_pending = this_slot;
+  return rc;
+}
+
+int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  int rc = train_pending_slot(e);
+  if (rc) return rc;
+  double total = 0.0;
+  if (e->slots_ready) {
+    HIP_TRY(hipMemcpyAsync(&total, e->d_loss_acc, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_loss_acc, 0, sizeof(double), e->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (loss_sum_out) *loss_sum_out = total;
   return check_device_errors(e);
 }
 

@@ -65,6 +65,8 @@ ABI = [
      [_vp, ctypes.c_int32, ctypes.c_int32] + _DCSR + [ctypes.c_int32, _vp, _vp]),
     ("ffm_engine_predict_finish_device", ctypes.c_int,
      [_vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, _vp, _vp]),
+    ("ffm_engine_train_batch_async", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
+    ("ffm_engine_train_flush", ctypes.c_int, [_vp, _f64p]),
     ("ffm_engine_prepare_device", ctypes.c_int,
      [_vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     ("ffm_engine_train_forward_device", ctypes.c_int,
@@ -199,6 +201,16 @@ class Engine:
         self._check(self.lib.ffm_engine_train_batch(self.h, *self._csr(c), _f(out),
                                                     ctypes.byref(loss)))
         return out[:c.n_rows], float(loss.value)
+
+    def train_batch_async(self, c):
+        """Pipelined: stages and groups this block, trains the one passed by the previous call."""
+        self._check(self.lib.ffm_engine_train_batch_async(self.h, *self._csr(c)))
+
+    def train_flush(self):
+        """Trains the last staged block, waits; the loss sum of all blocks since the last flush."""
+        loss = ctypes.c_double(0.0)
+        self._check(self.lib.ffm_engine_train_flush(self.h, ctypes.byref(loss)))
+        return float(loss.value)
 
     def train_rows(self, c):
         """Row after row (n_rows == 1 per call): the reference's sequential train() loop."""

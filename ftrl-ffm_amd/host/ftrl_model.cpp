@@ -97,6 +97,18 @@ double FtrlModel::train_block(const CsrBlock &blk, float *logit_out) {
   return loss_sum;
 }
 
+void FtrlModel::train_block_async(const CsrBlock &blk) {
+  check(ffm_engine_train_batch_async(eng_, blk.n_rows(), blk.row_ptr.data(), blk.field.data(),
+                                     blk.feat.data(), blk.val.data(), blk.label.data()),
+        "ffm_engine_train_batch_async");
+}
+
+double FtrlModel::train_flush() {
+  double loss_sum = 0.0;
+  check(ffm_engine_train_flush(eng_, &loss_sum), "ffm_engine_train_flush");
+  return loss_sum;
+}
+
 double FtrlModel::predict_block(const CsrBlock &blk, bool output_prob, float *out) {
   double loss_sum = 0.0;
   check(ffm_engine_predict_batch(eng_, blk.n_rows(), blk.row_ptr.data(), blk.field.data(),

@@ -35,6 +35,11 @@ class FtrlModel {
   // Block entry points used by FtrlOffline / FtrlOnline.  Return sum of loss(y, logit).
   double train_block(const CsrBlock &blk, float *logit_out = nullptr);
   double predict_block(const CsrBlock &blk, bool output_prob, float *out = nullptr);
+  // Pipelined training for callers that need only the loss (the trainers): queue blocks, then
+  // train_flush() returns the sum of loss(y, logit) over all blocks queued since the last flush.
+  // The block's arrays may be reused as soon as train_block_async returns.
+  void train_block_async(const CsrBlock &blk);
+  double train_flush();
 
   // Model files in the reference's formats (ffm.cpp:138-200, lr.cpp:26-39); available for every
   // model type here (the reference has none for FM).  save_state/load_state add the FTRL

@@ -51,10 +51,13 @@ double FtrlOffline::csr_epoch(const CsrData &d, bool train) {
   while (pos < total) {
     const size_t rows = std::min<size_t>(train ? sched_.next_block_rows() : sched_.max_block_rows(), total - pos);
     if (train) d.gather(indices.data() + pos, rows, blk); else d.slice(pos, pos + rows, blk);
-    total_loss += train ? model_ptr->train_block(blk) : model_ptr->predict_block(blk, false);
+    // training is pipelined: this block is uploaded and grouped while the previous one trains
+    // and the next one is gathered here
+    if (train) model_ptr->train_block_async(blk); else total_loss += model_ptr->predict_block(blk, false);
     if (train) sched_.consumed(static_cast<int>(rows));
     pos += rows;
   }
+  if (train) total_loss = model_ptr->train_flush();
   return total_loss / static_cast<double>(total);
 }
 
@@ -89,10 +92,11 @@ double FtrlOffline::one_epoch(std::vector<Sample> &samples, bool train, bool /*u
     const size_t rows = std::min<size_t>(train ? sched_.next_block_rows() : sched_.max_block_rows(), total - pos);
     blk.clear();
     for (size_t r = 0; r < rows; r++) blk.push(samples[indices[pos + r]]);
-    total_loss += train ? model_ptr->train_block(blk) : model_ptr->predict_block(blk, false);
+    if (train) model_ptr->train_block_async(blk); else total_loss += model_ptr->predict_block(blk, false);
     if (train) sched_.consumed(static_cast<int>(rows));
     pos += rows;
   }
+  if (train) total_loss = model_ptr->train_flush();
   return total_loss / static_cast<double>(total);
 }
 
@@ -137,10 +141,11 @@ double FtrlOnline::run_file(std::ifstream &ifs, bool train) {
       if (++line_num % 1000000 == 0) std::printf("%llu lines finished...\n", line_num);
     }
     if (blk.n_rows() == 0) break;
-    sum += train ? model_ptr->train_block(blk) : model_ptr->predict_block(blk, false);
+    if (train) model_ptr->train_block_async(blk); else sum += model_ptr->predict_block(blk, false);
     if (train) sched_.consumed(blk.n_rows());
     rows += blk.n_rows();
   }
+  if (train) sum = model_ptr->train_flush();  // parsing of block t+1 overlapped the training of t
   ifs.clear();
   ifs.seekg(0, std::ios::beg);
   loss_sum_ = sum;

@@ -159,6 +159,20 @@ int ffm_engine_predict_finish_device(ffm_engine *e, int32_t n_rows, const float 
                                      const int32_t *label, int32_t output_prob, float *out,
                                      double *loss_sum_out);
 
+/* Pipelined training from host buffers -- what a trainer that only needs the epoch's loss calls
+ * (FtrlOffline::one_epoch, src/task/ftrl_offline.cpp:74-83, accumulates loss(y, logit) and nothing
+ * else).  Each call copies the block into a pinned staging slot (the caller's arrays are reusable
+ * on return), uploads and groups it on a side stream, and starts training the block handed over
+ * by the PREVIOUS call -- so the upload and grouping of block t and the caller's preparation of
+ * block t+1 overlap the training of block t-1.  Blocks train in the order they were passed;
+ * results are those of ffm_engine_train_batch called block by block.  ffm_engine_train_flush
+ * trains the last block, waits, and returns (and resets) the sum of the losses of all blocks since
+ * the previous flush.  Do not mix with other training / predict calls before the flush. */
+int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                 const int32_t *field, const int32_t *feat, const float *val,
+                                 const int32_t *label);
+int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out);
+
 /* Optional look-ahead of the mini-batch scheduler: start grouping the NEXT block by feature (the
  * integer-only first stage of training) on a side stream while the current block is still being
  * updated.  The arrays must be complete in device memory when this is called and must be the very

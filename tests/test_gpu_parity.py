@@ -475,3 +475,38 @@ def test_learning_variant_matches_its_oracle(mt, F, k, per, B):
         ref.train_batch(blk.rows(r0, min(r0 + B, n)))
     assert not np.array_equal(ref.get_state()["vec_w"], o.get_state()["vec_w"])
     e.close()
+
+
+def test_pipelined_host_training_equals_block_by_block():
+    """ffm_engine_train_batch_async / train_flush: same blocks, same order -> the bits of
+    ffm_engine_train_batch called block by block, and the same loss sum (summation order of the
+    per-block sums aside)."""
+    F, k, per = 8, 16, 50
+    nf = F * per
+    g = synth.Generator(F, nf, "zipf", seed=6)
+    blocks = [g.block(n) for n in (1, 3, 64, 256, 17, 256, 256, 5)]
+    blocks.insert(4, g.block(64).rows(0, 0))  # an empty block in the middle
+
+    def make():
+        e = fa.Engine("FFM", nf, F, k, max_batch_rows=256, seed=3, **STRESS_HP)
+        e.fill_state(seed=9)
+        return e
+
+    a = make()
+    total_a = 0.0
+    for b in blocks:
+        total_a += a.train_batch(b)[1]
+    sa = a.get_state()
+    a.close()
+    b_ = make()
+    for b in blocks[:5]:
+        b_.train_batch_async(b)
+    part1 = b_.train_flush()
+    for b in blocks[5:]:
+        b_.train_batch_async(b)
+    part2 = b_.train_flush()
+    assert b_.train_flush() == 0.0  # nothing pending: empty sum
+    sb = b_.get_state()
+    b_.close()
+    assert_state_bitwise(sb, sa, "pipelined host training")
+    assert abs((part1 + part2) - total_a) <= 1e-9 * max(1.0, abs(total_a))

@@ -14,5 +14,5 @@ print("wrote 262144 rows in %.1fs" % (time.time() - t0))
 PY
 ls -la /tmp/synth.ffm
 for bs in 8192; do
-  time ftrl-ffm_amd/host/ftrl_ffm_main --train_data /tmp/synth.ffm --model_type FFM --n_fields 39 --n_feats 975000 --n_factors 16 --online false --n_epochs 3 --batch_size $bs --n_threads 8 2>&1 | head -40
+  time ftrl-ffm_amd/host/ftrl_ffm_main --train_data /tmp/synth.ffm --model_type FFM --n_fields 39 --n_feats 975000 --n_factors 16 --eval_data /tmp/synth.ffm --online false --n_epochs 3 --batch_size $bs --n_threads 8 2>&1 | head -40
 done

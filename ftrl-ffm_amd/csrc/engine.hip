@@ -373,6 +373,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_WAIT_GROUPING")) e->wait_grouping = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_GRID_SINGLE")) e->grid_single = std::max(1, std::atoi(sv));
+  // a sharded rank's very hot list holds n_shards times the rows' worth of features, each with
+  // 1/n_shards of its slots: more, shorter items (measured under bench.py --emulate-shards 8)
+  if (cfg->n_shards > 1) e->grid_huge = 4096;
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));

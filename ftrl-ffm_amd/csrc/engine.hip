@@ -899,7 +899,16 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   } else if (ffm) {
     LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
-    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    // the very hot features' long chains on their own stream, lane = (factor, touch)
+    if (forked) {
+      HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
+      LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, fm_update_huge_kernel, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
+    } else {
+      LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_huge_kernel, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    }
+    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1);
+    if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   }
   if (loss_sum_out && !(ffm && vec4 && !e->serial))
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);

@@ -267,6 +267,79 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
   }
 }
 
+// FM, very hot features (more than kHugeMin occurrences): the lane = (factor, touch) shape of
+// ffm_update_huge_kernel -- 16 factors x 4 consecutive touches per step, the running n and z as
+// left-to-right chains over the DPP quad -- for FM::update_vector_nz (fm.cpp:80-101).  One wave
+// walking such a chain touch by touch is what the whole FM update used to wait for.
+__global__ __launch_bounds__(kUpdThreads) void fm_update_huge_kernel(ModelDev m, Rows rows,
+                                                                     Scratch s) {
+  const int k = m.n_factors;
+  const unsigned groups = (k + kHotE - 1) / kHotE;
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & (kHotT - 1), el = lane >> kHotTShift;
+  const bool l0 = tl == 0;
+  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = gridDim.x * kUpdWaves;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * groups;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned li = item / groups;
+    const int u = wave_uniform(s.huge[li]);
+    const int e = static_cast<int>(item - li * groups) * kHotE + el;
+    const bool active = e < k;
+    const int ee = active ? e : 0;
+    const int i = wave_uniform(s.uniq[u]);
+    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    float *rec = lat_row(m, i);
+    float nc = rec[LAT_N * k + ee], zc = rec[LAT_Z * k + ee];
+    const float w = rec[LAT_W * k + ee];
+    const int2 *ocol = s.occ2 + start;
+    const int steps = (c + kHotT - 1) / kHotT;
+    // pipeline: {entry, row} two steps ahead; value, tmp_grad and the row's factor sum one ahead
+    int2 pr = ocol[min(tl, c - 1)];
+    int2 prN = ocol[min(kHotT + tl, c - 1)];
+    float x = rows.val[pr.x], tg = s.tg[pr.y], sv = s.svx[static_cast<int64_t>(pr.y) * k + ee];
+    for (int st = 0; st < steps; st++) {
+      const int t = st * kHotT + tl;
+      const float xN = rows.val[prN.x], tgN = s.tg[prN.y];
+      const float svN = s.svx[static_cast<int64_t>(prN.y) * k + ee];
+      const int2 prNN = ocol[min((st + 2) * kHotT + tl, c - 1)];
+      const bool live = t < c && active;
+      const float g = tg * (x * sv - w * x * x);  // fm.cpp:84-95
+      const float gg = g * g;
+      const float q = live ? gg : -0.0f;
+      const float qc = l0 ? -0.0f : q;
+      float S = nc + q;
+#pragma unroll
+      for (int r = 1; r < kHotT; r++) S = quad_left(S) + qc;
+      const float left = quad_left(S);
+      const float nb = l0 ? nc : left;  // n before this touch
+      nc = quad_last(S);
+      const float arg0 = nb + gg;
+      float sg;
+      if (__all(m.h.fast_div && chain_operand_ok(arg0) && chain_operand_ok(nb))) {
+        const float d = sqrt_fast(arg0) - sqrt_fast(nb);
+        sg = div_alpha_fast(m.h, live ? d : 0.0f);
+      } else {
+        const float d = sqrtf(arg0) - sqrtf(nb);
+        sg = (live ? d : 0.0f) / m.h.alpha;
+      }
+      const float mm = sg * w;
+      const float ga = live ? g : -0.0f, ms = live ? mm : 0.0f;
+      const float gc = l0 ? -0.0f : ga, mc = l0 ? 0.0f : ms;
+      float Z = (zc + ga) - ms;
+#pragma unroll
+      for (int r = 1; r < kHotT; r++) Z = (quad_left(Z) + gc) - mc;
+      zc = quad_last(Z);
+      pr = prN; x = xN; tg = tgN; sv = svN;
+      prN = prNN;
+    }
+    if (active && l0) {
+      rec[LAT_N * k + ee] = nc;
+      rec[LAT_Z * k + ee] = zc;
+    }
+  }
+}
+
 // Strictly left-to-right running sum over the 64 lanes: returns S_j = ((carry + a_0) + a_1) ... + a_j
 // in lane j, every addition rounded exactly as a one-lane sequential loop would round it.  Step t
 // finalises lane t (S_t = S_{t-1} + a_t through a whole-wave shift-right-by-one DPP move); lanes
@@ -746,7 +819,9 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev
 }
 
 // FM latent update.  Work item = (distinct feature u, chunk of 64 factors).
-__global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s) {
+// skip_huge: the features with more than kHugeMin occurrences belong to fm_update_huge_kernel
+__global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s,
+                                                                int skip_huge) {
   const int k = m.n_factors;
   const int chunks = (k + 63) / 64;
   const int lane = threadIdx.x & 63;
@@ -759,6 +834,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     if (e >= k) continue;
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    if (skip_huge && c > kHugeMin) continue;
     float *rec = lat_row(m, i);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
     const float w = rec[LAT_W * k + e];

@@ -26,10 +26,10 @@
 
 #include "../../include/ffm_engine.h"
 #include "engine_types.h"
+#include "init_rng.h"
 #include "kernels_group.h"
 #include "kernels_row.h"
 #include "kernels_update.h"
-#include "kernels_fused.h"
 
 using namespace ftrl_dev;
 
@@ -59,14 +59,14 @@ enum KernelId {
   K_GROUP_KEYS, K_GROUP_SORT, K_GROUP_FINISH, K_ROW, K_TMP_GRAD,
   K_HOT_META,
   K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_LATENT_UPDATE_HUGE,
-  K_PREDICT_ROW, K_FUSED_ROW, K_REFRESH, K_LATENT_UPDATE_SINGLE,
+  K_PREDICT_ROW, K_REFRESH, K_LATENT_UPDATE_SINGLE,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "group_keys_kernel", "group_radix_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
     "linear_update_kernel", "bias_update_kernel", "latent_update_kernel", "latent_update_hot_kernel",
     "latent_update_huge_kernel",
-    "row_kernel<predict>", "fused_row_kernel", "refresh_kernel", "latent_update_single_kernel"};
+    "row_kernel<predict>", "refresh_kernel", "latent_update_single_kernel"};
 
 struct ProfRec {
   int kid;
@@ -80,11 +80,11 @@ __global__ void init_weights_kernel(ModelDev m, float mean, float stddev, uint64
        idx += stride) {
     const int64_t feat = idx / m.row_len;
     const int e = static_cast<int>(idx - feat * m.row_len);
-    m.lat[feat * 3 * m.row_len + LAT_W * m.row_len + e] = mean + stddev * normal01(seed, 1, idx);
+    m.lat[feat * 3 * m.row_len + LAT_W * m.row_len + e] = ftrl_rng::init_weight(seed, 1, idx, mean, stddev);
   }
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < m.n_feats;
        i += stride)
-    m.lin_w[i] = mean + stddev * normal01(seed, 0, i);
+    m.lin_w[i] = ftrl_rng::init_weight(seed, 0, i, mean, stddev);
 }
 
 __global__ void fill_state_kernel(ModelDev m, uint64_t seed, float n_lo, float n_hi, float z_sd) {
@@ -92,9 +92,9 @@ __global__ void fill_state_kernel(ModelDev m, uint64_t seed, float n_lo, float n
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   const int64_t t0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   auto unif = [&](uint64_t stream, int64_t idx) {
-    const uint64_t h = mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) + idx);
-    return n_lo + (n_hi - n_lo) * (static_cast<float>(h >> 40) * (1.0f / 16777216.0f));
+    return n_lo + (n_hi - n_lo) * ftrl_rng::uniform01(seed, stream, idx);
   };
+  auto normal01 = [](uint64_t sd, uint64_t stream, int64_t idx) { return ftrl_rng::normal01(sd, stream, idx); };
   for (int64_t idx = t0; idx < n_lat; idx += stride) {
     const int64_t feat = idx / m.row_len;
     const int e = static_cast<int>(idx - feat * m.row_len);
@@ -137,6 +137,31 @@ __global__ void lat_component_copy_kernel(float *lat, int row_len, int comp, flo
     float *rec = lat + (feat0 + f) * 3 * row_len + static_cast<int64_t>(comp) * row_len + e;
     if (to_dense) dense[idx] = *rec; else *rec = dense[idx];
   }
+}
+
+// The same for a list of features: record component `comp` of ids[j] <-> dense[j][row_len]
+// (ffm_engine_get_rows / set_rows).  Ids out of range are skipped (the dense row is zeroed on reads).
+__global__ void lat_rows_copy_kernel(float *lat, int row_len, int n_feats, int comp, float *dense,
+                                     const int *ids, int64_t nf, int to_dense) {
+  const int64_t total = nf * row_len;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += stride) {
+    const int64_t j = idx / row_len;
+    const int e = static_cast<int>(idx - j * row_len);
+    const int i = ids[j];
+    if (i < 0 || i >= n_feats) { if (to_dense) dense[idx] = 0.0f; continue; }
+    float *rec = lat + static_cast<int64_t>(i) * 3 * row_len + static_cast<int64_t>(comp) * row_len + e;
+    if (to_dense) dense[idx] = *rec; else *rec = dense[idx];
+  }
+}
+__global__ void lin_rows_copy_kernel(float *lin, int n_feats, float *dense, const int *ids, int nf,
+                                     int to_dense) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nf) return;
+  const int i = ids[j];
+  if (i < 0 || i >= n_feats) { if (to_dense) dense[j] = 0.0f; return; }
+  if (to_dense) dense[j] = lin[i]; else lin[i] = dense[j];
 }
 
 }  // namespace
@@ -198,13 +223,14 @@ struct ffm_engine {
   unsigned sort_bits = 32;
   float *d_stage = nullptr;  // dense staging for get/set
   int64_t stage_floats = 0;
+  int *d_ids = nullptr;      // feature ids of one ffm_engine_get_rows / set_rows chunk
+  static constexpr int kIdsCap = 1 << 20;
+  int *d_err = nullptr;      // [1] sticky ERR_* flags of every block since the last report
   std::vector<void *> allocs;
   // split-phase bookkeeping
   Rows pending{};
   bool has_pending = false;
-  // fused row path (kernels_fused.h): statically possible / asked for by the current call /
-  // in use for the pending block (the block itself may still veto it on the device: CNT_NOFUSE)
-  bool fuse_ok = false, fuse_request = false, fuse_cur = false;
+  bool whole_step = false;  // the call in flight is train_batch_device (forward + update in one)
   // train_batch_device on one shard: the row kernel has the whole logit, so it also produces
   // tmp_grad, the row losses and the hot occurrences' facts (no tmp_grad / hot_meta passes)
   bool own_tg_cur = false;
@@ -213,7 +239,6 @@ struct ffm_engine {
   // of per occurrence inside the row kernel; FFM_ENGINE_ROW_REFRESH=1 keeps it in the row kernel
   bool pre_refresh = false;
   unsigned long long *d_ownmask = nullptr;
-  int fuse_threads = 0, fuse_max_nv = 0;
   // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
   // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
   int grid_small = 768, grid_hot = 2048, grid_huge = 2048, grid_single = 768;
@@ -247,14 +272,20 @@ struct ffm_engine {
       event_pool.pop_back();
       return e;
     }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
   }
   void prof_begin(int kid, hipStream_t st) {
     prof_skip = !prof_on || (prof_only >= 0 && kid != prof_only);
     if (prof_skip) return;
     ProfRec r{kid, get_event(), get_event()};
+    if (!r.e0 || !r.e1) {  // out of events: this launch goes untimed
+      if (r.e0) event_pool.push_back(r.e0);
+      if (r.e1) event_pool.push_back(r.e1);
+      prof_skip = true;
+      return;
+    }
     (void)hipEventRecord(r.e0, st);
     prof.push_back(r);
   }
@@ -380,20 +411,11 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
   {
-    const char *fe = std::getenv("FFM_ENGINE_FUSE");
-    const int k = cfg->n_factors;
-    e->fuse_ok = cfg->model_type == FFM_MODEL_FFM && cfg->n_shards == 1 && cfg->n_fields <= 64 &&
-                 (k == 4 || k == 8 || k == 16) &&
-                 ((fe && fe[0] == '1') || (cfg->flags & FFM_FLAG_FUSE)) &&
-                 !(cfg->flags & FFM_FLAG_LEARN);  // the fused kernel implements the reference rule only
     const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
     const int64_t per = cfg->n_factors % 4 == 0 ? static_cast<int64_t>(cfg->n_fields) * cfg->n_factors / 4
                                                 : static_cast<int64_t>(cfg->n_fields) * cfg->n_factors;
     e->pre_refresh = cfg->model_type == FFM_MODEL_FFM && cfg->n_fields <= 64 &&
                      static_cast<int64_t>(e->max_nnz) * per < (1ll << 31) && !(rr && rr[0] == '1');
-    e->fuse_max_nv = std::min(kFusedMaxNv, e->max_row_nnz);
-    const int pairs = e->fuse_max_nv * (e->fuse_max_nv - 1) / 2;
-    e->fuse_threads = std::max(64, (pairs + 63) / 64 * 64);
   }
   ModelDev &m = e->m;
   m.type = cfg->model_type;
@@ -452,6 +474,10 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.big, E));
   TRY_ALLOC(e->alloc(&s.huge, E));
   TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
+  TRY_ALLOC(e->alloc(&e->d_err, 1));
+  TRY_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), e->stream));
+  s.err = e->d_err;
+  TRY_ALLOC(e->alloc(&e->d_ids, static_cast<size_t>(ffm_engine::kIdsCap)));
   TRY_ALLOC(e->alloc(&s.head, R * static_cast<size_t>(m.n_fields)));
   TRY_ALLOC(e->alloc(&s.next, E));
   TRY_ALLOC(e->alloc(&s.rowtab, R * static_cast<size_t>(m.n_fields)));
@@ -490,12 +516,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   }
   TRY_ALLOC(e->alloc(&s.haux, ffm_model ? E * static_cast<size_t>(m.n_fields) : 1));
   TRY_ALLOC(e->alloc(&s.hmeta, ffm_model ? E : 1));
-  {
-    const size_t n_ps = e->fuse_ok ? E * static_cast<size_t>(m.row_len) : 1;
-    TRY_ALLOC(e->alloc(&s.pstream, n_ps));
-    // slots no pair touches are never written but are read (and ignored) by the stream readers
-    TRY_HIP(hipMemsetAsync(s.pstream, 0, n_ps * sizeof(float), e->stream));
-  }
   TRY_ALLOC(e->alloc(&s.logit, R));
   TRY_ALLOC(e->alloc(&s.tg, R));
   TRY_ALLOC(e->alloc(&s.loss, R));
@@ -574,6 +594,23 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipMemsetAsync(s.counters, 0, kNumCounters * sizeof(int), e->stream));
     m.h.fast_div = bad ? 0 : 1;
   }
+  {
+    // the row kernels stage one row in dynamic LDS: opt in to what the longest admissible row needs
+    const size_t lds = row_lds_bytes(e->max_row_nnz, m.n_fields);
+    if (lds > 150 * 1024) {
+      ffm_engine_destroy(e);
+      return fail(FFM_E_UNSUPPORTED, "max_row_nnz too large for the 160 KB of LDS per workgroup");
+    }
+    if (lds > 32 * 1024) {
+      const int bytes = static_cast<int>(lds);
+      TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fm_row_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fm_row_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
+  }
   if (!(cfg->flags & FFM_FLAG_SKIP_INIT))
     hipLaunchKernelGGL(init_weights_kernel, dim3(2048), dim3(256), 0, e->stream, m, cfg->init_mean,
                        cfg->init_stddev, cfg->seed);
@@ -582,6 +619,15 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
 #undef TRY_ALLOC
 #undef TRY_HIP
   *out = e;
+  return FFM_OK;
+}
+
+// What init_weights_kernel stored, computed on the host (csrc/init_rng.h: same bits).
+int ffm_engine_init_weights_host(uint64_t seed, float init_mean, float init_stddev, int32_t latent,
+                                 int64_t first, int64_t count, float *out) {
+  if (first < 0 || count < 0 || (count > 0 && !out)) return fail(FFM_E_INVALID, "bad range or null output");
+  for (int64_t j = 0; j < count; j++)
+    out[j] = ftrl_rng::init_weight(seed, latent ? 1 : 0, static_cast<uint64_t>(first + j), init_mean, init_stddev);
   return FFM_OK;
 }
 
@@ -609,12 +655,30 @@ int ffm_engine_eval_sigmoid(ffm_engine *e, int32_t n, const float *x, float *y) 
   return FFM_OK;
 }
 
+// Waits for the engine's stream, then reports (and clears) what the kernels flagged since the
+// last report: the device entry points are asynchronous, so this is where their callers learn
+// that a block could not be trained.
+static int check_device_errors(ffm_engine *e) {
+  int flags = 0;
+  HIP_TRY(hipMemcpyAsync(&flags, e->d_err, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (flags) HIP_TRY(hipMemsetAsync(e->d_err, 0, sizeof(int), e->stream));
+  if (flags & ERR_ROW_TOO_LONG)
+    return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz: its block was not trained "
+                                "(outputs of that block are NaN)");
+  if (flags) return fail(FFM_E_DEVICE, "device error flags " + std::to_string(flags));
+  return FFM_OK;
+}
+
 int ffm_engine_sync(ffm_engine *e) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  return FFM_OK;
+  return check_device_errors(e);
 }
+
+int ffm_engine_check_errors(ffm_engine *e) { return ffm_engine_sync(e); }
+
+void *ffm_engine_stream(ffm_engine *e) { return e ? static_cast<void *>(e->stream) : nullptr; }
 
 // ---- dense <-> record layout transfers ----------------------------------------------------
 
@@ -687,6 +751,57 @@ int ffm_engine_get_state(ffm_engine *e, float *bias_n, float *bias_z, float *lin
   return vec_transfer(e, LAT_Z, vec_z, true);
 }
 
+// Gather / scatter of the records of a list of features (host arrays).
+static int rows_transfer(ffm_engine *e, int32_t n, const int32_t *ids, float *const lin[3],
+                         float *const vec[3], bool to_host) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (n < 0 || (n > 0 && !ids)) return fail(FFM_E_INVALID, "bad feature id list");
+  for (int32_t j = 0; j < n; j++)
+    if (ids[j] < 0 || ids[j] >= e->m.n_feats) return fail(FFM_E_INVALID, "feature id out of range");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  const int64_t RL = e->m.row_len;
+  const int64_t per = std::min<int64_t>(ffm_engine::kIdsCap, RL > 0 ? e->stage_floats / RL : ffm_engine::kIdsCap);
+  float *const lin_dev[3] = {e->m.lin_n, e->m.lin_z, e->m.lin_w};
+  for (int64_t j0 = 0; j0 < n; j0 += per) {
+    const int nf = static_cast<int>(std::min<int64_t>(per, n - j0));
+    HIP_TRY(hipMemcpyAsync(e->d_ids, ids + j0, sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
+    for (int comp = 0; comp < 3; comp++) {
+      if (lin[comp]) {
+        if (!to_host) HIP_TRY(hipMemcpyAsync(e->d_stage, lin[comp] + j0, sizeof(float) * nf, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(lin_rows_copy_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, e->stream,
+                           lin_dev[comp], e->m.n_feats, e->d_stage, e->d_ids, nf, to_host ? 1 : 0);
+        if (to_host) HIP_TRY(hipMemcpyAsync(lin[comp] + j0, e->d_stage, sizeof(float) * nf, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+      }
+      if (vec[comp] && RL > 0) {
+        const size_t bytes = static_cast<size_t>(nf) * RL * sizeof(float);
+        if (!to_host) HIP_TRY(hipMemcpyAsync(e->d_stage, vec[comp] + j0 * RL, bytes, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(lat_rows_copy_kernel, dim3(1024), dim3(256), 0, e->stream, e->m.lat,
+                           static_cast<int>(RL), e->m.n_feats, comp, e->d_stage, e->d_ids,
+                           static_cast<int64_t>(nf), to_host ? 1 : 0);
+        if (to_host) HIP_TRY(hipMemcpyAsync(vec[comp] + j0 * RL, e->d_stage, bytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+      }
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+int ffm_engine_get_rows(ffm_engine *e, int32_t n, const int32_t *feat_ids, float *lin_w,
+                        float *lin_n, float *lin_z, float *vec_w, float *vec_n, float *vec_z) {
+  float *const lin[3] = {lin_n, lin_z, lin_w}, *const vec[3] = {vec_n, vec_z, vec_w};  // LAT_* order
+  return rows_transfer(e, n, feat_ids, lin, vec, true);
+}
+
+int ffm_engine_set_rows(ffm_engine *e, int32_t n, const int32_t *feat_ids, const float *lin_w,
+                        const float *lin_n, const float *lin_z, const float *vec_w,
+                        const float *vec_n, const float *vec_z) {
+  float *const lin[3] = {const_cast<float *>(lin_n), const_cast<float *>(lin_z), const_cast<float *>(lin_w)};
+  float *const vec[3] = {const_cast<float *>(vec_n), const_cast<float *>(vec_z), const_cast<float *>(vec_w)};
+  return rows_transfer(e, n, feat_ids, lin, vec, false);
+}
+
 // ---- one block of rows ---------------------------------------------------------------------
 
 static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *row_ptr,
@@ -714,26 +829,18 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
   } else {
     const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
     const int mr = row_cap;
-    const int fuse = train && e->fuse_cur ? 1 : 0;
     const int refreshed = train && e->pre_refresh ? 1 : 0;
     if (refreshed && rows.nnz > 0) {
       const int per = vec4 ? e->m.row_len / 4 : e->m.row_len;
       const int64_t items = static_cast<int64_t>(std::min(rows.nnz, e->max_nnz)) * per;
       const int grid = static_cast<int>(std::min<int64_t>((items + 255) / 256, 8192));
-      if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], fuse);
-      else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], fuse);
+      if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur]);
+      else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur]);
     }
-    if (fuse) {
-      // both are launched; CNT_NOFUSE (row_shape_kernel) decides on the device which one works
-      const int T = e->fuse_threads;
-      if (e->m.n_factors == 16) LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<4>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
-      else if (e->m.n_factors == 8) LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<2>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
-      else LAUNCH(e, K_FUSED_ROW, ffm_fused_row_kernel<1>, rows.n_rows, T, shmem, e->m, rows, e->sc[e->cur], mr);
-    }
-    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed, own_tg);
-    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, fuse, refreshed, own_tg);
-    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
-    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
+    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg);
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0);
   }
 }
 
@@ -750,7 +857,7 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
     const int nnz = rows.nnz;
     if (sc.rowmask)
       HIP_TRY(hipMemsetAsync(sc.rowmask, 0, sizeof(unsigned long long) * 2 * rows.n_rows, st));
-    LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->fuse_max_nv);
+    LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->max_row_nnz);
     e->prof_begin(K_GROUP_SORT, st);
     size_t bytes = e->sort_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
@@ -779,6 +886,9 @@ int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const 
   rc = launch_grouping(e, set, rows, e->prep);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(e->ev_grouped[set], e->prep));
+  // the set is in use from now on, also when this look-ahead ends up discarded: whoever takes the
+  // set next must wait for ev_set_free (recorded when the block trains or the look-ahead is dropped)
+  e->set_used[set] = true;
   e->last_set = set;
   e->prepared_set[e->n_prepared] = set;
   e->prepared_rows[e->n_prepared] = rows;
@@ -797,9 +907,9 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
   e->pending = rows;
   e->has_pending = true;
-  e->fuse_cur = e->fuse_ok && e->fuse_request;  // only train_batch_device asks: it owns tmp_grad
-  e->own_tg_cur = e->fuse_request && e->m.n_shards == 1 && e->m.type != FFM_MODEL_FM && !e->fuse_cur;
-  e->fuse_request = false;
+  // only train_batch_device has the whole logit in its row kernel (one shard, FFM / LR)
+  e->own_tg_cur = e->whole_step && e->m.n_shards == 1 && e->m.type != FFM_MODEL_FM;
+  e->whole_step = false;
   const bool use_prepared = e->n_prepared > 0 && same_block(e->prepared_rows[0], rows);
   if (e->n_prepared > 0 && !use_prepared) {
     // groupings made ahead for some other block: forget them all
@@ -847,7 +957,6 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   const bool lin_owner = e->m.shard_rank == 0;
   const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
   const bool vec4 = e->m.n_factors % 4 == 0;
-  const int fuse = e->fuse_cur && !logit ? 1 : 0;
   const int lin_blocks = rows.nnz > 0 ? std::min(cdiv(rows.nnz, kUpdThreads), 1024) : 0;
   // The bias and linear chains are short and serial: they run beside the latent update -- inside
   // the hot-feature launch when there is one (side_blocks), else on the side stream.
@@ -874,22 +983,22 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   }
   // small features on the main stream: the once-only ones through their descriptor kernel
   auto launch_small = [&]() {
-    const bool single = e->single_kernel && !fuse;
+    const bool single = e->single_kernel;
     if (single) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse, single ? 1 : 0);
+    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
   };
   if (ffm && vec4 && e->serial) {
-    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse, side_blocks);
+    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks);
     launch_small();
   } else if (ffm && vec4) {
     // the three owner shapes touch disjoint features: run them side by side (long sequential
     // chains of the hot ones beside the bandwidth-shaped small-feature pass)
     HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse);
+    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fuse, side_blocks);
+    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks);
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
     launch_small();
     if (loss_sum_out)
@@ -924,9 +1033,9 @@ int ffm_engine_train_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
                                   float *logit_out, double *loss_sum_out) {
   if (e && e->m.n_shards > 1)
     return fail(FFM_E_INVALID, "sharded engines train with train_forward + all-reduce + train_update");
-  if (e) { e->fuse_request = true; e->own_logit_out = logit_out; }
+  if (e) { e->whole_step = true; e->own_logit_out = logit_out; }
   int rc = ffm_engine_train_forward_device(e, n_rows, nnz, row_ptr, field, feat, val, label, nullptr);
-  if (e) e->fuse_request = false;
+  if (e) e->whole_step = false;
   if (rc) return rc;
   return ffm_engine_train_update_device(e, nullptr, logit_out, loss_sum_out);
 }
@@ -1008,14 +1117,6 @@ static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, co
   if (label && n_rows > 0)
     HIP_TRY(hipMemcpyAsync(e->d_label, label, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, e->stream));
   *nnz_out = nnz;
-  return FFM_OK;
-}
-
-static int check_device_errors(ffm_engine *e) {
-  int flags = 0;
-  HIP_TRY(hipMemcpyAsync(&flags, e->sc[e->cur].counters + CNT_ERROR, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (flags & ERR_ROW_TOO_LONG) return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz");
   return FFM_OK;
 }
 
@@ -1220,8 +1321,7 @@ int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms
   if (total_ms) *total_ms = ms[best];
   if (kernel_name && kernel_name_cap) {
     std::string name = kKernelNames[best];
-    if (best == K_FUSED_ROW) name = "ffm_fused_row_kernel";
-    else if (best == K_REFRESH) name = "ffm_refresh_kernel";
+    if (best == K_REFRESH) name = "ffm_refresh_kernel";
     else if (best == K_LATENT_UPDATE_SINGLE) name = "ffm_update_single_kernel";
     else if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT ||
         best == K_LATENT_UPDATE_HUGE)

@@ -91,10 +91,11 @@ struct Scratch {
   int *small;     // [nnz] indices into uniq of the features with <= kSmallMax occurrences
   int4 *sdesc;    // [nnz] one descriptor per feature that occurs once: {feature, entry, row, field}
   int *few;       // [nnz] ... with 2..kSmallMax occurrences (the small list minus the features
-                  //      that occur once, which the fused row kernel updates itself)
+                  //      that occur once, which ffm_update_single_kernel owns)
   int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
   int *huge;      // [nnz] ... with more ("very hot": present in a large share of the rows)
   int *counters;  // [kNumCounters] CNT_* below
+  int *err;       // [1] sticky ERR_* flags, shared by all sets: what ffm_engine_sync reports
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
   int *next;      // [nnz] next entry of the same row with the same field, -1 at the end
   int4 *rowtab;   // [n_rows*n_fields] {feat, val bits, entry, count} of the field's entry in the
@@ -113,8 +114,6 @@ struct Scratch {
                   //      flags | own field << 8, offset (in floats, 64 bits: lo, hi) of the
                   //      partner's weights for this touch inside lat} -- from the row kernel
   float2 *hmeta;  // [nnz] {tmp_grad, own value} of occurrence t
-  float *pstream; // [nnz*row_len] fused path: partner weights of hot occurrence t, laid out like
-                  //      the own record ([partner field][factor]) -- from the fused row kernel
   float *logit;   // [n_rows] this shard's (partial) logit
   float *tg;      // [n_rows] tmp_grad = sigmoid(logit) - y
   double *loss;   // [n_rows] logloss per row
@@ -122,7 +121,7 @@ struct Scratch {
 };
 
 enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5,
-       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NOFUSE = 8, CNT_NSINGLE = 9 };
+       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NSINGLE = 9 };
 constexpr int kNumCounters = 16;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 #ifndef FFM_HUGE_MIN

@@ -240,19 +240,4 @@ __device__ __forceinline__ double logloss_ref(int y, float logit) {
   return static_cast<double>(-y) * log(s) - static_cast<double>(1 - y) * log(1.0 - s);
 }
 
-// Counter-based N(0,1): one draw per (seed, stream, index), identical wherever it is evaluated.
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
-__device__ __forceinline__ float normal01(uint64_t seed, uint64_t stream, uint64_t index) {
-  const uint64_t h = mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) + index);
-  const uint32_t a = static_cast<uint32_t>(h >> 32), b = static_cast<uint32_t>(h);
-  const float u1 = (static_cast<float>(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
-  const float u2 = static_cast<float>(b >> 8) * (1.0f / 16777216.0f);           // [0,1)
-  return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
-}
-
 }  // namespace ftrl_dev

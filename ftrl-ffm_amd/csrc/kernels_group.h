@@ -50,11 +50,13 @@ __device__ __forceinline__ int wave_reserve(int *counter, int amount) {
 // Entry p: validate (remove_out_range, ftrl_model.cpp:36-42 / ffm.cpp:30-36), find its row, emit
 // its sort key (the feature id; n_feats for erased entries, which therefore sort last).  FFM with
 // n_fields <= 64 also collects, per row, the fields present once / more than once (s.rowmask: what
-// group_finish_kernel turns into the touched-slot masks) and decides whether the fused row kernel
-// may take the block: it needs every row to hold at most max_nv entries and at most one per
-// field, else CNT_NOFUSE.
+// group_finish_kernel turns into the touched-slot masks).
+// A row longer than max_row_nnz (the row kernels' LDS capacity) cannot be trained: it raises
+// ERR_ROW_TOO_LONG here, before anything has touched the model, and every later kernel of the
+// block then does nothing (CNT_ERROR) -- the block is a no-op and the caller learns about it from
+// the next ffm_engine_sync / check_errors / flush.
 __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, Rows rows, Scratch s,
-                                                                   int max_nv) {
+                                                                   int max_row_nnz) {
   const int pp = blockIdx.x * blockDim.x + threadIdx.x;  // the grid covers whole waves
   const bool in = pp < rows.nnz;
   const int p = in ? pp : rows.nnz - 1;  // idle lanes of the last wave shadow the last entry
@@ -75,6 +77,10 @@ __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, R
     if (s.gmask) s.gmask[p] = 0ull;
   }
   valid = valid && in;
+  if (in && p == rows.row_ptr[lo] && rows.row_ptr[lo + 1] - p > max_row_nnz) {
+    atomicOr(&s.counters[CNT_ERROR], ERR_ROW_TOO_LONG);
+    atomicOr(s.err, ERR_ROW_TOO_LONG);
+  }
   if (s.rowmask) {
     // fields present once / more than once per row: combined over the lanes of the wave that
     // share the row (entries of a row are consecutive), then one atomic per row piece
@@ -98,13 +104,8 @@ __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, R
         const unsigned long long before = atomicOr(&s.rowmask[2 * lo], once);
         twice |= before & once;
       }
-      if (twice) {
-        atomicOr(&s.rowmask[2 * lo + 1], twice);
-        atomicOr(&s.counters[CNT_NOFUSE], 1);
-      }
+      if (twice) atomicOr(&s.rowmask[2 * lo + 1], twice);
     }
-    if (in && p == rows.row_ptr[lo] && rows.row_ptr[lo + 1] - p > max_nv)
-      atomicOr(&s.counters[CNT_NOFUSE], 1);
   }
 }
 
@@ -128,6 +129,7 @@ __device__ __forceinline__ int sorted_bound(const unsigned *skey, int n, unsigne
 // into the group's (one atomic per group piece per wave).
 __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m, Rows rows,
                                                                      Scratch s) {
+  if (s.counters[CNT_ERROR]) return;  // untrainable block: no groups, no owners, nothing runs
   const int nnz = rows.nnz;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // the grid covers whole waves

@@ -225,22 +225,29 @@ __device__ __forceinline__ float wave_add_terms_in_order(const float *terms, int
 template <bool TRAIN, bool VEC4>
 __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
-                                                              int output_prob, int fuse,
-                                                              int refreshed, int own_tg) {
+                                                              int output_prob, int refreshed,
+                                                              int own_tg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv;
   __shared__ float s_tg;
   __shared__ uint64_t s_tab[32];  // expf's table, staged so the row's last step waits on no load
-  if (TRAIN && fuse && !s.counters[CNT_NOFUSE]) return;  // kernels_fused.h took this block
   if (TRAIN && own_tg && threadIdx.x < 32) s_tab[threadIdx.x] = kExpTab[threadIdx.x];
   const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
   RowLds lds = carve_row_lds(smem, max_row_nnz, F);
   const int r = blockIdx.x;
   const int b = rows.row_ptr[r];
-  int nnz = rows.row_ptr[r + 1] - b;
-  if (nnz > max_row_nnz) {
-    if (threadIdx.x == 0) atomicOr(&s.counters[CNT_ERROR], ERR_ROW_TOO_LONG);
-    nnz = max_row_nnz;
+  const int nnz = rows.row_ptr[r + 1] - b;
+  // a row beyond the LDS capacity: the grouping has flagged the whole training block (no kernel
+  // touches the model); a predict call flags it here.  Its outputs are NaN.
+  if ((TRAIN && s.counters[CNT_ERROR]) || nnz > max_row_nnz) {
+    if (threadIdx.x == 0) {
+      if (nnz > max_row_nnz) atomicOr(s.err, ERR_ROW_TOO_LONG);
+      const float nan = __int_as_float(0x7fc00000);
+      if (TRAIN) { s.logit[r] = nan; s.tg[r] = 0.0f; }
+      s.loss[r] = static_cast<double>(nan);
+      if (out) out[r] = nan;
+    }
+    return;
   }
   const bool is_ffm = m.type == 2;
   const bool lin_owner = m.shard_rank == 0;
@@ -467,8 +474,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
 // Work item = (distinct feature u, 16-byte vector l of its record); VEC4 as in the row kernel.
 // ------------------------------------------------------------------------------------------
 template <bool VEC4>
-__global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s, int fuse) {
-  if (fuse && !s.counters[CNT_NOFUSE]) return;  // kernels_fused.h refreshes its own block
+__global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s) {
   const int n_uniq = s.counters[CNT_NUNIQ];
   const int k = m.n_factors, RL = m.row_len;
   const int kv = VEC4 ? (k >> 2) : k;          // items per slot
@@ -520,10 +526,16 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
   RowLds lds = carve_row_lds(smem, max_row_nnz, 1);
   const int r = blockIdx.x;
   const int b = rows.row_ptr[r];
-  int nnz = rows.row_ptr[r + 1] - b;
-  if (nnz > max_row_nnz) {
-    if (threadIdx.x == 0) atomicOr(&s.counters[CNT_ERROR], ERR_ROW_TOO_LONG);
-    nnz = max_row_nnz;
+  const int nnz = rows.row_ptr[r + 1] - b;
+  if ((TRAIN && s.counters[CNT_ERROR]) || nnz > max_row_nnz) {  // as in ffm_row_kernel
+    if (threadIdx.x == 0) {
+      if (nnz > max_row_nnz) atomicOr(s.err, ERR_ROW_TOO_LONG);
+      const float nan = __int_as_float(0x7fc00000);
+      if (TRAIN) { s.logit[r] = nan; s.tg[r] = 0.0f; }
+      s.loss[r] = static_cast<double>(nan);
+      if (out) out[r] = nan;
+    }
+    return;
   }
   const int k = m.n_factors;
   stage_row(m, rows, b, nnz, lds, &s_nv);

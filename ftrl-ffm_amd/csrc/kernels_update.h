@@ -135,11 +135,8 @@ __device__ __forceinline__ float dpp_row_shr1(float keep, float v) {
 }
 
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m, Rows rows,
-                                                                      Scratch s, int fuse) {
+                                                                      Scratch s) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
-  // fused blocks: partner weights come as a stream by occurrence position (s.pstream) instead
-  // of being gathered from the partners' records
-  const bool stream = fuse && !s.counters[CNT_NOFUSE];
   const unsigned groups = (record_span(m, k) + kHotE - 1) / kHotE;
   const int lane = threadIdx.x & 63;
   const int tl = lane & (kHotT - 1);  // which of the step's touches
@@ -166,7 +163,6 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
     const float *wcol = m.lat + LAT_W * RL + kk;                       // + feat*rec + field*k
     const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;  // + t*F
     const float2 *mcol = s.hmeta + start;                              // + t
-    const float *pcol = s.pstream + static_cast<int64_t>(start) * RL + ee;  // + t*RL
     const int steps = (c + kHotT - 1) / kHotT;
     bool touched = false;
 
@@ -175,12 +171,10 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m
     float2 mt = mcol[min(tl, c - 1)];
     int4 axN = acol[static_cast<int64_t>(min(kHotT + tl, c - 1)) * F];
     float2 mtN = mcol[min(kHotT + tl, c - 1)];
-    float vp = stream ? pcol[static_cast<int64_t>(min(tl, c - 1)) * RL]
-                      : m.lat[haux_offset(ax.z, ax.w) + kk];
+    float vp = m.lat[haux_offset(ax.z, ax.w) + kk];
     for (int st = 0; st < steps; st++) {
       const int t = st * kHotT + tl;
-      const float vpN = stream ? pcol[static_cast<int64_t>(min(t + kHotT, c - 1)) * RL]
-                               : m.lat[haux_offset(axN.z, axN.w) + kk];  // weights of step st+1
+      const float vpN = m.lat[haux_offset(axN.z, axN.w) + kk];  // weights of step st+1
       const int tNN = min((st + 2) * kHotT + tl, c - 1);                  // facts of step st+2
       const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
       const float2 mtNN = mcol[tNN];
@@ -428,6 +422,7 @@ __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, 
 
 // Bias update: one wave walks all rows of the block in order (update_bias_nz, :79-85).
 __device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, const Scratch &s) {
+  if (s.counters[CNT_ERROR]) return;  // untrainable block (ERR_ROW_TOO_LONG): a no-op
   const int lane = threadIdx.x & 63;
   float n = m.bias3[1], z = m.bias3[2];
   const float w = m.bias3[0];
@@ -475,19 +470,12 @@ __device__ __forceinline__ void hot_issue_weights(const float *wcol, const HotFa
 #pragma unroll
   for (int j = 0; j < kUnroll; j++) vp[j] = wcol[haux_offset(f.fq[j], pe[j])];
 }
-// fused blocks: the same weights from the occurrence-ordered stream (touches t0 .. t0+kUnroll-1)
-__device__ __forceinline__ void hot_stream_weights(const float *pcol, int RL, int c, int t0,
-                                                   float (&vp)[kUnroll]) {
-#pragma unroll
-  for (int j = 0; j < kUnroll; j++) vp[j] = pcol[static_cast<int64_t>(min(t0 + j, c - 1)) * RL];
-}
 
 // side_blocks > 0: the first workgroups of the launch carry the block's two short serial jobs --
 // workgroup 0 the bias chain, workgroups 1..side_blocks-1 the linear update -- so that they run
 // beside the latent chains without a stream (and a hardware queue) of their own.
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m, Rows rows,
-                                                                     Scratch s, int fuse,
-                                                                     int side_blocks) {
+                                                                     Scratch s, int side_blocks) {
   if (static_cast<int>(blockIdx.x) < side_blocks) {
     if (blockIdx.x == 0) {
       // one wave, 8192 dependent touches: let it win the issue arbitration on its SIMD
@@ -499,7 +487,6 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     return;
   }
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
-  const bool stream = fuse && !s.counters[CNT_NOFUSE];
   const unsigned chunks = (record_span(m, k) + 63) / 64;
   const int lane = threadIdx.x & 63;
   const unsigned wave = (blockIdx.x - side_blocks) * kUpdWaves + wave_uniform(threadIdx.x >> 6);
@@ -524,7 +511,6 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     const float *wcol = m.lat + LAT_W * RL + kk;                          // + feat*rec + field*k
     const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;     // + t*F
     const float2 *mcol = s.hmeta + start;                                 // + t
-    const float *pcol = s.pstream + static_cast<int64_t>(start) * RL + ee;  // + t*RL
     bool touched = false;
     const int nb = (c + kUnroll - 1) / kUnroll;
 
@@ -533,8 +519,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     float vpB[kUnroll], vpC[kUnroll];
     hot_load_facts(acol, F, c, 0, fB, peB);
     if (nb > 1) hot_load_facts(acol, F, c, kUnroll, fA, peA);
-    if (stream) hot_stream_weights(pcol, RL, c, 0, vpB);
-    else hot_issue_weights(m.lat + kk, fB, peB, vpB);
+    hot_issue_weights(m.lat + kk, fB, peB, vpB);
     for (int b = 0; b < nb; b++) {
       const int t0 = b * kUnroll;
       fC = fB;
@@ -544,8 +529,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
         fB = fA;
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) peB[j] = peA[j];
-        if (stream) hot_stream_weights(pcol, RL, c, t0 + kUnroll, vpB);   // weights of group b+1
-        else hot_issue_weights(m.lat + kk, fB, peB, vpB);
+        hot_issue_weights(m.lat + kk, fB, peB, vpB);  // weights of group b+1
       }
       if (b + 2 < nb) hot_load_facts(acol, F, c, t0 + 2 * kUnroll, fA, peA);  // facts of group b+2
       float tgj[kUnroll], xmj[kUnroll];
@@ -672,20 +656,16 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
 // ---- small features: one wave per feature, lanes = 4 consecutive factors of a slot ---------
 // Requires n_factors % 4 == 0.  c <= kSmallMax occurrences.  Kept lean in registers: the
 // bandwidth comes from many resident waves, each with its record's loads in flight.
-// few_only: the features that occur once are somebody else's (ffm_update_single_kernel, or the
-// fused row kernel when `fuse` and the block allowed it)
+// few_only: the features that occur once are ffm_update_single_kernel's
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev m, Rows rows,
-                                                                       Scratch s, int fuse,
-                                                                       int few_only) {
+                                                                       Scratch s, int few_only) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int RL4 = RL >> 2, k4 = k >> 2;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const int n_waves = gridDim.x * kUpdWaves;
-  // fused blocks: the features that occur once were updated by the fused row kernel already
-  const bool fused = few_only || (fuse && !s.counters[CNT_NOFUSE]);
-  const int *list = fused ? s.few : s.small;
-  const int n_small = s.counters[fused ? CNT_NFEW : CNT_NSMALL];
+  const int *list = few_only ? s.few : s.small;
+  const int n_small = s.counters[few_only ? CNT_NFEW : CNT_NSMALL];
   const float inv_k4 = 1.0f / static_cast<float>(k4);
   const int span4 = record_span(m, k4);
   for (int li = wave; li < n_small; li += n_waves) {

@@ -13,7 +13,6 @@ LIB_PATH = os.path.join(HERE, "libffm_engine.so")
 LR, FM, FFM = 0, 1, 2
 MODEL_TYPES = {"LR": LR, "FM": FM, "FFM": FFM}
 FLAG_SKIP_INIT = 1
-FLAG_FUSE = 2
 FLAG_LEARN = 4
 
 _i32p = ctypes.POINTER(ctypes.c_int32)
@@ -48,6 +47,9 @@ _DCSR = [_vp, _vp, _vp, _vp, _vp]
 ABI = [
     ("ffm_engine_default_config", None, [ctypes.POINTER(Config)]),
     ("ffm_engine_create", ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(_vp)]),
+    ("ffm_engine_init_weights_host", ctypes.c_int,
+     [ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int64,
+      ctypes.c_int64, _f32p]),
     ("ffm_engine_destroy", None, [_vp]),
     ("ffm_engine_last_error", ctypes.c_char_p, []),
     ("ffm_engine_abi_version", ctypes.c_int, []),
@@ -56,6 +58,8 @@ ABI = [
     ("ffm_engine_get_weights", ctypes.c_int, [_vp, _f32p, _f32p, _f32p]),
     ("ffm_engine_set_state", ctypes.c_int, [_vp] + [_f32p] * 6),
     ("ffm_engine_get_state", ctypes.c_int, [_vp] + [_f32p] * 6),
+    ("ffm_engine_get_rows", ctypes.c_int, [_vp, ctypes.c_int32, _i32p] + [_f32p] * 6),
+    ("ffm_engine_set_rows", ctypes.c_int, [_vp, ctypes.c_int32, _i32p] + [_f32p] * 6),
     ("ffm_engine_train_batch", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR + [_f32p, _f64p]),
     ("ffm_engine_predict_batch", ctypes.c_int,
      [_vp, ctypes.c_int32] + _CSR + [ctypes.c_int32, _f32p, _f64p]),
@@ -76,6 +80,8 @@ ABI = [
      [_vp, ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.c_float]),
     ("ffm_engine_eval_sigmoid", ctypes.c_int, [_vp, ctypes.c_int32, _f32p, _f32p]),
     ("ffm_engine_sync", ctypes.c_int, [_vp]),
+    ("ffm_engine_check_errors", ctypes.c_int, [_vp]),
+    ("ffm_engine_stream", ctypes.c_void_p, [_vp]),
     ("ffm_engine_profile_enable", ctypes.c_int, [_vp, ctypes.c_int32]),
     ("ffm_engine_profile_read", ctypes.c_int,
      [_vp, _i32p, _f64p, ctypes.c_char_p, ctypes.c_size_t]),
@@ -84,6 +90,16 @@ ABI = [
 ]
 
 _lib = None
+
+
+def init_weights_host(seed, mean, stddev, latent, first, count):
+    """The weights a fresh engine holds, recomputed on the host (ffm_engine_init_weights_host)."""
+    out = np.empty(int(count), np.float32)
+    rc = load_library().ffm_engine_init_weights_host(int(seed), mean, stddev, int(bool(latent)),
+                                                     int(first), int(count), _f(out))
+    if rc != 0:
+        raise EngineError(rc, load_library().ffm_engine_last_error().decode())
+    return out
 
 
 def load_library(path=None):
@@ -122,7 +138,7 @@ class Engine:
     def __init__(self, model_type="FFM", n_feats=10000, n_fields=8, n_factors=16, w_alpha=1e-4,
                  w_beta=1.0, w_l1=0.1, w_l2=5.0, init_mean=0.0, init_stddev=0.02, seed=42,
                  max_batch_rows=8192, max_batch_nnz=None, device_id=0, n_shards=1, shard_rank=0,
-                 stream=None, skip_init=False, max_row_nnz=0, fuse=False, learn=False):
+                 stream=None, skip_init=False, max_row_nnz=0, learn=False):
         self.lib = load_library()
         cfg = Config()
         self.lib.ffm_engine_default_config(ctypes.byref(cfg))
@@ -134,7 +150,7 @@ class Engine:
         cfg.max_batch_nnz = int(max_batch_nnz if max_batch_nnz else max_batch_rows * 64)
         cfg.device_id, cfg.n_shards, cfg.shard_rank = int(device_id), int(n_shards), int(shard_rank)
         cfg.stream = stream
-        cfg.flags = (FLAG_SKIP_INIT if skip_init else 0) | (FLAG_FUSE if fuse else 0) | (FLAG_LEARN if learn else 0)
+        cfg.flags = (FLAG_SKIP_INIT if skip_init else 0) | (FLAG_LEARN if learn else 0)
         cfg.reserved[0] = int(max_row_nnz)
         self.cfg = cfg
         self.h = _vp()
@@ -188,6 +204,24 @@ class Engine:
             self.h, _f(b[1:2].copy()) if b is not None else None,
             _f(b[2:3].copy()) if b is not None else None, _f(g("lin_n")), _f(g("lin_z")),
             _f(g("vec_n")), _f(g("vec_z"))))
+
+    ROW_KEYS = ("lin_w", "lin_n", "lin_z", "vec_w", "vec_n", "vec_z")
+
+    def get_rows(self, ids):
+        """State of the listed features only: dict of lin_* [n] and vec_* [n, row_len]."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        n, L = ids.size, self.row_len
+        out = {k: np.zeros((n, L) if k.startswith("vec") else n, np.float32) for k in self.ROW_KEYS}
+        args = [_f(out[k]) if out[k].size else None for k in self.ROW_KEYS]
+        self._check(self.lib.ffm_engine_get_rows(self.h, n, _i(ids), *args))
+        return out
+
+    def set_rows(self, ids, st):
+        """Overwrites the listed features' state with the given arrays (any subset of ROW_KEYS)."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        st = {k: np.ascontiguousarray(v, np.float32) for k, v in st.items() if k in self.ROW_KEYS}
+        args = [_f(st[k]) if k in st and st[k].size else None for k in self.ROW_KEYS]
+        self._check(self.lib.ffm_engine_set_rows(self.h, ids.size, _i(ids), *args))
 
     # ---- blocks of rows in host memory ----
     def _csr(self, c):
@@ -271,7 +305,16 @@ class Engine:
         return y
 
     def sync(self):
+        """Waits for the stream; raises EngineError if the device flagged a block (-4: a row longer
+        than max_row_nnz reached a _device entry point; that block was skipped)."""
         self._check(self.lib.ffm_engine_sync(self.h))
+
+    check_errors = sync
+
+    @property
+    def stream(self):
+        """The hipStream_t (as an int) the engine runs on."""
+        return int(self.lib.ffm_engine_stream(self.h) or 0)
 
     # ---- kernel timing (HIP events on the engine's stream) ----
     def profile_enable(self, on=True):

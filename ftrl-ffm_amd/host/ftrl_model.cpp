@@ -35,8 +35,16 @@ FtrlModel::FtrlModel(const config_options &opt, int mt)
   cfg.init_mean = opt.init_mean;
   cfg.init_stddev = opt.init_stddev;
   cfg.seed = opt.seed;
-  cfg.max_batch_rows = std::max(1, opt.batch_size);
-  cfg.max_batch_nnz = cfg.max_batch_rows * 256;
+  // The reference accepts rows of any length (feat_vec).  Here one row may hold up to 4096
+  // entries (the row kernels stage a row in LDS) and one engine call up to max_nnz_ entries; a
+  // denser block is fed as several calls (for_each_fitting), so --batch_size never has to be
+  // chosen with the data's density in mind.
+  max_rows_ = std::max(1, opt.batch_size);
+  max_row_nnz_ = 4096;
+  max_nnz_ = static_cast<int>(std::min<long long>(std::max<long long>(256ll * max_rows_, max_row_nnz_), 1ll << 28));
+  cfg.max_batch_rows = max_rows_;
+  cfg.max_batch_nnz = max_nnz_;
+  cfg.reserved[0] = max_row_nnz_;
   cfg.device_id = opt.device;
   if (opt.learn) cfg.flags |= FFM_FLAG_LEARN;
   const int rc = ffm_engine_create(&cfg, &eng_);
@@ -88,19 +96,55 @@ float FtrlModel::predict(feat_vec &features, bool output_prob) {
   return out;
 }
 
+template <typename Fn>
+void FtrlModel::for_each_fitting(const CsrBlock &blk, Fn fn) {
+  const int n = blk.n_rows();
+  if (n <= max_rows_ && blk.row_ptr[n] <= max_nnz_) {
+    bool fits = true;
+    for (int r = 0; r < n && fits; r++) fits = blk.row_ptr[r + 1] - blk.row_ptr[r] <= max_row_nnz_;
+    if (fits) { fn(blk, 0); return; }
+  }
+  int r0 = 0;
+  while (r0 < n) {
+    int r1 = r0;
+    while (r1 < n && r1 - r0 < max_rows_ && blk.row_ptr[r1 + 1] - blk.row_ptr[r0] <= max_nnz_) {
+      if (blk.row_ptr[r1 + 1] - blk.row_ptr[r1] > max_row_nnz_)
+        throw std::length_error("a row has " + std::to_string(blk.row_ptr[r1 + 1] - blk.row_ptr[r1]) +
+                                " entries; this engine handles up to " + std::to_string(max_row_nnz_));
+      r1++;
+    }
+    if (r1 == r0) throw std::length_error("a row exceeds the engine's block capacity");
+    const int b = blk.row_ptr[r0], e = blk.row_ptr[r1];
+    part_.row_ptr.resize(static_cast<size_t>(r1 - r0) + 1);
+    for (int r = r0; r <= r1; r++) part_.row_ptr[r - r0] = blk.row_ptr[r] - b;
+    part_.field.assign(blk.field.begin() + b, blk.field.begin() + e);
+    part_.feat.assign(blk.feat.begin() + b, blk.feat.begin() + e);
+    part_.val.assign(blk.val.begin() + b, blk.val.begin() + e);
+    part_.label.assign(blk.label.begin() + r0, blk.label.begin() + r1);
+    fn(part_, r0);
+    r0 = r1;
+  }
+}
+
 double FtrlModel::train_block(const CsrBlock &blk, float *logit_out) {
-  double loss_sum = 0.0;
-  check(ffm_engine_train_batch(eng_, blk.n_rows(), blk.row_ptr.data(), blk.field.data(),
-                               blk.feat.data(), blk.val.data(), blk.label.data(), logit_out,
-                               &loss_sum),
-        "ffm_engine_train_batch");
-  return loss_sum;
+  double total = 0.0;
+  for_each_fitting(blk, [&](const CsrBlock &b, int r0) {
+    double loss_sum = 0.0;
+    check(ffm_engine_train_batch(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(), b.feat.data(),
+                                 b.val.data(), b.label.data(), logit_out ? logit_out + r0 : nullptr,
+                                 &loss_sum),
+          "ffm_engine_train_batch");
+    total += loss_sum;
+  });
+  return total;
 }
 
 void FtrlModel::train_block_async(const CsrBlock &blk) {
-  check(ffm_engine_train_batch_async(eng_, blk.n_rows(), blk.row_ptr.data(), blk.field.data(),
-                                     blk.feat.data(), blk.val.data(), blk.label.data()),
-        "ffm_engine_train_batch_async");
+  for_each_fitting(blk, [&](const CsrBlock &b, int) {
+    check(ffm_engine_train_batch_async(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(),
+                                       b.feat.data(), b.val.data(), b.label.data()),
+          "ffm_engine_train_batch_async");
+  });
 }
 
 double FtrlModel::train_flush() {
@@ -110,12 +154,16 @@ double FtrlModel::train_flush() {
 }
 
 double FtrlModel::predict_block(const CsrBlock &blk, bool output_prob, float *out) {
-  double loss_sum = 0.0;
-  check(ffm_engine_predict_batch(eng_, blk.n_rows(), blk.row_ptr.data(), blk.field.data(),
-                                 blk.feat.data(), blk.val.data(), blk.label.data(),
-                                 output_prob ? 1 : 0, out, &loss_sum),
-        "ffm_engine_predict_batch");
-  return loss_sum;
+  double total = 0.0;
+  for_each_fitting(blk, [&](const CsrBlock &b, int r0) {
+    double loss_sum = 0.0;
+    check(ffm_engine_predict_batch(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(),
+                                   b.feat.data(), b.val.data(), b.label.data(), output_prob ? 1 : 0,
+                                   out ? out + r0 : nullptr, &loss_sum),
+          "ffm_engine_predict_batch");
+    total += loss_sum;
+  });
+  return total;
 }
 
 void FtrlModel::pull_weights() {

@@ -68,6 +68,12 @@ class FtrlModel {
   int64_t row_len_ = 0;
   ffm_engine *eng_ = nullptr;
   CsrBlock one_;  // scratch for the one-row shims
+  // engine capacities chosen at construction; blocks beyond max_nnz_ are split into several
+  // engine calls (each still a block in row order), a single row beyond max_row_nnz_ is an error
+  int max_rows_ = 0, max_nnz_ = 0, max_row_nnz_ = 0;
+  CsrBlock part_;
+  // calls `fn(sub-block)` for consecutive row ranges of blk that fit the engine
+  template <typename Fn> void for_each_fitting(const CsrBlock &blk, Fn fn);
 };
 
 class LR : public FtrlModel {

@@ -26,22 +26,53 @@ def owned_pair_counts(n_fields, n_shards):
     return np.bincount(own[iu], minlength=n_shards)
 
 
+def shard_plan(n_fields, n_shards):
+    """Who owns what under field-pair sharding: dict(pair_owner [F, F] -- rank owning the unordered
+    field pair, i.e. both of its latent slots --, lin_owner [F] -- rank that adds and updates the
+    linear terms of a field's features --, bias_owner)."""
+    f = np.arange(n_fields)
+    return dict(pair_owner=pair_owner(f[:, None], f[None, :], n_fields, n_shards).astype(np.int32),
+                lin_owner=np.zeros(n_fields, np.int32), bias_owner=0)
+
+
 class ShardedStep:
     """One training block on a sharded engine: local forward -> all-reduce -> local update.
 
     `engine` needs train_forward_device / train_update_device (ftrl_ffm_amd.Engine);
     `dist` is torch.distributed (initialised) or None for a single shard;
     `logit` is a torch tensor of n_rows floats on the engine's device that receives the partial
-    and then the summed logits."""
+    and then the summed logits.
+
+    Stream ordering: the engine enqueues on ITS stream (ffm_engine_stream: the one given at create
+    or its own), the collective on torch's current stream.  When they differ, the collective is
+    made to wait for the forward and the update for the collective (events, no host sync)."""
 
     def __init__(self, engine, dist, logit):
         self.engine, self.dist, self.logit = engine, dist, logit
+        self._ext = None
+        if getattr(logit, "is_cuda", False) and getattr(engine, "stream", 0):
+            import torch
+            self._torch = torch
+            self._ext = torch.cuda.ExternalStream(engine.stream, device=logit.device)
+
+    def _exchange(self, n_rows):
+        if self.dist is None or self.dist.get_world_size() <= 1:
+            return
+        cur = None
+        if self._ext is not None:
+            cur = self._torch.cuda.current_stream(self.logit.device)
+            if cur.cuda_stream != self._ext.cuda_stream:
+                cur.wait_stream(self._ext)      # partial logits are complete before the sum
+            else:
+                cur = None
+        self.dist.all_reduce(self.logit[:n_rows])  # the path's one collective
+        if cur is not None:
+            self._ext.wait_stream(cur)          # and summed before the engine consumes them
 
     def __call__(self, n_rows, nnz, row_ptr, field, feat, val, label, loss_sum_out=None):
         ptr = self.logit.data_ptr()
         self.engine.train_forward_device(n_rows, nnz, row_ptr, field, feat, val, label, ptr)
-        if self.dist is not None and self.dist.get_world_size() > 1:
-            self.dist.all_reduce(self.logit[:n_rows])  # the path's one collective
+        self._exchange(n_rows)
         self.engine.train_update_device(ptr, None, loss_sum_out)
 
     def predict(self, n_rows, nnz, row_ptr, field, feat, val, label=None, output_prob=False,
@@ -49,7 +80,6 @@ class ShardedStep:
         """predict() on the sharded model: partial logits -> all-reduce -> value / logloss."""
         ptr = self.logit.data_ptr()
         self.engine.predict_batch_device(n_rows, nnz, row_ptr, field, feat, val, None, False, ptr)
-        if self.dist is not None and self.dist.get_world_size() > 1:
-            self.dist.all_reduce(self.logit[:n_rows])
+        self._exchange(n_rows)
         self.engine.predict_finish_device(n_rows, ptr, label, output_prob, out if out else ptr,
                                           loss_sum_out)

@@ -78,17 +78,13 @@ typedef struct ffm_engine_config {
 
 enum {
   FFM_FLAG_SKIP_INIT = 1, /* leave w zeroed; the caller will ffm_engine_set_weights */
-  FFM_FLAG_LEARN = 4,     /* opt-in "learning" variant, NOT the reference's arithmetic (SURVEY.md
+  FFM_FLAG_LEARN = 4      /* opt-in "learning" variant, NOT the reference's arithmetic (SURVEY.md
                            * 8(f) rank 4): (1) the lazy refresh keeps a latent slot's initial
                            * weight until its first gradient (n > 0) instead of overwriting it
                            * with W(0,0) = 0 (ffm.cpp:72-88, fm.cpp:69-78), (2) ffm.cpp:118 uses
                            * g2*g2 instead of g2*g1 -- so that FM / FFM factors actually train.
-                           * Off: the reference bit for bit. */
-  FFM_FLAG_FUSE = 2       /* take the fused row kernel (csrc/kernels_fused.h: one pass per row over
-                           * (n,z,w), features that occur once in the block finished in registers)
-                           * for the blocks it can handle.  Same bits as the general kernels;
-                           * slower than them on gfx950 at n_fields=39, so off by
-                           * default.  Env FFM_ENGINE_FUSE=1 sets it for every engine. */
+                           * Off: the reference bit for bit.  (Flag value 2 was round 1's
+                           * optional fused row kernel: measured slower, removed.) */
 };
 
 void ffm_engine_default_config(ffm_engine_config *cfg);
@@ -97,6 +93,13 @@ void ffm_engine_default_config(ffm_engine_config *cfg);
  * ffm.cpp:17-28): allocates bias, linear and latent (w,n,z) in HBM, zeroes n,z and draws w from
  * N(init_mean, init_stddev) with a counter-based generator keyed by cfg->seed. */
 int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out);
+/* The initial weights ffm_engine_create draws, recomputed on the HOST (no device needed): element
+ * j of out is lin_w[first + j] (latent == 0) or vec_w flattened [feat][row_len] at first + j
+ * (latent != 0).  The generator is a pure function of (seed, array, index) evaluated with
+ * correctly rounded operations only (csrc/init_rng.h), so these are the device's bits -- the
+ * reference's initialiser (utils.h:30-61) is unseeded and cannot be reproduced at all. */
+int ffm_engine_init_weights_host(uint64_t seed, float init_mean, float init_stddev, int32_t latent,
+                                 int64_t first, int64_t count, float *out);
 void ffm_engine_destroy(ffm_engine *e);
 const char *ffm_engine_last_error(void);
 int ffm_engine_abi_version(void);
@@ -118,6 +121,17 @@ int ffm_engine_set_state(ffm_engine *e, const float *bias_n, const float *bias_z
 int ffm_engine_get_state(ffm_engine *e, float *bias_n, float *bias_z, float *lin_n, float *lin_z,
                          float *vec_n, float *vec_z);
 
+/* The same access for a LIST of features instead of the whole model: row j of every array is
+ * feature feat_ids[j] (lin_* [n], vec_* [n][row_len], host arrays, any may be NULL).  What a test
+ * at the headline size (33 M features: the dense arrays above would be 82 GB each) injects and
+ * reads back, and the natural primitive for checkpoint deltas.  Ids must be in [0, n_feats).
+ * Synchronous. */
+int ffm_engine_get_rows(ffm_engine *e, int32_t n, const int32_t *feat_ids, float *lin_w,
+                        float *lin_n, float *lin_z, float *vec_w, float *vec_n, float *vec_z);
+int ffm_engine_set_rows(ffm_engine *e, int32_t n, const int32_t *feat_ids, const float *lin_w,
+                        const float *lin_n, const float *lin_z, const float *vec_w,
+                        const float *vec_n, const float *vec_z);
+
 /* Replaces the loop over FtrlModel::train (ffm.cpp:38-49, fm.cpp:21-32, lr.cpp:9-18) in
  * FtrlOffline::one_epoch / FtrlOnline::run_task for one block of rows held in HOST memory.
  * logit_out[n_rows] receives each row's pre-update logit (train()'s return value); *loss_sum_out
@@ -138,7 +152,11 @@ int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_p
 
 /* Same two calls for blocks already resident in HBM (all pointers are DEVICE pointers, including
  * logit_out[n_rows] float and loss_sum_out[1] double; either output may be NULL).  Asynchronous on
- * the engine's stream; nnz is row_ptr[n_rows], passed so the host never reads device memory. */
+ * the engine's stream; nnz is row_ptr[n_rows], passed so the host never reads device memory.
+ * A row with more than max_row_nnz entries cannot be seen by the host here: the device detects it
+ * before the block touches the model, the WHOLE block is then skipped (its outputs are NaN), and
+ * the next ffm_engine_sync / ffm_engine_check_errors / ffm_engine_train_flush returns
+ * FFM_E_CAPACITY.  (The host-buffer entry points check row lengths up front.) */
 int ffm_engine_train_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
                                   const int32_t *row_ptr, const int32_t *field,
                                   const int32_t *feat, const float *val, const int32_t *label,
@@ -208,8 +226,15 @@ int ffm_engine_fill_state(ffm_engine *e, uint64_t seed, float n_lo, float n_hi, 
  * host libm on millions of inputs. */
 int ffm_engine_eval_sigmoid(ffm_engine *e, int32_t n, const float *x, float *y);
 
-/* Blocks until everything queued on the engine's stream has finished. */
+/* Blocks until everything queued on the engine's stream has finished; returns (and clears) the
+ * error the device raised since the last report, if any -- see the _device entry points. */
 int ffm_engine_sync(ffm_engine *e);
+int ffm_engine_check_errors(ffm_engine *e); /* the same, named for what device callers use it for */
+
+/* The hipStream_t the engine's kernels run on (cfg->stream, or the one it created): callers that
+ * run their own work between two engine calls -- the all-reduce between train_forward_device and
+ * train_update_device -- order it against this stream. */
+void *ffm_engine_stream(ffm_engine *e);
 
 /* Timing of the dominant kernel, measured with HIP events on the engine's stream around every
  * launch since the last reset (used by bench.py's roofline line). */

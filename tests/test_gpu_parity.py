@@ -61,19 +61,15 @@ def test_golden_replay_one_row_per_call(name):
     e.close()
 
 
-# The "fused" variants send the same inputs through the optional fused row kernel
-# (csrc/kernels_fused.h, FFM_FLAG_FUSE): FFM with n_factors in {4, 8, 16}, one entry per field.
-CASES = [("FFM", 8, 16, 40, False), ("FFM", 39, 4, 30, False),
-         ("FFM", 8, 16, 40, True), ("FFM", 39, 4, 30, True), ("FFM", 12, 8, 25, True),
-         ("FFM", 5, 3, 20, False), ("FM", 1, 64, 300, False), ("FM", 1, 7, 100, False),
-         ("LR", 1, 1, 300, False)]
-CASE_IDS = ["%s-%d-%d%s" % (c[0], c[1], c[2], "-fused" if c[4] else "") for c in CASES]
+CASES = [("FFM", 8, 16, 40), ("FFM", 39, 4, 30), ("FFM", 12, 8, 25), ("FFM", 5, 3, 20),
+         ("FM", 1, 64, 300), ("FM", 1, 7, 100), ("LR", 1, 1, 300)]
+CASE_IDS = ["%s-%d-%d" % (c[0], c[1], c[2]) for c in CASES]
 
 
-@pytest.mark.parametrize("mt,F,k,per,fuse", CASES, ids=CASE_IDS)
+@pytest.mark.parametrize("mt,F,k,per", CASES, ids=CASE_IDS)
 @pytest.mark.parametrize("B", [1, 7, 64, 512])
 @pytest.mark.parametrize("hp", [DEFAULT_HP, STRESS_HP], ids=["default_hp", "stress_hp"])
-def test_block_semantics_match_oracle(mt, F, k, per, fuse, B, hp):
+def test_block_semantics_match_oracle(mt, F, k, per, B, hp):
     """Blocks of B rows against oracle fo_train_batch on the same seeded inputs, injected warm
     state, Zipf ids (so features repeat inside a block): bitwise."""
     rng = np.random.default_rng(7)
@@ -83,7 +79,7 @@ def test_block_semantics_match_oracle(mt, F, k, per, fuse, B, hp):
     for key in ("vec_n", "lin_n"):
         st[key] += np.float32(0.05)
     o.set_state(st)
-    e = fa.Engine(mt, nf, F, k, skip_init=True, max_batch_rows=512, fuse=fuse, **hp)
+    e = fa.Engine(mt, nf, F, k, skip_init=True, max_batch_rows=512, **hp)
     e.set_state(st)
     blk = synth.Generator(F if mt == "FFM" else 13, nf, "zipf", seed=3).block(512)
     if mt != "FFM":

@@ -1,0 +1,323 @@
+"""Parity on the configurations and code paths the bench actually runs:
+
+ * the BASELINE headline model itself -- FFM 39x16 with 33 M features, 6.2e10 floats of state, every
+   64-bit offset in play -- and FM k=64 with 10 M features, against the oracle on an ID-REMAPPED
+   compact model (FFM/FM arithmetic depends on (field, record) only, so renaming ids is exact);
+ * the ffm.cpp:118 NaN flowing through the hot / very hot chain kernels inside big blocks;
+ * eight field-pair shards at 39x16, all on this GPU, merged state against the oracle;
+ * duplicate ids in a row, one id under two fields, n_fields > 64, over-long rows on the _device
+   entry points, a discarded look-ahead on a fresh engine.
+
+Tolerances: bit for bit everywhere (NaN positions must agree) except the cross-shard logit sum,
+whose association order differs from the reference's pair order: rtol 1e-5 / atol 1e-6.
+"""
+import numpy as np
+import pytest
+import torch  # noqa: F401  (first: one HIP runtime per process)
+
+import ftrl_ffm_amd as fa
+from ftrl_ffm_amd import sharding, synth
+from oracle.pyoracle import CpuModel, Csr
+from util import (DEFAULT_HP, STRESS_HP, assert_bitwise, assert_state_bitwise, rand_state)
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_gb():
+    free_b, _ = torch.cuda.mem_get_info()
+    return free_b / 1e9
+
+
+def _remapped_oracle(mt, F, k, blocks, hp, seed):
+    """Compact model over the blocks' distinct features + the state injected for them."""
+    feats = np.unique(np.concatenate([b.feat for b in blocks]))
+    U = feats.size
+    o = CpuModel("oracle", mt, U, F if mt == "FFM" else 1, k, **hp)
+    rng = np.random.default_rng(seed)
+    st = rand_state(rng, o)
+    st["vec_n"] += np.float32(0.05)
+    st["lin_n"] += np.float32(0.05)
+    o.set_state(st)
+    return o, feats, st
+
+
+@pytest.mark.parametrize("name,mt,F,k,n_feats,need_gb", [
+    ("C5", "FFM", 39, 16, 33_000_000 - 33_000_000 % 39, 255.0),
+    ("C4", "FM", 39, 64, 10_000_000 - 10_000_000 % 39, 12.0),
+])
+def test_headline_size_model_matches_remapped_oracle(name, mt, F, k, n_feats, need_gb):
+    """Two 8192-row Zipf blocks on the full-size model: logits, and (w, n, z) of every touched
+    record, equal the oracle's on the id-remapped compact model bit for bit; a sample of untouched
+    records (incl. the very last one, beyond 2^31 floats) is unchanged."""
+    if _free_gb() < need_gb:
+        pytest.skip("needs %.0f GB of free HBM, have %.0f" % (need_gb, _free_gb()))
+    B = 8192
+    g = synth.Generator(F, n_feats, "zipf", seed=42)
+    blocks = [g.block(B) for _ in range(2)]
+    if mt != "FFM":
+        for b in blocks:
+            b.field[:] = 0
+    o, feats, st = _remapped_oracle(mt, F, k, blocks, DEFAULT_HP, seed=17)
+    e = fa.Engine(mt, n_feats, F, k, skip_init=True, max_batch_rows=B, max_batch_nnz=B * F,
+                  max_row_nnz=F, **DEFAULT_HP)
+    e.set_rows(feats, {key: st[key] for key in fa.Engine.ROW_KEYS})
+    bias3 = st["bias3"]  # (the dense get/set_state would be 82 GB per array at this size)
+    lib = e.lib
+    import ctypes
+    f32p = ctypes.POINTER(ctypes.c_float)
+    one = lambda v: np.array([v], np.float32).ctypes.data_as(f32p)  # noqa: E731
+    e._check(lib.ffm_engine_set_weights(e.h, one(bias3[0]), None, None))
+    e._check(lib.ffm_engine_set_state(e.h, one(bias3[1]), one(bias3[2]), None, None, None, None))
+    # untouched probes: first, last and random records that no block contains
+    rng = np.random.default_rng(3)
+    probes = np.setdiff1d(np.concatenate([[0, n_feats - 1], rng.integers(0, n_feats, 64)]), feats)
+    probes = probes.astype(np.int32)
+    junk = {key: rng.normal(0, 1, (probes.size, e.row_len) if key.startswith("vec") else probes.size)
+            .astype(np.float32) for key in fa.Engine.ROW_KEYS}
+    e.set_rows(probes, junk)
+    for b in blocks:
+        remapped = Csr(b.row_ptr, b.field, np.searchsorted(feats, b.feat).astype(np.int32), b.val, b.label)
+        lo, so = o.train_batch(remapped)
+        lg, sg = e.train_batch(b)
+        assert_bitwise(lg, lo, name + " logits")
+        assert abs(sg - so) <= 1e-9 * max(1.0, abs(so))
+    got = e.get_rows(feats)
+    want = o.get_state()
+    for key in fa.Engine.ROW_KEYS:
+        assert_bitwise(got[key], want[key], name + " " + key)
+    after = e.get_rows(probes)
+    for key in fa.Engine.ROW_KEYS:
+        assert_bitwise(after[key], junk[key], name + " untouched " + key)
+    # predict on the trained model, too
+    remapped = Csr(blocks[0].row_ptr, blocks[0].field,
+                   np.searchsorted(feats, blocks[0].feat).astype(np.int32), blocks[0].val, blocks[0].label)
+    pe, _ = e.predict_batch(blocks[0])
+    po, _ = o.predict_batch(remapped)
+    assert_bitwise(pe, po, name + " predict")
+    e.close()
+
+
+@pytest.mark.parametrize("F,k,per,B", [(8, 16, 40, 512), (39, 16, 6, 2048), (6, 4, 3, 1500)])
+def test_quirk_nans_flow_through_the_chain_kernels(F, k, per, B):
+    """No +0.05 on n here: with n near 0 the reference's sqrt(n + g2*g1) (ffm.cpp:118) goes NaN for
+    many j-side touches, and with so few ids per field every feature is hot (5..96 occurrences)
+    or very hot (> 96): the NaNs must propagate through the DPP chains exactly as through the
+    oracle's sequential loop -- same positions in n, z, w and in the next block's logits."""
+    rng = np.random.default_rng(23)
+    nf = F * per
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o, n_hi=0.02)
+    st["vec_n"][rng.random(st["vec_n"].shape) < 0.3] = 0.0
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=B, **STRESS_HP)
+    e.set_state(st)
+    blk = synth.Generator(F, nf, "zipf", seed=8).block(2 * B)
+    for r0 in (0, B):
+        sub = blk.rows(r0, r0 + B)
+        lo, _ = o.train_batch(sub)
+        lg, _ = e.train_batch(sub)
+        assert_bitwise(lg, lo, "logits of block at %d" % r0)
+    so, se = o.get_state(), e.get_state()
+    assert np.isnan(so["vec_z"]).any(), "the case must actually produce NaNs"
+    assert_state_bitwise(se, so, "NaN chains F=%d" % F)
+    _, cnt = np.unique(blk.rows(0, B).feat, return_counts=True)
+    assert (cnt > 96).any()  # very hot chains are exercised ...
+    assert F == 6 or ((cnt > 4) & (cnt <= 96)).any()  # ... and (but for the tiny case) hot ones
+    e.close()
+
+
+def test_eight_shards_at_39x16_on_one_gpu():
+    """n_shards = 8 at the headline shape: eight engines on this GPU, each owning 1/8 of the field
+    pairs.  (1) Their partial logits sum to the unsharded logits (rtol 1e-5: the association order
+    differs).  (2) Given the SAME logits (the oracle's bits), every shard's update of the slots it
+    owns is the oracle's, bit for bit: merging the shards' records by ownership reproduces the
+    oracle's whole state."""
+    F, k, per, B, S = 39, 16, 40, 1024, 8
+    nf = F * per
+    rng = np.random.default_rng(5)
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o)
+    st["vec_n"] += np.float32(0.05)
+    st["lin_n"] += np.float32(0.05)
+    o.set_state(st)
+    blk = synth.Generator(F, nf, "zipf", seed=9).block(B)
+    lo, _ = o.train_batch(blk)
+    want = o.get_state()
+    dev = {k_: torch.from_numpy(getattr(blk, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+    shards = [fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=B, max_batch_nnz=B * F,
+                        n_shards=S, shard_rank=r, max_row_nnz=F, **STRESS_HP) for r in range(S)]
+    parts = torch.zeros(S, B, device="cuda")
+    for r, e in enumerate(shards):
+        e.set_state(st)
+        e.train_forward_device(B, blk.nnz, dev["row_ptr"].data_ptr(), dev["field"].data_ptr(),
+                               dev["feat"].data_ptr(), dev["val"].data_ptr(), dev["label"].data_ptr(),
+                               parts[r].data_ptr())
+        e.sync()
+    total = parts.sum(0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(total.cpu().numpy(), lo, rtol=1e-5, atol=1e-6)
+    exact = torch.from_numpy(lo).cuda()  # the oracle's logits: what an exact all-reduce would give
+    for e in shards:
+        e.train_update_device(exact.data_ptr())
+        e.sync()
+    states = [e.get_state() for e in shards]
+    fld = np.arange(nf) // per
+    plan = fa.shard_plan(F, S)
+    owner = np.repeat(plan["pair_owner"][fld], k, axis=1)  # [feat][partner field] -> [feat][slot elem]
+    for key in ("vec_n", "vec_z", "vec_w"):
+        merged = np.zeros_like(want[key])
+        for r in range(S):
+            merged = np.where(owner == r, states[r][key], merged)
+        assert_bitwise(merged, want[key], "8 shards " + key)
+    lin_owner = plan["lin_owner"][fld]
+    for key in ("lin_n", "lin_z", "lin_w"):
+        merged = np.zeros_like(want[key])
+        for r in range(S):
+            merged = np.where(lin_owner == r, states[r][key], merged)
+        assert_bitwise(merged, want[key], "8 shards " + key)
+    assert_bitwise(states[plan["bias_owner"]]["bias3"], want["bias3"], "8 shards bias")
+    for e in shards:
+        e.close()
+
+
+def test_duplicate_ids_one_id_under_two_fields_and_65_fields():
+    """Inputs the reference mishandles or never sees: the same id twice in one row (the reference
+    deadlocks on its own mutex, ffm.cpp:95-103; the oracle defines the arithmetic), the same id
+    under different fields in different rows, and n_fields = 65 (no 64-bit field masks)."""
+    rng = np.random.default_rng(31)
+    for F, k, per, dup in ((6, 8, 5, True), (65, 4, 3, False), (65, 4, 3, True)):
+        nf = F * per
+        rows, labels = [], []
+        for r in range(300):
+            row = [(f, f * per + int(rng.integers(0, per)), float(np.float32(rng.random() + 0.3)))
+                   for f in range(F) if rng.random() < 0.8]
+            if dup and row and r % 3 == 0:
+                j = int(rng.integers(0, len(row)))
+                row.append(row[j])                                  # the same (field, id) again
+            if dup and len(row) > 2 and r % 5 == 0:
+                row.append(((row[0][0] + 1) % F, row[1][1], 0.7))    # an id under a foreign field
+            rows.append(row)
+            labels.append(int(rng.integers(0, 2)))
+        csr = Csr.from_rows(rows, labels)
+        o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+        st = rand_state(rng, o)
+        st["vec_n"] += np.float32(0.05)
+        o.set_state(st)
+        e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=128, max_row_nnz=2 * F + 2,
+                      **STRESS_HP)
+        e.set_state(st)
+        for r0 in range(0, 300, 100):
+            sub = csr.rows(r0, r0 + 100)
+            lo, _ = o.train_batch(sub)
+            lg, _ = e.train_batch(sub)
+            assert_bitwise(lg, lo, "F=%d dup=%s logits" % (F, dup))
+        assert_state_bitwise(e.get_state(), o.get_state(), "F=%d dup=%s" % (F, dup))
+        e.close()
+
+
+def test_device_entry_points_report_an_overlong_row():
+    """A row longer than max_row_nnz reaching train_batch_device: the block is skipped as a whole
+    (model untouched, outputs NaN) and the next sync returns FFM_E_CAPACITY; the engine keeps
+    working afterwards.  predict_batch_device reports it the same way."""
+    F, k, per = 4, 4, 30
+    nf = F * per
+    e = fa.Engine("FFM", nf, F, k, max_batch_rows=64, max_batch_nnz=4096, max_row_nnz=8, seed=2)
+    e.fill_state(seed=1)
+    before = e.get_state()
+    good = synth.Generator(F, nf, "zipf", seed=1).block(32)
+    rows = [[(f, f * per + (r + f) % per, 1.0) for f in range(F)] for r in range(10)]
+    rows[6] = [(f % F, (f % F) * per + f % per, 1.0) for f in range(9)]  # 9 entries > 8
+    bad = Csr.from_rows(rows, [r % 2 for r in range(10)])
+
+    def dev(c):
+        return {k_: torch.from_numpy(getattr(c, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+
+    d = dev(bad)
+    out = torch.zeros(10, device="cuda")
+    e.train_batch_device(10, int(bad.row_ptr[-1]), d["row_ptr"].data_ptr(), d["field"].data_ptr(),
+                         d["feat"].data_ptr(), d["val"].data_ptr(), d["label"].data_ptr(), out.data_ptr())
+    with pytest.raises(fa.EngineError) as ei:
+        e.sync()
+    assert ei.value.code == -4
+    assert torch.isnan(out).all()
+    assert_state_bitwise(e.get_state(), before, "skipped block leaves the model alone")
+    e.sync()  # the flag was cleared by the report
+    e.predict_batch_device(10, int(bad.row_ptr[-1]), d["row_ptr"].data_ptr(), d["field"].data_ptr(),
+                           d["feat"].data_ptr(), d["val"].data_ptr(), None, False, out.data_ptr())
+    with pytest.raises(fa.EngineError) as ei:
+        e.check_errors()
+    assert ei.value.code == -4
+    # and the engine still trains: same bits as a fresh twin that never saw the bad block
+    twin = fa.Engine("FFM", nf, F, k, max_batch_rows=64, max_batch_nnz=4096, max_row_nnz=8, seed=2)
+    twin.fill_state(seed=1)
+    la, _ = e.train_batch(good)
+    lb, _ = twin.train_batch(good)
+    assert_bitwise(la, lb, "after the error")
+    assert_state_bitwise(e.get_state(), twin.get_state(), "after the error")
+    e.close()
+    twin.close()
+
+
+def test_discarded_lookahead_on_a_fresh_engine():
+    """Prepare A and B on a brand-new engine, then train C, D, E (never A or B): the discarded
+    groupings must not race with the inline ones that reuse their scratch sets."""
+    F, k, per, B = 8, 16, 60, 2048
+    nf = F * per
+    g = synth.Generator(F, nf, "zipf", seed=5)
+    blocks = [g.block(B) for _ in range(5)]
+    dev = [{k_: torch.from_numpy(getattr(b, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+           for b in blocks]
+    torch.cuda.synchronize()
+
+    def run(prepare_first):
+        e = fa.Engine("FFM", nf, F, k, max_batch_rows=B, seed=3, **STRESS_HP)
+        e.fill_state(seed=9)
+        out = torch.zeros(3, B, device="cuda")
+        if prepare_first:
+            for j in (0, 1):
+                d = dev[j]
+                e.prepare_device(B, blocks[j].nnz, d["row_ptr"].data_ptr(), d["field"].data_ptr(),
+                                 d["feat"].data_ptr(), d["val"].data_ptr())
+        for n, j in enumerate((2, 3, 4)):
+            d = dev[j]
+            e.train_batch_device(B, blocks[j].nnz, d["row_ptr"].data_ptr(), d["field"].data_ptr(),
+                                 d["feat"].data_ptr(), d["val"].data_ptr(), d["label"].data_ptr(),
+                                 out[n].data_ptr())
+        e.sync()
+        st, lg = e.get_state(), out.cpu().numpy()
+        e.close()
+        return lg, st
+
+    base_l, base_s = run(False)
+    for _ in range(3):
+        lg, st = run(True)
+        assert_bitwise(lg, base_l, "logits")
+        assert_state_bitwise(st, base_s, "discarded look-ahead")
+
+
+def test_seeded_init_is_the_host_function_bit_for_bit():
+    """the device's initial weights == ffm_engine_init_weights_host (csrc/init_rng.h
+    evaluated on the host), same bits; N(mean, stddev) within 4 sigma of the estimators; n, z
+    zero-filled (ftrl_model.cpp:29-32, ffm.cpp:21-26); shape as tests/test_utils.cpp:26-38."""
+    nf, F, k = 5000, 10, 4
+    mean, sd, seed = 0.01, 0.02, 1234
+    e = fa.Engine("FFM", nf, F, k, init_mean=mean, init_stddev=sd, seed=seed)
+    st = e.get_state()
+    e.close()
+    assert st["vec_w"].shape == (nf, F * k) and st["lin_w"].shape == (nf,)
+    assert_bitwise(st["vec_w"].ravel(), fa.init_weights_host(seed, mean, sd, 1, 0, nf * F * k), "vec_w")
+    assert_bitwise(st["lin_w"], fa.init_weights_host(seed, mean, sd, 0, 0, nf), "lin_w")
+    n = st["vec_w"].size
+    assert abs(st["vec_w"].mean() - mean) < 4 * sd / np.sqrt(n)
+    assert abs(st["vec_w"].std() - sd) < 4 * sd / np.sqrt(2 * n)
+    assert ((st["vec_w"] > mean - 5 * sd) & (st["vec_w"] < mean + 5 * sd)).any(axis=1).all()
+    for key in ("vec_n", "vec_z", "lin_n", "lin_z"):
+        assert not st[key].any()
+    # another seed, another model; the same seed, the same model
+    e2 = fa.Engine("FFM", nf, F, k, init_mean=mean, init_stddev=sd, seed=seed + 1)
+    assert not np.array_equal(e2.get_state()["vec_w"], st["vec_w"])
+    e2.close()
+    # FM and LR shapes draw from the same streams
+    e3 = fa.Engine("FM", nf, 1, 8, init_mean=mean, init_stddev=sd, seed=seed)
+    assert_bitwise(e3.get_state()["vec_w"].ravel(), fa.init_weights_host(seed, mean, sd, 1, 0, nf * 8), "FM vec_w")
+    e3.close()

@@ -4,18 +4,25 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (group -> lazy refresh + forward -> FTRL update) over one
-block of synthetic libffm rows that is already resident in HBM.  Workload at N = 1: BASELINE.json's
-headline configuration itself -- FFM n_fields=39 n_factors=16 n_feats=33M (247 GB of (w,n,z): it
-fits one MI355X), block = 8192 rows, Zipf(1.1) ids.  N > 1: the same 33M-feature tensor is
-field-pair sharded over the ranks and the block grows with N (8192 * N rows); every rank sees the
-whole block, computes the partial logits of the field pairs it owns, one RCCL all-reduce sums
-them, every rank updates its own slots -- per-GPU work is constant, so scaling is "weak".
-(This round every rank keeps full-length records, so capacity, not bandwidth, is replicated.)
-PyTorch is plumbing here (device buffers for the inputs, the process group); every byte of the
-path is moved by the hand-written kernels in ftrl-ffm_amd/csrc behind include/ffm_engine.h.
+One "step" = one pass of the hot path (H2D of the CSR block -> group -> lazy refresh + forward ->
+FTRL update) over one block of synthetic libffm rows.  The metric is SURVEY.md 8(d)'s: rows / wall
+time of the train loop with the rows parsed and resident in HOST memory and the H2D of every CSR
+block INSIDE the timed region -- what the reference times at src/task/ftrl_offline.cpp:46-48.  The
+blocks go through the engine's pipelined host entry points (ffm_engine_train_batch_async on one
+GPU; ffm_engine_stage_batch + train_forward_staged + all-reduce + train_update_device on a sharded
+rank): block t+1 is uploaded and grouped on a side stream while block t trains.  The same loop over
+blocks already resident in HBM is timed afterwards and reported as `resident` (never as `value`).
+
+Workload at N = 1: BASELINE.json's headline configuration itself -- FFM n_fields=39 n_factors=16
+n_feats=33M (247 GB of (w,n,z): it fits one MI355X), block = 8192 rows, Zipf(1.1) ids, 64 distinct
+blocks.  N > 1: the same 33M-feature tensor is field-pair sharded over the ranks; every rank sees
+the whole block and computes / updates the field pairs it owns; one RCCL all-reduce of n_rows
+partial logits per step.  `--scaling weak` (default): the block grows with N (8192 * N rows) so
+per-GPU pair work is constant; `--scaling strong`: SURVEY 8(d)'s literal C5, 8192 rows per step
+globally.  PyTorch is plumbing here (the process group, device buffers of the resident leg).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -26,7 +33,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_FIELDS, N_FACTORS, ROWS_PER_GPU = 39, 16, 8192
+N_FIELDS, N_FACTORS = 39, 16
 FEATS_C5 = 33_000_000
 # BASELINE.json configs; only c5's single-GPU slice is the bench line, the others are for DESIGN.md
 CONFIGS = {
@@ -36,6 +43,7 @@ CONFIGS = {
     "c4": dict(model="FM", fields=39, factors=64, rows=8192, feats=10_000_000),
 }
 PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+SMALL_MAX, HUGE_MIN = 4, 96  # occurrence classes of the update kernels (csrc/engine_types.h)
 
 
 def algorithmic_bytes_per_row(nnz, k):
@@ -54,8 +62,8 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
                              block algorithm needs; the per-row figure of 8(d) counts it per
                              occurrence, and step_algorithmic_GBps keeps that accounting)
       row kernel           : CSR in, linear weights, logit / tmp_grad / loss out
-      update_small/hot/huge: write (n,z) = 8 B per slot-factor of the occurrences each owns
-                             (features with <= 4, 5..96, > 96 occurrences in the block)
+      update kernels       : write (n,z) = 8 B per slot-factor of the occurrences each owns
+                             (features with 1, 2..4, 5..96, > 96 occurrences in the block)
     Under field-pair sharding every rank moves 1/n_shards of the slot-factors."""
     per_occ = (nnz - 1) * k  # slot-factors one occurrence of a feature touches
     rows = [len(f) // nnz for f in blocks_feat]
@@ -66,64 +74,84 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
     shares = []
     for f in blocks_feat:
         _, c = np.unique(f, return_counts=True)
-        occ = {"small": c[c <= 4].sum(), "hot": c[(c > 4) & (c <= 96)].sum(), "huge": c[c > 96].sum()}
-        key = "small" if "small" in kernel else "huge" if "huge" in kernel else "hot"
+        occ = {"single": c[c == 1].sum(), "small": c[(c > 1) & (c <= SMALL_MAX)].sum(),
+               "hot": c[(c > SMALL_MAX) & (c <= HUGE_MIN)].sum(), "huge": c[c > HUGE_MIN].sum()}
+        key = next((kk for kk in ("single", "small", "huge") if kk in kernel), "hot")
         shares.append(occ[key] * per_occ * 8 / n_shards)
     return float(np.mean(shares))
 
 
 def cpu_baseline(args, gen_kwargs):
-    """The oracle (CPU restatement of the reference, oracle/ffm_oracle.c) timed on this host on a
-    bounded sample of the same workload.  Checker code, used here only as the reported baseline."""
+    """The reference's own multi-thread CPU path timed on this host on a bounded sample of the same
+    workload: oracle/_ref (the unmodified reference model classes compiled from /root/reference by
+    oracle/Makefile; the harness runs FtrlOffline::one_epoch's loop, ftrl_offline.cpp:63-91, over
+    them) -- kind "reference".  Where that build is absent, the oracle's restatement -- kind "port"
+    (profiles/r02_cpu_baseline_validation.json: port/reference = 1.23 at 1 thread, 0.89 at 8).
+    Checker code, used here only as the reported baseline."""
+    from oracle import pyoracle
     from oracle.pyoracle import CpuModel
     from ftrl_ffm_amd import synth
     n_feats = N_FIELDS * 2048  # host-RAM bound sample of the same F / k / nnz / id distribution
     rows = args.cpu_rows
     g = synth.Generator(N_FIELDS, n_feats, **gen_kwargs)
     blk = g.block(rows)
-    best, best_t = 0.0, 1
-    tried = {}
+    kind = "ref" if pyoracle.have_ref() else "oracle"
+    if kind == "ref":
+        try:
+            lib, _ = pyoracle._lib("ref")
+            if not (hasattr(lib, "fr_create_sized") and hasattr(lib, "fr_train_rows_threaded")):
+                kind = "oracle"
+        except OSError:
+            kind = "oracle"
     ncpu = os.cpu_count() or 1
-    for threads in sorted({1, min(8, ncpu)}):
-        m = CpuModel("oracle", "FFM", n_feats, N_FIELDS, N_FACTORS)
-        st = m.zero_state()
-        rng = np.random.default_rng(5)
-        st["vec_w"][...] = rng.normal(0, 0.02, st["vec_w"].shape).astype(np.float32)
-        st["vec_n"][...] = rng.uniform(0.05, 1.0, st["vec_n"].shape).astype(np.float32)
-        st["vec_z"][...] = rng.normal(0, 0.3, st["vec_z"].shape).astype(np.float32)
+    rng = np.random.default_rng(5)
+    st = None
+    tried = {}
+    for threads in sorted({1, min(8, ncpu), ncpu}):
+        m = CpuModel(kind, "FFM", n_feats, N_FIELDS, N_FACTORS)
+        if st is None:
+            st = m.zero_state()
+            st["vec_w"][...] = rng.normal(0, 0.02, st["vec_w"].shape).astype(np.float32)
+            st["vec_n"][...] = rng.uniform(0.05, 1.0, st["vec_n"].shape).astype(np.float32)
+            st["vec_z"][...] = rng.normal(0, 0.3, st["vec_z"].shape).astype(np.float32)
         m.set_state(st)
-        if threads == 1:
-            t0 = time.perf_counter()
-            m.train_rows(blk)
-            sec = time.perf_counter() - t0
-        else:
-            sec, _ = m.train_rows_threaded(blk, threads)
+        sec, _ = m.train_rows_threaded(blk, threads)
         tried[threads] = rows / sec
-        if rows / sec > best:
-            best, best_t = rows / sec, threads
         del m
-    return {"value": round(best, 1), "unit": "samples/s", "cores": best_t, "kind": "port",
-            "sample": "%d rows, FFM F=%d k=%d nnz=%d Zipf(1.1), n_feats=%d, warm state, oracle "
-                      "fo_train_rows at 1 thread and reference-style locked threads at %d; best "
-                      "reported (%s); host has %d cores" % (
-                          rows, N_FIELDS, N_FACTORS, N_FIELDS, n_feats, min(8, ncpu),
+    best_t = max(tried, key=tried.get)
+    return {"value": round(tried[best_t], 1), "unit": "samples/s", "cores": best_t,
+            "kind": "reference" if kind == "ref" else "port",
+            "sample": "%d rows, FFM F=%d k=%d nnz=%d Zipf(1.1), n_feats=%d, warm state; %s at n_threads in "
+                      "{1, 8, all}: %s; best reported; host has %d cores" % (
+                          rows, N_FIELDS, N_FACTORS, N_FIELDS, n_feats,
+                          "the reference's FtrlOffline::one_epoch loop over its own FFM model "
+                          "(oracle/_ref)" if kind == "ref" else "oracle fo_train_rows_threaded",
                           ", ".join("%dT=%.0f/s" % kv for kv in sorted(tried.items())), ncpu)}
+
+
+def latest_pmc_summary():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.json")))
+    return files[-1] if files else None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n-feats", type=int, default=0, help="override total n_feats")
     ap.add_argument("--rows", type=int, default=0, help="override rows per step (global)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--dist", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--state", default="warm", choices=["warm", "fresh"])
-    ap.add_argument("--n-blocks", type=int, default=8, help="distinct synthetic blocks cycled")
-    ap.add_argument("--cpu-rows", type=int, default=20000)
+    ap.add_argument("--n-blocks", type=int, default=0, help="distinct synthetic blocks cycled (default 64)")
+    ap.add_argument("--cpu-rows", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-lookahead", action="store_true", help="group each block inline")
+    ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident leg")
+    ap.add_argument("--resident-only", action="store_true",
+                    help="time only the HBM-resident loop (tuning aid: `value` is then NOT the metric)")
+    ap.add_argument("--no-lookahead", action="store_true", help="resident leg: group each block inline")
     ap.add_argument("--config", default="c5", choices=sorted(CONFIGS))
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (gloo + --same-device: functional dry run of the "
@@ -131,14 +159,14 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (dry run)")
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="tuning aid on one GPU: run ONE rank's share of an N-GPU field-pair-sharded "
-                         "job (N x rows per step, 1/N of the field pairs, no all-reduce) and print "
-                         "what the N-GPU job's rate would be if the exchange were free")
+                         "job (1/N of the field pairs, no all-reduce) and print what the N-GPU "
+                         "job's rate would be if the exchange were free")
     ap.add_argument("--emulate-rank", type=int, default=0)
     args = ap.parse_args()
 
     import torch
     import ftrl_ffm_amd as fa
-    from ftrl_ffm_amd import synth
+    from ftrl_ffm_amd import sharding, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -169,7 +197,8 @@ def main():
     model = cfgw["model"]
     N_FIELDS, N_FACTORS = cfgw["fields"], cfgw["factors"]
     emu = args.emulate_shards if world == 1 else 0
-    rows = args.rows or cfgw["rows"] * (emu or n_gpus)
+    n_shards = emu or world
+    rows = args.rows or cfgw["rows"] * (n_shards if args.scaling == "weak" else 1)
     n_feats = args.n_feats or cfgw["feats"]
     n_feats -= n_feats % N_FIELDS
     rec_bytes = 3 * (N_FIELDS if model == "FFM" else 1) * N_FACTORS * 4
@@ -178,7 +207,7 @@ def main():
     budget = int(free_b * 0.9) - (4 << 30)
     if args.same_device:
         budget //= max(world, 1)
-    if n_feats * rec_bytes > budget:  # this round every shard stores full-length records
+    if n_feats * rec_bytes > budget:  # every shard stores full-length records
         n_feats = budget // rec_bytes
         n_feats -= n_feats % N_FIELDS
         reduced = True
@@ -188,13 +217,17 @@ def main():
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
+
+    def make_engine(nf):
+        return fa.Engine(model, nf, N_FIELDS, N_FACTORS, max_batch_rows=rows,
+                         max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=n_shards,
+                         shard_rank=args.emulate_rank if emu else rank, stream=stream, seed=42,
+                         max_row_nnz=N_FIELDS)
+
     eng = None
     while eng is None:  # an allocation that does not fit is retried 10 % smaller, never fatal
         try:
-            eng = fa.Engine(model, n_feats, N_FIELDS, N_FACTORS, max_batch_rows=rows,
-                            max_batch_nnz=rows * N_FIELDS, device_id=local_rank,
-                            n_shards=emu or world, shard_rank=args.emulate_rank if emu else rank,
-                            stream=stream, seed=42, max_row_nnz=N_FIELDS)
+            eng = make_engine(n_feats)
         except fa.EngineError as err:
             if err.code != -3 or n_feats < 10 * N_FIELDS:
                 raise
@@ -207,49 +240,26 @@ def main():
         if int(t.item()) != n_feats:
             n_feats = int(t.item())
             eng.close()
-            eng = fa.Engine(model, n_feats, N_FIELDS, N_FACTORS, max_batch_rows=rows,
-                            max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=world,
-                            shard_rank=rank, stream=stream, seed=42, max_row_nnz=N_FIELDS)
+            eng = make_engine(n_feats)
             reduced = True
     if args.state == "warm":
         eng.fill_state(seed=7, n_lo=0.05, n_hi=1.0, z_stddev=0.3)
 
-    # identical synthetic blocks on every rank, uploaded once: resident in HBM before timing
+    # identical synthetic blocks on every rank, parsed and resident in HOST memory
+    n_blocks = args.n_blocks or max(8, min(64, (1 << 19) // rows))
     gen = synth.Generator(N_FIELDS, n_feats, **gen_kwargs)
-    blocks = []
-    blocks_feat = []
-    for _ in range(args.n_blocks):
+    host_blocks = []
+    for _ in range(n_blocks):
         b = gen.block(rows)
         if model != "FFM":
             b.field[:] = 0  # libsvm rows
-        blocks_feat.append(b.feat.copy())
-        blocks.append(dict(
-            n_rows=b.n_rows, nnz=b.nnz,
-            row_ptr=torch.from_numpy(b.row_ptr).cuda(), field=torch.from_numpy(b.field).cuda(),
-            feat=torch.from_numpy(b.feat).cuda(), val=torch.from_numpy(b.val).cuda(),
-            label=torch.from_numpy(b.label).cuda()))
+        host_blocks.append(b)
+    blocks_feat = [b.feat for b in host_blocks[:8]]
+    total_steps = args.steps + args.warmup + 1
     logit = torch.zeros(rows, dtype=torch.float32, device="cuda")
-    loss_sum = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device="cuda")
-
-    def step(i, blk):
-        ptr = lambda t: t.data_ptr()  # noqa: E731
-        out_loss = loss_sum.data_ptr() + 8 * i
-        if world == 1 and not emu:
-            eng.train_batch_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
-                                   ptr(blk["feat"]), ptr(blk["val"]), ptr(blk["label"]),
-                                   ptr(logit), out_loss)
-        else:
-            eng.train_forward_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]),
-                                     ptr(blk["field"]), ptr(blk["feat"]), ptr(blk["val"]),
-                                     ptr(blk["label"]), ptr(logit))
-            if dist is not None:
-                dist.all_reduce(logit)  # the path's one exchange: n_rows partial logits over xGMI
-            eng.train_update_device(ptr(logit), None, out_loss)
-
-    def prepare(blk):  # the scheduler's look-ahead: group the next block beside this one's update
-        ptr = lambda t: t.data_ptr()  # noqa: E731
-        eng.prepare_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
-                           ptr(blk["feat"]), ptr(blk["val"]))
+    loss_sum = torch.zeros(2 * total_steps, dtype=torch.float64, device="cuda")
+    sharded = n_shards > 1
+    sstep = sharding.ShardedStep(eng, dist, logit) if sharded else None
 
     def fence():
         torch.cuda.synchronize()
@@ -257,45 +267,107 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up with every kernel timed (the table on stderr, and which kernel dominates); the timed
-    # region then carries HIP events only around that dominant kernel
-    if not args.no_profile:
-        eng.profile_enable(True)
+    # ---- leg 1 (the metric): rows stream from host memory, H2D inside the timed region ----
+    def run_host(first, count):
+        """`count` steps; returns the sum of the steps' losses (all enqueued work is flushed)."""
+        if count == 0:
+            return 0.0
+        if not sharded:
+            for i in range(count):
+                eng.train_batch_async(host_blocks[(first + i) % n_blocks])
+            return eng.train_flush()
+        sstep.stage(host_blocks[first % n_blocks])
+        for i in range(count):
+            if i + 1 < count:
+                sstep.stage(host_blocks[(first + i + 1) % n_blocks])
+            sstep.train_staged(rows, loss_sum.data_ptr() + 8 * (first + i))
+        eng.sync()
+        return float(loss_sum[first:first + count].sum().item())
+
+    # ---- leg 2 (extra): the same blocks already resident in HBM ----
+    dev_blocks = []
+
+    def upload_resident():
+        for b in host_blocks[:8]:
+            dev_blocks.append(dict(
+                n_rows=b.n_rows, nnz=b.nnz,
+                row_ptr=torch.from_numpy(b.row_ptr).cuda(), field=torch.from_numpy(b.field).cuda(),
+                feat=torch.from_numpy(b.feat).cuda(), val=torch.from_numpy(b.val).cuda(),
+                label=torch.from_numpy(b.label).cuda()))
+
+    def step_resident(i, blk):
+        ptr = lambda t: t.data_ptr()  # noqa: E731
+        out_loss = loss_sum.data_ptr() + 8 * (total_steps + i)
+        if not sharded:
+            eng.train_batch_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
+                                   ptr(blk["feat"]), ptr(blk["val"]), ptr(blk["label"]),
+                                   ptr(logit), out_loss)
+        else:
+            sstep(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]), ptr(blk["feat"]),
+                  ptr(blk["val"]), ptr(blk["label"]), out_loss)
+
+    def prepare(blk):  # the scheduler's look-ahead: group the next block beside this one's update
+        ptr = lambda t: t.data_ptr()  # noqa: E731
+        eng.prepare_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
+                           ptr(blk["feat"]), ptr(blk["val"]))
+
     DEPTH = 2  # blocks grouped ahead (ffm_engine_prepare_device): two hide the grouping completely
 
-    def run(first, count):
-        """`count` steps starting at global step `first`; every grouping of these steps -- ahead or
-        inline -- is issued inside the call, none for later steps."""
+    def run_resident(first, count):
         ahead = 0  # blocks currently prepared ahead
         for i in range(count):
-            step(first + i, blocks[(first + i) % len(blocks)])
+            step_resident(first + i, dev_blocks[(first + i) % len(dev_blocks)])
             ahead = max(ahead - 1, 0)
             while not args.no_lookahead and ahead < DEPTH and i + ahead + 1 < count:
-                prepare(blocks[(first + i + ahead + 1) % len(blocks)])
+                prepare(dev_blocks[(first + i + ahead + 1) % len(dev_blocks)])
                 ahead += 1
 
-    run(0, args.warmup)
+    def timed(run, first, count):
+        fence()
+        t0 = time.perf_counter()
+        out = run(first, count)
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    # warm-up with every kernel timed (the table on stderr, and which kernel dominates); the timed
+    # region then carries HIP events only around that dominant kernel
+    host_leg = not args.resident_only
+    if args.resident_only or not args.no_resident:
+        upload_resident()
+    if not args.no_profile:
+        eng.profile_enable(True)
+    (run_host if host_leg else run_resident)(0, args.warmup)
     fence()
     table = ""
     if not args.no_profile:
         table = eng.profile_dump()
         eng.profile_focus()
-    t0 = time.perf_counter()
-    run(args.warmup, args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    elapsed, host_loss = timed(run_host if host_leg else run_resident, args.warmup, args.steps)
     kname, klaunches, kms = ("", 0, 0.0)
     if not args.no_profile:
         kname, klaunches, kms = eng.profile_read()
         eng.profile_enable(False)
-    losses = loss_sum[args.warmup:args.warmup + args.steps].cpu().numpy()
     total_rows = rows * args.steps
     value = total_rows / elapsed
+    if host_leg:
+        train_loss = host_loss / total_rows
+    else:
+        train_loss = float(loss_sum[total_steps + args.warmup:total_steps + args.warmup + args.steps]
+                           .sum().item()) / total_rows
+    resident = None
+    if host_leg and not args.no_resident:
+        run_resident(0, min(args.warmup, 3))
+        el2, _ = timed(run_resident, args.warmup, args.steps)
+        resident = {"value": round(total_rows / el2, 1), "unit": "samples/s",
+                    "ms_per_step": round(1000.0 * el2 / args.steps, 4),
+                    "note": "same loop over %d blocks already resident in HBM (no H2D); not the metric"
+                            % len(dev_blocks)}
+
     if model == "FFM":
         bytes_row = algorithmic_bytes_per_row(N_FIELDS, N_FACTORS)
     else:  # FM, SURVEY.md 8(d): nnz*k*20 + nnz*20 + 20 + nnz*8 + 8 + 12
@@ -307,30 +379,36 @@ def main():
                       "train samples/sec + logloss, " + args.config, "value": round(value, 1),
             "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "h2d_included": bool(host_leg),
             "config": {
                 "workload": "%s n_fields=%d n_factors=%d nnz=%d, %s ids, block=%d rows, n_feats=%d "
-                            "(%.1f GB of w,n,z per GPU), %s state, reference default hyper-parameters"
-                            % (model, N_FIELDS, N_FACTORS, N_FIELDS,
-                               "Zipf(1.1)" if args.dist == "zipf" else "uniform", rows, n_feats,
-                               n_feats * rec_bytes / 1e9, args.state),
+                            "(%.1f GB of w,n,z per GPU), %s state, reference default hyper-parameters, "
+                            "%s" % (model, N_FIELDS, N_FACTORS, N_FIELDS,
+                                    "Zipf(1.1)" if args.dist == "zipf" else "uniform", rows, n_feats,
+                                    n_feats * rec_bytes / 1e9, args.state,
+                                    "%d distinct blocks streamed from host memory (H2D in the timed region)"
+                                    % n_blocks if host_leg else "blocks resident in HBM (no H2D)"),
                 "rows_per_step": rows, "n_feats": n_feats, "n_feats_reduced_to_fit": reduced,
+                "n_blocks": n_blocks,
                 "sharding": "field-pair x%d, one all-reduce of %d partial logits per step"
                             % (world, rows) if world > 1 else "none",
             },
             **({"emulated": "one rank's compute of a %d-GPU job on one GPU, no exchange; `value` is "
                             "what the %d-GPU job would reach if the all-reduce were free (tuning "
                             "aid, not a result)" % (emu, emu)} if emu else {}),
-            "train_logloss": round(float(losses.sum() / total_rows), 6),
+            "train_logloss": round(train_loss, 6),
             "step_algorithmic_GBps": round(value * bytes_row / n_gpus / 1e9, 1),
         }
+        if resident:
+            out["resident"] = resident
         if kname and model == "FFM":
-            share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, max(emu or world, 1))
+            share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, n_shards)
             avg_s = kms / 1000.0 / max(klaunches, 1)
             achieved = share / avg_s / 1e9
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_summary.json")
-            if os.path.exists(pmc) and world == 1 and not args.n_feats and not args.rows:
+            pmc = latest_pmc_summary()
+            if pmc and world == 1 and not emu and not args.n_feats and not args.rows:
                 with open(pmc) as f:  # rocprofv3 --pmc passes of this same command (tools/)
                     for name, v in json.load(f).items():
                         if name.split("<")[0] == kname.split("<")[0]:
@@ -338,16 +416,17 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
-                "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": klaunches,
+                "traffic": traffic, "traffic_source": os.path.basename(pmc) if traffic else None,
+                "avg_launch_us": round(avg_s * 1e6, 2), "launches": klaunches,
                 "algorithmic_bytes_per_launch": int(share),
                 # the whole step against the same roof: SURVEY.md 8(d)'s bytes per row x rows/s
                 "whole_step": {"achieved": out["step_algorithmic_GBps"],
                                "frac": round(out["step_algorithmic_GBps"] / PEAK_HBM_GBPS, 4),
                                "bytes_per_row": int(bytes_row)},
-                "note": "the three update kernels (small/hot/huge) run side by side on separate "
-                        "streams, so a kernel's span includes waiting for CUs; they are bound by "
-                        "VALU issue and dependent-load latency, not HBM (DESIGN.md); warm-up "
-                        "spans of all kernels are in other_kernels",
+                "note": "the update kernels run side by side on separate streams, so a kernel's span "
+                        "includes waiting for CUs; the chain kernels are bound by VALU issue and "
+                        "dependent-load latency, not HBM (DESIGN.md); warm-up spans of all kernels "
+                        "are in other_kernels",
             }
             # the other big kernels, from the fully timed warm-up launches (same accounting)
             others = []
@@ -356,19 +435,20 @@ def main():
                 nm = parts[0]
                 full = {"row_kernel<train>": "ffm_row_kernel<train>",
                         "refresh_kernel": "ffm_refresh_kernel",
+                        "latent_update_single_kernel": "ffm_update_single_kernel",
                         "latent_update_kernel": "ffm_update_small_kernel",
                         "latent_update_hot_kernel": "ffm_update_hot_kernel",
                         "latent_update_huge_kernel": "ffm_update_huge_kernel"}.get(nm)
                 if not full:
                     continue
                 us = float(parts[-1])
-                sh = kernel_share_bytes(full, blocks_feat, N_FIELDS, N_FACTORS, max(emu or world, 1))
+                sh = kernel_share_bytes(full, blocks_feat, N_FIELDS, N_FACTORS, n_shards)
                 others.append({"kernel": full, "avg_launch_us": us,
                                "algorithmic_bytes_per_launch": int(sh),
                                "achieved": round(sh / (us * 1e-6) / 1e9, 1),
                                "frac": round(sh / (us * 1e-6) / 1e9 / PEAK_HBM_GBPS, 4)})
             out["roofline"]["other_kernels"] = others
-        if n_gpus == 1 and not args.no_cpu_baseline and args.config == "c5":
+        if n_gpus == 1 and not emu and not args.no_cpu_baseline and args.config == "c5":
             out["cpu_baseline"] = cpu_baseline(args, gen_kwargs)
         print(json.dumps(out), flush=True)
         if table:

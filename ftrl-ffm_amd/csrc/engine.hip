@@ -216,7 +216,10 @@ struct ffm_engine {
     bool has_field = false;
   } slots[kSlots];
   bool slots_ready = false;
-  int slot_next = 0, slot_pending = -1;
+  int slot_next = 0;
+  int staged[kSlots] = {};  // slots staged and not yet in training, oldest first
+  int n_staged = 0;
+  int cur_slot = -1;        // slot of the block between train_forward_staged and train_update
   double *d_loss_acc = nullptr;  // [1] sum of the async blocks' losses since the last flush
   void *d_sort_tmp[kSets] = {};  // rocPRIM radix sort workspace per scratch set
   size_t sort_tmp_bytes = 0;
@@ -1023,6 +1026,10 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
   if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
   HIP_TRY(hipEventRecord(e->ev_set_free[e->cur], e->stream));
+  if (e->cur_slot >= 0) {  // a staged block: its staging slot may be refilled from here on
+    HIP_TRY(hipEventRecord(e->slots[e->cur_slot].ev_trained, e->stream));
+    e->cur_slot = -1;
+  }
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }
@@ -1182,33 +1189,21 @@ static int slots_init(ffm_engine *e) {
   return FFM_OK;
 }
 
-static int train_pending_slot(ffm_engine *e) {
-  if (e->slot_pending < 0) return FFM_OK;
-  ffm_engine::Slot &sl = e->slots[e->slot_pending];
-  e->slot_pending = -1;
-  e->staged_row_cap = sl.row_cap;
-  int rc = ffm_engine_train_batch_device(e, sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr,
-                                         sl.feat, sl.val, sl.label, nullptr, e->d_loss_sum);
-  if (rc) return rc;
-  hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
-  HIP_TRY(hipEventRecord(sl.ev_trained, e->stream));
-  return FFM_OK;
-}
-
-int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
-                                 const int32_t *field, const int32_t *feat, const float *val,
-                                 const int32_t *label) {
+// Stage one block of host rows: pinned image -> HBM -> grouping, all on the prep stream.
+int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                           const int32_t *field, const int32_t *feat, const float *val,
+                           const int32_t *label) {
   int32_t nnz = 0;
   int longest = 1;
   int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
   if (rc) return rc;
   if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
-  if (e->m.n_shards > 1) return fail(FFM_E_INVALID, "sharded engines train with train_forward + all-reduce + train_update");
+  if (e->n_staged >= ffm_engine::kSlots - 1) return fail(FFM_E_CAPACITY, "two staged blocks are already waiting");
+  if (e->has_pending) return fail(FFM_E_INVALID, "stage between train_forward and train_update");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   if ((rc = slots_init(e))) return rc;
   ffm_engine::Slot &sl = e->slots[e->slot_next];
   const int this_slot = e->slot_next;
-  e->slot_next = (e->slot_next + 1) % ffm_engine::kSlots;
   if (sl.used) {
     HIP_TRY(hipEventSynchronize(sl.ev_copied));                   // its pinned image is free again
     HIP_TRY(hipStreamWaitEvent(e->prep, sl.ev_trained, 0));      // and nothing reads its device arrays
@@ -1229,24 +1224,72 @@ int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *r
   HIP_TRY(put(val, 4 * E, sl.val));
   HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
   HIP_TRY(hipEventRecord(sl.ev_copied, e->prep));
+  // group it ahead, behind its own upload on the prep stream
+  rc = ffm_engine_prepare_device(e, n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val);
+  if (rc) return rc;
   sl.used = true;
   sl.n_rows = n_rows;
   sl.nnz = nnz;
   sl.row_cap = longest;
   sl.has_field = field != nullptr;
-  // group it ahead on the prep stream, then train the block staged by the previous call
-  rc = ffm_engine_prepare_device(e, n_rows, nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr, sl.feat, sl.val);
+  e->slot_next = (e->slot_next + 1) % ffm_engine::kSlots;
+  e->staged[e->n_staged++] = this_slot;
+  return FFM_OK;
+}
+
+// Phase 1 (grouping is done: refresh + forward) on the oldest staged block.
+int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (e->n_staged == 0) return fail(FFM_E_INVALID, "no staged block");
+  if (e->has_pending) return fail(FFM_E_INVALID, "the previous block still awaits train_update");
+  const int slot = e->staged[0];
+  ffm_engine::Slot &sl = e->slots[slot];
+  e->staged_row_cap = sl.row_cap;
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));  // (also when its grouping was discarded)
+  int rc = ffm_engine_train_forward_device(e, sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr,
+                                           sl.feat, sl.val, sl.label, partial_logit);
   if (rc) return rc;
-  rc = train_pending_slot(e);
-  e->slot_pending = this_slot;
-  return rc;
+  e->staged[0] = e->staged[1];
+  e->n_staged--;
+  e->cur_slot = slot;  // released (ev_trained) by the train_update that follows
+  return FFM_OK;
+}
+
+// Whole step on the oldest staged block; its loss goes into the running sum of the flush.
+static int train_one_staged(ffm_engine *e) {
+  e->whole_step = e->m.n_shards == 1;
+  e->own_logit_out = nullptr;
+  int rc = ffm_engine_train_forward_staged(e, nullptr);
+  e->whole_step = false;
+  if (rc) return rc;
+  rc = ffm_engine_train_update_device(e, nullptr, nullptr, e->d_loss_sum);
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
+  return FFM_OK;
+}
+
+int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                 const int32_t *field, const int32_t *feat, const float *val,
+                                 const int32_t *label) {
+  if (e && e->m.n_shards > 1)
+    return fail(FFM_E_INVALID, "sharded engines train with stage_batch + train_forward_staged + all-reduce + train_update");
+  int rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label);
+  if (rc) return rc;
+  // train what the previous call staged; the block staged just now keeps uploading and grouping
+  // beside it (and beside the caller's preparation of the next one)
+  while (e->n_staged > 1)
+    if ((rc = train_one_staged(e))) return rc;
+  return FFM_OK;
 }
 
 int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
-  int rc = train_pending_slot(e);
-  if (rc) return rc;
+  int rc;
+  if (e->m.n_shards == 1)
+    while (e->n_staged > 0)
+      if ((rc = train_one_staged(e))) return rc;
   double total = 0.0;
   if (e->slots_ready) {
     HIP_TRY(hipMemcpyAsync(&total, e->d_loss_acc, sizeof(double), hipMemcpyDeviceToHost, e->stream));

@@ -71,6 +71,8 @@ ABI = [
      [_vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     ("ffm_engine_train_batch_async", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
     ("ffm_engine_train_flush", ctypes.c_int, [_vp, _f64p]),
+    ("ffm_engine_stage_batch", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
+    ("ffm_engine_train_forward_staged", ctypes.c_int, [_vp, _vp]),
     ("ffm_engine_prepare_device", ctypes.c_int,
      [_vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     ("ffm_engine_train_forward_device", ctypes.c_int,
@@ -239,6 +241,14 @@ class Engine:
     def train_batch_async(self, c):
         """Pipelined: stages and groups this block, trains the one passed by the previous call."""
         self._check(self.lib.ffm_engine_train_batch_async(self.h, *self._csr(c)))
+
+    def stage_batch(self, c):
+        """Host block -> pinned slot -> HBM + grouping on the side stream (returns at once)."""
+        self._check(self.lib.ffm_engine_stage_batch(self.h, *self._csr(c)))
+
+    def train_forward_staged(self, partial_logit=None):
+        """Phase 1 on the oldest staged block; follow with train_update_device."""
+        self._check(self.lib.ffm_engine_train_forward_staged(self.h, partial_logit))
 
     def train_flush(self):
         """Trains the last staged block, waits; the loss sum of all blocks since the last flush."""

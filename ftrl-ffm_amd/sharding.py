@@ -75,6 +75,18 @@ class ShardedStep:
         self._exchange(n_rows)
         self.engine.train_update_device(ptr, None, loss_sum_out)
 
+    def stage(self, block):
+        """Hand the NEXT host block to the engine: it is uploaded and grouped on the engine's side
+        stream while the current one trains (up to two may wait)."""
+        self.engine.stage_batch(block)
+
+    def train_staged(self, n_rows, loss_sum_out=None):
+        """One training block from the oldest staged host block: forward -> all-reduce -> update."""
+        ptr = self.logit.data_ptr()
+        self.engine.train_forward_staged(ptr)
+        self._exchange(n_rows)
+        self.engine.train_update_device(ptr, None, loss_sum_out)
+
     def predict(self, n_rows, nnz, row_ptr, field, feat, val, label=None, output_prob=False,
                 out=None, loss_sum_out=None):
         """predict() on the sharded model: partial logits -> all-reduce -> value / logloss."""

@@ -191,6 +191,19 @@ int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *r
                                  const int32_t *label);
 int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out);
 
+/* The two halves of ffm_engine_train_batch_async, for callers that put something between forward
+ * and update -- the sharded trainer's all-reduce: ffm_engine_stage_batch copies the host block into
+ * a pinned staging slot, uploads it and groups it on the side stream (returns at once; the
+ * caller's arrays are reusable; FFM_E_CAPACITY when two staged blocks are already waiting);
+ * ffm_engine_train_forward_staged runs phase 1 of ffm_engine_train_forward_device on the OLDEST
+ * staged block (partial_logit: device, may be NULL), to be followed by
+ * ffm_engine_train_update_device.  So rows stream host -> HBM inside the training loop on every
+ * rank, overlapped with the previous block's training. */
+int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                           const int32_t *field, const int32_t *feat, const float *val,
+                           const int32_t *label);
+int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit);
+
 /* Optional look-ahead of the mini-batch scheduler: start grouping the NEXT block by feature (the
  * integer-only first stage of training) on a side stream while the current block is still being
  * updated.  The arrays must be complete in device memory when this is called and must be the very

@@ -90,6 +90,9 @@ def _lib(kind):
     f = getattr(lib, p + "create")
     f.restype = vp
     f.argtypes = [ctypes.c_int] * 4 + [ctypes.c_float] * 4
+    if kind == "ref" and hasattr(lib, "fr_create_sized"):
+        lib.fr_create_sized.restype = vp
+        lib.fr_create_sized.argtypes = f.argtypes
     getattr(lib, p + "destroy").argtypes = [vp]
     if kind == "oracle":
         lib.fo_set_variant.argtypes = [vp, ctypes.c_int]
@@ -134,6 +137,11 @@ def _lib(kind):
         lib.fr_load_model.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
         lib.fr_sgn_int.restype = ctypes.c_int
         lib.fr_sgn_int.argtypes = [ctypes.c_int]
+        if hasattr(lib, "fr_train_rows_threaded"):  # (a prebuilt _ref from before round 2 lacks it)
+            f = lib.fr_train_rows_threaded
+            f.restype = ctypes.c_double
+            f.argtypes = [vp, ctypes.c_int, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p,
+                          ctypes.POINTER(ctypes.c_double)]
     _libs[kind] = (lib, p)
     return _libs[kind]
 
@@ -151,8 +159,14 @@ class CpuModel:
         self.lib, self.p = _lib(kind)
         self.model_type = MODEL_TYPES[model_type] if isinstance(model_type, str) else model_type
         self.n_feats, self.n_fields, self.n_factors = n_feats, n_fields, n_factors
-        self.h = getattr(self.lib, self.p + "create")(self.model_type, n_feats, n_fields, n_factors,
-                                                      w_alpha, w_beta, w_l1, w_l2)
+        # "ref" above ~1e5 weights: the reference constructor takes ~32 us per weight, so the harness
+        # sizes the (zero-filled) members itself around the unmodified classes (fr_create_sized)
+        n_weights = n_feats * (n_fields * n_factors if self.model_type == FFM else
+                               n_factors if self.model_type == FM else 1)
+        ctor = "create_sized" if (kind == "ref" and n_weights > 100_000
+                                  and hasattr(self.lib, "fr_create_sized")) else "create"
+        self.h = getattr(self.lib, self.p + ctor)(self.model_type, n_feats, n_fields, n_factors,
+                                                  w_alpha, w_beta, w_l1, w_l2)
         self.row_len = int(getattr(self.lib, self.p + "row_len")(self.h))
         if learn:
             if kind != "oracle":
@@ -240,11 +254,11 @@ class CpuModel:
         return out, float(loss)
 
     def train_rows_threaded(self, c, n_threads):
-        """Reference-style threaded epoch (oracle only).  Returns (seconds, loss_sum)."""
-        assert self.kind == "oracle"
+        """Reference-style threaded epoch: the oracle's restatement, or (kind="ref") the reference's
+        own loop over its own model (ftrl_offline.cpp:63-91).  Returns (seconds, loss_sum)."""
         loss = ctypes.c_double(0.0)
-        sec = self.lib.fo_train_rows_threaded(self.h, int(n_threads), *self._csr_args(c),
-                                              ctypes.byref(loss))
+        fn = getattr(self.lib, self.p + "train_rows_threaded")
+        sec = fn(self.h, int(n_threads), *self._csr_args(c), ctypes.byref(loss))
         return float(sec), float(loss.value)
 
     # --- scalar helpers ---

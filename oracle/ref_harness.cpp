@@ -8,9 +8,12 @@
 //
 // The entry points mirror oracle/ffm_oracle.h one for one (fr_ instead of fo_), so the same
 // python wrapper drives either and tests compare them bit for bit.
+#include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "eval/loss.h"
@@ -91,6 +94,39 @@ void *fr_create(int model_type, int n_feats, int n_fields, int n_factors, float 
     m->model = std::make_unique<ftrl::LR>(opt);
     m->row_len = 0;
   }
+  return m;
+}
+
+// The same model at a size the reference's own constructor cannot reach in reasonable time (it
+// draws each of the n_feats*n_fields*n_factors weights from a fresh std::random_device, ~32 us
+// apiece -- 26 minutes for the CPU baseline's 50 M weights): construct the reference object with
+// ONE feature, then give its members the real size from here (possible because this harness is
+// built with -fno-access-control), exactly as its constructors would (ftrl_model.cpp:28-33,
+// ffm.cpp:19-27, fm.cpp:11-18) but zero-filled; callers inject the state with fr_set_state.  The
+// reference's train()/predict() code is untouched and runs on these members as on its own.
+void *fr_create_sized(int model_type, int n_feats, int n_fields, int n_factors, float w_alpha,
+                      float w_beta, float w_l1, float w_l2) {
+  auto *m = static_cast<fr_model *>(fr_create(model_type, 1, n_fields, n_factors, w_alpha, w_beta, w_l1, w_l2));
+  const size_t nf = static_cast<size_t>(n_feats);
+  ftrl::FtrlModel *b = m->model.get();
+  b->n_feats = n_feats;
+  b->lin_w.assign(nf, 0.0f);
+  b->lin_w_n.assign(nf, 0.0f);
+  b->lin_w_z.assign(nf, 0.0f);
+  b->lin_w_mutex = std::vector<std::mutex>(nf);
+  const size_t L = static_cast<size_t>(m->row_len);
+  if (m->ffm) {
+    m->ffm->vec_w.assign(nf, std::vector<float>(L, 0.0f));
+    m->ffm->vec_w_n.assign(nf, std::vector<float>(L, 0.0f));
+    m->ffm->vec_w_z.assign(nf, std::vector<float>(L, 0.0f));
+    m->ffm->vec_w_mutex = std::vector<std::shared_mutex>(nf);
+  } else if (m->fm) {
+    m->fm->vec_w.assign(nf, std::vector<float>(L, 0.0f));
+    m->fm->vec_w_n.assign(nf, std::vector<float>(L, 0.0f));
+    m->fm->vec_w_z.assign(nf, std::vector<float>(L, 0.0f));
+    m->fm->vec_w_mutex = std::vector<std::shared_mutex>(nf);
+  }
+  m->n_feats = n_feats;
   return m;
 }
 
@@ -182,6 +218,43 @@ double fr_train_rows(void *h, int n_rows, const int32_t *row_ptr, const int32_t 
     tmp_loss += loss(label[r], logit);
   }
   return tmp_loss;
+}
+
+// The reference's threaded epoch itself (src/task/ftrl_offline.cpp:63-91, the `use_pool == false`
+// branch: n_threads std::threads, contiguous chunks of rows, one shared model whose train() takes
+// its own per-feature locks), on rows parsed beforehand as Reader::data holds them.  Returns the
+// seconds spent in the loop -- what ftrl_offline.cpp:46-48 times; *loss_sum = sum of loss(y, logit).
+// The CPU baseline's speed is validated against this (tools/validate_cpu_baseline.py).
+double fr_train_rows_threaded(void *h, int n_threads, int n_rows, const int32_t *row_ptr,
+                              const int32_t *field, const int32_t *feat, const float *val,
+                              const int32_t *label, double *loss_sum) {
+  auto *m = static_cast<fr_model *>(h);
+  if (n_threads < 1) n_threads = 1;
+  std::vector<feat_vec> xs(static_cast<size_t>(n_rows));
+  for (int r = 0; r < n_rows; r++) {
+    const int b = row_ptr[r], e = row_ptr[r + 1];
+    xs[r] = make_row(e - b, field ? field + b : nullptr, feat + b, val + b);
+  }
+  const size_t total = static_cast<size_t>(n_rows);
+  const size_t unit = static_cast<size_t>(std::ceil(static_cast<double>(total) / n_threads));
+  std::vector<double> losses(static_cast<size_t>(n_threads), 0.0);
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> threads;
+  for (int i = 0; i < n_threads; i++) {
+    const size_t start = std::min(static_cast<size_t>(i) * unit, total);
+    const size_t end = std::min(start + unit, total);
+    threads.emplace_back([&, i, start, end] {
+      double tmp_loss = 0.0;
+      for (size_t r = start; r < end; r++) tmp_loss += loss(label[r], m->model->train(xs[r], label[r]));
+      losses[static_cast<size_t>(i)] = tmp_loss;
+    });
+  }
+  for (auto &t : threads) t.join();
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  double sum = 0.0;
+  for (double l : losses) sum += l;
+  if (loss_sum) *loss_sum = sum;
+  return sec;
 }
 
 double fr_predict_batch(void *h, int n_rows, const int32_t *row_ptr, const int32_t *field,

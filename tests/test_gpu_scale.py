@@ -321,3 +321,85 @@ def test_seeded_init_is_the_host_function_bit_for_bit():
     e3 = fa.Engine("FM", nf, 1, 8, init_mean=mean, init_stddev=sd, seed=seed)
     assert_bitwise(e3.get_state()["vec_w"].ravel(), fa.init_weights_host(seed, mean, sd, 1, 0, nf * 8), "FM vec_w")
     e3.close()
+
+
+def test_logloss_within_1e4_of_sequential_reference_at_39x16_blocks_of_8192():
+    """BASELINE.json's north-star bound at the headline shape: FFM F=39 k=16, reference default
+    hyper-parameters, fresh model, the host scheduler's block policy (block t = min(8192,
+    max(1, rows_seen // 32)) rows -- DESIGN.md "Block-size ramp"; 8192-row blocks from row 262144
+    on).  Mean train logloss (progressive, pre-update) and eval logloss (post-training predict on
+    held-out rows) stay within 1e-4 of the oracle's strictly sequential fo_train_rows -- the
+    reference's one-thread loop -- over 327 680 training rows."""
+    F, k, per = 39, 16, 2000
+    nf = F * per
+    n_train, n_eval, Bmax, ramp = 327_680, 32_768, 8192, 32
+    g = synth.Generator(F, nf, "zipf", seed=42)
+    train = g.block(n_train)
+    held = g.block(n_eval)
+    rng = np.random.default_rng(1)
+    o = CpuModel("oracle", "FFM", nf, F, k, **DEFAULT_HP)
+    st = o.zero_state()
+    st["lin_w"][...] = rng.normal(0, 0.02, st["lin_w"].shape).astype(np.float32)
+    st["vec_w"][...] = rng.normal(0, 0.02, st["vec_w"].shape).astype(np.float32)
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=Bmax, max_batch_nnz=Bmax * F,
+                  max_row_nnz=F, **DEFAULT_HP)
+    e.set_state(st)
+    del st
+    _, seq_train = o.train_rows(train)
+    _, seq_eval = o.predict_batch(held)
+    seen, tl, n_full = 0, 0.0, 0
+    while seen < n_train:
+        rows = min(Bmax, max(1, seen // ramp), n_train - seen)
+        e.train_batch_async(train.rows(seen, seen + rows))
+        n_full += rows == Bmax
+        seen += rows
+    tl = e.train_flush()
+    el = sum(e.predict_batch(held.rows(r0, min(r0 + Bmax, n_eval)))[1] for r0 in range(0, n_eval, Bmax))
+    e.close()
+    assert n_full >= 7  # the bound is exercised at full 8192-row blocks
+    d_train = tl / n_train - seq_train / n_train
+    d_eval = el / n_eval - seq_eval / n_eval
+    print("delta logloss: train %+.3e eval %+.3e (sequential %.6f / %.6f)" % (
+        d_train, d_eval, seq_train / n_train, seq_eval / n_eval))
+    assert abs(d_train) < 1e-4 and abs(d_eval) < 1e-4
+
+
+def test_staged_host_blocks_equal_block_by_block():
+    """ffm_engine_stage_batch + train_forward_staged + train_update_device (what a sharded rank
+    runs around its all-reduce, rows streaming host -> HBM inside the loop): the bits of
+    ffm_engine_train_batch called block by block; at most two staged blocks may wait."""
+    F, k, per = 8, 16, 50
+    nf = F * per
+    g = synth.Generator(F, nf, "zipf", seed=6)
+    blocks = [g.block(n) for n in (5, 256, 64, 256, 256, 1)]
+
+    def make():
+        e = fa.Engine("FFM", nf, F, k, max_batch_rows=256, seed=3, **STRESS_HP)
+        e.fill_state(seed=9)
+        return e
+
+    a = make()
+    ref_logits = [a.train_batch(b)[0] for b in blocks]
+    sa = a.get_state()
+    a.close()
+    b_ = make()
+    logit = torch.zeros(256, device="cuda")
+    got = []
+    b_.stage_batch(blocks[0])
+    for i, blk in enumerate(blocks):
+        if i + 1 < len(blocks):
+            b_.stage_batch(blocks[i + 1])
+        b_.train_forward_staged(logit.data_ptr())
+        b_.train_update_device(logit.data_ptr())
+        b_.sync()
+        got.append(logit[:blk.n_rows].cpu().numpy().copy())
+    for x, y in zip(got, ref_logits):
+        assert_bitwise(x, y, "staged logits")
+    assert_state_bitwise(b_.get_state(), sa, "staged host blocks")
+    b_.stage_batch(blocks[0])
+    b_.stage_batch(blocks[1])
+    with pytest.raises(fa.EngineError) as ei:
+        b_.stage_batch(blocks[2])
+    assert ei.value.code == -4
+    b_.close()

@@ -1,0 +1,113 @@
+"""The N > 1 path with real engines in separate processes (one GPU, two ranks, gloo): each rank
+creates its shard with the engine's OWN stream (stream=None -- the configuration ADVICE r01 flagged:
+the collective runs on torch's current stream, the engine on a private non-blocking one),
+ShardedStep orders the two, and the merged result must be the unsharded engine's.
+
+Tolerance: the cross-shard logit sum has a different association order than the reference's pair
+loop, so logits and everything downstream agree to rtol 2e-4 / atol 1e-6 (as in the in-process
+two-shard test); a missing stream wait shows up as garbage, not as rounding.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+F, K, PER, B, NBLK = 12, 8, 30, 4096, 4
+HP = dict(w_alpha=0.1, w_beta=1.0, w_l1=0.01, w_l2=0.1)
+
+
+class HostBounce:
+    """dist.all_reduce for a CUDA tensor through the host: .cpu() waits for torch's CURRENT stream
+    only, so partial logits still in flight on an unordered engine stream would be summed stale."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def get_world_size(self):
+        return self.dist.get_world_size()
+
+    def all_reduce(self, t):
+        c = t.cpu()
+        self.dist.all_reduce(c)
+        t.copy_(c, non_blocking=True)
+
+
+def _blocks():
+    from ftrl_ffm_amd import synth
+    g = synth.Generator(F, F * PER, "zipf", seed=12)
+    return [g.block(B) for _ in range(NBLK)]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import ftrl_ffm_amd as fa
+    from ftrl_ffm_amd import sharding
+    nf = F * PER
+    e = fa.Engine("FFM", nf, F, K, max_batch_rows=B, max_batch_nnz=B * F, n_shards=world,
+                  shard_rank=rank, seed=4, max_row_nnz=F, **HP)  # stream=None: the engine's own
+    e.fill_state(seed=6)
+    logit = torch.zeros(B, device="cuda")
+    step = sharding.ShardedStep(e, HostBounce(dist), logit)
+    outs = []
+    for blk in _blocks():
+        d = {k_: torch.from_numpy(getattr(blk, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+        # keep torch's current stream busy so that it runs well behind the engine's own stream
+        busy = torch.randn(2048, 2048, device="cuda")
+        for _ in range(4):
+            busy = busy @ busy * 1e-3
+        step(B, blk.nnz, d["row_ptr"].data_ptr(), d["field"].data_ptr(), d["feat"].data_ptr(),
+             d["val"].data_ptr(), d["label"].data_ptr())
+        e.sync()
+        outs.append(logit.cpu().numpy().copy())
+    st = e.get_state()
+    e.close()
+    q.put((rank, outs, {k_: st[k_] for k_ in ("vec_n", "vec_z", "lin_n", "lin_z", "bias3")}))
+    dist.destroy_process_group()
+
+
+def test_two_processes_two_shards_default_streams():
+    import ftrl_ffm_amd as fa
+    nf = F * PER
+    ref = fa.Engine("FFM", nf, F, K, max_batch_rows=B, max_batch_nnz=B * F, seed=4, max_row_nnz=F, **HP)
+    ref.fill_state(seed=6)
+    ref_logits = [ref.train_batch(b)[0] for b in _blocks()]
+    want = ref.get_state()
+    ref.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs, _ in res:
+        for got, exp in zip(outs, ref_logits):
+            np.testing.assert_allclose(got, exp, rtol=2e-4, atol=1e-6, err_msg="rank %d logits" % rank)
+    plan = fa.shard_plan(F, 2)
+    fld = np.arange(nf) // PER
+    owner = np.repeat(plan["pair_owner"][fld], K, axis=1)
+    for key in ("vec_n", "vec_z"):
+        merged = np.where(owner == 0, res[0][2][key], res[1][2][key])
+        np.testing.assert_allclose(merged, want[key], rtol=2e-4, atol=1e-6, err_msg=key)
+    lin_owner = plan["lin_owner"][fld]
+    for key in ("lin_n", "lin_z"):
+        merged = np.where(lin_owner == 0, res[0][2][key], res[1][2][key])
+        np.testing.assert_allclose(merged, want[key], rtol=2e-4, atol=1e-6, err_msg=key)
+    np.testing.assert_allclose(res[plan["bias_owner"]][2]["bias3"], want["bias3"], rtol=2e-4, atol=1e-6)

@@ -155,6 +155,35 @@ def test_oracle_vs_compiled_reference_random(model_type, hp):
 
 
 @needs_ref
+@pytest.mark.parametrize("model_type", ["FM", "FFM"])
+def test_sized_reference_model_behaves_as_the_constructed_one(model_type):
+    """The CPU baseline's reference model is sized by the harness around the unmodified classes
+    (fr_create_sized, above 1e5 weights): same bits as the oracle, i.e. as the reference's own
+    constructor + fr_set_state, on a shape just above that threshold; also its threaded loop
+    (the baseline's timed region) at one thread."""
+    rng = np.random.default_rng(99)
+    F, k, per = 13, 16, 60
+    nf = F * per if model_type == "FFM" else 7000
+    a = CpuModel("oracle", model_type, nf, F, k, **STRESS_HP)
+    b = CpuModel("ref", model_type, nf, F, k, **STRESS_HP)
+    st = rand_state(rng, a)
+    st["vec_n"] += np.float32(0.05)
+    a.set_state(st)
+    b.set_state(st)
+    rows = [[(f if model_type == "FFM" else 0, (f * per if model_type == "FFM" else f * 500) + int(rng.integers(0, per)),
+              float(np.float32(rng.random() + 0.1))) for f in range(F)] for _ in range(200)]
+    csr = Csr.from_rows(rows, list(rng.integers(0, 2, 200)))
+    la, lossa = a.train_rows(csr.rows(0, 100))
+    lb, lossb = b.train_rows(csr.rows(0, 100))
+    assert_bitwise(la, lb, "logits")
+    assert lossa == lossb
+    _, la2 = a.train_rows_threaded(csr.rows(100, 200), 1)
+    _, lb2 = b.train_rows_threaded(csr.rows(100, 200), 1)
+    assert la2 == lb2
+    assert_state_bitwise(a.get_state(), b.get_state(), model_type)
+
+
+@needs_ref
 def test_remove_out_range_rule():
     """tests/test_model.cpp:27-29 (LR keeps 1 of 3) and :46-48 (FFM drops all 3)."""
     import os

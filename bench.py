@@ -76,7 +76,8 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
         _, c = np.unique(f, return_counts=True)
         occ = {"single": c[c == 1].sum(), "small": c[(c > 1) & (c <= SMALL_MAX)].sum(),
                "hot": c[(c > SMALL_MAX) & (c <= HUGE_MIN)].sum(), "huge": c[c > HUGE_MIN].sum()}
-        key = next((kk for kk in ("single", "small", "huge") if kk in kernel), "hot")
+        key = ("huge" if "chain" in kernel or "huge" in kernel else
+               next((kk for kk in ("single", "small") if kk in kernel), "hot"))
         shares.append(occ[key] * per_occ * 8 / n_shards)
     return float(np.mean(shares))
 
@@ -438,7 +439,7 @@ def main():
                         "latent_update_single_kernel": "ffm_update_single_kernel",
                         "latent_update_kernel": "ffm_update_small_kernel",
                         "latent_update_hot_kernel": "ffm_update_hot_kernel",
-                        "latent_update_huge_kernel": "ffm_update_huge_kernel"}.get(nm)
+                        "latent_update_huge_kernel": "ffm_update_chain_kernel"}.get(nm)
                 if not full:
                     continue
                 us = float(parts[-1])

@@ -30,6 +30,7 @@
 #include "kernels_group.h"
 #include "kernels_row.h"
 #include "kernels_update.h"
+#include "kernels_chain.h"
 
 using namespace ftrl_dev;
 
@@ -309,6 +310,15 @@ struct ffm_engine {
   LAUNCH_ON(e, (e)->stream, kid, kernel, grid, block, shmem, __VA_ARGS__)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// The very-hot-feature chain kernels are instantiated per number of interleaved chains (groups of
+// 4 factors of a slot handled by one wave): 1, 2 or 4.
+static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows) {
+  const int groups = e->m.n_factors / 4;
+  if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+  else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+}
 
 extern "C" {
 
@@ -991,14 +1001,14 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
   };
   if (ffm && vec4 && e->serial) {
-    LAUNCH(e, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    launch_ffm_chain(e, e->stream, rows);
     LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks);
     launch_small();
   } else if (ffm && vec4) {
     // the three owner shapes touch disjoint features: run them side by side (long sequential
     // chains of the hot ones beside the bandwidth-shaped small-feature pass)
     HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, ffm_update_huge_kernel, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    launch_ffm_chain(e, e->aux3, rows);
     HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
     LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks);
@@ -1014,10 +1024,10 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // the very hot features' long chains on their own stream, lane = (factor, touch)
     if (forked) {
       HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-      LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, fm_update_huge_kernel, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     } else {
-      LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_huge_kernel, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     }
     LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1);
     if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
@@ -1172,7 +1182,7 @@ __global__ void loss_accumulate_kernel(double *acc, const double *one) { *acc +=
 static int slots_init(ffm_engine *e) {
   if (e->slots_ready) return FFM_OK;
   const size_t R = static_cast<size_t>(e->max_rows), E = static_cast<size_t>(e->max_nnz);
-  const size_t bytes = 4 * (R + 1) + 4 * E * 3 + 4 * R;
+  const size_t bytes = 4 * (R + 1) + 4 * E * 3 + 4 * R + 5 * 16;  // each of the 5 arrays is padded to 16 B
   for (auto &sl : e->slots) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.pinned), bytes, hipHostMallocDefault));
     int rc;
@@ -1371,7 +1381,7 @@ int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms
       name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +
              (best == K_LATENT_UPDATE ? (e->m.type == FFM_MODEL_FM ? "update_kernel" : "update_small_kernel")
               : best == K_LATENT_UPDATE_HOT ? "update_hot_kernel"
-              : best == K_LATENT_UPDATE_HUGE ? "update_huge_kernel"
+              : best == K_LATENT_UPDATE_HUGE ? "update_chain_kernel"
               : (best == K_ROW ? "row_kernel<train>" : "row_kernel<predict>"));
     std::snprintf(kernel_name, kernel_name_cap, "%s", name.c_str());
   }

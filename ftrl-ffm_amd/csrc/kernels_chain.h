@@ -1,0 +1,384 @@
+// kernels_chain.h -- the FTRL (n, z) update of VERY HOT features: those that occur in more than
+// kHugeMin rows of the block (FFM::update_vector_nz src/model/ffm.cpp:90-136 incl. :118, and
+// FM::update_vector_nz src/model/fm.cpp:80-101, applied to one element by hundreds of rows).
+//
+// A hot feature's touches form one sequential chain per element: n_t = n_{t-1} + g_t^2,
+// z_t = (z_{t-1} + g_t) - sigma_t * w, with sigma_t a function of n_{t-1}.  Only those two
+// recurrences are serial; the gradients, both square roots and the alpha divide of a touch depend
+// on n_{t-1} alone.  So the chain is laid across the lanes of a DPP row: lane = (element, touch),
+// 16 consecutive touches of 4 elements per wave step.  Per step:
+//   (1) parallel: gradient g, g^2 and the :118 product for all 16 touches;
+//   (2) serial:   running n by fifteen in-place `v_add_f32_dpp row_shr:1` steps -- lane t adds its
+//                 increment to its left neighbour's running value; lane 0 has no left neighbour in
+//                 its row, so the hardware leaves it alone (bound_ctrl off): it keeps
+//                 "carry + own increment".  After step r lanes 0..r hold the exact sequential
+//                 prefix, each addition rounded as the one-thread loop rounds it
+//                 (tools/dpp_probe.hip checks the bits against a scalar loop);
+//   (3) parallel: every touch's sigma * w from its n-before (the left neighbour's running n);
+//   (4) serial:   running z the same way, one fused DPP add and one subtract per touch;
+//   the carries into the next step come back to lane 0 with one row_mirror move.
+// A wave owns one whole slot (k = 16: four such chains, one per group of 4 factors) and issues the
+// four independent chains interleaved, so the DPP read-after-write wait states are filled with the
+// other chains' adds instead of s_nop.  Against the previous shape (4 touches per step, quad DPP)
+// the serial part per touch is the same three instructions, but the parallel part, the loads and
+// the wave votes are amortised over four times as many touches, and a chain of c touches takes
+// c/16 step latencies instead of c/4: the 1000-touch chains that used to set the update phase's
+// span (~430 us) finish in a few tens of microseconds.
+#pragma once
+#include "engine_types.h"
+
+namespace ftrl_dev {
+
+constexpr int kChainT = 16;  // touches per step = lanes of a DPP row
+
+#define FTRL_DPP_SHR " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define FTRL_REP15(x) x x x x x x x x x x x x x x x
+
+// G independent running sums, one per register, over the 16 lanes of every DPP row:
+// S[g] (lane t) <- S[g] (lane t-1) + q[g] (lane t), fifteen times; lane 0 of a row is never written.
+template <int G>
+__device__ __forceinline__ void row_chain_add(float (&S)[G], const float (&q)[G]);
+template <>
+__device__ __forceinline__ void row_chain_add<4>(float (&S)[4], const float (&q)[4]) {
+  asm volatile("s_nop 1\n\t" FTRL_REP15(
+                   "v_add_f32_dpp %0, %0, %4" FTRL_DPP_SHR "v_add_f32_dpp %1, %1, %5" FTRL_DPP_SHR
+                   "v_add_f32_dpp %2, %2, %6" FTRL_DPP_SHR "v_add_f32_dpp %3, %3, %7" FTRL_DPP_SHR)
+               : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3])
+               : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
+}
+template <>
+__device__ __forceinline__ void row_chain_add<2>(float (&S)[2], const float (&q)[2]) {
+  asm volatile("s_nop 1\n\t" FTRL_REP15("v_add_f32_dpp %0, %0, %2" FTRL_DPP_SHR
+                                        "v_add_f32_dpp %1, %1, %3" FTRL_DPP_SHR "s_nop 0\n\t")
+               : "+v"(S[0]), "+v"(S[1])
+               : "v"(q[0]), "v"(q[1]));
+}
+template <>
+__device__ __forceinline__ void row_chain_add<1>(float (&S)[1], const float (&q)[1]) {
+  asm volatile("s_nop 1\n\t" FTRL_REP15("v_add_f32_dpp %0, %0, %1" FTRL_DPP_SHR "s_nop 1\n\t")
+               : "+v"(S[0])
+               : "v"(q[0]));
+}
+
+// The z recurrence: Z (lane t) <- (Z (lane t-1) + ga (lane t)) - mc (lane t).  Lane 0 of a row skips
+// the add (no source lane) but not the subtract: callers pass mc = +0.0f there (x - +0.0f == x).
+template <int G>
+__device__ __forceinline__ void row_chain_addsub(float (&Z)[G], const float (&ga)[G],
+                                                 const float (&mc)[G]);
+template <>
+__device__ __forceinline__ void row_chain_addsub<4>(float (&Z)[4], const float (&ga)[4],
+                                                    const float (&mc)[4]) {
+  asm volatile("s_nop 1\n\t" FTRL_REP15(
+                   "v_add_f32_dpp %0, %0, %4" FTRL_DPP_SHR "v_add_f32_dpp %1, %1, %5" FTRL_DPP_SHR
+                   "v_add_f32_dpp %2, %2, %6" FTRL_DPP_SHR "v_add_f32_dpp %3, %3, %7" FTRL_DPP_SHR
+                   "v_sub_f32 %0, %0, %8\n\tv_sub_f32 %1, %1, %9\n\t"
+                   "v_sub_f32 %2, %2, %10\n\tv_sub_f32 %3, %3, %11\n\t")
+               : "+v"(Z[0]), "+v"(Z[1]), "+v"(Z[2]), "+v"(Z[3])
+               : "v"(ga[0]), "v"(ga[1]), "v"(ga[2]), "v"(ga[3]), "v"(mc[0]), "v"(mc[1]), "v"(mc[2]),
+                 "v"(mc[3]));
+}
+template <>
+__device__ __forceinline__ void row_chain_addsub<2>(float (&Z)[2], const float (&ga)[2],
+                                                    const float (&mc)[2]) {
+  asm volatile("s_nop 1\n\t" FTRL_REP15("v_add_f32_dpp %0, %0, %2" FTRL_DPP_SHR
+                                        "v_add_f32_dpp %1, %1, %3" FTRL_DPP_SHR
+                                        "v_sub_f32 %0, %0, %4\n\tv_sub_f32 %1, %1, %5\n\t")
+               : "+v"(Z[0]), "+v"(Z[1])
+               : "v"(ga[0]), "v"(ga[1]), "v"(mc[0]), "v"(mc[1]));
+}
+template <>
+__device__ __forceinline__ void row_chain_addsub<1>(float (&Z)[1], const float (&ga)[1],
+                                                    const float (&mc)[1]) {
+  asm volatile("s_nop 1\n\t" FTRL_REP15("v_add_f32_dpp %0, %0, %1" FTRL_DPP_SHR
+                                        "v_sub_f32 %0, %0, %2\n\ts_nop 1\n\t")
+               : "+v"(Z[0])
+               : "v"(ga[0]), "v"(mc[0]));
+}
+#undef FTRL_REP15
+#undef FTRL_DPP_SHR
+
+// every lane gets its left neighbour's value inside its DPP row; lane 0 of the row gets `first`
+__device__ __forceinline__ float row_left(float first, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v),
+                                                    0x111 /* row_shr:1 */, 0xf, 0xf, false));
+}
+// lane t of a row gets lane 15-t: what lane 0 reads is the row's last lane (the step's carry-out)
+__device__ __forceinline__ float row_mirror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140 /* row_mirror */,
+                                                    0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_first(float v) {  // lane 0 of my row, to every lane of the row
+  return __shfl(v, threadIdx.x & 48, 64);
+}
+
+// One step's worth of (3): sigma * w of every touch from its n-before, in the short exact forms
+// when one wave vote says every operand is comfortably normal (ftrl_math.h), else IEEE.
+template <int G>
+__device__ __forceinline__ void chain_sigma_w(const Hyper &h, const float (&nb)[G],
+                                              const float (&arg0)[G], const bool (&simple)[G],
+                                              const float (&w)[G], float (&mm)[G]) {
+  bool ok = h.fast_div != 0;
+#pragma unroll
+  for (int g = 0; g < G; g++) ok = ok && chain_operand_ok(arg0[g]) && chain_operand_ok(nb[g]);
+  if (__all(ok)) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const float d = sqrt_fast(arg0[g]) - sqrt_fast(nb[g]);
+      mm[g] = div_alpha_fast(h, simple[g] ? d : 0.0f) * w[g];
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const float d = sqrtf(arg0[g]) - sqrtf(nb[g]);
+      mm[g] = ((simple[g] ? d : 0.0f) / h.alpha) * w[g];
+    }
+  }
+}
+
+// ---- FFM ------------------------------------------------------------------------------------
+// Work item = (very hot feature, slot of its record, pass over G groups of 4 factors of the slot);
+// one wave per item.  Lane: tl = touch inside the step (DPP row position), el = factor inside a
+// group.  Touch facts come as the occurrence-ordered streams the row kernel wrote (s.haux, s.hmeta),
+// prefetched two steps ahead; the partner weights one step ahead.
+template <int G>
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev m, Rows rows,
+                                                                       Scratch s) {
+  const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & (kChainT - 1), el = lane >> 4;
+  const bool l0 = tl == 0;
+  const int groups = k >> 2;                    // groups of 4 factors per slot
+  const int passes = (groups + G - 1) / G;      // 1 for k <= 16
+  const int slots = record_span(m, 1);          // slots walked per record
+  const unsigned per_feat = static_cast<unsigned>(slots) * passes;
+  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = gridDim.x * kUpdWaves;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * per_feat;
+  const size_t rec_floats = static_cast<size_t>(3) * RL;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned li = item / per_feat;
+    const int rem = static_cast<int>(item - li * per_feat);
+    const int sc = rem / passes, pass = rem - sc * passes;
+    const int u = wave_uniform(s.huge[li]);
+    const int fp = wave_uniform(record_index(m, wave_uniform(s.ufield[u]), sc, 1));  // partner field
+    if (fp < 0) continue;
+    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    if (s.gmask && !((s.gmask[start] >> fp) & 1ull)) continue;  // no row of the block touches the slot
+    const int i = wave_uniform(s.uniq[u]);
+    float *rec = lat_row(m, i);
+    int kk[G];
+    bool act[G];
+    float nc[G], zc[G], w[G];  // carries: valid in lane 0 of every row
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int grp = pass * G + g;
+      act[g] = grp < groups;
+      kk[g] = (act[g] ? grp : 0) * 4 + el;
+      nc[g] = rec[LAT_N * RL + fp * k + kk[g]];
+      zc[g] = rec[LAT_Z * RL + fp * k + kk[g]];
+      w[g] = rec[LAT_W * RL + fp * k + kk[g]];
+    }
+    const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;  // + t*F
+    const float2 *mcol = s.hmeta + start;                              // + t
+    const float *wcol = m.lat + LAT_W * RL;                            // + feat*rec + field*k + kk
+    const int steps = (c + kChainT - 1) / kChainT;
+
+    // pipeline: facts two steps ahead, partner weights one step ahead
+    int4 ax = acol[static_cast<int64_t>(min(tl, c - 1)) * F];
+    float2 mt = mcol[min(tl, c - 1)];
+    int4 axN = acol[static_cast<int64_t>(min(kChainT + tl, c - 1)) * F];
+    float2 mtN = mcol[min(kChainT + tl, c - 1)];
+    float vp[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) vp[g] = m.lat[haux_offset(ax.z, ax.w) + kk[g]];
+    for (int st = 0; st < steps; st++) {
+      const int t = st * kChainT + tl;
+      float vpN[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) vpN[g] = m.lat[haux_offset(axN.z, axN.w) + kk[g]];  // step st+1
+      const int tNN = min((st + 2) * kChainT + tl, c - 1);                              // step st+2
+      const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
+      const float2 mtNN = mcol[tNN];
+
+      const int fl = ax.y;
+      const bool live = t < c && owns_pair(m, fl >> 8, fp);
+      const bool smp = live & ((fl & HF_SIMPLE) != 0);
+      if (!__any(live & ((fl & HF_CHAIN) != 0))) {
+        const bool first = (fl & HF_FIRST) || m.h.learn;
+        const float tg = mt.x;
+        const float x = mt.y * __int_as_float(ax.x);  // x_own*x_other or x_other*x_own: same product
+        float g1v[G], q[G], S[G], ga[G], arg0[G], nb[G], mm[G], mc[G], Z[G];
+        bool simple[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          simple[g] = smp && act[g];
+          const float gr = tg * vp[g] * x;  // own slot's gradient (g1 if own entry first, else g2)
+          const float g1 = tg * w[g] * x;   // second-entry case: the first entry's gradient
+          const float gg = gr * gr;
+          g1v[g] = first ? gg : gr * g1;    // what the square root sees added to n (ffm.cpp:113 / :118)
+          ga[g] = simple[g] ? gr : -0.0f;
+          q[g] = simple[g] ? gg : -0.0f;    // x + -0.0f == x bit for bit: idle touches apply nothing
+          S[g] = nc[g] + q[g];              // lane 0: n after its touch
+        }
+        row_chain_add<G>(S, q);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          nb[g] = row_left(nc[g], S[g]);    // n before this touch
+          arg0[g] = nb[g] + g1v[g];
+          nc[g] = row_mirror(S[g]);         // lane 0: the row's last running n
+        }
+        chain_sigma_w<G>(m.h, nb, arg0, simple, w, mm);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          const float ms = simple[g] ? mm[g] : 0.0f;
+          mc[g] = l0 ? 0.0f : ms;
+          Z[g] = (zc[g] + ga[g]) - ms;      // lane 0: z after its touch
+        }
+        row_chain_addsub<G>(Z, ga, mc);
+#pragma unroll
+        for (int g = 0; g < G; g++) zc[g] = row_mirror(Z[g]);
+      } else {
+        // a multi-valued field somewhere in this step: its 16 touches one after another, every
+        // lane of the row applying them to its own copy of the running (n, z)
+#pragma unroll
+        for (int g = 0; g < G; g++) { nc[g] = row_first(nc[g]); zc[g] = row_first(zc[g]); }
+        for (int tt = 0; tt < kChainT; tt++) {
+          const int src = (lane & ~(kChainT - 1)) | tt;
+          const int flt = __shfl(fl, src, 64);
+          const float xot = __shfl(__int_as_float(ax.x), src, 64);
+          const float tgt = __shfl(mt.x, src, 64), xmt = __shfl(mt.y, src, 64);
+          float vpt[G];
+#pragma unroll
+          for (int g = 0; g < G; g++) vpt[g] = __shfl(vp[g], src, 64);
+          const int fm = flt >> 8;
+          if (st * kChainT + tt >= c || !owns_pair(m, fm, fp)) continue;
+          if (flt & HF_SIMPLE) {
+#pragma unroll
+            for (int g = 0; g < G; g++)
+              ffm_touch(m.h, flt & HF_FIRST, tgt, xmt, xot, vpt[g], w[g], nc[g], zc[g]);
+          } else if (flt & HF_CHAIN) {
+            const int pt = s.occ2[start + st * kChainT + tt].x;  // the touch's own entry
+            const int r = s.row_of[pt];
+            for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+              if (qq == pt) continue;
+              const float xq = rows.val[qq];
+#pragma unroll
+              for (int g = 0; g < G; g++) {
+                const float vq = wcol[rows.feat[qq] * rec_floats + fm * k + kk[g]];
+                ffm_touch(m.h, pt < qq, tgt, xmt, xq, vq, w[g], nc[g], zc[g]);
+              }
+            }
+          }
+        }
+      }
+      ax = axN; mt = mtN;
+      axN = axNN; mtN = mtNN;
+#pragma unroll
+      for (int g = 0; g < G; g++) vp[g] = vpN[g];
+    }
+    if (l0) {
+#pragma unroll
+      for (int g = 0; g < G; g++)
+        if (act[g]) {
+          rec[LAT_N * RL + fp * k + kk[g]] = nc[g];
+          rec[LAT_Z * RL + fp * k + kk[g]] = zc[g];
+        }
+    }
+  }
+}
+
+// ---- FM -------------------------------------------------------------------------------------
+// The same shape for FM::update_vector_nz (fm.cpp:80-101): work item = (very hot feature, pass over
+// 16 of its factors); the per-touch inputs are the row's value, tmp_grad and factor sum (s.svx).
+template <int G>
+__global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m, Rows rows,
+                                                                      Scratch s) {
+  const int k = m.n_factors;
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & (kChainT - 1), el = lane >> 4;
+  const bool l0 = tl == 0;
+  const int groups = (k + 3) >> 2;
+  const unsigned passes = (groups + G - 1) / G;
+  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = gridDim.x * kUpdWaves;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * passes;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned li = item / passes;
+    const int pass = static_cast<int>(item - li * passes);
+    const int u = wave_uniform(s.huge[li]);
+    const int i = wave_uniform(s.uniq[u]);
+    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    float *rec = lat_row(m, i);
+    int kk[G];
+    bool act[G];
+    float nc[G], zc[G], w[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int e = (pass * G + g) * 4 + el;
+      act[g] = e < k;
+      kk[g] = act[g] ? e : 0;
+      nc[g] = rec[LAT_N * k + kk[g]];
+      zc[g] = rec[LAT_Z * k + kk[g]];
+      w[g] = rec[LAT_W * k + kk[g]];
+    }
+    const int2 *ocol = s.occ2 + start;
+    const int steps = (c + kChainT - 1) / kChainT;
+    // pipeline: {entry, row} two steps ahead; value, tmp_grad and the row's factor sums one ahead
+    int2 pr = ocol[min(tl, c - 1)];
+    int2 prN = ocol[min(kChainT + tl, c - 1)];
+    float x = rows.val[pr.x], tg = s.tg[pr.y];
+    float sv[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) sv[g] = s.svx[static_cast<int64_t>(pr.y) * k + kk[g]];
+    for (int st = 0; st < steps; st++) {
+      const int t = st * kChainT + tl;
+      const float xN = rows.val[prN.x], tgN = s.tg[prN.y];
+      float svN[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) svN[g] = s.svx[static_cast<int64_t>(prN.y) * k + kk[g]];
+      const int2 prNN = ocol[min((st + 2) * kChainT + tl, c - 1)];
+      const bool live = t < c;
+      float q[G], S[G], ga[G], arg0[G], nb[G], mm[G], mc[G], Z[G];
+      bool simple[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        simple[g] = live && act[g];
+        const float gr = tg * (x * sv[g] - w[g] * x * x);  // fm.cpp:84-95
+        const float gg = gr * gr;
+        ga[g] = simple[g] ? gr : -0.0f;
+        q[g] = simple[g] ? gg : -0.0f;
+        arg0[g] = gg;
+        S[g] = nc[g] + q[g];
+      }
+      row_chain_add<G>(S, q);
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        nb[g] = row_left(nc[g], S[g]);
+        arg0[g] = nb[g] + arg0[g];
+        nc[g] = row_mirror(S[g]);
+      }
+      chain_sigma_w<G>(m.h, nb, arg0, simple, w, mm);
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const float ms = simple[g] ? mm[g] : 0.0f;
+        mc[g] = l0 ? 0.0f : ms;
+        Z[g] = (zc[g] + ga[g]) - ms;
+      }
+      row_chain_addsub<G>(Z, ga, mc);
+#pragma unroll
+      for (int g = 0; g < G; g++) { zc[g] = row_mirror(Z[g]); sv[g] = svN[g]; }
+      pr = prN; x = xN; tg = tgN;
+      prN = prNN;
+    }
+    if (l0) {
+#pragma unroll
+      for (int g = 0; g < G; g++)
+        if (act[g]) {
+          rec[LAT_N * k + kk[g]] = nc[g];
+          rec[LAT_Z * k + kk[g]] = zc[g];
+        }
+    }
+  }
+}
+
+}  // namespace ftrl_dev

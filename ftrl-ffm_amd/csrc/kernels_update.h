@@ -102,236 +102,11 @@ __device__ __forceinline__ void ffm_touch4(const Hyper &h, bool own_first, float
   z4 = make_float4(z[0], z[1], z[2], z[3]);
 }
 
-// ---- very hot features (more than kHugeMin occurrences) ----------------------------------
-// A hot feature's touches form one long sequential chain per element.  A wave that walks such a
-// chain one touch at a time runs at the LATENCY of ~100 dependent instructions per touch (measured
-// 0.45 us per touch: a feature present in 1100 rows of the block then costs 0.5 ms on its own).
-// So the chain is laid across lanes instead: a wave owns 8 elements of the record and applies 8
-// consecutive touches per step, lane = (element, touch).  Everything that does not depend on the
-// running accumulators -- gradients, the two square roots, the alpha divide -- is one instruction
-// for all 8 touches at once; the running n and z are strictly left-to-right prefix chains over
-// the 8 touch lanes of each element (7 DPP shift-right-by-one steps: step s finalises lane s, lanes
-// already final recompute the same value), i.e. exactly the additions the one-thread loop performs,
-// in its order.  Touch facts come as contiguous streams laid out by occurrence position (s.haux
-// from the row kernel, s.hmeta), prefetched two steps ahead; partner weights one step ahead.
-constexpr int kHotT = 4;             // touches per step (lanes per element)
-constexpr int kHotE = 64 / kHotT;    // elements per wave
-constexpr int kHotTShift = 2;        // log2(kHotT)
-
-// quad (4 consecutive lanes) moves: every lane gets its left neighbour's value, lane 0 its own;
-// every lane gets lane 3's value
-__device__ __forceinline__ float quad_left(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x90 /* quad_perm:[0,0,1,2] */,
-                                                    0xf, 0xf, false));
-}
-__device__ __forceinline__ float quad_last(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xff /* quad_perm:[3,3,3,3] */,
-                                                    0xf, 0xf, false));
-}
+// (Very hot features -- more than kHugeMin occurrences -- are kernels_chain.h's.)
 
 __device__ __forceinline__ float dpp_row_shr1(float keep, float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v),
                                                     0x111 /* row_shr:1 */, 0xf, 0xf, false));
-}
-
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_huge_kernel(ModelDev m, Rows rows,
-                                                                      Scratch s) {
-  const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
-  const unsigned groups = (record_span(m, k) + kHotE - 1) / kHotE;
-  const int lane = threadIdx.x & 63;
-  const int tl = lane & (kHotT - 1);  // which of the step's touches
-  const int el = lane >> kHotTShift;  // which of the wave's elements
-  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const unsigned n_waves = gridDim.x * kUpdWaves;
-  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * groups;
-  const float inv_k = 1.0f / static_cast<float>(k);
-  const size_t rec_floats = static_cast<size_t>(3) * RL;
-  for (unsigned item = wave; item < n_items; item += n_waves) {
-    const unsigned li = item / groups;
-    const int u = wave_uniform(s.huge[li]);
-    const int e = record_index(m, wave_uniform(s.ufield[u]), static_cast<int>(item - li * groups) * kHotE + el, k);
-    const bool active = e >= 0;
-    const int ee = active ? e : 0;
-    int fp = static_cast<int>((ee + 0.5f) * inv_k);  // this lane's partner field
-    fp += (fp + 1) * k <= ee ? 1 : (fp * k > ee ? -1 : 0);
-    const int kk = ee - fp * k;  // and factor
-    const int i = wave_uniform(s.uniq[u]);
-    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
-    float *rec = lat_row(m, i);
-    float nc = rec[LAT_N * RL + ee], zc = rec[LAT_Z * RL + ee];  // running (n, z) of element e
-    const float w = rec[LAT_W * RL + ee];
-    const float *wcol = m.lat + LAT_W * RL + kk;                       // + feat*rec + field*k
-    const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;  // + t*F
-    const float2 *mcol = s.hmeta + start;                              // + t
-    const int steps = (c + kHotT - 1) / kHotT;
-    bool touched = false;
-
-    // pipeline: facts two steps ahead, partner weight one step ahead
-    int4 ax = acol[static_cast<int64_t>(min(tl, c - 1)) * F];
-    float2 mt = mcol[min(tl, c - 1)];
-    int4 axN = acol[static_cast<int64_t>(min(kHotT + tl, c - 1)) * F];
-    float2 mtN = mcol[min(kHotT + tl, c - 1)];
-    float vp = m.lat[haux_offset(ax.z, ax.w) + kk];
-    for (int st = 0; st < steps; st++) {
-      const int t = st * kHotT + tl;
-      const float vpN = m.lat[haux_offset(axN.z, axN.w) + kk];  // weights of step st+1
-      const int tNN = min((st + 2) * kHotT + tl, c - 1);                  // facts of step st+2
-      const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
-      const float2 mtNN = mcol[tNN];
-
-      const int fl = ax.y;
-      const bool live = t < c && active && owns_pair(m, fl >> 8, fp);
-      const bool simple = live & ((fl & HF_SIMPLE) != 0);
-      if (!__any(live & ((fl & HF_CHAIN) != 0))) {
-        const bool first = fl & HF_FIRST;
-        const float tg = mt.x;
-        const float x = mt.y * __int_as_float(ax.x);  // x_own*x_other or x_other*x_own: same product
-        const float g = tg * vp * x;   // own slot's gradient (g1 if own entry first, else g2)
-        const float g1 = tg * w * x;   // second-entry case: the first entry's gradient
-        const float gg = g * g;
-        // Running n and z are strictly left-to-right chains over the quad's four touch lanes.  One
-        // chain step is "take the left neighbour's value, apply my touch": a quad-permuted add in
-        // which lane 0 re-reads ITSELF and applies nothing (+ -0.0f, - +0.0f leave every float,
-        // either zero included, bit for bit), so no lane needs masking; lanes already final
-        // recompute the same value.  Idle touches apply nothing either.
-        const bool l0 = tl == 0;
-        const float q = simple ? gg : -0.0f;
-        const float qc = l0 ? -0.0f : q;
-        float S = nc + q;  // lane 0: n after its touch
-#pragma unroll
-        for (int r = 1; r < kHotT; r++) S = quad_left(S) + qc;
-        const float left = quad_left(S);
-        const float nb = l0 ? nc : left;  // n before this touch
-        nc = quad_last(S);
-        const float arg0 = nb + ((first || m.h.learn) ? gg : g * g1);  // ffm.cpp:113 / :118
-        // both square roots and the alpha divide in their short exact forms when every lane's
-        // operands are comfortably normal (ftrl_math.h: chain_operand_ok), else IEEE
-        float sg;
-        if (__all(m.h.fast_div && chain_operand_ok(arg0) && chain_operand_ok(nb))) {
-          const float d = sqrt_fast(arg0) - sqrt_fast(nb);
-          sg = div_alpha_fast(m.h, simple ? d : 0.0f);
-        } else {
-          const float d = sqrtf(arg0) - sqrtf(nb);
-          sg = (simple ? d : 0.0f) / m.h.alpha;
-        }
-        const float mm = sg * w;
-        // running z: z' = (z + g) - sigma*w per live touch
-        const float ga = simple ? g : -0.0f, ms = simple ? mm : 0.0f;
-        const float gc = l0 ? -0.0f : ga, mc = l0 ? 0.0f : ms;
-        float Z = (zc + ga) - ms;  // lane 0: z after its touch
-#pragma unroll
-        for (int r = 1; r < kHotT; r++) Z = (quad_left(Z) + gc) - mc;
-        zc = quad_last(Z);
-        touched = touched | simple;
-      } else {
-        // a multi-valued field in this step: its 8 touches one after another, every lane of an
-        // element's group applying them to its copy of the running (n, z)
-        for (int tt = 0; tt < kHotT; tt++) {
-          const int src = (lane & ~(kHotT - 1)) | tt;
-          const int flt = __shfl(fl, src, 64);
-          const int pt = s.occ2[start + min(st * kHotT + tt, c - 1)].x;  // the touch's own entry
-          const float xot = __shfl(__int_as_float(ax.x), src, 64);
-          const float tgt = __shfl(mt.x, src, 64), xmt = __shfl(mt.y, src, 64);
-          const float vpt = __shfl(vp, src, 64);
-          const int fm = flt >> 8;
-          if (st * kHotT + tt >= c || !active || !owns_pair(m, fm, fp)) continue;
-          if (flt & HF_SIMPLE) {
-            ffm_touch(m.h, flt & HF_FIRST, tgt, xmt, xot, vpt, w, nc, zc);
-            touched = true;
-          } else if (flt & HF_CHAIN) {
-            const int r = s.row_of[pt];
-            for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
-              if (qq == pt) continue;
-              const float vq = wcol[rows.feat[qq] * rec_floats + fm * k];
-              ffm_touch(m.h, pt < qq, tgt, xmt, rows.val[qq], vq, w, nc, zc);
-              touched = true;
-            }
-          }
-        }
-      }
-      ax = axN; mt = mtN; vp = vpN;
-      axN = axNN; mtN = mtNN;
-    }
-    // any of the element's four touch lanes touched it?
-    const unsigned long long tm = __ballot(touched);
-    if (((tm >> (el * kHotT)) & ((1ull << kHotT) - 1ull)) != 0ull && active && tl == 0) {
-      rec[LAT_N * RL + ee] = nc;
-      rec[LAT_Z * RL + ee] = zc;
-    }
-  }
-}
-
-// FM, very hot features (more than kHugeMin occurrences): the lane = (factor, touch) shape of
-// ffm_update_huge_kernel -- 16 factors x 4 consecutive touches per step, the running n and z as
-// left-to-right chains over the DPP quad -- for FM::update_vector_nz (fm.cpp:80-101).  One wave
-// walking such a chain touch by touch is what the whole FM update used to wait for.
-__global__ __launch_bounds__(kUpdThreads) void fm_update_huge_kernel(ModelDev m, Rows rows,
-                                                                     Scratch s) {
-  const int k = m.n_factors;
-  const unsigned groups = (k + kHotE - 1) / kHotE;
-  const int lane = threadIdx.x & 63;
-  const int tl = lane & (kHotT - 1), el = lane >> kHotTShift;
-  const bool l0 = tl == 0;
-  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const unsigned n_waves = gridDim.x * kUpdWaves;
-  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * groups;
-  for (unsigned item = wave; item < n_items; item += n_waves) {
-    const unsigned li = item / groups;
-    const int u = wave_uniform(s.huge[li]);
-    const int e = static_cast<int>(item - li * groups) * kHotE + el;
-    const bool active = e < k;
-    const int ee = active ? e : 0;
-    const int i = wave_uniform(s.uniq[u]);
-    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
-    float *rec = lat_row(m, i);
-    float nc = rec[LAT_N * k + ee], zc = rec[LAT_Z * k + ee];
-    const float w = rec[LAT_W * k + ee];
-    const int2 *ocol = s.occ2 + start;
-    const int steps = (c + kHotT - 1) / kHotT;
-    // pipeline: {entry, row} two steps ahead; value, tmp_grad and the row's factor sum one ahead
-    int2 pr = ocol[min(tl, c - 1)];
-    int2 prN = ocol[min(kHotT + tl, c - 1)];
-    float x = rows.val[pr.x], tg = s.tg[pr.y], sv = s.svx[static_cast<int64_t>(pr.y) * k + ee];
-    for (int st = 0; st < steps; st++) {
-      const int t = st * kHotT + tl;
-      const float xN = rows.val[prN.x], tgN = s.tg[prN.y];
-      const float svN = s.svx[static_cast<int64_t>(prN.y) * k + ee];
-      const int2 prNN = ocol[min((st + 2) * kHotT + tl, c - 1)];
-      const bool live = t < c && active;
-      const float g = tg * (x * sv - w * x * x);  // fm.cpp:84-95
-      const float gg = g * g;
-      const float q = live ? gg : -0.0f;
-      const float qc = l0 ? -0.0f : q;
-      float S = nc + q;
-#pragma unroll
-      for (int r = 1; r < kHotT; r++) S = quad_left(S) + qc;
-      const float left = quad_left(S);
-      const float nb = l0 ? nc : left;  // n before this touch
-      nc = quad_last(S);
-      const float arg0 = nb + gg;
-      float sg;
-      if (__all(m.h.fast_div && chain_operand_ok(arg0) && chain_operand_ok(nb))) {
-        const float d = sqrt_fast(arg0) - sqrt_fast(nb);
-        sg = div_alpha_fast(m.h, live ? d : 0.0f);
-      } else {
-        const float d = sqrtf(arg0) - sqrtf(nb);
-        sg = (live ? d : 0.0f) / m.h.alpha;
-      }
-      const float mm = sg * w;
-      const float ga = live ? g : -0.0f, ms = live ? mm : 0.0f;
-      const float gc = l0 ? -0.0f : ga, mc = l0 ? 0.0f : ms;
-      float Z = (zc + ga) - ms;
-#pragma unroll
-      for (int r = 1; r < kHotT; r++) Z = (quad_left(Z) + gc) - mc;
-      zc = quad_last(Z);
-      pr = prN; x = xN; tg = tgN; sv = svN;
-      prN = prNN;
-    }
-    if (active && l0) {
-      rec[LAT_N * k + ee] = nc;
-      rec[LAT_Z * k + ee] = zc;
-    }
-  }
 }
 
 // Strictly left-to-right running sum over the 64 lanes: returns S_j = ((carry + a_0) + a_1) ... + a_j

@@ -244,7 +244,26 @@ static void ffm_update_vector_nz(fo_model *m, const rowview *rv, float tmp_grad)
       const int field2 = RV_FIELD(rv, b), j = RV_FEAT(rv, b);
       const float x = RV_VAL(rv, a) * RV_VAL(rv, b);
       const int64_t o1 = i * L + (int64_t)field2 * k, o2 = j * L + (int64_t)field1 * k;
-      if (k <= 256) {
+      if (o1 == o2) {
+        /* The same (field, id) twice in one row: both sides of the pair are ONE slot.  The
+         * reference never gets here -- std::scoped_lock on the same mutex twice (ffm.cpp:99-101,
+         * :124) deadlocks, SURVEY.md section 0 item 3 -- so nothing pins this case; the block
+         * algorithm's rule applies: every touch of a slot is applied in order to the running
+         * (n, z): first the pair's i-side step (:112-115), then its j-side step (:117-120) on the
+         * result, with w frozen. */
+        for (int f = 0; f < k; f++) {
+          const float w = m->vec_w[o1 + f];
+          const float g = tmp_grad * w * x; /* g1 == g2: both partner weights are this slot's */
+          float nn = m->vec_n[o1 + f], zz = m->vec_z[o1 + f];
+          const float s1 = (sqrtf(nn + g * g) - sqrtf(nn)) / m->w_alpha;
+          zz = zz + g - s1 * w;
+          nn = nn + g * g;
+          const float s2 = (sqrtf(nn + g * g) - sqrtf(nn)) / m->w_alpha;
+          zz = zz + g - s2 * w;
+          nn = nn + g * g;
+          m->vec_n[o1 + f] = nn; m->vec_z[o1 + f] = zz;
+        }
+      } else if (k <= 256) {
         /* read phase into temporaries, then copy back (ffm.cpp:96-132) */
         for (int f = 0; f < k; f++) {
           tn1[f] = m->vec_n[o1 + f]; tz1[f] = m->vec_z[o1 + f];

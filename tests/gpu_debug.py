@@ -1,44 +1,42 @@
-import os, sys
+"""Scratch diagnostics for a failing GPU parity case (not collected by pytest)."""
+import sys, os
 import numpy as np
+import torch  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
 import ftrl_ffm_amd as fa
-from ftrl_ffm_amd import synth
-from oracle.pyoracle import CpuModel
-from util import DEFAULT_HP, STRESS_HP, rand_state, bits
-mt, F, k, nf, B = "FFM", 8, 16, 10000, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-per = nf // F
-hp = DEFAULT_HP
-e = fa.Engine(mt, nf, F, k, max_batch_rows=B, max_batch_nnz=B * F, seed=11, **hp)
-e.fill_state(seed=5, n_lo=0.05, n_hi=1.0, z_stddev=0.3)
-st = e.get_state()
-o = CpuModel("oracle", mt, nf, F, k, **hp)
-o.set_state(st)
-g = synth.Generator(F, nf, "zipf", seed=42)
-for it in range(2):
-    sub = g.block(B)
-    lo, _ = o.train_batch(sub); lg, _ = e.train_batch(sub)
-    so, sg = o.get_state(), e.get_state()
-    bad = False
-    dl = np.flatnonzero(bits(lo) != bits(lg))
-    print("block", it, "logit mismatches", len(dl), dl[:10])
-    for key in ("bias3", "vec_n", "vec_z", "vec_w", "lin_n", "lin_z", "lin_w"):
-        d = np.argwhere(bits(so[key]) != bits(sg[key]))
-        if len(d):
-            bad = True
-            print("block", it, key, "mismatches", len(d))
-            for idx in d[:8]:
-                idx = tuple(idx)
-                if len(idx) == 2:
-                    feat, el = idx
-                    c = int((sub.feat == feat).sum())
-                    print("   feat", feat, "field", feat // per, "el", el, "fp", el // k, "kk", el % k,
-                          "count in block", c, "got", sg[key][idx], "want", so[key][idx], "init", st[key][idx])
-                else:
-                    c = int((sub.feat == idx[0]).sum()) if key.startswith("lin") else -1
-                    print("   ", idx, "count", c, sg[key][idx], so[key][idx])
-    if bad or len(dl):
-        break
-else:
-    print("all blocks match")
+from oracle.pyoracle import CpuModel, Csr
+from util import STRESS_HP, rand_state
+
+def run(dup_mode):
+    rng = np.random.default_rng(31)
+    F, k, per = 6, 8, 5
+    nf = F * per
+    rows, labels = [], []
+    for r in range(100):
+        row = [(f, f * per + int(rng.integers(0, per)), float(np.float32(rng.random() + 0.3)))
+               for f in range(F) if rng.random() < 0.8]
+        if dup_mode in (1, 3) and row and r % 3 == 0:
+            j = int(rng.integers(0, len(row)))
+            row.append(row[j])
+        if dup_mode in (2, 3) and len(row) > 2 and r % 5 == 0:
+            row.append(((row[0][0] + 1) % F, row[1][1], 0.7))
+        rows.append(row); labels.append(int(rng.integers(0, 2)))
+    csr = Csr.from_rows(rows, labels)
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o); st["vec_n"] += np.float32(0.05); o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=128, max_row_nnz=2 * F + 2, **STRESS_HP)
+    e.set_state(st)
+    lo, _ = o.train_batch(csr); lg, _ = e.train_batch(csr)
+    bad = np.flatnonzero(lo.view(np.uint32) != lg.view(np.uint32))
+    print("mode", dup_mode, "bad logits", bad.size, bad[:10])
+    so, se = o.get_state(), e.get_state()
+    for key in ("vec_w", "lin_w", "vec_n", "vec_z"):
+        d = np.argwhere(so[key].view(np.uint32) != se[key].view(np.uint32))
+        print(" ", key, "differs at", len(d), d[:8].tolist())
+    for r in bad[:3]:
+        print("  row", r, rows[r])
+    e.close()
+
+for mode in (0, 1, 2, 3):
+    run(mode)

@@ -4,8 +4,8 @@ the collective runs on torch's current stream, the engine on a private non-block
 ShardedStep orders the two, and the merged result must be the unsharded engine's.
 
 Tolerance: the cross-shard logit sum has a different association order than the reference's pair
-loop, so logits and everything downstream agree to rtol 2e-4 / atol 1e-6 (as in the in-process
-two-shard test); a missing stream wait shows up as garbage, not as rounding.
+loop, so logits and everything downstream agree to rtol 2e-4 / atol 2e-5 (logits of magnitude ~5
+summed from ~70 terms in another order); a missing stream wait shows up as garbage, not rounding.
 """
 import os
 import sys
@@ -99,15 +99,15 @@ def test_two_processes_two_shards_default_streams():
         assert p.exitcode == 0
     for rank, outs, _ in res:
         for got, exp in zip(outs, ref_logits):
-            np.testing.assert_allclose(got, exp, rtol=2e-4, atol=1e-6, err_msg="rank %d logits" % rank)
+            np.testing.assert_allclose(got, exp, rtol=2e-4, atol=2e-5, err_msg="rank %d logits" % rank)
     plan = fa.shard_plan(F, 2)
     fld = np.arange(nf) // PER
     owner = np.repeat(plan["pair_owner"][fld], K, axis=1)
     for key in ("vec_n", "vec_z"):
         merged = np.where(owner == 0, res[0][2][key], res[1][2][key])
-        np.testing.assert_allclose(merged, want[key], rtol=2e-4, atol=1e-6, err_msg=key)
+        np.testing.assert_allclose(merged, want[key], rtol=2e-4, atol=2e-5, err_msg=key)
     lin_owner = plan["lin_owner"][fld]
     for key in ("lin_n", "lin_z"):
         merged = np.where(lin_owner == 0, res[0][2][key], res[1][2][key])
-        np.testing.assert_allclose(merged, want[key], rtol=2e-4, atol=1e-6, err_msg=key)
-    np.testing.assert_allclose(res[plan["bias_owner"]][2]["bias3"], want["bias3"], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(merged, want[key], rtol=2e-4, atol=2e-5, err_msg=key)
+    np.testing.assert_allclose(res[plan["bias_owner"]][2]["bias3"], want["bias3"], rtol=2e-4, atol=2e-5)

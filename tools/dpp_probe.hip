@@ -46,7 +46,7 @@ __global__ void probe(const float *a, const float *g, const float *m, float *out
     float S = tl == 0 ? nc + av : 0.0f;
     S = row_chain15(S, av);
     float Z = tl == 0 ? (zc + gv) - mv : 0.0f;
-    Z = row_chain15_z(Z, gv, mv);
+    Z = row_chain15_z(Z, gv, tl == 0 ? 0.0f : mv);  // lane 0 keeps its value: the sub must be - (+0)
     // carry = lane 15 of the row
     nc = __shfl(S, (lane & ~15) | 15, 64);
     zc = __shfl(Z, (lane & ~15) | 15, 64);

@@ -188,6 +188,15 @@ struct ffm_engine {
   hipEvent_t ev_rows_done = nullptr;  // row phase of the most recently enqueued training block
   bool rows_done_recorded = false;
   bool prep_after_rows = false;  // FFM_PREP_AFTER_ROWS=1: group beside the update phase only
+  // Scheduling of a look-ahead grouping (FFM_PREP_WINDOW=0 turns it off): the block being
+  // prepared will start training when its predecessor's update ends; its grouping is made to
+  // START when the block before that one ends -- so it runs beside the predecessor's refresh and
+  // row phases (memory-bound, ~400 us, the grouping takes ~300 us there) and never beside an
+  // update phase, where the persistent chain kernels starve it (a Onesweep pass then takes
+  // 250-300 us instead of 7) and it slows them.  trained_set[0] / [1]: the scratch sets of the
+  // training blocks enqueued last / before that (their ev_set_free marks the end of the update).
+  bool prep_window = true;
+  int trained_set[2] = {-1, -1};
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // Streams: the runtime multiplexes streams onto few hardware queues (4 by default), and two
@@ -411,6 +420,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (cfg->reserved[0] > 0) e->max_row_nnz = cfg->reserved[0];
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_PREP_AFTER_ROWS")) e->prep_after_rows = sv[0] == '1';
+  if (const char *sv = std::getenv("FFM_PREP_WINDOW")) e->prep_window = sv[0] != '0';
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
   if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::min(kRowThreads, std::max(64, std::atoi(sv) / 64 * 64));
@@ -896,6 +906,12 @@ int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const 
   // Optionally group beside the UPDATE phase of the block enqueued last instead of beside its
   // refresh + row phase (measured: the grouping's atomics slow whichever phase they share).
   if (e->prep_after_rows && e->rows_done_recorded) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_rows_done, 0));
+  if (e->prep_window) {
+    // n_prepared == 1: the predecessor is prepared but not enqueued yet -> wait for the block
+    // enqueued last; n_prepared == 0: the predecessor IS the block enqueued last -> the one before
+    const int ws = e->trained_set[e->n_prepared >= 1 ? 0 : 1];
+    if (ws >= 0 && ws != set) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[ws], 0));
+  }
   rc = launch_grouping(e, set, rows, e->prep);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(e->ev_grouped[set], e->prep));
@@ -1036,6 +1052,8 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
   if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
   HIP_TRY(hipEventRecord(e->ev_set_free[e->cur], e->stream));
+  e->trained_set[1] = e->trained_set[0];
+  e->trained_set[0] = e->cur;
   if (e->cur_slot >= 0) {  // a staged block: its staging slot may be refilled from here on
     HIP_TRY(hipEventRecord(e->slots[e->cur_slot].ev_trained, e->stream));
     e->cur_slot = -1;

@@ -8,10 +8,12 @@ One "step" = one pass of the hot path (H2D of the CSR block -> group -> lazy ref
 FTRL update) over one block of synthetic libffm rows.  The metric is SURVEY.md 8(d)'s: rows / wall
 time of the train loop with the rows parsed and resident in HOST memory and the H2D of every CSR
 block INSIDE the timed region -- what the reference times at src/task/ftrl_offline.cpp:46-48.  The
-blocks go through the engine's pipelined host entry points (ffm_engine_train_batch_async on one
-GPU; ffm_engine_stage_batch + train_forward_staged + all-reduce + train_update_device on a sharded
-rank): block t+1 is uploaded and grouped on a side stream while block t trains.  The same loop over
-blocks already resident in HBM is timed afterwards and reported as `resident` (never as `value`).
+blocks live in page-locked host memory and go through the engine's pipelined host entry points
+(ffm_engine_stage_batch + ffm_engine_train_staged on one GPU; + train_forward_staged + all-reduce +
+train_update_device on a sharded rank): block t+1 is DMA-ed to HBM and grouped on a side stream
+while block t trains (`--host-copy`: through ffm_engine_train_batch_async, which first copies the
+caller's pageable arrays into the engine's pinned staging slot).  The same loop over blocks already
+resident in HBM is timed afterwards and reported as `resident` (never as `value`).
 
 Workload at N = 1: BASELINE.json's headline configuration itself -- FFM n_fields=39 n_factors=16
 n_feats=33M (247 GB of (w,n,z): it fits one MI355X), block = 8192 rows, Zipf(1.1) ids, 64 distinct
@@ -150,6 +152,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident leg")
+    ap.add_argument("--host-copy", action="store_true",
+                    help="host leg through ffm_engine_train_batch_async (pageable caller arrays, "
+                         "copied into the engine's pinned slot) instead of zero-copy staging")
     ap.add_argument("--resident-only", action="store_true",
                     help="time only the HBM-resident loop (tuning aid: `value` is then NOT the metric)")
     ap.add_argument("--no-lookahead", action="store_true", help="resident leg: group each block inline")
@@ -269,19 +274,27 @@ def main():
         torch.cuda.synchronize()
 
     # ---- leg 1 (the metric): rows stream from host memory, H2D inside the timed region ----
+    zero_copy = not args.host_copy
+    if zero_copy and not args.resident_only:
+        for b in host_blocks:  # parsed rows in page-locked host memory: the DMA reads them in place
+            eng.pin_block(b)
+
     def run_host(first, count):
         """`count` steps; returns the sum of the steps' losses (all enqueued work is flushed)."""
         if count == 0:
             return 0.0
-        if not sharded:
+        if not sharded and not zero_copy:
             for i in range(count):
                 eng.train_batch_async(host_blocks[(first + i) % n_blocks])
             return eng.train_flush()
-        sstep.stage(host_blocks[first % n_blocks])
+        eng.stage_batch(host_blocks[first % n_blocks], zero_copy)
         for i in range(count):
             if i + 1 < count:
-                sstep.stage(host_blocks[(first + i + 1) % n_blocks])
-            sstep.train_staged(rows, loss_sum.data_ptr() + 8 * (first + i))
+                eng.stage_batch(host_blocks[(first + i + 1) % n_blocks], zero_copy)
+            if sharded:
+                sstep.train_staged(rows, loss_sum.data_ptr() + 8 * (first + i))
+            else:
+                eng.train_staged(None, loss_sum.data_ptr() + 8 * (first + i))
         eng.sync()
         return float(loss_sum[first:first + count].sum().item())
 
@@ -388,8 +401,9 @@ def main():
                             "%s" % (model, N_FIELDS, N_FACTORS, N_FIELDS,
                                     "Zipf(1.1)" if args.dist == "zipf" else "uniform", rows, n_feats,
                                     n_feats * rec_bytes / 1e9, args.state,
-                                    "%d distinct blocks streamed from host memory (H2D in the timed region)"
-                                    % n_blocks if host_leg else "blocks resident in HBM (no H2D)"),
+                                    "%d distinct blocks streamed from %s host memory (H2D in the timed region)"
+                                    % (n_blocks, "page-locked" if zero_copy else "pageable")
+                                    if host_leg else "blocks resident in HBM (no H2D)"),
                 "rows_per_step": rows, "n_feats": n_feats, "n_feats_reduced_to_fit": reduced,
                 "n_blocks": n_blocks,
                 "sharding": "field-pair x%d, one all-reduce of %d partial logits per step"

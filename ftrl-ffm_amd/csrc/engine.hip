@@ -1217,10 +1217,21 @@ static int slots_init(ffm_engine *e) {
   return FFM_OK;
 }
 
-// Stage one block of host rows: pinned image -> HBM -> grouping, all on the prep stream.
+int ffm_engine_pin_host(void *p, size_t bytes) {
+  if (!p || !bytes) return fail(FFM_E_INVALID, "null range");
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return FFM_OK;
+}
+int ffm_engine_unpin_host(void *p) {
+  if (!p) return fail(FFM_E_INVALID, "null pointer");
+  HIP_TRY(hipHostUnregister(p));
+  return FFM_OK;
+}
+
+// Stage one block of host rows: (pinned image ->) HBM -> grouping, all on the prep stream.
 int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
                            const int32_t *field, const int32_t *feat, const float *val,
-                           const int32_t *label) {
+                           const int32_t *label, int32_t zero_copy) {
   int32_t nnz = 0;
   int longest = 1;
   int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
@@ -1241,6 +1252,8 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   char *p = sl.pinned;
   auto put = [&](const void *src, size_t bytes, void *dst) -> hipError_t {
     if (!bytes) return hipSuccess;
+    if (zero_copy)  // page-locked caller memory, untouched until the block has trained: DMA from it
+      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->prep);
     std::memcpy(p, src, bytes);
     hipError_t err = hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, e->prep);
     p += (bytes + 15) & ~static_cast<size_t>(15);
@@ -1284,14 +1297,20 @@ int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit) {
   return FFM_OK;
 }
 
-// Whole step on the oldest staged block; its loss goes into the running sum of the flush.
-static int train_one_staged(ffm_engine *e) {
-  e->whole_step = e->m.n_shards == 1;
-  e->own_logit_out = nullptr;
+// Whole step (ffm_engine_train_batch_device) on the oldest staged block.
+int ffm_engine_train_staged(ffm_engine *e, float *logit_out, double *loss_sum_out) {
+  if (e && e->m.n_shards > 1)
+    return fail(FFM_E_INVALID, "sharded engines train with train_forward_staged + all-reduce + train_update");
+  if (e) { e->whole_step = true; e->own_logit_out = logit_out; }
   int rc = ffm_engine_train_forward_staged(e, nullptr);
-  e->whole_step = false;
+  if (e) e->whole_step = false;
   if (rc) return rc;
-  rc = ffm_engine_train_update_device(e, nullptr, nullptr, e->d_loss_sum);
+  return ffm_engine_train_update_device(e, nullptr, logit_out, loss_sum_out);
+}
+
+// ... with its loss going into the running sum of the flush.
+static int train_one_staged(ffm_engine *e) {
+  int rc = ffm_engine_train_staged(e, nullptr, e->d_loss_sum);
   if (rc) return rc;
   hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
   return FFM_OK;
@@ -1302,7 +1321,7 @@ int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *r
                                  const int32_t *label) {
   if (e && e->m.n_shards > 1)
     return fail(FFM_E_INVALID, "sharded engines train with stage_batch + train_forward_staged + all-reduce + train_update");
-  int rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label);
+  int rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label, 0);
   if (rc) return rc;
   // train what the previous call staged; the block staged just now keeps uploading and grouping
   // beside it (and beside the caller's preparation of the next one)

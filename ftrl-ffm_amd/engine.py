@@ -71,8 +71,11 @@ ABI = [
      [_vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     ("ffm_engine_train_batch_async", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
     ("ffm_engine_train_flush", ctypes.c_int, [_vp, _f64p]),
-    ("ffm_engine_stage_batch", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
+    ("ffm_engine_stage_batch", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR + [ctypes.c_int32]),
     ("ffm_engine_train_forward_staged", ctypes.c_int, [_vp, _vp]),
+    ("ffm_engine_train_staged", ctypes.c_int, [_vp, _vp, _vp]),
+    ("ffm_engine_pin_host", ctypes.c_int, [_vp, ctypes.c_size_t]),
+    ("ffm_engine_unpin_host", ctypes.c_int, [_vp]),
     ("ffm_engine_prepare_device", ctypes.c_int,
      [_vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     ("ffm_engine_train_forward_device", ctypes.c_int,
@@ -242,9 +245,25 @@ class Engine:
         """Pipelined: stages and groups this block, trains the one passed by the previous call."""
         self._check(self.lib.ffm_engine_train_batch_async(self.h, *self._csr(c)))
 
-    def stage_batch(self, c):
-        """Host block -> pinned slot -> HBM + grouping on the side stream (returns at once)."""
-        self._check(self.lib.ffm_engine_stage_batch(self.h, *self._csr(c)))
+    def stage_batch(self, c, zero_copy=False):
+        """Host block -> (pinned slot ->) HBM + grouping on the side stream (returns at once).
+        zero_copy: the block's arrays are page-locked (pin_block) and stay untouched until trained."""
+        self._check(self.lib.ffm_engine_stage_batch(self.h, *self._csr(c), int(zero_copy)))
+
+    def train_staged(self, logit_out=None, loss_sum_out=None):
+        """The whole step on the oldest staged block (unsharded engines; device outputs)."""
+        self._check(self.lib.ffm_engine_train_staged(self.h, logit_out, loss_sum_out))
+
+    def pin_block(self, c):
+        """Page-locks the block's five arrays in place (for stage_batch(zero_copy=True))."""
+        for a in (c.row_ptr, c.field, c.feat, c.val, c.label):
+            if a is not None and a.size:
+                self._check(self.lib.ffm_engine_pin_host(a.ctypes.data, a.nbytes))
+
+    def unpin_block(self, c):
+        for a in (c.row_ptr, c.field, c.feat, c.val, c.label):
+            if a is not None and a.size:
+                self.lib.ffm_engine_unpin_host(a.ctypes.data)
 
     def train_forward_staged(self, partial_logit=None):
         """Phase 1 on the oldest staged block; follow with train_update_device."""

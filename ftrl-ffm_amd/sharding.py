@@ -75,10 +75,10 @@ class ShardedStep:
         self._exchange(n_rows)
         self.engine.train_update_device(ptr, None, loss_sum_out)
 
-    def stage(self, block):
+    def stage(self, block, zero_copy=False):
         """Hand the NEXT host block to the engine: it is uploaded and grouped on the engine's side
         stream while the current one trains (up to two may wait)."""
-        self.engine.stage_batch(block)
+        self.engine.stage_batch(block, zero_copy)
 
     def train_staged(self, n_rows, loss_sum_out=None):
         """One training block from the oldest staged host block: forward -> all-reduce -> update."""

@@ -380,10 +380,13 @@ def test_logloss_within_1e4_of_sequential_reference_at_39x16_blocks_of_8192():
     assert abs(d_train) < 1e-4 and abs(d_eval) < 1e-4
 
 
-def test_staged_host_blocks_equal_block_by_block():
+@pytest.mark.parametrize("zero_copy", [False, True], ids=["copied", "zero_copy"])
+def test_staged_host_blocks_equal_block_by_block(zero_copy):
     """ffm_engine_stage_batch + train_forward_staged + train_update_device (what a sharded rank
-    runs around its all-reduce, rows streaming host -> HBM inside the loop): the bits of
-    ffm_engine_train_batch called block by block; at most two staged blocks may wait."""
+    runs around its all-reduce, rows streaming host -> HBM inside the loop) and
+    ffm_engine_train_staged (the whole step): the bits of ffm_engine_train_batch called block by
+    block; at most two staged blocks may wait.  zero_copy: the blocks are page-locked in place
+    (ffm_engine_pin_host) and DMA-ed from there."""
     F, k, per = 8, 16, 50
     nf = F * per
     g = synth.Generator(F, nf, "zipf", seed=6)
@@ -399,22 +402,32 @@ def test_staged_host_blocks_equal_block_by_block():
     sa = a.get_state()
     a.close()
     b_ = make()
+    if zero_copy:
+        for blk in blocks:
+            b_.pin_block(blk)
     logit = torch.zeros(256, device="cuda")
     got = []
-    b_.stage_batch(blocks[0])
+    b_.stage_batch(blocks[0], zero_copy)
     for i, blk in enumerate(blocks):
         if i + 1 < len(blocks):
-            b_.stage_batch(blocks[i + 1])
-        b_.train_forward_staged(logit.data_ptr())
-        b_.train_update_device(logit.data_ptr())
+            b_.stage_batch(blocks[i + 1], zero_copy)
+        if i % 2 == 0:
+            b_.train_forward_staged(logit.data_ptr())
+            b_.train_update_device(logit.data_ptr())
+        else:
+            b_.train_staged(logit.data_ptr())
         b_.sync()
         got.append(logit[:blk.n_rows].cpu().numpy().copy())
     for x, y in zip(got, ref_logits):
         assert_bitwise(x, y, "staged logits")
     assert_state_bitwise(b_.get_state(), sa, "staged host blocks")
-    b_.stage_batch(blocks[0])
-    b_.stage_batch(blocks[1])
+    b_.stage_batch(blocks[0], zero_copy)
+    b_.stage_batch(blocks[1], zero_copy)
     with pytest.raises(fa.EngineError) as ei:
-        b_.stage_batch(blocks[2])
+        b_.stage_batch(blocks[2], zero_copy)
     assert ei.value.code == -4
+    b_.sync()
     b_.close()
+    if zero_copy:
+        for blk in blocks:
+            b_.unpin_block(blk)

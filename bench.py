@@ -275,9 +275,15 @@ def main():
 
     # ---- leg 1 (the metric): rows stream from host memory, H2D inside the timed region ----
     zero_copy = not args.host_copy
+    pinned_keep = []
     if zero_copy and not args.resident_only:
-        for b in host_blocks:  # parsed rows in page-locked host memory: the DMA reads them in place
-            eng.pin_block(b)
+        # the parsed rows live in page-locked host memory (allocated pinned, as a loader that
+        # targets this engine would): the DMA reads them in place
+        for b in host_blocks:
+            for name in ("row_ptr", "field", "feat", "val", "label"):
+                t = torch.from_numpy(getattr(b, name)).pin_memory()
+                pinned_keep.append(t)
+                setattr(b, name, t.numpy())
 
     def run_host(first, count):
         """`count` steps; returns the sum of the steps' losses (all enqueued work is flushed)."""

@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident leg")
+    ap.add_argument("--resident-blocks", type=int, default=8, help="blocks uploaded for the resident leg")
     ap.add_argument("--host-copy", action="store_true",
                     help="host leg through ffm_engine_train_batch_async (pageable caller arrays, "
                          "copied into the engine's pinned slot) instead of zero-copy staging")
@@ -308,7 +309,7 @@ def main():
     dev_blocks = []
 
     def upload_resident():
-        for b in host_blocks[:8]:
+        for b in host_blocks[:args.resident_blocks]:
             dev_blocks.append(dict(
                 n_rows=b.n_rows, nnz=b.nnz,
                 row_ptr=torch.from_numpy(b.row_ptr).cuda(), field=torch.from_numpy(b.field).cuda(),

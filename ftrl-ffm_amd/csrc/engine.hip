@@ -17,6 +17,7 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +43,35 @@ using GroupSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocp
 namespace {
 
 thread_local std::string g_last_error;
+
+// FFM_HOST_TIMING=1: wall time the submitting thread spends in labelled sections (debug aid)
+struct HostTimers {
+  bool on = std::getenv("FFM_HOST_TIMING") != nullptr;
+  struct Acc { const char *name; double total = 0, worst = 0; long n = 0; } acc[16];
+  int n_acc = 0;
+  Acc &get(const char *name) {
+    for (int i = 0; i < n_acc; i++) if (acc[i].name == name) return acc[i];
+    acc[n_acc].name = name;
+    return acc[n_acc < 15 ? n_acc++ : 15];
+  }
+  ~HostTimers() {
+    if (!on) return;
+    for (int i = 0; i < n_acc; i++)
+      std::fprintf(stderr, "[host timing] %-22s n=%6ld total=%9.3f ms mean=%8.1f us worst=%9.1f us\n",
+                   acc[i].name, acc[i].n, acc[i].total * 1e3, acc[i].total * 1e6 / std::max(1l, acc[i].n), acc[i].worst * 1e6);
+  }
+} g_timers;
+struct ScopedTimer {
+  const char *name;
+  std::chrono::steady_clock::time_point t0;
+  explicit ScopedTimer(const char *n) : name(n) { if (g_timers.on) t0 = std::chrono::steady_clock::now(); }
+  ~ScopedTimer() {
+    if (!g_timers.on) return;
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    auto &a = g_timers.get(name);
+    a.total += s; a.n++; if (s > a.worst) a.worst = s;
+  }
+};
 
 int fail(int code, const std::string &msg) {
   g_last_error = msg;
@@ -221,7 +251,7 @@ struct ffm_engine {
     int *row_ptr = nullptr, *field = nullptr, *feat = nullptr, *label = nullptr;
     float *val = nullptr;
     hipEvent_t ev_copied = nullptr, ev_trained = nullptr;
-    bool used = false;
+    bool used = false, zero_copy = false;
     int n_rows = 0, nnz = 0, row_cap = 0;
     bool has_field = false;
   } slots[kSlots];
@@ -875,6 +905,7 @@ static bool same_block(const Rows &a, const Rows &b) {
 // Groups `rows` by feature into scratch set `set` on stream `st`.
 static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st) {
   Scratch &sc = e->sc[set];
+  ScopedTimer tm_all("grouping:all");
   HIP_TRY(hipMemsetAsync(sc.counters, 0, kNumCounters * sizeof(int), st));
   if (rows.nnz > 0) {
     const int nnz = rows.nnz;
@@ -882,6 +913,7 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
       HIP_TRY(hipMemsetAsync(sc.rowmask, 0, sizeof(unsigned long long) * 2 * rows.n_rows, st));
     LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->max_row_nnz);
     e->prof_begin(K_GROUP_SORT, st);
+    ScopedTimer tm_sort("grouping:sort");
     size_t bytes = e->sort_tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
                                       rocprim::counting_iterator<int>(0), sc.occ,
@@ -1244,8 +1276,9 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   ffm_engine::Slot &sl = e->slots[e->slot_next];
   const int this_slot = e->slot_next;
   if (sl.used) {
-    HIP_TRY(hipEventSynchronize(sl.ev_copied));                   // its pinned image is free again
-    HIP_TRY(hipStreamWaitEvent(e->prep, sl.ev_trained, 0));      // and nothing reads its device arrays
+    ScopedTimer tm("stage:slot_wait");
+    if (!sl.zero_copy) HIP_TRY(hipEventSynchronize(sl.ev_copied));  // its pinned image is free again
+    HIP_TRY(hipStreamWaitEvent(e->prep, sl.ev_trained, 0));        // and nothing reads its device arrays
   }
   // host arrays -> pinned image (the caller may reuse its buffers on return) -> device, prep stream
   const size_t R1 = static_cast<size_t>(n_rows) + 1, E = static_cast<size_t>(nnz);
@@ -1259,16 +1292,23 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
     p += (bytes + 15) & ~static_cast<size_t>(15);
     return err;
   };
-  HIP_TRY(put(row_ptr, 4 * R1, sl.row_ptr));
-  if (field) HIP_TRY(put(field, 4 * E, sl.field));
-  HIP_TRY(put(feat, 4 * E, sl.feat));
-  HIP_TRY(put(val, 4 * E, sl.val));
-  HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
-  HIP_TRY(hipEventRecord(sl.ev_copied, e->prep));
+  {
+    ScopedTimer tm("stage:copies");
+    HIP_TRY(put(row_ptr, 4 * R1, sl.row_ptr));
+    if (field) HIP_TRY(put(field, 4 * E, sl.field));
+    HIP_TRY(put(feat, 4 * E, sl.feat));
+    HIP_TRY(put(val, 4 * E, sl.val));
+    HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
+    HIP_TRY(hipEventRecord(sl.ev_copied, e->prep));
+  }
   // group it ahead, behind its own upload on the prep stream
-  rc = ffm_engine_prepare_device(e, n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val);
+  {
+    ScopedTimer tm("stage:prepare");
+    rc = ffm_engine_prepare_device(e, n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val);
+  }
   if (rc) return rc;
   sl.used = true;
+  sl.zero_copy = zero_copy != 0;
   sl.n_rows = n_rows;
   sl.nnz = nnz;
   sl.row_cap = longest;

@@ -294,10 +294,13 @@ def main():
             for i in range(count):
                 eng.train_batch_async(host_blocks[(first + i) % n_blocks])
             return eng.train_flush()
-        eng.stage_batch(host_blocks[first % n_blocks], zero_copy)
+        # two blocks are kept staged ahead of the one in training (the engine's limit): the upload
+        # and grouping of block t+2 then has a whole step of slack
+        staged = 0
         for i in range(count):
-            if i + 1 < count:
-                eng.stage_batch(host_blocks[(first + i + 1) % n_blocks], zero_copy)
+            while staged < min(i + 2, count) and staged - i < 2:
+                eng.stage_batch(host_blocks[(first + staged) % n_blocks], zero_copy)
+                staged += 1
             if sharded:
                 sstep.train_staged(rows, loss_sum.data_ptr() + 8 * (first + i))
             else:

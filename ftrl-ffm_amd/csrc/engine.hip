@@ -214,6 +214,10 @@ struct ffm_engine {
   int last_set = 0;            // set handed out most recently (to a prepare or to a training block)
   bool set_used[kSets] = {};
   hipStream_t prep = nullptr;  // side stream of ffm_engine_prepare_device
+  // uploads of staged host blocks: DMA only, no kernels -- so it costs no compute queue, and a
+  // block's upload (possible as soon as its staging slot is free, one step before its grouping
+  // window opens) is off the grouping's critical chain
+  hipStream_t copy = nullptr;
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
   hipEvent_t ev_rows_done = nullptr;  // row phase of the most recently enqueued training block
   bool rows_done_recorded = false;
@@ -407,6 +411,7 @@ void ffm_engine_destroy(ffm_engine *e) {
   }
   if (e->ev_rows_done) (void)hipEventDestroy(e->ev_rows_done);
   if (e->prep) (void)hipStreamDestroy(e->prep);
+  if (e->copy) (void)hipStreamDestroy(e->copy);
   if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
   if (e->ev_join3) (void)hipEventDestroy(e->ev_join3);
   if (e->aux3) (void)hipStreamDestroy(e->aux3);
@@ -614,6 +619,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   }
   // (a high-priority queue for the look-ahead grouping was tried: the whole step got 45% slower)
   TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
+  TRY_HIP(hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_rows_done, hipEventDisableTiming));
   for (int i = 0; i < ffm_engine::kSets; i++) {
     TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));
@@ -1278,7 +1284,7 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   if (sl.used) {
     ScopedTimer tm("stage:slot_wait");
     if (!sl.zero_copy) HIP_TRY(hipEventSynchronize(sl.ev_copied));  // its pinned image is free again
-    HIP_TRY(hipStreamWaitEvent(e->prep, sl.ev_trained, 0));        // and nothing reads its device arrays
+    HIP_TRY(hipStreamWaitEvent(e->copy, sl.ev_trained, 0));        // and nothing reads its device arrays
   }
   // host arrays -> pinned image (the caller may reuse its buffers on return) -> device, prep stream
   const size_t R1 = static_cast<size_t>(n_rows) + 1, E = static_cast<size_t>(nnz);
@@ -1286,9 +1292,9 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   auto put = [&](const void *src, size_t bytes, void *dst) -> hipError_t {
     if (!bytes) return hipSuccess;
     if (zero_copy)  // page-locked caller memory, untouched until the block has trained: DMA from it
-      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->prep);
+      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->copy);
     std::memcpy(p, src, bytes);
-    hipError_t err = hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, e->prep);
+    hipError_t err = hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, e->copy);
     p += (bytes + 15) & ~static_cast<size_t>(15);
     return err;
   };
@@ -1299,7 +1305,8 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
     HIP_TRY(put(feat, 4 * E, sl.feat));
     HIP_TRY(put(val, 4 * E, sl.val));
     HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
-    HIP_TRY(hipEventRecord(sl.ev_copied, e->prep));
+    HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
+    HIP_TRY(hipStreamWaitEvent(e->prep, sl.ev_copied, 0));  // the grouping reads the uploaded arrays
   }
   // group it ahead, behind its own upload on the prep stream
   {

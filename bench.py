@@ -294,11 +294,12 @@ def main():
             for i in range(count):
                 eng.train_batch_async(host_blocks[(first + i) % n_blocks])
             return eng.train_flush()
-        # two blocks are kept staged ahead of the one in training (the engine's limit): the upload
-        # and grouping of block t+2 then has a whole step of slack
+        # block t+2 is staged BEFORE block t's training is enqueued: its upload then sits ahead of
+        # block t's hot update on that stream (it runs when block t-1 ends) and its grouping is
+        # scheduled into block t's refresh / row window with until the end of block t+1 to finish
         staged = 0
         for i in range(count):
-            while staged < min(i + 2, count) and staged - i < 2:
+            while staged < min(i + 3, count):
                 eng.stage_batch(host_blocks[(first + staged) % n_blocks], zero_copy)
                 staged += 1
             if sharded:
@@ -338,13 +339,14 @@ def main():
     DEPTH = 2  # blocks grouped ahead (ffm_engine_prepare_device): two hide the grouping completely
 
     def run_resident(first, count):
-        ahead = 0  # blocks currently prepared ahead
+        prepared = 0  # blocks of this run prepared so far (block i itself counts once i is prepared)
         for i in range(count):
+            # the look-ahead for block i+2 goes in BEFORE block i's training (see run_host)
+            while not args.no_lookahead and prepared < min(i + DEPTH + 1, count):
+                if prepared >= i:
+                    prepare(dev_blocks[(first + prepared) % len(dev_blocks)])
+                prepared += 1
             step_resident(first + i, dev_blocks[(first + i) % len(dev_blocks)])
-            ahead = max(ahead - 1, 0)
-            while not args.no_lookahead and ahead < DEPTH and i + ahead + 1 < count:
-                prepare(dev_blocks[(first + i + ahead + 1) % len(dev_blocks)])
-                ahead += 1
 
     def timed(run, first, count):
         fence()

@@ -204,7 +204,7 @@ struct ffm_engine {
   // the set block t-2 used, so it never waits for block t-1 or t to retire (with two sets the
   // grouping could only start when the previous block ended, and then sat starved of wave slots
   // behind that block's persistent update kernels).  What the row kernel writes is shared.
-  static constexpr int kSets = 3;
+  static constexpr int kSets = 4;
   Scratch sc[kSets]{};
   int cur = 0;                 // set of the block being trained
   // groupings made ahead by ffm_engine_prepare_device, oldest first (at most kSets - 1)
@@ -252,7 +252,7 @@ struct ffm_engine {
   // pipelined host-buffer training (ffm_engine_train_batch_async): kSlots staging slots, each a
   // pinned host image and device arrays of one block; block t is copied + grouped on the prep
   // stream while block t-1 trains on the main stream and the caller builds block t+1
-  static constexpr int kSlots = 3;
+  static constexpr int kSlots = 4;
   struct Slot {
     char *pinned = nullptr;
     int *row_ptr = nullptr, *field = nullptr, *feat = nullptr, *label = nullptr;
@@ -939,7 +939,7 @@ int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const 
   int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
   if (rc) return rc;
   if (e->has_pending) return fail(FFM_E_INVALID, "prepare between train_forward and train_update");
-  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "two prepared blocks are already waiting");
+  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "three prepared blocks are already waiting");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   const int set = (e->last_set + 1) % ffm_engine::kSets;
   Rows rows{n_rows, nnz, row_ptr, field, feat, val, nullptr};
@@ -1278,7 +1278,7 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
   if (rc) return rc;
   if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
-  if (e->n_staged >= ffm_engine::kSlots - 1) return fail(FFM_E_CAPACITY, "two staged blocks are already waiting");
+  if (e->n_staged >= ffm_engine::kSlots - 1) return fail(FFM_E_CAPACITY, "three staged blocks are already waiting");
   if (e->has_pending) return fail(FFM_E_INVALID, "stage between train_forward and train_update");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   if ((rc = slots_init(e))) return rc;
@@ -1341,7 +1341,7 @@ int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit) {
   int rc = ffm_engine_train_forward_device(e, sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr,
                                            sl.feat, sl.val, sl.label, partial_logit);
   if (rc) return rc;
-  e->staged[0] = e->staged[1];
+  for (int i = 1; i < e->n_staged; i++) e->staged[i - 1] = e->staged[i];
   e->n_staged--;
   e->cur_slot = slot;  // released (ev_trained) by the train_update that follows
   return FFM_OK;

@@ -194,7 +194,7 @@ int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out);
 /* The two halves of ffm_engine_train_batch_async, for callers that put something between forward
  * and update -- the sharded trainer's all-reduce: ffm_engine_stage_batch copies the host block into
  * a pinned staging slot, uploads it and groups it on the side stream (returns at once; the
- * caller's arrays are reusable; FFM_E_CAPACITY when two staged blocks are already waiting);
+ * caller's arrays are reusable; FFM_E_CAPACITY when three staged blocks are already waiting);
  * ffm_engine_train_forward_staged runs phase 1 of ffm_engine_train_forward_device on the OLDEST
  * staged block (partial_logit: device, may be NULL), to be followed by
  * ffm_engine_train_update_device; ffm_engine_train_staged is the whole step
@@ -220,10 +220,11 @@ int ffm_engine_unpin_host(void *p);
  * updated.  The arrays must be complete in device memory when this is called and must be the very
  * ones passed to the following ffm_engine_train_batch_device / train_forward_device call (same
  * pointers and sizes); if a different block is trained next the look-ahead is discarded.  Up to
- * two blocks can be prepared ahead; they are consumed in the order they were prepared.  (Two ahead
- * is what hides the grouping completely: the grouping of block t+2 then runs beside block t's
- * refresh and row phases and is long finished when block t+1 ends.)  FFM_E_CAPACITY when two
- * prepared blocks are already waiting. */
+ * three blocks can be prepared ahead; they are consumed in the order they were prepared.  (Two
+ * ahead is what hides the grouping: the grouping of block t+2 is scheduled to start when block
+ * t-1 ends, runs beside block t's refresh and row phases and has until block t+1 ends.  Prepare
+ * block t+2 BEFORE enqueuing block t's training to get that schedule.)  FFM_E_CAPACITY when
+ * three prepared blocks are already waiting. */
 int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
                               const int32_t *field, const int32_t *feat, const float *val);
 

@@ -422,15 +422,15 @@ def test_lookahead_grouping_is_transparent():
         lg, st = run(mode)
         assert_bitwise(lg, base_l, mode + " logits")
         assert_state_bitwise(st, base_s, mode)
-    # at most two prepared blocks may wait
+    # at most three prepared blocks may wait
     e = fa.Engine("FFM", nf, F, k, max_batch_rows=B, seed=3, **STRESS_HP)
-    for j in range(2):
+    for j in range(3):
         dn = dev[j]
         e.prepare_device(B, blocks[j].nnz, dn["row_ptr"].data_ptr(), dn["field"].data_ptr(),
                          dn["feat"].data_ptr(), dn["val"].data_ptr())
     with pytest.raises(fa.EngineError) as err:
-        dn = dev[2]
-        e.prepare_device(B, blocks[2].nnz, dn["row_ptr"].data_ptr(), dn["field"].data_ptr(),
+        dn = dev[3]
+        e.prepare_device(B, blocks[3].nnz, dn["row_ptr"].data_ptr(), dn["field"].data_ptr(),
                          dn["feat"].data_ptr(), dn["val"].data_ptr())
     assert err.value.code == -4  # FFM_E_CAPACITY
     e.close()

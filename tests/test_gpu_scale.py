@@ -385,7 +385,7 @@ def test_staged_host_blocks_equal_block_by_block(zero_copy):
     """ffm_engine_stage_batch + train_forward_staged + train_update_device (what a sharded rank
     runs around its all-reduce, rows streaming host -> HBM inside the loop) and
     ffm_engine_train_staged (the whole step): the bits of ffm_engine_train_batch called block by
-    block; at most two staged blocks may wait.  zero_copy: the blocks are page-locked in place
+    block; at most three staged blocks may wait.  zero_copy: the blocks are page-locked in place
     (ffm_engine_pin_host) and DMA-ed from there."""
     F, k, per = 8, 16, 50
     nf = F * per
@@ -423,8 +423,9 @@ def test_staged_host_blocks_equal_block_by_block(zero_copy):
     assert_state_bitwise(b_.get_state(), sa, "staged host blocks")
     b_.stage_batch(blocks[0], zero_copy)
     b_.stage_batch(blocks[1], zero_copy)
+    b_.stage_batch(blocks[2], zero_copy)
     with pytest.raises(fa.EngineError) as ei:
-        b_.stage_batch(blocks[2], zero_copy)
+        b_.stage_batch(blocks[3], zero_copy)
     assert ei.value.code == -4
     b_.sync()
     b_.close()

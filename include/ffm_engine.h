@@ -203,9 +203,10 @@ int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out);
  * on every rank, overlapped with the previous block's training.
  *   zero_copy != 0: the five arrays are page-locked host memory (hipHostMalloc, hipHostRegister or
  * ffm_engine_pin_host) and the caller leaves them untouched until the block has been trained (two
- * further ffm_engine_stage_batch calls have returned, or ffm_engine_sync): they are uploaded
- * straight from there, without the copy into the engine's own staging slot -- the host's share of
- * one 8192 x 39 block drops from a 3.9 MB memcpy to five DMA descriptors. */
+ * further ffm_engine_stage_batch calls have returned, or ffm_engine_sync), each 16-byte aligned:
+ * the device pulls them straight from there (a kernel reading the mapped host memory), without the
+ * copy into the engine's own staging slot -- the host's share of one 8192 x 39 block drops from a
+ * 3.9 MB memcpy to one kernel launch. */
 int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
                            const int32_t *field, const int32_t *feat, const float *val,
                            const int32_t *label, int32_t zero_copy);

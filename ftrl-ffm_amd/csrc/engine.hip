@@ -104,22 +104,41 @@ struct ProfRec {
   hipEvent_t e0, e1;
 };
 
-__global__ void init_weights_kernel(ModelDev m, float mean, float stddev, uint64_t seed) {
-  const int64_t n_lat = static_cast<int64_t>(m.n_feats) * m.row_len;
+// Where element e of the LOGICAL latent row of feature `feat` ([n_fields][n_factors] for FFM, the
+// reference's layout, ffm.cpp:138-146) lives: a pointer to component `comp` of it, or null when
+// this shard does not store it (compact storage keeps only the owned slots of the kept fields).
+__device__ __forceinline__ float *logical_elem(const ModelDev &m, int64_t feat, int e, int comp) {
+  if (!m.field_start)
+    return m.lat + feat * 3 * m.row_len + static_cast<int64_t>(comp) * m.row_len + e;
+  int lo = 0, hi = m.n_fields;  // field of the id: field_start[fa] <= feat < field_start[fa + 1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (m.field_start[mid] <= feat) lo = mid; else hi = mid;
+  }
+  const int fa = lo, fp = e / m.n_factors, kk = e - fp * m.n_factors;
+  const int sl = fp - m.own_lo[fa];
+  if (static_cast<unsigned>(sl) >= static_cast<unsigned>(m.own_n[fa])) return nullptr;
+  return lat_row(m, static_cast<int>(feat), fa) + static_cast<int64_t>(comp) * m.row_len + sl * m.n_factors + kk;
+}
+
+// `logical_len` = n_fields * n_factors (FFM) or n_factors (FM): every draw is addressed by its
+// logical coordinates, so a shard initialises its slots to the values the unsharded model holds.
+__global__ void init_weights_kernel(ModelDev m, int logical_len, float mean, float stddev, uint64_t seed) {
+  const int64_t n_lat = static_cast<int64_t>(m.n_feats) * logical_len;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < n_lat;
        idx += stride) {
-    const int64_t feat = idx / m.row_len;
-    const int e = static_cast<int>(idx - feat * m.row_len);
-    m.lat[feat * 3 * m.row_len + LAT_W * m.row_len + e] = ftrl_rng::init_weight(seed, 1, idx, mean, stddev);
+    const int64_t feat = idx / logical_len;
+    float *p = logical_elem(m, feat, static_cast<int>(idx - feat * logical_len), LAT_W);
+    if (p) *p = ftrl_rng::init_weight(seed, 1, idx, mean, stddev);
   }
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < m.n_feats;
        i += stride)
     m.lin_w[i] = ftrl_rng::init_weight(seed, 0, i, mean, stddev);
 }
 
-__global__ void fill_state_kernel(ModelDev m, uint64_t seed, float n_lo, float n_hi, float z_sd) {
-  const int64_t n_lat = static_cast<int64_t>(m.n_feats) * m.row_len;
+__global__ void fill_state_kernel(ModelDev m, int logical_len, uint64_t seed, float n_lo, float n_hi, float z_sd) {
+  const int64_t n_lat = static_cast<int64_t>(m.n_feats) * logical_len;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   const int64_t t0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   auto unif = [&](uint64_t stream, int64_t idx) {
@@ -127,11 +146,12 @@ __global__ void fill_state_kernel(ModelDev m, uint64_t seed, float n_lo, float n
   };
   auto normal01 = [](uint64_t sd, uint64_t stream, int64_t idx) { return ftrl_rng::normal01(sd, stream, idx); };
   for (int64_t idx = t0; idx < n_lat; idx += stride) {
-    const int64_t feat = idx / m.row_len;
-    const int e = static_cast<int>(idx - feat * m.row_len);
-    float *rec = m.lat + feat * 3 * m.row_len;
-    rec[LAT_N * m.row_len + e] = unif(11, idx);
-    rec[LAT_Z * m.row_len + e] = z_sd * normal01(seed, 12, idx);
+    const int64_t feat = idx / logical_len;
+    const int e = static_cast<int>(idx - feat * logical_len);
+    float *pn = logical_elem(m, feat, e, LAT_N);
+    if (!pn) continue;
+    *pn = unif(11, idx);
+    pn[m.row_len] = z_sd * normal01(seed, 12, idx);  // the z row follows the n row
   }
   for (int64_t i = t0; i < m.n_feats; i += stride) {
     m.lin_n[i] = unif(13, i);
@@ -155,35 +175,34 @@ __global__ void verify_div_alpha_kernel(Hyper h, int *bad) {
   if (__float_as_uint(a) != __float_as_uint(b)) atomicOr(bad, 1);
 }
 
-// Copies one component (n, z or w) of features [feat0, feat0+nf) between the interleaved record
-// layout and a dense [feat][row_len] staging buffer (the reference's save order).
-__global__ void lat_component_copy_kernel(float *lat, int row_len, int comp, float *dense,
+// Copies one component (n, z or w) of features [feat0, feat0+nf) between the stored records and a
+// dense [feat][logical_len] staging buffer (the reference's save order).  Slots this shard does
+// not store read as 0 and ignore writes.
+__global__ void lat_component_copy_kernel(ModelDev m, int logical_len, int comp, float *dense,
                                           int64_t feat0, int64_t nf, int to_dense) {
-  const int64_t total = nf * row_len;
+  const int64_t total = nf * logical_len;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
        idx += stride) {
-    const int64_t f = idx / row_len;
-    const int e = static_cast<int>(idx - f * row_len);
-    float *rec = lat + (feat0 + f) * 3 * row_len + static_cast<int64_t>(comp) * row_len + e;
-    if (to_dense) dense[idx] = *rec; else *rec = dense[idx];
+    const int64_t f = idx / logical_len;
+    float *p = logical_elem(m, feat0 + f, static_cast<int>(idx - f * logical_len), comp);
+    if (to_dense) dense[idx] = p ? *p : 0.0f; else if (p) *p = dense[idx];
   }
 }
 
-// The same for a list of features: record component `comp` of ids[j] <-> dense[j][row_len]
-// (ffm_engine_get_rows / set_rows).  Ids out of range are skipped (the dense row is zeroed on reads).
-__global__ void lat_rows_copy_kernel(float *lat, int row_len, int n_feats, int comp, float *dense,
+// The same for a list of features: component `comp` of ids[j] <-> dense[j][logical_len]
+// (ffm_engine_get_rows / set_rows).
+__global__ void lat_rows_copy_kernel(ModelDev m, int logical_len, int comp, float *dense,
                                      const int *ids, int64_t nf, int to_dense) {
-  const int64_t total = nf * row_len;
+  const int64_t total = nf * logical_len;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
        idx += stride) {
-    const int64_t j = idx / row_len;
-    const int e = static_cast<int>(idx - j * row_len);
+    const int64_t j = idx / logical_len;
     const int i = ids[j];
-    if (i < 0 || i >= n_feats) { if (to_dense) dense[idx] = 0.0f; continue; }
-    float *rec = lat + static_cast<int64_t>(i) * 3 * row_len + static_cast<int64_t>(comp) * row_len + e;
-    if (to_dense) dense[idx] = *rec; else *rec = dense[idx];
+    float *p = (i < 0 || i >= m.n_feats) ? nullptr
+                                          : logical_elem(m, i, static_cast<int>(idx - j * logical_len), comp);
+    if (to_dense) dense[idx] = p ? *p : 0.0f; else if (p) *p = dense[idx];
   }
 }
 __global__ void lin_rows_copy_kernel(float *lin, int n_feats, float *dense, const int *ids, int nf,
@@ -193,6 +212,118 @@ __global__ void lin_rows_copy_kernel(float *lin, int n_feats, float *dense, cons
   const int i = ids[j];
   if (i < 0 || i >= n_feats) { if (to_dense) dense[j] = 0.0f; return; }
   if (to_dense) dense[j] = lin[i]; else lin[i] = dense[j];
+}
+
+// ---- field-pair partition (include/ffm_engine.h: ffm_engine_shard_plan) -----------------------
+// The fields are cut into g contiguous groups; the unit of ownership is a BLOCK (a, b), a <= b: all
+// field pairs with one field in group a and the other in group b.  Every shard gets a set of blocks
+// such that, for each group, the partner groups it owns form one interval -- so every field's owned
+// partner fields are ONE contiguous range and the owned slots of a record are contiguous.
+//   1 shard : everything.
+//   2 shards: g = 2; {(0,1)} | {(0,0),(1,1)}.
+//   4 shards: g = 4; {(0,1),(2,3)} | {(0,2),(1,3)} | {(0,3),(1,2)} | the four diagonal blocks.
+//   8 shards: g = 4; the six off-diagonal blocks one each | {(0,0),(1,1)} | {(2,2),(3,3)}: every
+//             shard needs the columns of only two groups (about half of the fields); 100 vs 92.6
+//             cross-field pairs on the busiest shard at 39 fields.
+//   other   : g = n "strips": shard r owns the blocks (r, s), s >= r, with the group sizes chosen
+//             so that the shards' pair counts are as even as the field count allows.
+struct ShardPlan {
+  int n_fields = 0, n_shards = 1;
+  std::vector<int> own_lo, own_n;  // [shard][field]
+  std::vector<int> lin_owner;      // [field] shard that owns the field's linear terms
+  int bias_owner = 0;
+  std::vector<long long> pairs;    // [shard] cross-field pairs owned (load measure)
+  int lo(int r, int f) const { return own_lo[static_cast<size_t>(r) * n_fields + f]; }
+  int n(int r, int f) const { return own_n[static_cast<size_t>(r) * n_fields + f]; }
+  bool owns(int r, int fa, int fb) const { return static_cast<unsigned>(fb - lo(r, fa)) < static_cast<unsigned>(n(r, fa)); }
+};
+
+static ShardPlan make_shard_plan(int F, int N, bool field_map) {
+  ShardPlan p;
+  p.n_fields = F;
+  p.n_shards = N;
+  p.own_lo.assign(static_cast<size_t>(N) * F, 0);
+  p.own_n.assign(static_cast<size_t>(N) * F, 0);
+  p.lin_owner.assign(F, 0);
+  p.pairs.assign(N, 0);
+  std::vector<int> gb;                                  // group boundaries, g + 1 entries
+  std::vector<std::vector<std::pair<int, int>>> blocks(N);
+  auto even_groups = [&](int g) { gb.clear(); for (int j = 0; j <= g; j++) gb.push_back(static_cast<int>(static_cast<long long>(j) * F / g)); };
+  if (N == 1) {
+    even_groups(1);
+    blocks[0] = {{0, 0}};
+  } else if (N == 2 && F >= 2) {
+    even_groups(2);
+    blocks[0] = {{0, 1}};
+    blocks[1] = {{0, 0}, {1, 1}};
+  } else if (N == 4 && F >= 4) {
+    even_groups(4);
+    blocks[0] = {{0, 1}, {2, 3}};
+    blocks[1] = {{0, 2}, {1, 3}};
+    blocks[2] = {{0, 3}, {1, 2}};
+    blocks[3] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}};
+  } else if (N == 8 && F >= 4) {
+    even_groups(4);
+    blocks[0] = {{0, 1}}; blocks[1] = {{0, 2}}; blocks[2] = {{0, 3}};
+    blocks[3] = {{1, 2}}; blocks[4] = {{1, 3}}; blocks[5] = {{2, 3}};
+    blocks[6] = {{0, 0}, {1, 1}};
+    blocks[7] = {{2, 2}, {3, 3}};
+  } else {
+    // strips: choose the boundaries greedily so that shard r's cross-field pair count
+    // |G_r| * (F - end_r) + C(|G_r|, 2) tracks what is left divided by the shards left
+    gb.assign(1, 0);
+    long long left = static_cast<long long>(F) * (F - 1) / 2;
+    for (int r = 0; r < N; r++) {
+      const int b0 = gb.back();
+      int b1 = b0;
+      if (r == N - 1) {
+        b1 = F;
+      } else {
+        const double target = static_cast<double>(left) / (N - r);
+        long long best_cnt = 0;
+        for (int c = b0; c <= F; c++) {
+          const long long sz = c - b0, cnt = sz * (F - c) + sz * (sz - 1) / 2;
+          if (c == b0 || std::abs(static_cast<double>(cnt) - target) <= std::abs(static_cast<double>(best_cnt) - target)) { b1 = c; best_cnt = cnt; }
+          if (static_cast<double>(cnt) > target) break;
+        }
+        left -= best_cnt;
+      }
+      gb.push_back(b1);
+      for (int s2 = r; s2 < N; s2++) blocks[r].push_back({r, s2});
+    }
+  }
+  const int g = static_cast<int>(gb.size()) - 1;
+  for (int r = 0; r < N; r++) {
+    std::vector<int> pmin(g, g), pmax(g, -1);  // partner-group interval of every group on shard r
+    for (auto [a, b] : blocks[r]) {
+      if (b >= g || a >= g) continue;
+      pmin[a] = std::min(pmin[a], b); pmax[a] = std::max(pmax[a], b);
+      pmin[b] = std::min(pmin[b], a); pmax[b] = std::max(pmax[b], a);
+      const long long sa = gb[a + 1] - gb[a], sb = gb[b + 1] - gb[b];
+      p.pairs[r] += a == b ? sa * (sa - 1) / 2 : sa * sb;
+    }
+    for (int a = 0; a < g; a++) {
+      if (pmax[a] < 0) continue;
+      for (int f = gb[a]; f < gb[a + 1]; f++) {
+        p.own_lo[static_cast<size_t>(r) * F + f] = gb[pmin[a]];
+        p.own_n[static_cast<size_t>(r) * F + f] = gb[pmax[a] + 1] - gb[pmin[a]];
+      }
+    }
+  }
+  // the bias and (without a field map: all of) the linear terms go to the least loaded shard;
+  // with a field map a field's linear terms go to the least loaded shard that keeps that column
+  p.bias_owner = static_cast<int>(std::min_element(p.pairs.begin(), p.pairs.end()) - p.pairs.begin());
+  for (int f = 0; f < F; f++) {
+    int best = p.bias_owner;
+    if (field_map) {
+      best = -1;
+      for (int r = 0; r < N; r++)
+        if (p.n(r, f) > 0 && (best < 0 || p.pairs[r] < p.pairs[best])) best = r;
+      if (best < 0) best = p.bias_owner;
+    }
+    p.lin_owner[f] = best;
+  }
+  return p;
 }
 
 }  // namespace
@@ -286,6 +417,10 @@ struct ffm_engine {
   // of per occurrence inside the row kernel; FFM_ENGINE_ROW_REFRESH=1 keeps it in the row kernel
   bool pre_refresh = false;
   unsigned long long *d_ownmask = nullptr;
+  bool lin_any = true;          // this shard owns the linear terms of at least one field
+  int logical_len = 0;          // n_fields * n_factors (FFM), n_factors (FM), 0 (LR): the reference's row
+  int64_t n_records = 0;        // stored latent records (n_feats, or fewer on a compact shard)
+  std::vector<int> field_start; // copy of cfg->field_start (compact shards)
   // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
   // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
   int grid_small = 768, grid_hot = 2048, grid_huge = 2048, grid_single = 768;
@@ -389,7 +524,7 @@ void ffm_engine_default_config(ffm_engine_config *cfg) {
   cfg->shard_rank = 0;
 }
 
-int64_t ffm_engine_row_len(const ffm_engine *e) { return e ? e->m.row_len : 0; }
+int64_t ffm_engine_row_len(const ffm_engine *e) { return e ? e->logical_len : 0; }
 
 void ffm_engine_destroy(ffm_engine *e) {
   if (!e) return;
@@ -452,7 +587,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   e->cfg = *cfg;
   e->max_rows = cfg->max_batch_rows;
   e->max_nnz = cfg->max_batch_nnz;
-  if (cfg->reserved[0] > 0) e->max_row_nnz = cfg->reserved[0];
+  if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_PREP_AFTER_ROWS")) e->prep_after_rows = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_PREP_WINDOW")) e->prep_window = sv[0] != '0';
@@ -480,10 +615,37 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.n_feats = cfg->n_feats;
   m.n_fields = cfg->model_type == FFM_MODEL_FFM ? cfg->n_fields : 1;
   m.n_factors = cfg->model_type == FFM_MODEL_LR ? 0 : cfg->n_factors;
-  m.row_len = cfg->model_type == FFM_MODEL_FFM ? cfg->n_fields * cfg->n_factors
-              : cfg->model_type == FFM_MODEL_FM ? cfg->n_factors : 0;
+  e->logical_len = cfg->model_type == FFM_MODEL_FFM ? cfg->n_fields * cfg->n_factors
+                   : cfg->model_type == FFM_MODEL_FM ? cfg->n_factors : 0;
   m.n_shards = cfg->n_shards;
   m.shard_rank = cfg->shard_rank;
+  m.bias_own = 1;
+  m.rec_slots = m.n_fields;
+  e->n_records = cfg->n_feats;
+  // field-pair partition: this shard's ranges, and (with per-field id ranges) compact storage
+  ShardPlan plan;
+  const bool compact = cfg->n_shards > 1 && cfg->field_start != nullptr;
+  if (cfg->field_start && cfg->model_type == FFM_MODEL_FFM) {
+    e->field_start.assign(cfg->field_start, cfg->field_start + cfg->n_fields + 1);
+    bool ok = e->field_start[0] == 0 && e->field_start[cfg->n_fields] == cfg->n_feats;
+    for (int f = 0; f < cfg->n_fields; f++) ok = ok && e->field_start[f] <= e->field_start[f + 1];
+    if (!ok) { delete e; return fail(FFM_E_INVALID, "field_start must ascend from 0 to n_feats"); }
+  }
+  if (cfg->n_shards > 1) {
+    plan = make_shard_plan(cfg->n_fields, cfg->n_shards, compact);
+    m.bias_own = plan.bias_owner == cfg->shard_rank ? 1 : 0;
+    if (compact) {
+      int widest = 1;
+      for (int f = 0; f < cfg->n_fields; f++) widest = std::max(widest, plan.n(cfg->shard_rank, f));
+      m.rec_slots = widest;
+      e->n_records = 0;
+      for (int f = 0; f < cfg->n_fields; f++)
+        if (plan.n(cfg->shard_rank, f) > 0) e->n_records += e->field_start[f + 1] - e->field_start[f];
+      if (e->n_records == 0) e->n_records = 1;
+    }
+  }
+  m.row_len = cfg->model_type == FFM_MODEL_FFM ? m.rec_slots * cfg->n_factors
+              : cfg->model_type == FFM_MODEL_FM ? cfg->n_factors : 0;
   m.h = Hyper{cfg->w_alpha, cfg->w_beta, cfg->w_l1, cfg->w_l2, 1.0f / cfg->w_alpha, 0,
               (cfg->flags & FFM_FLAG_LEARN) ? 1 : 0};
   if (static_cast<int64_t>(cfg->n_fields) * cfg->n_factors > (1 << 24))
@@ -509,7 +671,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   const size_t nf = static_cast<size_t>(cfg->n_feats);
-  const size_t n_lat = nf * 3 * static_cast<size_t>(m.row_len);
+  const size_t n_lat = static_cast<size_t>(e->n_records) * 3 * static_cast<size_t>(m.row_len);
   TRY_ALLOC(e->alloc(&m.bias3, 4));
   TRY_ALLOC(e->alloc(&m.lin_n, nf));
   TRY_ALLOC(e->alloc(&m.lin_z, nf));
@@ -547,29 +709,44 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&s.gmask, E));
     std::vector<unsigned long long> own(m.n_fields, 0ull);
     for (int fa = 0; fa < m.n_fields; fa++)
-      for (int fb = 0; fb < m.n_fields; fb++) {
-        const int lo = std::min(fa, fb), hi = std::max(fa, fb);
-        const int idx = lo * m.n_fields - lo * (lo - 1) / 2 + (hi - lo);  // as owns_pair()
-        if (m.n_shards <= 1 || idx % m.n_shards == m.shard_rank) own[fa] |= 1ull << fb;
-      }
+      for (int fb = 0; fb < m.n_fields; fb++)
+        if (m.n_shards <= 1 || plan.owns(m.shard_rank, fa, fb)) own[fa] |= 1ull << fb;
     TRY_ALLOC(e->alloc(&e->d_ownmask, static_cast<size_t>(m.n_fields)));
     TRY_HIP(hipMemcpy(e->d_ownmask, own.data(), own.size() * sizeof(own[0]), hipMemcpyHostToDevice));
     m.ownmask = e->d_ownmask;
-    if (m.n_shards > 1) {
-      // the same ownership as lists: the partner fields this shard owns for each own field
-      const int F = m.n_fields;
-      std::vector<int> cnt(F, 0), fp(static_cast<size_t>(F) * F, 0);
-      for (int fa = 0; fa < F; fa++)
-        for (int fb = 0; fb < F; fb++)
-          if ((own[fa] >> fb) & 1ull) fp[static_cast<size_t>(fa) * F + cnt[fa]++] = fb;
-      m.own_max = *std::max_element(cnt.begin(), cnt.end());
-      int *d_cnt = nullptr, *d_fp = nullptr;
-      TRY_ALLOC(e->alloc(&d_cnt, cnt.size()));
-      TRY_ALLOC(e->alloc(&d_fp, fp.size()));
-      TRY_HIP(hipMemcpy(d_cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
-      TRY_HIP(hipMemcpy(d_fp, fp.data(), fp.size() * sizeof(int), hipMemcpyHostToDevice));
-      m.own_cnt = d_cnt;
-      m.own_fp = d_fp;
+  }
+  if (m.n_shards > 1) {
+    // this shard's ranges (and, compact, the record index of every kept field) on the device
+    const int F = m.n_fields, r = m.shard_rank;
+    std::vector<int> lo(F), cnt(F), lin(F);
+    std::vector<long long> base(F, -1);
+    long long next = 0;
+    for (int f = 0; f < F; f++) {
+      lo[f] = plan.lo(r, f);
+      cnt[f] = plan.n(r, f);
+      lin[f] = plan.lin_owner[f] == r ? 1 : 0;
+      if (compact && cnt[f] > 0) { base[f] = next; next += e->field_start[f + 1] - e->field_start[f]; }
+    }
+    int *d_lo = nullptr, *d_n = nullptr, *d_lin = nullptr;
+    TRY_ALLOC(e->alloc(&d_lo, lo.size()));
+    TRY_ALLOC(e->alloc(&d_n, cnt.size()));
+    TRY_ALLOC(e->alloc(&d_lin, lin.size()));
+    TRY_HIP(hipMemcpy(d_lo, lo.data(), lo.size() * sizeof(int), hipMemcpyHostToDevice));
+    TRY_HIP(hipMemcpy(d_n, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+    TRY_HIP(hipMemcpy(d_lin, lin.data(), lin.size() * sizeof(int), hipMemcpyHostToDevice));
+    m.own_lo = d_lo;
+    m.own_n = d_n;
+    m.lin_own = d_lin;
+    e->lin_any = std::any_of(lin.begin(), lin.end(), [](int v) { return v != 0; });
+    if (compact) {
+      int *d_fs = nullptr;
+      long long *d_base = nullptr;
+      TRY_ALLOC(e->alloc(&d_fs, e->field_start.size()));
+      TRY_ALLOC(e->alloc(&d_base, base.size()));
+      TRY_HIP(hipMemcpy(d_fs, e->field_start.data(), e->field_start.size() * sizeof(int), hipMemcpyHostToDevice));
+      TRY_HIP(hipMemcpy(d_base, base.data(), base.size() * sizeof(long long), hipMemcpyHostToDevice));
+      m.field_start = d_fs;
+      m.rec_base = d_base;
     }
   }
   TRY_ALLOC(e->alloc(&s.haux, ffm_model ? E * static_cast<size_t>(m.n_fields) : 1));
@@ -633,7 +810,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&e->d_out, R));
   TRY_ALLOC(e->alloc(&e->d_loss_sum, 2));
   e->stage_floats = 16 << 20;  // 64 MiB dense staging for get/set
-  if (static_cast<int64_t>(m.row_len) > e->stage_floats) e->stage_floats = m.row_len;
+  if (static_cast<int64_t>(e->logical_len) > e->stage_floats) e->stage_floats = e->logical_len;
   TRY_ALLOC(e->alloc(&e->d_stage, static_cast<size_t>(e->stage_floats)));
 
   TRY_HIP(hipMemsetAsync(m.bias3, 0, 4 * sizeof(float), e->stream));
@@ -671,8 +848,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     }
   }
   if (!(cfg->flags & FFM_FLAG_SKIP_INIT))
-    hipLaunchKernelGGL(init_weights_kernel, dim3(2048), dim3(256), 0, e->stream, m, cfg->init_mean,
-                       cfg->init_stddev, cfg->seed);
+    hipLaunchKernelGGL(init_weights_kernel, dim3(2048), dim3(256), 0, e->stream, m, e->logical_len,
+                       cfg->init_mean, cfg->init_stddev, cfg->seed);
   TRY_HIP(hipGetLastError());
   TRY_HIP(hipStreamSynchronize(e->stream));
 #undef TRY_ALLOC
@@ -694,7 +871,7 @@ int ffm_engine_fill_state(ffm_engine *e, uint64_t seed, float n_lo, float n_hi, 
   if (!e) return fail(FFM_E_INVALID, "null engine");
   if (!(n_lo >= 0.0f) || !(n_hi >= n_lo)) return fail(FFM_E_INVALID, "need 0 <= n_lo <= n_hi");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
-  hipLaunchKernelGGL(fill_state_kernel, dim3(2048), dim3(256), 0, e->stream, e->m, seed, n_lo, n_hi, z_stddev);
+  hipLaunchKernelGGL(fill_state_kernel, dim3(2048), dim3(256), 0, e->stream, e->m, e->logical_len, seed, n_lo, n_hi, z_stddev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));
   return FFM_OK;
@@ -725,6 +902,9 @@ static int check_device_errors(ffm_engine *e) {
   if (flags & ERR_ROW_TOO_LONG)
     return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz: its block was not trained "
                                 "(outputs of that block are NaN)");
+  if (flags & ERR_FIELD_MAP)
+    return fail(FFM_E_INVALID, "an entry's feature id lies outside its field's id range (field_start): "
+                               "its block was not trained");
   if (flags) return fail(FFM_E_DEVICE, "device error flags " + std::to_string(flags));
   return FFM_OK;
 }
@@ -739,17 +919,36 @@ int ffm_engine_check_errors(ffm_engine *e) { return ffm_engine_sync(e); }
 
 void *ffm_engine_stream(ffm_engine *e) { return e ? static_cast<void *>(e->stream) : nullptr; }
 
+// Who owns what under field-pair sharding (host arithmetic only, no device needed).
+int ffm_engine_shard_plan(int32_t n_fields, int32_t n_shards, int32_t field_map, int32_t *pair_owner,
+                          int32_t *lin_owner, int32_t *bias_owner) {
+  if (n_fields <= 0 || n_shards <= 0) return fail(FFM_E_INVALID, "n_fields and n_shards must be positive");
+  const ShardPlan p = make_shard_plan(n_fields, n_shards, field_map != 0);
+  // self-check: every unordered pair has exactly one owner, symmetrically
+  for (int fa = 0; fa < n_fields; fa++)
+    for (int fb = 0; fb < n_fields; fb++) {
+      int owner = -1, count = 0;
+      for (int r = 0; r < n_shards; r++)
+        if (p.owns(r, fa, fb)) { owner = r; count++; }
+      if (count != 1 || !p.owns(owner, fb, fa)) return fail(FFM_E_UNSUPPORTED, "no field-pair partition for this shape");
+      if (pair_owner) pair_owner[static_cast<size_t>(fa) * n_fields + fb] = owner;
+    }
+  if (lin_owner) for (int f = 0; f < n_fields; f++) lin_owner[f] = p.lin_owner[f];
+  if (bias_owner) *bias_owner = p.bias_owner;
+  return FFM_OK;
+}
+
 // ---- dense <-> record layout transfers ----------------------------------------------------
 
 static int vec_transfer(ffm_engine *e, int comp, float *host, bool to_host) {
-  if (!host || e->m.row_len == 0) return FFM_OK;
-  const int64_t RL = e->m.row_len;
+  if (!host || e->logical_len == 0) return FFM_OK;
+  const int64_t RL = e->logical_len;
   const int64_t chunk = e->stage_floats / RL;
   for (int64_t f0 = 0; f0 < e->m.n_feats; f0 += chunk) {
     const int64_t nf = std::min<int64_t>(chunk, e->m.n_feats - f0);
     const size_t bytes = static_cast<size_t>(nf * RL) * sizeof(float);
     if (!to_host) HIP_TRY(hipMemcpyAsync(e->d_stage, host + f0 * RL, bytes, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(lat_component_copy_kernel, dim3(1024), dim3(256), 0, e->stream, e->m.lat,
+    hipLaunchKernelGGL(lat_component_copy_kernel, dim3(1024), dim3(256), 0, e->stream, e->m,
                        static_cast<int>(RL), comp, e->d_stage, f0, nf, to_host ? 1 : 0);
     if (to_host) HIP_TRY(hipMemcpyAsync(host + f0 * RL, e->d_stage, bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -818,7 +1017,7 @@ static int rows_transfer(ffm_engine *e, int32_t n, const int32_t *ids, float *co
   for (int32_t j = 0; j < n; j++)
     if (ids[j] < 0 || ids[j] >= e->m.n_feats) return fail(FFM_E_INVALID, "feature id out of range");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
-  const int64_t RL = e->m.row_len;
+  const int64_t RL = e->logical_len;
   const int64_t per = std::min<int64_t>(ffm_engine::kIdsCap, RL > 0 ? e->stage_floats / RL : ffm_engine::kIdsCap);
   float *const lin_dev[3] = {e->m.lin_n, e->m.lin_z, e->m.lin_w};
   for (int64_t j0 = 0; j0 < n; j0 += per) {
@@ -835,8 +1034,8 @@ static int rows_transfer(ffm_engine *e, int32_t n, const int32_t *ids, float *co
       if (vec[comp] && RL > 0) {
         const size_t bytes = static_cast<size_t>(nf) * RL * sizeof(float);
         if (!to_host) HIP_TRY(hipMemcpyAsync(e->d_stage, vec[comp] + j0 * RL, bytes, hipMemcpyHostToDevice, e->stream));
-        hipLaunchKernelGGL(lat_rows_copy_kernel, dim3(1024), dim3(256), 0, e->stream, e->m.lat,
-                           static_cast<int>(RL), e->m.n_feats, comp, e->d_stage, e->d_ids,
+        hipLaunchKernelGGL(lat_rows_copy_kernel, dim3(1024), dim3(256), 0, e->stream, e->m,
+                           static_cast<int>(RL), comp, e->d_stage, e->d_ids,
                            static_cast<int64_t>(nf), to_host ? 1 : 0);
         if (to_host) HIP_TRY(hipMemcpyAsync(vec[comp] + j0 * RL, e->d_stage, bytes, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1021,7 +1220,8 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->sc[e->cur].tg, e->sc[e->cur].loss, logit_out);
   if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0 && !own_tg)
     LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
-  const bool lin_owner = e->m.shard_rank == 0;
+  // this shard runs the bias chain / a linear update when it owns the bias / any field's linear terms
+  const bool lin_owner = e->m.bias_own != 0 || e->lin_any;
   const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
   const bool vec4 = e->m.n_factors % 4 == 0;
   const int lin_blocks = rows.nnz > 0 ? std::min(cdiv(rows.nnz, kUpdThreads), 1024) : 0;

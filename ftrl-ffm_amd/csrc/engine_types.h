@@ -20,15 +20,28 @@ struct Rows {
 // Model state in HBM.
 //   bias3  = {bias, bias_n, bias_z}
 //   lin_*  = [n_feats] each
-//   lat    = [n_feats][3][row_len] floats; component 0 = n, 1 = z, 2 = w.  One feature's
+//   lat    = [records][3][row_len] floats; component 0 = n, 1 = z, 2 = w.  One feature's
 //            accumulators and weights are one contiguous 3*row_len*4-byte record (7488 B at
 //            n_fields=39, n_factors=16), so a row's gather is nnz coalesced streams.
+//
+// Field-pair sharding (include/ffm_engine.h: n_shards / shard_rank, ffm_engine_shard_plan): this
+// shard owns, for a feature whose field is fa, the latent slots of the partner fields
+// [own_lo[fa], own_lo[fa] + own_n[fa]) -- one contiguous range per field, symmetric
+// (fb in range(fa) <=> fa in range(fb)), so both slots of a pair live on one shard.
+//   * With per-field id ranges (field_start: field(i) is a function of the id) the storage is
+//     COMPACT: only features of fields with own_n > 0 have a record, and a record holds just the
+//     owned slots (rec_slots = the widest range): about 1/n_shards of the tensor per shard.
+//     Record index = rec_base[fa] + (i - field_start[fa]); slot s <-> partner field own_lo[fa] + s.
+//   * Without id ranges every shard keeps full-length records of all features (slot = partner
+//     field) and only the ownership test shards the work.
+// An unsharded model is the second layout with every pair owned.
 struct ModelDev {
   int type;  // FFM_MODEL_*
   int n_feats;
   int n_fields;
   int n_factors;
-  int row_len;  // n_fields*n_factors (FFM), n_factors (FM), 0 (LR)
+  int row_len;    // floats per component of one STORED record: rec_slots * n_factors (FM: n_factors)
+  int rec_slots;  // slots per stored record: n_fields, or the widest owned range (compact)
   int n_shards, shard_rank;
   Hyper h;
   float *bias3;
@@ -37,44 +50,53 @@ struct ModelDev {
   // ownmask[fa] = bit fp set when this shard owns the field pair {fa, fp} (all ones when the
   // model is not sharded); n_fields <= 64 only, else null
   const unsigned long long *ownmask;
-  // Sharded engines walk a record through the partner fields this shard owns for the feature's
-  // own field fa: own_fp[fa*n_fields + j], j < own_cnt[fa] <= own_max (ascending).  Null when
-  // n_shards == 1.
-  const int *own_cnt;
-  const int *own_fp;
-  int own_max;
+  const int *own_lo, *own_n;  // [n_fields] owned partner-field range per own field; null: all pairs
+  const int *field_start;     // [n_fields + 1] id range of every field: compact storage; else null
+  const long long *rec_base;  // [n_fields] first stored record of a field (compact); -1: none
+  const int *lin_own;         // [n_fields] 1 when this shard owns the field's linear terms; null: all
+  int bias_own;               // 1 when this shard owns the bias
 };
 
 enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };
 
-__device__ __forceinline__ float *lat_row(const ModelDev &m, int feat) {
-  return m.lat + static_cast<int64_t>(feat) * 3 * m.row_len;
-}
-
-// Field-pair ownership (include/ffm_engine.h: n_shards / shard_rank).  Both latent slots of a
-// pair (i, field_j) and (j, field_i) belong to the shard that owns {field_i, field_j}.
+// Field-pair ownership: both latent slots of a pair (i, field_j) and (j, field_i) belong to the
+// shard that owns {field_i, field_j}.
 __device__ __forceinline__ bool owns_pair(const ModelDev &m, int fa, int fb) {
-  if (m.n_shards <= 1) return true;
-  const int lo = fa < fb ? fa : fb, hi = fa < fb ? fb : fa;
-  // index of {lo, hi} in the upper triangle (diagonal included), dealt round-robin: balanced
-  const int idx = lo * m.n_fields - lo * (lo - 1) / 2 + (hi - lo);
-  return idx % m.n_shards == m.shard_rank;
+  if (!m.own_n) return true;
+  return static_cast<unsigned>(fb - m.own_lo[fa]) < static_cast<unsigned>(m.own_n[fa]);
+}
+__device__ __forceinline__ bool owns_linear(const ModelDev &m, int fa) {
+  return !m.lin_own || m.lin_own[fa] != 0;
+}
+// Does this shard look at entries of field fa at all?  (Compact shards drop the other columns.)
+__device__ __forceinline__ bool keeps_field(const ModelDev &m, int fa) {
+  return !m.field_start || m.own_n[fa] > 0 || m.lin_own[fa] != 0;
 }
 
-// A record's elements as the feature-major kernels walk them, in units of `unit` floats per slot
-// (n_factors, n_factors/4 for 16-byte vectors, ...).  One shard: all n_fields slots, in place.
-// Sharded: only the slots whose field pair this shard owns -- 1/n_shards of the record -- so the
-// work per occurrence shrinks with the number of shards instead of leaving lanes idle.
-__device__ __forceinline__ int record_span(const ModelDev &m, int unit) {
-  return (m.n_shards > 1 ? m.own_max : m.n_fields) * unit;
+// The stored record of feature `feat` whose field is fa (fa is ignored unless storage is compact).
+__device__ __forceinline__ float *lat_row(const ModelDev &m, int feat, int fa) {
+  const long long rec = m.field_start ? m.rec_base[fa] + (feat - m.field_start[fa]) : feat;
+  return m.lat + rec * 3 * m.row_len;
 }
-// index into the record of walk position ec of a feature whose field is fa; -1 past its last slot
-__device__ __forceinline__ int record_index(const ModelDev &m, int fa, int ec, int unit) {
-  if (m.n_shards <= 1) return ec < m.n_fields * unit ? ec : -1;
-  int c = static_cast<int>((ec + 0.5f) / static_cast<float>(unit));
-  c += (c + 1) * unit <= ec ? 1 : (c * unit > ec ? -1 : 0);
-  if (c >= m.own_cnt[fa]) return -1;
-  return m.own_fp[fa * m.n_fields + c] * unit + (ec - c * unit);
+// Slot, inside the record of a feature of field fa, that holds partner field fb.
+__device__ __forceinline__ int slot_of(const ModelDev &m, int fa, int fb) {
+  return m.field_start ? fb - m.own_lo[fa] : fb;
+}
+// Float offset of the w row of that slot from the start of m.lat (what the fact stream carries).
+__device__ __forceinline__ long long w_slot_offset(const ModelDev &m, int feat, int fa, int fb) {
+  const long long rec = m.field_start ? m.rec_base[fa] + (feat - m.field_start[fa]) : feat;
+  return rec * 3 * m.row_len + LAT_W * m.row_len + slot_of(m, fa, fb) * m.n_factors;
+}
+
+// A record as the feature-major kernels walk it: walk position c = storage slot c, for
+// c < record_span.  walk_field gives the partner field at that position, or -1 when the record of
+// a feature of field fa has no (owned) slot there.  Full-length records are walked whole (slot =
+// partner field; the ownership test then filters touch by touch, which is also right when one id
+// shows up under several fields); compact records hold exactly the owned range.
+__device__ __forceinline__ int record_span(const ModelDev &m, int unit) { return m.rec_slots * unit; }
+__device__ __forceinline__ int walk_field(const ModelDev &m, int fa, int c) {
+  if (!m.field_start) return c < m.n_fields ? c : -1;
+  return c < m.own_n[fa] ? m.own_lo[fa] + c : -1;
 }
 
 // Per-block scratch: the block grouped by feature ("postings"), per-row field chains, outputs.
@@ -134,6 +156,6 @@ enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain pa
 #define FFM_SMALL_MAX 4
 #endif
 constexpr int kSmallMax = FFM_SMALL_MAX;  // occurrences per block up to which a feature takes the "small" path
-enum { ERR_ROW_TOO_LONG = 1 };
+enum { ERR_ROW_TOO_LONG = 1, ERR_FIELD_MAP = 2 };
 
 }  // namespace ftrl_dev

@@ -154,18 +154,18 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
   const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const unsigned n_waves = gridDim.x * kUpdWaves;
   const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * per_feat;
-  const size_t rec_floats = static_cast<size_t>(3) * RL;
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned li = item / per_feat;
     const int rem = static_cast<int>(item - li * per_feat);
     const int sc = rem / passes, pass = rem - sc * passes;
     const int u = wave_uniform(s.huge[li]);
-    const int fp = wave_uniform(record_index(m, wave_uniform(s.ufield[u]), sc, 1));  // partner field
+    const int fa = wave_uniform(s.ufield[u]);
+    const int fp = wave_uniform(walk_field(m, fa, sc));  // partner field of slot sc
     if (fp < 0) continue;
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     if (s.gmask && !((s.gmask[start] >> fp) & 1ull)) continue;  // no row of the block touches the slot
     const int i = wave_uniform(s.uniq[u]);
-    float *rec = lat_row(m, i);
+    float *rec = lat_row(m, i, fa) + sc * k;  // the slot's n row; z and w rows follow at RL, 2 RL
     int kk[G];
     bool act[G];
     float nc[G], zc[G], w[G];  // carries: valid in lane 0 of every row
@@ -174,13 +174,12 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
       const int grp = pass * G + g;
       act[g] = grp < groups;
       kk[g] = (act[g] ? grp : 0) * 4 + el;
-      nc[g] = rec[LAT_N * RL + fp * k + kk[g]];
-      zc[g] = rec[LAT_Z * RL + fp * k + kk[g]];
-      w[g] = rec[LAT_W * RL + fp * k + kk[g]];
+      nc[g] = rec[LAT_N * RL + kk[g]];
+      zc[g] = rec[LAT_Z * RL + kk[g]];
+      w[g] = rec[LAT_W * RL + kk[g]];
     }
     const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;  // + t*F
     const float2 *mcol = s.hmeta + start;                              // + t
-    const float *wcol = m.lat + LAT_W * RL;                            // + feat*rec + field*k + kk
     const int steps = (c + kChainT - 1) / kChainT;
 
     // pipeline: facts two steps ahead, partner weights one step ahead
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
               const float xq = rows.val[qq];
 #pragma unroll
               for (int g = 0; g < G; g++) {
-                const float vq = wcol[rows.feat[qq] * rec_floats + fm * k + kk[g]];
+                const float vq = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk[g]];
                 ffm_touch(m.h, pt < qq, tgt, xmt, xq, vq, w[g], nc[g], zc[g]);
               }
             }
@@ -280,8 +279,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
 #pragma unroll
       for (int g = 0; g < G; g++)
         if (act[g]) {
-          rec[LAT_N * RL + fp * k + kk[g]] = nc[g];
-          rec[LAT_Z * RL + fp * k + kk[g]] = zc[g];
+          rec[LAT_N * RL + kk[g]] = nc[g];
+          rec[LAT_Z * RL + kk[g]] = zc[g];
         }
     }
   }
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m
     const int u = wave_uniform(s.huge[li]);
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
-    float *rec = lat_row(m, i);
+    float *rec = lat_row(m, i, 0);
     int kk[G];
     bool act[G];
     float nc[G], zc[G], w[G];

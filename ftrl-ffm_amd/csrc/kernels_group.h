@@ -70,6 +70,16 @@ __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, R
   const int f = rows.field ? rows.field[p] : 0;
   bool valid = i >= 0 && i < m.n_feats;
   if (m.type == 2) valid = valid && f >= 0 && f < m.n_fields;
+  if (m.field_start && valid) {
+    // compact shard: an id must lie in its field's id range (that is what makes field(i) a
+    // function of i); an entry that does not is a caller error and voids the block like an
+    // over-long row.  Columns this shard owns nothing of are dropped here.
+    if (in && (i < m.field_start[f] || i >= m.field_start[f + 1])) {
+      atomicOr(&s.counters[CNT_ERROR], ERR_FIELD_MAP);
+      atomicOr(s.err, ERR_FIELD_MAP);
+    }
+    valid = keeps_field(m, f);
+  }
   if (in) {
     s.row_of[p] = lo;
     s.key[p] = valid ? static_cast<unsigned>(i) : static_cast<unsigned>(m.n_feats);

@@ -71,6 +71,7 @@ __device__ __forceinline__ void stage_row(const ModelDev &m, const Rows &rows, i
         if (m.type == 2) {
           f = rows.field[b + p];
           valid = valid && f >= 0 && f < m.n_fields;
+          if (valid) valid = keeps_field(m, f);  // a compact shard drops the columns it owns nothing of
         }
       }
       const unsigned long long mask = __ballot(valid);
@@ -124,38 +125,34 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
   auto emit_facts = [&](int a, int f, int op) {
     const int cnt = lds.fcnt[f];
     const int a0 = lds.ffirst[f];
-    int flags = 0, fq = lds.feat[a];  // harmless partner when there is no plain partner
+    int flags = 0;
     float xo = 0.0f;
+    // where the partner's weights for this touch start inside m.lat (floats): its record, the w
+    // row, the slot of the own entry's field -- the owners add their factor index and load.
+    // Without a plain partner: a harmless valid address (the own record's slot for f).
+    int64_t woff = w_slot_offset(m, lds.feat[a], lds.field[a], f);
     if (cnt == 1 && a0 != a) {
       flags = HF_SIMPLE | (a < a0 ? HF_FIRST : 0);
       xo = lds.val[a0];
-      fq = lds.feat[a0];
+      woff = w_slot_offset(m, lds.feat[a0], f, lds.field[a]);
     } else if (cnt > 1) {
       flags = HF_CHAIN;
     }
-    // where the partner's weights for this touch start inside m.lat (floats): its record, the w
-    // row, the slot of the own entry's field -- the owners add their factor index and load
-    const int64_t woff = static_cast<int64_t>(fq) * 3 * m.row_len + LAT_W * m.row_len +
-                         lds.field[a] * m.n_factors;
     s.haux[static_cast<int64_t>(op) * F + f] =
         make_int4(__float_as_int(xo), flags | (lds.field[a] << 8), static_cast<int>(woff & 0xffffffff),
                   static_cast<int>(woff >> 32));
   };
-  if (m.n_shards > 1) {
-    // only the partner fields this shard owns for the entry's field (m.own_fp): 1/n_shards of them
-    const int om = m.own_max;
-    for (int t = threadIdx.x; t < nv * om; t += blockDim.x) {
-      const int a = t / om, j = t - a * om;
-      const int op = lds.opos[a];
-      const int fa = lds.field[a];
-      if (op < 0 || j >= m.own_cnt[fa]) continue;
-      emit_facts(a, m.own_fp[fa * F + j], op);
-    }
-  } else {
-    for (int t = threadIdx.x; t < nv * F; t += blockDim.x) {
-      const int a = t / F, f = t - a * F;
+  {
+    // one fact per (hot entry, slot of its record): the partner fields this shard owns for the
+    // entry's field -- all of them when the model is not sharded
+    const int span = record_span(m, 1);
+    for (int t = threadIdx.x; t < nv * span; t += blockDim.x) {
+      const int a = t / span, j = t - a * span;
       const int op = lds.opos[a];
       if (op < 0) continue;
+      const int fa = lds.field[a];
+      const int f = walk_field(m, fa, j);
+      if (f < 0 || !owns_pair(m, fa, f)) continue;
       emit_facts(a, f, op);
     }
   }
@@ -250,7 +247,6 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     return;
   }
   const bool is_ffm = m.type == 2;
-  const bool lin_owner = m.shard_rank == 0;
 
   for (int f = threadIdx.x; f < F; f += blockDim.x) { lds.fcnt[f] = 0; lds.ffirst[f] = -1; }
   stage_row(m, rows, b, nnz, lds, &s_nv);
@@ -260,18 +256,21 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   // linear weights of the surviving entries (update_linear_w, ftrl_model.cpp:52-59).  The first
   // blockDim.x of them are fetched now into a register each, so that the loads fly while the row's
   // tables are built, and parked in LDS afterwards.
-  auto linear_weight = [&](int i) {
+  // (a shard adds -- and refreshes -- the linear terms of the fields it owns them for only)
+  auto linear_weight = [&](int a) {
+    const int i = lds.feat[a];
+    if (!owns_linear(m, lds.field[a])) return 0.0f;
     float lw;
     if (TRAIN && !refreshed) {
       lw = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
-      if (lin_owner) m.lin_w[i] = lw;
+      m.lin_w[i] = lw;
     } else {
       lw = m.lin_w[i];
     }
     return lw;
   };
   float lw_early = 0.0f;
-  if (static_cast<int>(threadIdx.x) < nv) lw_early = linear_weight(lds.feat[threadIdx.x]);
+  if (static_cast<int>(threadIdx.x) < nv) lw_early = linear_weight(threadIdx.x);
   if (is_ffm) {
     for (int a = threadIdx.x; a < nv; a += blockDim.x) {
       atomicAdd(&lds.fcnt[lds.field[a]], 1);
@@ -293,12 +292,13 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
         int a = static_cast<int>((t + 0.5f) * inv_RL4);
         a += (a + 1) * RL4 <= t ? 1 : (a * RL4 > t ? -1 : 0);  // exact for any size
         const int c4 = t - a * RL4;
-        int fp = static_cast<int>((c4 + 0.5f) * inv_k4);
-        fp += (fp + 1) * k4 <= c4 ? 1 : (fp * k4 > c4 ? -1 : 0);
+        int sl = static_cast<int>((c4 + 0.5f) * inv_k4);  // slot of the record
+        sl += (sl + 1) * k4 <= c4 ? 1 : (sl * k4 > c4 ? -1 : 0);
         const int fa = lds.field[a];
-        const bool touched = (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
+        const int fp = walk_field(m, fa, sl);
+        const bool touched = fp >= 0 && (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
         if (touched) {
-          float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a]));
+          float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a], fa));
           const float4 n4 = row[LAT_N * RL4 + c4], z4 = row[LAT_Z * RL4 + c4];
           const float4 w4 = m.h.learn ? row[LAT_W * RL4 + c4] : n4;
           row[LAT_W * RL4 + c4] = latent_weight4(m.h, n4, z4, w4);
@@ -308,11 +308,11 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
       const int total = nv * RL;
       for (int t = threadIdx.x; t < total; t += blockDim.x) {
         const int a = t / RL, e = t - a * RL;
-        const int fp = e / k;
         const int fa = lds.field[a];
-        const bool touched = (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
+        const int fp = walk_field(m, fa, e / k);
+        const bool touched = fp >= 0 && (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
         if (touched) {
-          float *row = lat_row(m, lds.feat[a]);
+          float *row = lat_row(m, lds.feat[a], fa);
           row[LAT_W * RL + e] = latent_weight(m.h, row[LAT_N * RL + e], row[LAT_Z * RL + e],
                                              m.h.learn ? row[LAT_W * RL + e] : 0.0f);
         }
@@ -321,21 +321,28 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   }
 
   if (static_cast<int>(threadIdx.x) < nv) lds.linw[threadIdx.x] = lw_early;
-  for (int a = threadIdx.x + blockDim.x; a < nv; a += blockDim.x) lds.linw[a] = linear_weight(lds.feat[a]);
+  for (int a = threadIdx.x + blockDim.x; a < nv; a += blockDim.x) lds.linw[a] = linear_weight(a);
   __syncthreads();  // this row's refreshed weights are now readable by the whole workgroup
 
   // linear logit, sequential in row order (compute_linear_logit, ftrl_model.cpp:44-50)
   float result = 0.0f;
-  if (threadIdx.x == 0 && lin_owner) {
-    float bias;
-    if (TRAIN) {
-      bias = ftrl_weight(m.h, m.bias3[1], m.bias3[2]);  // update_bias, ftrl_model.cpp:61-64
-      if (r == 0) m.bias3[0] = bias;
-    } else {
-      bias = m.bias3[0];
+  if (threadIdx.x == 0) {
+    if (m.bias_own) {
+      float bias;
+      if (TRAIN) {
+        bias = ftrl_weight(m.h, m.bias3[1], m.bias3[2]);  // update_bias, ftrl_model.cpp:61-64
+        if (r == 0) m.bias3[0] = bias;
+      } else {
+        bias = m.bias3[0];
+      }
+      result = bias;
     }
-    result = bias;
-    for (int a = 0; a < nv; a++) result = result + lds.linw[a] * lds.val[a];
+    if (!m.lin_own) {
+      for (int a = 0; a < nv; a++) result = result + lds.linw[a] * lds.val[a];
+    } else {
+      for (int a = 0; a < nv; a++)
+        if (m.lin_own[lds.field[a]]) result = result + lds.linw[a] * lds.val[a];
+    }
   }
 
   // A shard owns 1/n_shards of the field pairs: walk (entry a, owned partner field of a's field)
@@ -349,19 +356,19 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     shard_walk = !multi;
   }
   if (shard_walk) {
-    const int om = m.own_max, items = nv * om;
+    const int om = record_span(m, 1), items = nv * om;
     for (int q0 = 0; q0 < items; q0 += kTermsCap) {
       const int q1 = min(q0 + kTermsCap, items);
       for (int t = q0 + threadIdx.x; t < q1; t += blockDim.x) {
         const int a = t / om, j = t - a * om;
         const int fa = lds.field[a];
         float term = __int_as_float(0x7fc00001);  // "no pair here"
-        if (j < m.own_cnt[fa]) {
-          const int fb = m.own_fp[fa * F + j];
+        const int fb = walk_field(m, fa, j);
+        if (fb >= 0 && owns_pair(m, fa, fb)) {
           const int bb = lds.ffirst[fb];
           if (lds.fcnt[fb] == 1 && bb > a) {
-            const float *va = lat_row(m, lds.feat[a]) + LAT_W * RL + fb * k;
-            const float *vb = lat_row(m, lds.feat[bb]) + LAT_W * RL + fa * k;
+            const float *va = lat_row(m, lds.feat[a], fa) + LAT_W * RL + slot_of(m, fa, fb) * k;
+            const float *vb = lat_row(m, lds.feat[bb], fb) + LAT_W * RL + slot_of(m, fb, fa) * k;
             float dot = 0.0f;
             if (VEC4) {
               const float4 *va4 = reinterpret_cast<const float4 *>(va);
@@ -396,8 +403,8 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
         float term = 0.0f;
         const bool own = owns_pair(m, fa, fb);
         if (own) {
-          const float *va = lat_row(m, lds.feat[a]) + LAT_W * RL + fb * k;
-          const float *vb = lat_row(m, lds.feat[bb]) + LAT_W * RL + fa * k;
+          const float *va = lat_row(m, lds.feat[a], fa) + LAT_W * RL + slot_of(m, fa, fb) * k;
+          const float *vb = lat_row(m, lds.feat[bb], fb) + LAT_W * RL + slot_of(m, fb, fa) * k;
           float dot = 0.0f;
           if (VEC4) {
             const float4 *va4 = reinterpret_cast<const float4 *>(va);
@@ -483,31 +490,32 @@ __global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s)
   const double inv_per = 1.0 / static_cast<double>(per);
   const unsigned total = static_cast<unsigned>(n_uniq) * static_cast<unsigned>(per);  // < 2^31 (engine)
   const unsigned stride = gridDim.x * blockDim.x;
-  const bool lin_owner = m.shard_rank == 0;
   for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     // u = t / per through the double reciprocal (exact after one correction for t < 2^31)
     int u = static_cast<int>((static_cast<double>(t) + 0.5) * inv_per);
     u += static_cast<unsigned>(u + 1) * per <= t ? 1 : (static_cast<unsigned>(u) * per > t ? -1 : 0);
     const int lc = static_cast<int>(t - static_cast<unsigned>(u) * per);
-    if (lc == 0 && lin_owner) {
+    const int fa = s.ufield[u];
+    if (lc == 0 && owns_linear(m, fa)) {
       const int i0 = s.uniq[u];
       m.lin_w[i0] = ftrl_weight(m.h, m.lin_n[i0], m.lin_z[i0]);
     }
-    const int l = record_index(m, s.ufield[u], lc, kv);
-    if (l < 0) continue;
-    int fp = static_cast<int>((l + 0.5f) * inv_kv);
-    fp += (fp + 1) * kv <= l ? 1 : (fp * kv > l ? -1 : 0);
+    const int l = lc;  // walk position = element of the stored record
+    int sl = static_cast<int>((l + 0.5f) * inv_kv);  // its slot
+    sl += (sl + 1) * kv <= l ? 1 : (sl * kv > l ? -1 : 0);
+    const int fp = walk_field(m, fa, sl);
+    if (fp < 0) continue;
     const int i = s.uniq[u];
     const unsigned long long mask = s.gmask[s.ustart[u]];
     if (!((mask >> fp) & 1ull)) continue;
     if (VEC4) {
       const int RL4 = RL >> 2;
-      float4 *row = reinterpret_cast<float4 *>(lat_row(m, i));
+      float4 *row = reinterpret_cast<float4 *>(lat_row(m, i, fa));
       const float4 n4 = row[LAT_N * RL4 + l], z4 = row[LAT_Z * RL4 + l];
       const float4 w4 = m.h.learn ? row[LAT_W * RL4 + l] : n4;
       row[LAT_W * RL4 + l] = latent_weight4(m.h, n4, z4, w4);
     } else {
-      float *row = lat_row(m, i);
+      float *row = lat_row(m, i, fa);
       row[LAT_W * RL + l] = latent_weight(m.h, row[LAT_N * RL + l], row[LAT_Z * RL + l],
                                          m.h.learn ? row[LAT_W * RL + l] : 0.0f);
     }
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
       int a = static_cast<int>((t + 0.5f) * inv_k);
       a += (a + 1) * k <= t ? 1 : (a * k > t ? -1 : 0);
       const int e = t - a * k;
-      float *row = lat_row(m, lds.feat[a]);
+      float *row = lat_row(m, lds.feat[a], 0);
       row[LAT_W * k + e] = latent_weight(m.h, row[LAT_N * k + e], row[LAT_Z * k + e],
                                         m.h.learn ? row[LAT_W * k + e] : 0.0f);
     }
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
   for (int f = threadIdx.x; f < k; f += blockDim.x) {
     float s_vx = 0.0f, sum_sqr = 0.0f;
     for (int a = 0; a < nv; a++) {
-      const float vx = lat_row(m, lds.feat[a])[LAT_W * k + f] * lds.val[a];
+      const float vx = lat_row(m, lds.feat[a], 0)[LAT_W * k + f] * lds.val[a];
       s_vx += vx;
       sum_sqr += vx * vx;
     }

@@ -154,6 +154,7 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
   const int gtid = block * blockDim.x + threadIdx.x;
   for (int li = gtid; li < n_small; li += n_blocks * blockDim.x) {
     const int u = s.small[li];
+    if (!owns_linear(m, s.ufield[u])) continue;  // another shard's linear terms
     const int i = s.uniq[u];
     const int start = s.ustart[u], c = s.ucount[u];
     float n = m.lin_n[i], z = m.lin_z[i];
@@ -171,6 +172,7 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
   const int n_huge = s.counters[CNT_NHUGE];
   for (int li = wave; li < n_big + n_huge; li += n_waves) {
     const int u = wave_uniform(li < n_big ? s.big[li] : s.huge[li - n_big]);
+    if (!owns_linear(m, wave_uniform(s.ufield[u]))) continue;
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     float n = m.lin_n[i], z = m.lin_z[i];
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, 
 
 // Bias update: one wave walks all rows of the block in order (update_bias_nz, :79-85).
 __device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, const Scratch &s) {
+  if (!m.bias_own) return;            // another shard's
   if (s.counters[CNT_ERROR]) return;  // untrainable block (ERR_ROW_TOO_LONG): a no-op
   const int lane = threadIdx.x & 63;
   float n = m.bias3[1], z = m.bias3[2];
@@ -268,22 +271,25 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
   const unsigned n_waves = (gridDim.x - side_blocks) * kUpdWaves;
   const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NBIG]) * chunks;
   const float inv_k = 1.0f / static_cast<float>(k);
-  const size_t rec_floats = static_cast<size_t>(3) * RL;
+  const int span = record_span(m, k);
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned li = item / chunks;
     const int u = wave_uniform(s.big[li]);
-    const int e = record_index(m, wave_uniform(s.ufield[u]), static_cast<int>(item - li * chunks) * 64 + lane, k);
-    const bool active = e >= 0;
-    const int ee = active ? e : 0;
-    int fp = static_cast<int>((ee + 0.5f) * inv_k);  // this lane's partner field
-    fp += (fp + 1) * k <= ee ? 1 : (fp * k > ee ? -1 : 0);
-    const int kk = ee - fp * k;  // and factor
+    const int fa = wave_uniform(s.ufield[u]);
+    const int epos = static_cast<int>(item - li * chunks) * 64 + lane;  // element of the stored record
+    const int eb = epos < span ? epos : 0;
+    int sl = static_cast<int>((eb + 0.5f) * inv_k);  // this lane's slot
+    sl += (sl + 1) * k <= eb ? 1 : (sl * k > eb ? -1 : 0);
+    const int fpw = epos < span ? walk_field(m, fa, sl) : -1;  // its partner field
+    const bool active = fpw >= 0;
+    const int ee = active ? eb : 0;
+    const int fp = active ? fpw : 0;  // (idle lanes still form valid fact addresses)
+    const int kk = active ? eb - sl * k : 0;  // and factor
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
-    float *rec = lat_row(m, i);
+    float *rec = lat_row(m, i, fa);
     float n = rec[LAT_N * RL + ee], z = rec[LAT_Z * RL + ee];
     const float w = rec[LAT_W * RL + ee];
-    const float *wcol = m.lat + LAT_W * RL + kk;                          // + feat*rec + field*k
     const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;     // + t*F
     const float2 *mcol = s.hmeta + start;                                 // + t
     bool touched = false;
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
               const int r = s.row_of[p];
               for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
                 if (qq == p) continue;
-                const float vp = wcol[rows.feat[qq] * rec_floats + fm * k];
+                const float vp = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk];
                 ffm_touch(m.h, p < qq, tgj[j], xmj[j], rows.val[qq], vp, w, n, z);
                 touched = true;
               }
@@ -401,10 +407,13 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
     const unsigned u = item / chunks;
     const int e = static_cast<int>(item - u * chunks) * 64 + lane;
     if (e >= RL) continue;
-    const int fp = e / k, kk = e - fp * k;
+    const int fa = s.ufield[u];
+    const int sl = e / k, kk = e - sl * k;
+    const int fp = walk_field(m, fa, sl);
+    if (fp < 0) continue;
     const int i = s.uniq[u];
     const int start = s.ustart[u], c = s.ucount[u];
-    float *rec = lat_row(m, i);
+    float *rec = lat_row(m, i, fa);
     float n = rec[LAT_N * RL + e], z = rec[LAT_Z * RL + e];
     const float w = rec[LAT_W * RL + e];
     bool touched = false;
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
       const float tg = s.tg[r], xm = rows.val[p];
       for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
         if (qq == p) continue;
-        const float vp = lat_row(m, rows.feat[qq])[LAT_W * RL + fm * k + kk];
+        const float vp = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk];
         ffm_touch(m.h, p < qq, tg, xm, rows.val[qq], vp, w, n, z);
         touched = true;
       }
@@ -447,14 +456,16 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
     const int u = wave_uniform(list[li]);
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
-    float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i));
     const int fa = wave_uniform(s.ufield[u]);
+    float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
     for (int l0 = 0; l0 < span4; l0 += 64) {
-      const int l = record_index(m, fa, l0 + lane, k4);
-      if (l < 0) continue;
-      int fp = static_cast<int>((l + 0.5f) * inv_k4);  // partner field of this lane's slot
-      fp += (fp + 1) * k4 <= l ? 1 : (fp * k4 > l ? -1 : 0);
-      const int kq = l - fp * k4;  // which 16-byte quarter of the slot
+      const int l = l0 + lane;  // 16-byte vector of the stored record
+      if (l >= span4) continue;
+      int sl = static_cast<int>((l + 0.5f) * inv_k4);  // its slot
+      sl += (sl + 1) * k4 <= l ? 1 : (sl * k4 > l ? -1 : 0);
+      const int fp = walk_field(m, fa, sl);  // partner field of this lane's slot
+      if (fp < 0) continue;
+      const int kq = l - sl * k4;  // which 16-byte quarter of the slot
       float4 n4 = rec4[LAT_N * RL4 + l], z4 = rec4[LAT_Z * RL4 + l];
       const float4 w4 = rec4[LAT_W * RL4 + l];
       bool touched = false;
@@ -468,8 +479,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
         const int q = rt.z;
         if (q >= 0) {
           if (q != p) {
-            const float4 vp =
-                reinterpret_cast<const float4 *>(lat_row(m, rt.x))[LAT_W * RL4 + fm * k4 + kq];
+            const float4 vp = reinterpret_cast<const float4 *>(
+                lat_row(m, rt.x, fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
             const bool first = p < q;
             const float xo = __int_as_float(rt.y);
             ffm_touch4(m.h, first, tg, xm, xo, vp, w4, n4, z4);
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
           for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
             if (qq == p) continue;
             const float4 vp = reinterpret_cast<const float4 *>(
-                lat_row(m, rows.feat[qq]))[LAT_W * RL4 + fm * k4 + kq];
+                lat_row(m, rows.feat[qq], fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
             const bool first = p < qq;
             const float xo = rows.val[qq];
             ffm_touch4(m.h, first, tg, xm, xo, vp, w4, n4, z4);
@@ -517,19 +528,23 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev
     const int i = wave_uniform(d.x), p = wave_uniform(d.y), r = wave_uniform(d.z);
     const int fa = wave_uniform(d.w);
     const float xm = rows.val[p], tg = s.tg[r];
-    float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i));
+    float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
     const int4 *rtab = s.rowtab + static_cast<int64_t>(r) * F;
     for (int l0 = 0; l0 < span4; l0 += 64 * kSingleTrips) {
-      int l[kSingleTrips], fp[kSingleTrips];
+      int l[kSingleTrips], fp[kSingleTrips], kq[kSingleTrips];
       float4 n4[kSingleTrips], z4[kSingleTrips], w4[kSingleTrips], vp[kSingleTrips];
       int4 rt[kSingleTrips];
 #pragma unroll
       for (int t = 0; t < kSingleTrips; t++) {
-        const int lc = l0 + t * 64 + lane;
-        l[t] = lc < span4 ? record_index(m, fa, lc, k4) : -1;
-        const int ll = l[t] < 0 ? 0 : l[t];
-        int f = static_cast<int>((ll + 0.5f) * inv_k4);  // partner field of this vector's slot
-        f += (f + 1) * k4 <= ll ? 1 : (f * k4 > ll ? -1 : 0);
+        const int lc = l0 + t * 64 + lane;  // 16-byte vector of the stored record
+        const int ll = lc < span4 ? lc : 0;
+        int sl = static_cast<int>((ll + 0.5f) * inv_k4);  // its slot
+        sl += (sl + 1) * k4 <= ll ? 1 : (sl * k4 > ll ? -1 : 0);
+        int f = lc < span4 ? walk_field(m, fa, sl) : -1;  // partner field of this vector's slot
+        if (f >= 0 && !owns_pair(m, fa, f)) f = -1;
+        l[t] = f >= 0 ? ll : -1;
+        kq[t] = ll - sl * k4;
+        f = f < 0 ? 0 : f;
         fp[t] = f;
         if (l[t] >= 0) {
           n4[t] = rec4[LAT_N * RL4 + ll];
@@ -541,8 +556,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev
 #pragma unroll
       for (int t = 0; t < kSingleTrips; t++) {
         if (l[t] >= 0 && rt[t].z >= 0 && rt[t].z != p)
-          vp[t] = reinterpret_cast<const float4 *>(lat_row(m, rt[t].x))[LAT_W * RL4 + fa * k4 +
-                                                                       (l[t] - fp[t] * k4)];
+          vp[t] = reinterpret_cast<const float4 *>(
+              lat_row(m, rt[t].x, fp[t]))[LAT_W * RL4 + slot_of(m, fp[t], fa) * k4 + kq[t]];
       }
 #pragma unroll
       for (int t = 0; t < kSingleTrips; t++) {
@@ -555,11 +570,10 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev
             touched = true;
           }
         } else if (q == -2) {  // several entries of that field in the row: walk them in row order
-          const int kq = l[t] - fp[t] * k4;
           for (int qq = s.head[static_cast<int64_t>(r) * F + fp[t]]; qq >= 0; qq = s.next[qq]) {
             if (qq == p) continue;
             const float4 vq = reinterpret_cast<const float4 *>(
-                lat_row(m, rows.feat[qq]))[LAT_W * RL4 + fa * k4 + kq];
+                lat_row(m, rows.feat[qq], fp[t]))[LAT_W * RL4 + slot_of(m, fp[t], fa) * k4 + kq[t]];
             ffm_touch4(m.h, p < qq, tg, xm, rows.val[qq], vq, w4[t], n4[t], z4[t]);
             touched = true;
           }
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     if (skip_huge && c > kHugeMin) continue;
-    float *rec = lat_row(m, i);
+    float *rec = lat_row(m, i, 0);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
     const float w = rec[LAT_W * k + e];
     for (int t0 = 0; t0 < c; t0 += kFmUnroll) {

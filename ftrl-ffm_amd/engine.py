@@ -38,7 +38,8 @@ class Config(ctypes.Structure):
                 ("max_batch_nnz", ctypes.c_int32), ("device_id", ctypes.c_int32),
                 ("n_shards", ctypes.c_int32), ("shard_rank", ctypes.c_int32),
                 ("stream", ctypes.c_void_p), ("flags", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 7)]
+                ("max_row_nnz", ctypes.c_int32), ("field_start", _i32p),
+                ("reserved", ctypes.c_int32 * 4)]
 
 
 # every symbol include/ffm_engine.h declares: (name, restype, argtypes)
@@ -54,6 +55,8 @@ ABI = [
     ("ffm_engine_last_error", ctypes.c_char_p, []),
     ("ffm_engine_abi_version", ctypes.c_int, []),
     ("ffm_engine_row_len", ctypes.c_int64, [_vp]),
+    ("ffm_engine_shard_plan", ctypes.c_int,
+     [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i32p, _i32p, _i32p]),
     ("ffm_engine_set_weights", ctypes.c_int, [_vp, _f32p, _f32p, _f32p]),
     ("ffm_engine_get_weights", ctypes.c_int, [_vp, _f32p, _f32p, _f32p]),
     ("ffm_engine_set_state", ctypes.c_int, [_vp] + [_f32p] * 6),
@@ -95,6 +98,21 @@ ABI = [
 ]
 
 _lib = None
+
+
+def shard_plan(n_fields, n_shards, field_map=False):
+    """Who owns what under field-pair sharding (ffm_engine_shard_plan): dict(pair_owner [F, F] --
+    shard owning the unordered field pair, i.e. both of its latent slots --, lin_owner [F] -- shard
+    that adds and updates the linear terms of a field's entries --, bias_owner)."""
+    lib = load_library()
+    po = np.zeros((n_fields, n_fields), np.int32)
+    lo = np.zeros(n_fields, np.int32)
+    bo = ctypes.c_int32(0)
+    rc = lib.ffm_engine_shard_plan(int(n_fields), int(n_shards), int(bool(field_map)), _i(po), _i(lo),
+                                   ctypes.byref(bo))
+    if rc != 0:
+        raise EngineError(rc, lib.ffm_engine_last_error().decode())
+    return dict(pair_owner=po, lin_owner=lo, bias_owner=int(bo.value))
 
 
 def init_weights_host(seed, mean, stddev, latent, first, count):
@@ -143,7 +161,7 @@ class Engine:
     def __init__(self, model_type="FFM", n_feats=10000, n_fields=8, n_factors=16, w_alpha=1e-4,
                  w_beta=1.0, w_l1=0.1, w_l2=5.0, init_mean=0.0, init_stddev=0.02, seed=42,
                  max_batch_rows=8192, max_batch_nnz=None, device_id=0, n_shards=1, shard_rank=0,
-                 stream=None, skip_init=False, max_row_nnz=0, learn=False):
+                 stream=None, skip_init=False, max_row_nnz=0, learn=False, field_start=None):
         self.lib = load_library()
         cfg = Config()
         self.lib.ffm_engine_default_config(ctypes.byref(cfg))
@@ -156,7 +174,11 @@ class Engine:
         cfg.device_id, cfg.n_shards, cfg.shard_rank = int(device_id), int(n_shards), int(shard_rank)
         cfg.stream = stream
         cfg.flags = (FLAG_SKIP_INIT if skip_init else 0) | (FLAG_LEARN if learn else 0)
-        cfg.reserved[0] = int(max_row_nnz)
+        cfg.max_row_nnz = int(max_row_nnz)
+        self._field_start = None
+        if field_start is not None:
+            self._field_start = np.ascontiguousarray(field_start, np.int32)
+            cfg.field_start = _i(self._field_start)
         self.cfg = cfg
         self.h = _vp()
         self._check(self.lib.ffm_engine_create(ctypes.byref(cfg), ctypes.byref(self.h)))

@@ -44,7 +44,7 @@ FtrlModel::FtrlModel(const config_options &opt, int mt)
   max_nnz_ = static_cast<int>(std::min<long long>(std::max<long long>(256ll * max_rows_, max_row_nnz_), 1ll << 28));
   cfg.max_batch_rows = max_rows_;
   cfg.max_batch_nnz = max_nnz_;
-  cfg.reserved[0] = max_row_nnz_;
+  cfg.max_row_nnz = max_row_nnz_;
   cfg.device_id = opt.device;
   if (opt.learn) cfg.flags |= FFM_FLAG_LEARN;
   const int rc = ffm_engine_create(&cfg, &eng_);

@@ -3,36 +3,26 @@
 Both latent slots of a pair -- (feature i, field of j) and (feature j, field of i) -- belong to the
 rank that owns the unordered field pair {field_i, field_j}, so forward, gradient and FTRL update of
 a pair are local; the only exchange per block is ONE all-reduce (sum) of n_rows partial logits
-(RCCL over xGMI when the process group is "nccl"; "gloo" in the CPU tests).  Rank 0 also owns the
-bias and the linear terms.  The rule is the same arithmetic as owns_pair() in csrc/engine_types.h.
+(RCCL over xGMI when the process group is "nccl"; "gloo" in the CPU tests).  Who owns which pair,
+which field's linear terms and the bias is ffm_engine_shard_plan's answer (contiguous blocks of the
+field x field triangle), read here through engine.shard_plan.
 """
 import numpy as np
 
+from .engine import shard_plan  # noqa: F401  (the partition itself is the library's: ffm_engine_shard_plan)
+
 
 def pair_owner(field_a, field_b, n_fields, n_shards):
-    """Rank owning the unordered field pair (works on ints or numpy arrays)."""
-    lo = np.minimum(field_a, field_b)
-    hi = np.maximum(field_a, field_b)
-    # index of {lo, hi} in the upper triangle (diagonal included), dealt round-robin: balanced
-    return (lo * n_fields - lo * (lo - 1) // 2 + (hi - lo)) % n_shards
+    """Shard owning the unordered field pair (ints or numpy arrays), per ffm_engine_shard_plan."""
+    return shard_plan(n_fields, n_shards)["pair_owner"][field_a, field_b]
 
 
 def owned_pair_counts(n_fields, n_shards):
-    """How many of the n_fields*(n_fields-1)/2 cross-field pairs (+ n_fields same-field pairs)
-    each rank owns: the load balance of the partition."""
-    f = np.arange(n_fields)
-    own = pair_owner(f[:, None], f[None, :], n_fields, n_shards)
-    iu = np.triu_indices(n_fields, 0)
+    """How many of the n_fields*(n_fields-1)/2 cross-field pairs each shard owns: the load balance
+    of the partition (same-field pairs, which only multi-valued fields produce, not counted)."""
+    own = shard_plan(n_fields, n_shards)["pair_owner"]
+    iu = np.triu_indices(n_fields, 1)
     return np.bincount(own[iu], minlength=n_shards)
-
-
-def shard_plan(n_fields, n_shards):
-    """Who owns what under field-pair sharding: dict(pair_owner [F, F] -- rank owning the unordered
-    field pair, i.e. both of its latent slots --, lin_owner [F] -- rank that adds and updates the
-    linear terms of a field's features --, bias_owner)."""
-    f = np.arange(n_fields)
-    return dict(pair_owner=pair_owner(f[:, None], f[None, :], n_fields, n_shards).astype(np.int32),
-                lin_owner=np.zeros(n_fields, np.int32), bias_owner=0)
 
 
 class ShardedStep:

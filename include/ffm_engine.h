@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FFM_ENGINE_ABI_VERSION 1
+#define FFM_ENGINE_ABI_VERSION 2
 
 /* ModelType, reference src/include/utils/types.h:21-25 */
 enum { FFM_MODEL_LR = 0, FFM_MODEL_FM = 1, FFM_MODEL_FFM = 2 };
@@ -66,14 +66,24 @@ typedef struct ffm_engine_config {
   int32_t max_batch_nnz;   /* capacity in entries of one call */
   int32_t device_id;       /* HIP device ordinal */
   /* Field-pair sharding of the latent tensor over the GPUs of a node (FFM; DESIGN.md
-   * "Multi-GPU"): this engine owns the unordered field pairs {f,f'} whose index in the
-   * upper triangle (min*n_fields - min*(min-1)/2 + max-min), taken modulo n_shards, equals
-   * shard_rank -- a balanced round-robin deal -- plus bias/linear when shard_rank == 0. */
+   * "Multi-GPU"): this engine owns both latent slots of the field pairs ffm_engine_shard_plan
+   * assigns to shard_rank -- contiguous blocks of the field x field triangle -- and the bias /
+   * linear terms that plan gives it. */
   int32_t n_shards;        /* 1 */
   int32_t shard_rank;      /* 0 */
   void *stream;            /* hipStream_t to run on; NULL = the engine creates its own */
   int32_t flags;           /* FFM_FLAG_* */
-  int32_t reserved[7];
+  int32_t max_row_nnz;     /* longest row a call may hold (LDS staging of the row kernels); 0 = 1024 */
+  /* Per-field id ranges: field f owns the ids [field_start[f], field_start[f+1]), n_fields + 1
+   * ascending values from 0 to n_feats (python/generate_data.py:272-306 and the bundled data lay
+   * ids out like this).  NULL = unknown.  With it a sharded engine stores only the records of the
+   * fields it has pairs of, and in each record only the slots it owns -- about 1/n_shards of the
+   * (n_feats x n_fields x n_factors) tensor -- and it skips the columns of the other fields; an
+   * entry whose id is outside its field's range then voids its block (FFM_E_INVALID at the next
+   * sync).  Without it every shard keeps full-length records and only the work is sharded.  The
+   * array is copied; ignored when n_shards == 1. */
+  const int32_t *field_start;
+  int32_t reserved[4];
 } ffm_engine_config;
 
 enum {
@@ -104,7 +114,20 @@ void ffm_engine_destroy(ffm_engine *e);
 const char *ffm_engine_last_error(void);
 int ffm_engine_abi_version(void);
 
-/* Row length of the latent arrays: n_fields*n_factors (FFM), n_factors (FM), 0 (LR). */
+/* The partition behind n_shards / shard_rank, as plain host arithmetic (no device needed): the
+ * fields are cut into contiguous groups and every shard owns whole group x group blocks of field
+ * pairs, so the partner fields a shard owns for any field form ONE contiguous range (2 shards: 2
+ * groups; 4 and 8 shards: 4 groups -- at 8 a shard needs the columns of only two groups; other
+ * counts: triangular strips).  pair_owner[fa * n_fields + fb] = the shard owning the unordered pair
+ * {fa, fb} (symmetric; both latent slots of a pair, (i, field_j) and (j, field_i), live there --
+ * the locality ffm.cpp:63-65,104-120 needs); lin_owner[f] = the shard that adds and updates the
+ * linear terms of field f's entries (with field_map == 0 all of them sit on bias_owner, because a
+ * shard then cannot tell a feature's field from its id); *bias_owner = the shard holding the bias.
+ * Any output may be NULL. */
+int ffm_engine_shard_plan(int32_t n_fields, int32_t n_shards, int32_t field_map, int32_t *pair_owner,
+                          int32_t *lin_owner, int32_t *bias_owner);
+
+/* Row length of the (logical) latent arrays: n_fields*n_factors (FFM), n_factors (FM), 0 (LR). */
 int64_t ffm_engine_row_len(const ffm_engine *e);
 
 /* Replaces direct access to the public members bias / lin_w / vec_w (ftrl_model.h:35-37,

@@ -280,15 +280,15 @@ def test_field_pair_sharding_two_shards_on_one_gpu():
         e.sync()
     s0, s1 = shards[0].get_state(), shards[1].get_state()
     # ownership: slot (feature of field f, partner field fp) belongs to the owner of {f, fp}
-    from ftrl_ffm_amd import sharding
+    plan = fa.shard_plan(F, 2)
     fld = np.arange(nf) // per
-    fp = np.arange(F)
-    owner = np.repeat(sharding.pair_owner(fld[:, None], fp[None, :], F, 2), k, axis=1)
+    owner = np.repeat(plan["pair_owner"][fld], k, axis=1)
     for key in ("vec_n", "vec_z", "vec_w"):
         merged = np.where(owner == 0, s0[key], s1[key])
         np.testing.assert_allclose(merged, s_ref[key], rtol=2e-4, atol=1e-6, err_msg=key)
+    lin_state = (s0, s1)[plan["bias_owner"]]  # no field map: bias and all linear terms on one shard
     for key in ("lin_n", "lin_z", "lin_w", "bias3"):
-        np.testing.assert_allclose(s0[key], s_ref[key], rtol=2e-4, atol=1e-6, err_msg=key)
+        np.testing.assert_allclose(lin_state[key], s_ref[key], rtol=2e-4, atol=1e-6, err_msg=key)
     # predict on the shards: partial logits summed, then finished by any shard
     pl_ref, ploss_ref = ref.predict_batch(blk)
     pp_ref, _ = ref.predict_batch(blk, output_prob=True)

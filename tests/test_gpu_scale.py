@@ -126,12 +126,15 @@ def test_quirk_nans_flow_through_the_chain_kernels(F, k, per, B):
     e.close()
 
 
-def test_eight_shards_at_39x16_on_one_gpu():
+@pytest.mark.parametrize("compact", [False, True], ids=["full_records", "compact"])
+def test_eight_shards_at_39x16_on_one_gpu(compact):
     """n_shards = 8 at the headline shape: eight engines on this GPU, each owning 1/8 of the field
-    pairs.  (1) Their partial logits sum to the unsharded logits (rtol 1e-5: the association order
-    differs).  (2) Given the SAME logits (the oracle's bits), every shard's update of the slots it
-    owns is the oracle's, bit for bit: merging the shards' records by ownership reproduces the
-    oracle's whole state."""
+    pairs (ffm_engine_shard_plan).  (1) Their partial logits sum to the unsharded logits (rtol
+    1e-5: the association order differs).  (2) Given the SAME logits (the oracle's bits), every
+    shard's update of the slots it owns is the oracle's, bit for bit: merging the shards' records
+    by ownership reproduces the oracle's whole state.  compact: with per-field id ranges every
+    shard stores only the owned slots of the fields it keeps (about 1/8 of the tensor) and skips
+    the other columns; full_records: no id ranges, every shard keeps whole records."""
     F, k, per, B, S = 39, 16, 40, 1024, 8
     nf = F * per
     rng = np.random.default_rng(5)
@@ -140,29 +143,35 @@ def test_eight_shards_at_39x16_on_one_gpu():
     st["vec_n"] += np.float32(0.05)
     st["lin_n"] += np.float32(0.05)
     o.set_state(st)
-    blk = synth.Generator(F, nf, "zipf", seed=9).block(B)
-    lo, _ = o.train_batch(blk)
-    want = o.get_state()
-    dev = {k_: torch.from_numpy(getattr(blk, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+    g = synth.Generator(F, nf, "zipf", seed=9)
+    blocks = [g.block(B) for _ in range(2)]
+    fs = (np.arange(F + 1) * per).astype(np.int32) if compact else None
+    free0 = torch.cuda.mem_get_info()[0]
     shards = [fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=B, max_batch_nnz=B * F,
-                        n_shards=S, shard_rank=r, max_row_nnz=F, **STRESS_HP) for r in range(S)]
-    parts = torch.zeros(S, B, device="cuda")
-    for r, e in enumerate(shards):
-        e.set_state(st)
-        e.train_forward_device(B, blk.nnz, dev["row_ptr"].data_ptr(), dev["field"].data_ptr(),
-                               dev["feat"].data_ptr(), dev["val"].data_ptr(), dev["label"].data_ptr(),
-                               parts[r].data_ptr())
-        e.sync()
-    total = parts.sum(0)
-    torch.cuda.synchronize()
-    np.testing.assert_allclose(total.cpu().numpy(), lo, rtol=1e-5, atol=1e-6)
-    exact = torch.from_numpy(lo).cuda()  # the oracle's logits: what an exact all-reduce would give
+                        n_shards=S, shard_rank=r, max_row_nnz=F, field_start=fs, **STRESS_HP)
+              for r in range(S)]
     for e in shards:
-        e.train_update_device(exact.data_ptr())
-        e.sync()
+        e.set_state(st)
+    plan = fa.shard_plan(F, S, field_map=compact)
+    for blk in blocks:
+        lo, _ = o.train_batch(blk)
+        dev = {k_: torch.from_numpy(getattr(blk, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+        parts = torch.zeros(S, B, device="cuda")
+        for r, e in enumerate(shards):
+            e.train_forward_device(B, blk.nnz, dev["row_ptr"].data_ptr(), dev["field"].data_ptr(),
+                                   dev["feat"].data_ptr(), dev["val"].data_ptr(), dev["label"].data_ptr(),
+                                   parts[r].data_ptr())
+            e.sync()
+        total = parts.sum(0)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(total.cpu().numpy(), lo, rtol=1e-5, atol=2e-6)
+        exact = torch.from_numpy(lo).cuda()  # the oracle's logits: what an exact all-reduce would give
+        for e in shards:
+            e.train_update_device(exact.data_ptr())
+            e.sync()
+    want = o.get_state()
     states = [e.get_state() for e in shards]
     fld = np.arange(nf) // per
-    plan = fa.shard_plan(F, S)
     owner = np.repeat(plan["pair_owner"][fld], k, axis=1)  # [feat][partner field] -> [feat][slot elem]
     for key in ("vec_n", "vec_z", "vec_w"):
         merged = np.zeros_like(want[key])
@@ -176,6 +185,107 @@ def test_eight_shards_at_39x16_on_one_gpu():
             merged = np.where(lin_owner == r, states[r][key], merged)
         assert_bitwise(merged, want[key], "8 shards " + key)
     assert_bitwise(states[plan["bias_owner"]]["bias3"], want["bias3"], "8 shards bias")
+    if compact:  # what a shard does not own it does not store: it reads back as zero
+        for r in range(S):
+            assert not states[r]["vec_n"][owner != r].any()
+    # prediction on the trained shards: partial logits summed, finished by any shard
+    po, _ = o.predict_batch(blocks[0])
+    blk = blocks[0]
+    dev = {k_: torch.from_numpy(getattr(blk, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+    pparts = torch.zeros(S, B, device="cuda")
+    for r, e in enumerate(shards):
+        e.predict_batch_device(B, blk.nnz, dev["row_ptr"].data_ptr(), dev["field"].data_ptr(),
+                               dev["feat"].data_ptr(), dev["val"].data_ptr(), None, False, pparts[r].data_ptr())
+        e.sync()
+    np.testing.assert_allclose(pparts.sum(0).cpu().numpy(), po, rtol=1e-5, atol=2e-6)
+    for e in shards:
+        e.close()
+    del free0
+
+
+def test_compact_shard_rejects_ids_outside_their_field_range():
+    """With per-field id ranges an entry whose id belongs to another field voids its block:
+    FFM_E_INVALID at the next sync, model untouched."""
+    F, k, per = 8, 4, 10
+    nf = F * per
+    fs = (np.arange(F + 1) * per).astype(np.int32)
+    e = fa.Engine("FFM", nf, F, k, max_batch_rows=16, n_shards=2, shard_rank=0, field_start=fs, seed=1)
+    e.fill_state(seed=2)
+    before = e.get_state()
+    rows = [[(f, f * per + (r + f) % per, 1.0) for f in range(F)] for r in range(8)]
+    rows[3][2] = (2, 5 * per + 1, 1.0)  # field 2 carrying an id of field 5
+    bad = Csr.from_rows(rows, [r % 2 for r in range(8)])
+    d = {k_: torch.from_numpy(getattr(bad, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+    out = torch.zeros(8, device="cuda")
+    e.train_forward_device(8, int(bad.row_ptr[-1]), d["row_ptr"].data_ptr(), d["field"].data_ptr(),
+                           d["feat"].data_ptr(), d["val"].data_ptr(), d["label"].data_ptr(), out.data_ptr())
+    e.train_update_device(out.data_ptr())
+    with pytest.raises(fa.EngineError) as ei:
+        e.sync()
+    assert ei.value.code == -1
+    assert_state_bitwise(e.get_state(), before, "voided block")
+    e.close()
+
+
+def test_full_headline_model_sharded_eight_ways_on_one_gpu():
+    """The 33 M-feature FFM 39x16 model as EIGHT compact shard engines co-resident on this GPU
+    (about 31 GB each instead of 247 GB: the storage is sharded, not just the work): one 8192-row
+    Zipf block against the oracle on the id-remapped compact model -- summed partial logits to
+    rtol 1e-5, every shard's owned slots bit for bit (updates driven by the oracle's logits)."""
+    F, k, B, S = 39, 16, 8192, 8
+    n_feats = 33_000_000 - 33_000_000 % F
+    per = n_feats // F
+    if _free_gb() < 275.0:
+        pytest.skip("needs ~270 GB of free HBM, have %.0f" % _free_gb())
+    fs = (np.arange(F + 1, dtype=np.int64) * per).astype(np.int32)
+    g = synth.Generator(F, n_feats, "zipf", seed=42)
+    blk = g.block(B)
+    o, feats, st = _remapped_oracle("FFM", F, k, [blk], DEFAULT_HP, seed=17)
+    free0 = torch.cuda.mem_get_info()[0]
+    shards = []
+    for r in range(S):
+        shards.append(fa.Engine("FFM", n_feats, F, k, skip_init=True, max_batch_rows=B, max_batch_nnz=B * F,
+                                n_shards=S, shard_rank=r, max_row_nnz=F, field_start=fs, **DEFAULT_HP))
+    used_gb = (free0 - torch.cuda.mem_get_info()[0]) / 1e9
+    assert used_gb < 1.12 * 247.1, used_gb  # all eight shards together ~ ONE copy of the model (+ scratch)
+    print("8 compact shards hold %.1f GB in total (unsharded model: 247.1 GB)" % used_gb)
+    import ctypes
+    f32p = ctypes.POINTER(ctypes.c_float)
+    one = lambda v: np.array([v], np.float32).ctypes.data_as(f32p)  # noqa: E731
+    for e in shards:
+        e.set_rows(feats, {key: st[key] for key in fa.Engine.ROW_KEYS})
+        e._check(e.lib.ffm_engine_set_weights(e.h, one(st["bias3"][0]), None, None))
+        e._check(e.lib.ffm_engine_set_state(e.h, one(st["bias3"][1]), one(st["bias3"][2]), None, None, None, None))
+    remapped = Csr(blk.row_ptr, blk.field, np.searchsorted(feats, blk.feat).astype(np.int32), blk.val, blk.label)
+    lo, _ = o.train_batch(remapped)
+    dev = {k_: torch.from_numpy(getattr(blk, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+    parts = torch.zeros(S, B, device="cuda")
+    for r, e in enumerate(shards):
+        e.train_forward_device(B, blk.nnz, dev["row_ptr"].data_ptr(), dev["field"].data_ptr(),
+                               dev["feat"].data_ptr(), dev["val"].data_ptr(), dev["label"].data_ptr(),
+                               parts[r].data_ptr())
+        e.sync()
+    np.testing.assert_allclose(parts.sum(0).cpu().numpy(), lo, rtol=1e-5, atol=2e-6)
+    exact = torch.from_numpy(lo).cuda()
+    for e in shards:
+        e.train_update_device(exact.data_ptr())
+        e.sync()
+    want = o.get_state()
+    plan = fa.shard_plan(F, S, field_map=True)
+    fld = feats // per
+    owner = np.repeat(plan["pair_owner"][fld], k, axis=1)
+    got = [e.get_rows(feats) for e in shards]
+    for key in ("vec_n", "vec_z", "vec_w"):
+        merged = np.zeros_like(want[key])
+        for r in range(S):
+            merged = np.where(owner == r, got[r][key], merged)
+        assert_bitwise(merged, want[key], "sharded headline " + key)
+    lin_owner = plan["lin_owner"][fld]
+    for key in ("lin_n", "lin_z", "lin_w"):
+        merged = np.zeros_like(want[key])
+        for r in range(S):
+            merged = np.where(lin_owner == r, got[r][key], merged)
+        assert_bitwise(merged, want[key], "sharded headline " + key)
     for e in shards:
         e.close()
 

@@ -23,9 +23,16 @@ def test_partition_covers_every_pair_once_and_is_balanced():
         own = sharding.pair_owner(f[:, None], f[None, :], F, S)
         assert np.array_equal(own, own.T)                      # unordered: both slots co-located
         assert own.min() >= 0 and own.max() < S
-        counts = sharding.owned_pair_counts(F, S)
-        assert counts.sum() == F * (F + 1) // 2
-        assert counts.max() - counts.min() <= max(2, counts.mean() * 0.15), counts
+        counts = sharding.owned_pair_counts(F, S)  # cross-field pairs per shard
+        assert counts.sum() == F * (F - 1) // 2
+        # whole group x group blocks: the busiest shard stays within 25 % of the mean (39 fields on
+        # 8 shards: 100 vs 92.6; the round-robin deal of round 1 was even but scattered the slots)
+        assert counts.max() <= max(counts.mean() * 1.25, counts.mean() + 2), counts
+        # every field's owned partner fields are one contiguous range on every shard
+        for r in range(S):
+            for fa in range(F):
+                idx = np.flatnonzero(own[fa] == r)
+                assert idx.size == 0 or idx[-1] - idx[0] + 1 == idx.size
 
 
 class FakeEngine:

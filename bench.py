@@ -169,6 +169,9 @@ def main():
                          "job (1/N of the field pairs, no all-reduce) and print what the N-GPU "
                          "job's rate would be if the exchange were free")
     ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--no-field-map", action="store_true",
+                    help="sharded runs: do not tell the engine the per-field id ranges (every shard "
+                         "then keeps full-length records and all columns)")
     args = ap.parse_args()
 
     import torch
@@ -214,8 +217,10 @@ def main():
     budget = int(free_b * 0.9) - (4 << 30)
     if args.same_device:
         budget //= max(world, 1)
-    if n_feats * rec_bytes > budget:  # every shard stores full-length records
-        n_feats = budget // rec_bytes
+    compact = n_shards > 1 and model == "FFM" and not args.no_field_map
+    shard_bytes = rec_bytes // n_shards * 5 // 4 if compact else rec_bytes  # compact: ~1/n of a record (+ padding)
+    if n_feats * shard_bytes > budget:
+        n_feats = budget // shard_bytes
         n_feats -= n_feats % N_FIELDS
         reduced = True
     gen_kwargs = dict(dist=args.dist, seed=42)
@@ -226,10 +231,13 @@ def main():
     stream = tstream.cuda_stream
 
     def make_engine(nf):
+        # sharded: the generator's per-field id ranges go to the engine, so every shard stores only
+        # its slots (~1/n_shards of the tensor) and looks only at the columns it has pairs of
+        fs = (np.arange(N_FIELDS + 1, dtype=np.int64) * (nf // N_FIELDS)).astype(np.int32) if compact else None
         return fa.Engine(model, nf, N_FIELDS, N_FACTORS, max_batch_rows=rows,
                          max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=n_shards,
                          shard_rank=args.emulate_rank if emu else rank, stream=stream, seed=42,
-                         max_row_nnz=N_FIELDS)
+                         max_row_nnz=N_FIELDS, field_start=fs)
 
     eng = None
     while eng is None:  # an allocation that does not fit is retried 10 % smaller, never fatal
@@ -412,14 +420,15 @@ def main():
                             "(%.1f GB of w,n,z per GPU), %s state, reference default hyper-parameters, "
                             "%s" % (model, N_FIELDS, N_FACTORS, N_FIELDS,
                                     "Zipf(1.1)" if args.dist == "zipf" else "uniform", rows, n_feats,
-                                    n_feats * rec_bytes / 1e9, args.state,
+                                    n_feats * shard_bytes / 1e9, args.state,
                                     "%d distinct blocks streamed from %s host memory (H2D in the timed region)"
                                     % (n_blocks, "page-locked" if zero_copy else "pageable")
                                     if host_leg else "blocks resident in HBM (no H2D)"),
                 "rows_per_step": rows, "n_feats": n_feats, "n_feats_reduced_to_fit": reduced,
                 "n_blocks": n_blocks,
-                "sharding": "field-pair x%d, one all-reduce of %d partial logits per step"
-                            % (world, rows) if world > 1 else "none",
+                "sharding": "field-pair x%d (%s), one all-reduce of %d partial logits per step"
+                            % (n_shards, "compact storage, per-field id ranges" if compact else "full records",
+                               rows) if n_shards > 1 else "none",
             },
             **({"emulated": "one rank's compute of a %d-GPU job on one GPU, no exchange; `value` is "
                             "what the %d-GPU job would reach if the all-reduce were free (tuning "

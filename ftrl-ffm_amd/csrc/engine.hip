@@ -707,6 +707,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (masks) {
     TRY_ALLOC(e->alloc(&s.rowmask, 2 * R));
     TRY_ALLOC(e->alloc(&s.gmask, E));
+    TRY_ALLOC(e->alloc(&s.cmask, E));
     std::vector<unsigned long long> own(m.n_fields, 0ull);
     for (int fa = 0; fa < m.n_fields; fa++)
       for (int fb = 0; fb < m.n_fields; fb++)
@@ -788,6 +789,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     if (masks) {
       TRY_ALLOC(e->alloc(&t.rowmask, 2 * R));
       TRY_ALLOC(e->alloc(&t.gmask, E));
+      TRY_ALLOC(e->alloc(&t.cmask, E));
     }
     unsigned char *tmp = nullptr;
     TRY_ALLOC(e->alloc(&tmp, e->sort_tmp_bytes));

@@ -130,6 +130,8 @@ struct Scratch {
   unsigned long long *rowmask;  // [2*n_rows] per row: fields with >= 1 / >= 2 surviving entries
   unsigned long long *gmask;    // [nnz] per distinct feature, at index ustart[u]: bit fp set when
                                 //      some row of the block touches slot fp of the feature
+  unsigned long long *cmask;    // [nnz] the same for slots whose partner field is MULTI-VALUED in some
+                                //      row of the feature (the row holds >= 2 entries of field fp)
   int *occpos;    // [nnz] entry -> its position t in occ when its feature is hot, else
                   //      OCC_FEW (2..kSmallMax occurrences) or OCC_ONCE (this entry only)
   int4 *haux;     // [nnz*n_fields] per (occurrence t, partner field): {partner value bits,

@@ -138,11 +138,72 @@ __device__ __forceinline__ void chain_sigma_w(const Hyper &h, const float (&nb)[
 // ---- FFM ------------------------------------------------------------------------------------
 // Work item = (very hot feature, slot of its record, pass over G groups of 4 factors of the slot);
 // one wave per item.  Lane: tl = touch inside the step (DPP row position), el = factor inside a
-// group.  Touch facts come as the occurrence-ordered streams the row kernel wrote (s.haux, s.hmeta),
-// prefetched two steps ahead; the partner weights one step ahead.
+// group.  Touch facts come as the occurrence-ordered streams the row kernel wrote (s.haux, s.hmeta).
+//
+// A chain of c touches is c/16 dependent steps, and a step's inputs are gathers (the fact of every
+// touch, then -- at the address the fact carries -- the partner's weights): ~2 us of latency each
+// when the chip is busy.  With the loads one step ahead a step cost that latency (measured 2.4 us
+// per step for the 8600-touch chains of an 8-GPU job's 65536-row blocks: one wave per slot, alone
+// on the chip, 1.3 ms).  So the loop runs in chunks of kChainChunk steps over three stages: the
+// raw facts of chunk c+2 are in flight while the partner weights of chunk c+1 are requested (from
+// the facts that arrived a chunk ago) and chunk c is computed -- eight steps of latency tolerance
+// for the facts, four for the weights, in straight-line code so that the loads retire in order
+// behind one counted wait.  Slots with a multi-valued partner field somewhere in the block
+// (s.cmask) take the plain one-step-ahead loop with the sequential fallback inside.
+constexpr int kChainChunk = 4;
+
+struct ChainTouch {  // what a step needs of one touch once its partner weights are requested
+  float tg, xm, xo;
+  int fl;
+};
+
+// One fast step: all 16 touches plain (no multi-valued field among them).
+template <int G>
+__device__ __forceinline__ void chain_step(const ModelDev &m, int fp, bool in_range, bool l0,
+                                           const ChainTouch &f, const float (&vp)[G],
+                                           const bool (&act)[G], const float (&w)[G],
+                                           float (&nc)[G], float (&zc)[G]) {
+  const int fl = f.fl;
+  const bool smp = in_range && owns_pair(m, fl >> 8, fp) && (fl & HF_SIMPLE) != 0;
+  const bool first = (fl & HF_FIRST) || m.h.learn;
+  const float tg = f.tg;
+  const float x = f.xm * f.xo;  // x_own*x_other or x_other*x_own: same product
+  float g1v[G], q[G], S[G], ga[G], arg0[G], nb[G], mm[G], mc[G], Z[G];
+  bool simple[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    simple[g] = smp && act[g];
+    const float gr = tg * vp[g] * x;  // own slot's gradient (g1 if own entry first, else g2)
+    const float g1 = tg * w[g] * x;   // second-entry case: the first entry's gradient
+    const float gg = gr * gr;
+    g1v[g] = first ? gg : gr * g1;    // what the square root sees added to n (ffm.cpp:113 / :118)
+    ga[g] = simple[g] ? gr : -0.0f;
+    q[g] = simple[g] ? gg : -0.0f;    // x + -0.0f == x bit for bit: idle touches apply nothing
+    S[g] = nc[g] + q[g];              // lane 0: n after its touch
+  }
+  row_chain_add<G>(S, q);
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    nb[g] = row_left(nc[g], S[g]);    // n before this touch
+    arg0[g] = nb[g] + g1v[g];
+    nc[g] = row_mirror(S[g]);         // lane 0: the row's last running n
+  }
+  chain_sigma_w<G>(m.h, nb, arg0, simple, w, mm);
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const float ms = simple[g] ? mm[g] : 0.0f;
+    mc[g] = l0 ? 0.0f : ms;
+    Z[g] = (zc[g] + ga[g]) - ms;      // lane 0: z after its touch
+  }
+  row_chain_addsub<G>(Z, ga, mc);
+#pragma unroll
+  for (int g = 0; g < G; g++) zc[g] = row_mirror(Z[g]);
+}
+
 template <int G>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev m, Rows rows,
                                                                        Scratch s) {
+  constexpr int CH = kChainChunk;
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int lane = threadIdx.x & 63;
   const int tl = lane & (kChainT - 1), el = lane >> 4;
@@ -164,6 +225,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
     if (fp < 0) continue;
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     if (s.gmask && !((s.gmask[start] >> fp) & 1ull)) continue;  // no row of the block touches the slot
+    const bool chainy = !s.cmask || ((s.cmask[start] >> fp) & 1ull) != 0ull;  // multi-valued partner field
     const int i = wave_uniform(s.uniq[u]);
     float *rec = lat_row(m, i, fa) + sc * k;  // the slot's n row; z and w rows follow at RL, 2 RL
     int kk[G];
@@ -182,98 +244,113 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
     const float2 *mcol = s.hmeta + start;                              // + t
     const int steps = (c + kChainT - 1) / kChainT;
 
-    // pipeline: facts two steps ahead, partner weights one step ahead
-    int4 ax = acol[static_cast<int64_t>(min(tl, c - 1)) * F];
-    float2 mt = mcol[min(tl, c - 1)];
-    int4 axN = acol[static_cast<int64_t>(min(kChainT + tl, c - 1)) * F];
-    float2 mtN = mcol[min(kChainT + tl, c - 1)];
-    float vp[G];
+    if (!chainy) {
+      // ---- three-stage pipeline over chunks of CH steps ----
+      const int n_chunks = (steps + CH - 1) / CH;
+      int4 axA[CH], axB[CH];
+      float2 mtA[CH], mtB[CH];
+      ChainTouch fB[CH], fC[CH];
+      float vpB[CH][G], vpC[CH][G];
+      auto load_raw = [&](int chunk, int4 (&ax)[CH], float2 (&mt)[CH]) {
 #pragma unroll
-    for (int g = 0; g < G; g++) vp[g] = m.lat[haux_offset(ax.z, ax.w) + kk[g]];
-    for (int st = 0; st < steps; st++) {
-      const int t = st * kChainT + tl;
-      float vpN[G];
-#pragma unroll
-      for (int g = 0; g < G; g++) vpN[g] = m.lat[haux_offset(axN.z, axN.w) + kk[g]];  // step st+1
-      const int tNN = min((st + 2) * kChainT + tl, c - 1);                              // step st+2
-      const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
-      const float2 mtNN = mcol[tNN];
-
-      const int fl = ax.y;
-      const bool live = t < c && owns_pair(m, fl >> 8, fp);
-      const bool smp = live & ((fl & HF_SIMPLE) != 0);
-      if (!__any(live & ((fl & HF_CHAIN) != 0))) {
-        const bool first = (fl & HF_FIRST) || m.h.learn;
-        const float tg = mt.x;
-        const float x = mt.y * __int_as_float(ax.x);  // x_own*x_other or x_other*x_own: same product
-        float g1v[G], q[G], S[G], ga[G], arg0[G], nb[G], mm[G], mc[G], Z[G];
-        bool simple[G];
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-          simple[g] = smp && act[g];
-          const float gr = tg * vp[g] * x;  // own slot's gradient (g1 if own entry first, else g2)
-          const float g1 = tg * w[g] * x;   // second-entry case: the first entry's gradient
-          const float gg = gr * gr;
-          g1v[g] = first ? gg : gr * g1;    // what the square root sees added to n (ffm.cpp:113 / :118)
-          ga[g] = simple[g] ? gr : -0.0f;
-          q[g] = simple[g] ? gg : -0.0f;    // x + -0.0f == x bit for bit: idle touches apply nothing
-          S[g] = nc[g] + q[g];              // lane 0: n after its touch
+        for (int j = 0; j < CH; j++) {
+          const int t = min((chunk * CH + j) * kChainT + tl, c - 1);  // past the end: repeats, unused
+          ax[j] = acol[static_cast<int64_t>(t) * F];
+          mt[j] = mcol[t];
         }
-        row_chain_add<G>(S, q);
+      };
+      auto request_weights = [&](const int4 (&ax)[CH], const float2 (&mt)[CH], float (&vp)[CH][G],
+                                 ChainTouch (&f)[CH]) {
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-          nb[g] = row_left(nc[g], S[g]);    // n before this touch
-          arg0[g] = nb[g] + g1v[g];
-          nc[g] = row_mirror(S[g]);         // lane 0: the row's last running n
+        for (int j = 0; j < CH; j++) {
+          const int64_t off = haux_offset(ax[j].z, ax[j].w);
+#pragma unroll
+          for (int g = 0; g < G; g++) vp[j][g] = m.lat[off + kk[g]];
+          f[j] = ChainTouch{mt[j].x, mt[j].y, __int_as_float(ax[j].x), ax[j].y};
         }
-        chain_sigma_w<G>(m.h, nb, arg0, simple, w, mm);
+      };
+      load_raw(0, axB, mtB);
+      load_raw(1, axA, mtA);
+      request_weights(axB, mtB, vpC, fC);
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-          const float ms = simple[g] ? mm[g] : 0.0f;
-          mc[g] = l0 ? 0.0f : ms;
-          Z[g] = (zc[g] + ga[g]) - ms;      // lane 0: z after its touch
+      for (int j = 0; j < CH; j++) { axB[j] = axA[j]; mtB[j] = mtA[j]; }
+      for (int ch = 0; ch < n_chunks; ch++) {
+        load_raw(ch + 2, axA, mtA);                // raw facts of chunk ch+2
+        request_weights(axB, mtB, vpB, fB);        // partner weights of chunk ch+1
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+          const int st = ch * CH + j;
+          if (st < steps) chain_step<G>(m, fp, st * kChainT + tl < c, l0, fC[j], vpC[j], act, w, nc, zc);
         }
-        row_chain_addsub<G>(Z, ga, mc);
 #pragma unroll
-        for (int g = 0; g < G; g++) zc[g] = row_mirror(Z[g]);
-      } else {
-        // a multi-valued field somewhere in this step: its 16 touches one after another, every
-        // lane of the row applying them to its own copy of the running (n, z)
+        for (int j = 0; j < CH; j++) {
+          fC[j] = fB[j];
+          axB[j] = axA[j];
+          mtB[j] = mtA[j];
 #pragma unroll
-        for (int g = 0; g < G; g++) { nc[g] = row_first(nc[g]); zc[g] = row_first(zc[g]); }
-        for (int tt = 0; tt < kChainT; tt++) {
-          const int src = (lane & ~(kChainT - 1)) | tt;
-          const int flt = __shfl(fl, src, 64);
-          const float xot = __shfl(__int_as_float(ax.x), src, 64);
-          const float tgt = __shfl(mt.x, src, 64), xmt = __shfl(mt.y, src, 64);
-          float vpt[G];
+          for (int g = 0; g < G; g++) vpC[j][g] = vpB[j][g];
+        }
+      }
+    } else {
+      // ---- a multi-valued partner field somewhere: facts two steps ahead, weights one ----
+      int4 ax = acol[static_cast<int64_t>(min(tl, c - 1)) * F];
+      float2 mt = mcol[min(tl, c - 1)];
+      int4 axN = acol[static_cast<int64_t>(min(kChainT + tl, c - 1)) * F];
+      float2 mtN = mcol[min(kChainT + tl, c - 1)];
+      float vp[G];
 #pragma unroll
-          for (int g = 0; g < G; g++) vpt[g] = __shfl(vp[g], src, 64);
-          const int fm = flt >> 8;
-          if (st * kChainT + tt >= c || !owns_pair(m, fm, fp)) continue;
-          if (flt & HF_SIMPLE) {
+      for (int g = 0; g < G; g++) vp[g] = m.lat[haux_offset(ax.z, ax.w) + kk[g]];
+      for (int st = 0; st < steps; st++) {
+        const int t = st * kChainT + tl;
+        float vpN[G];
 #pragma unroll
-            for (int g = 0; g < G; g++)
-              ffm_touch(m.h, flt & HF_FIRST, tgt, xmt, xot, vpt[g], w[g], nc[g], zc[g]);
-          } else if (flt & HF_CHAIN) {
-            const int pt = s.occ2[start + st * kChainT + tt].x;  // the touch's own entry
-            const int r = s.row_of[pt];
-            for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
-              if (qq == pt) continue;
-              const float xq = rows.val[qq];
+        for (int g = 0; g < G; g++) vpN[g] = m.lat[haux_offset(axN.z, axN.w) + kk[g]];  // step st+1
+        const int tNN = min((st + 2) * kChainT + tl, c - 1);                              // step st+2
+        const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
+        const float2 mtNN = mcol[tNN];
+        const int fl = ax.y;
+        const bool live = t < c && owns_pair(m, fl >> 8, fp);
+        if (!__any(live & ((fl & HF_CHAIN) != 0))) {
+          chain_step<G>(m, fp, t < c, l0, ChainTouch{mt.x, mt.y, __int_as_float(ax.x), fl}, vp, act, w, nc, zc);
+        } else {
+          // its 16 touches one after another, every lane of the row applying them to its own copy
+          // of the running (n, z)
 #pragma unroll
-              for (int g = 0; g < G; g++) {
-                const float vq = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk[g]];
-                ffm_touch(m.h, pt < qq, tgt, xmt, xq, vq, w[g], nc[g], zc[g]);
+          for (int g = 0; g < G; g++) { nc[g] = row_first(nc[g]); zc[g] = row_first(zc[g]); }
+          for (int tt = 0; tt < kChainT; tt++) {
+            const int src = (lane & ~(kChainT - 1)) | tt;
+            const int flt = __shfl(fl, src, 64);
+            const float xot = __shfl(__int_as_float(ax.x), src, 64);
+            const float tgt = __shfl(mt.x, src, 64), xmt = __shfl(mt.y, src, 64);
+            float vpt[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) vpt[g] = __shfl(vp[g], src, 64);
+            const int fm = flt >> 8;
+            if (st * kChainT + tt >= c || !owns_pair(m, fm, fp)) continue;
+            if (flt & HF_SIMPLE) {
+#pragma unroll
+              for (int g = 0; g < G; g++)
+                ffm_touch(m.h, flt & HF_FIRST, tgt, xmt, xot, vpt[g], w[g], nc[g], zc[g]);
+            } else if (flt & HF_CHAIN) {
+              const int pt = s.occ2[start + st * kChainT + tt].x;  // the touch's own entry
+              const int r = s.row_of[pt];
+              for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+                if (qq == pt) continue;
+                const float xq = rows.val[qq];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                  const float vq = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk[g]];
+                  ffm_touch(m.h, pt < qq, tgt, xmt, xq, vq, w[g], nc[g], zc[g]);
+                }
               }
             }
           }
         }
-      }
-      ax = axN; mt = mtN;
-      axN = axNN; mtN = mtNN;
+        ax = axN; mt = mtN;
+        axN = axNN; mtN = mtNN;
 #pragma unroll
-      for (int g = 0; g < G; g++) vp[g] = vpN[g];
+        for (int g = 0; g < G; g++) vp[g] = vpN[g];
+      }
     }
     if (l0) {
 #pragma unroll

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, R
     s.row_of[p] = lo;
     s.key[p] = valid ? static_cast<unsigned>(i) : static_cast<unsigned>(m.n_feats);
     s.occpos[p] = OCC_FEW;
-    if (s.gmask) s.gmask[p] = 0ull;
+    if (s.gmask) { s.gmask[p] = 0ull; s.cmask[p] = 0ull; }
   }
   valid = valid && in;
   if (in && p == rows.row_ptr[lo] && rows.row_ptr[lo + 1] - p > max_row_nnz) {
@@ -222,21 +222,25 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
   // entry of field fp (FFM::update_vector_w refreshes exactly those, ffm.cpp:72-88), within the
   // field pairs this shard owns; OR-ed over the group
   if (s.gmask) {
-    unsigned long long tm = 0ull;
+    unsigned long long tm = 0ull, tc = 0ull;
     if (valid) {
       const int r = s.row_of[p], f = rows.field[p];
       const unsigned long long once = s.rowmask[2 * r], twice = s.rowmask[2 * r + 1];
       const unsigned long long self = 1ull << f;
       tm = ((once & ~self) | (twice & self)) & m.ownmask[f];
+      tc = twice & m.ownmask[f];  // partner fields that hold several entries in this row
     }
     const int seg0 = hl >= 0 ? hl : 0;  // first lane of my group's piece in this wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long v = __shfl_up(tm, d, 64);
-      if (lane - d >= seg0) tm |= v;
+      const unsigned long long v = __shfl_up(tm, d, 64), vc = __shfl_up(tc, d, 64);
+      if (lane - d >= seg0) { tm |= v; tc |= vc; }
     }
     const bool piece_end = valid && (last || lane == 63 || t == nnz - 1);
-    if (piece_end) atomicOr(&s.gmask[lower], tm);
+    if (piece_end) {
+      atomicOr(&s.gmask[lower], tm);
+      if (tc) atomicOr(&s.cmask[lower], tc);
+    }
   }
 }
 

@@ -65,6 +65,15 @@ __device__ __forceinline__ bool owns_pair(const ModelDev &m, int fa, int fb) {
   if (!m.own_n) return true;
   return static_cast<unsigned>(fb - m.own_lo[fa]) < static_cast<unsigned>(m.own_n[fa]);
 }
+// The same test for a FIXED partner field fp against varying own fields, without memory traffic
+// inside a loop: own_bits = owner_bits(m, fp) once, then owns_bit(own_bits, fa) per touch.  (By
+// symmetry "fa owns fp" == "fp owns fa" == bit fa of ownmask[fp]; sharding needs n_fields <= 64.)
+__device__ __forceinline__ unsigned long long owner_bits(const ModelDev &m, int fp) {
+  return m.own_n ? m.ownmask[fp] : ~0ull;
+}
+__device__ __forceinline__ bool owns_bit(unsigned long long own_bits, int fa) {
+  return (own_bits >> (fa & 63)) & 1ull;
+}
 __device__ __forceinline__ bool owns_linear(const ModelDev &m, int fa) {
   return !m.lin_own || m.lin_own[fa] != 0;
 }

@@ -150,7 +150,10 @@ __device__ __forceinline__ void chain_sigma_w(const Hyper &h, const float (&nb)[
 // for the facts, four for the weights, in straight-line code so that the loads retire in order
 // behind one counted wait.  Slots with a multi-valued partner field somewhere in the block
 // (s.cmask) take the plain one-step-ahead loop with the sequential fallback inside.
-constexpr int kChainChunk = 4;
+#ifndef FFM_CHAIN_CHUNK
+#define FFM_CHAIN_CHUNK 4
+#endif
+constexpr int kChainChunk = FFM_CHAIN_CHUNK;
 
 struct ChainTouch {  // what a step needs of one touch once its partner weights are requested
   float tg, xm, xo;
@@ -159,12 +162,12 @@ struct ChainTouch {  // what a step needs of one touch once its partner weights 
 
 // One fast step: all 16 touches plain (no multi-valued field among them).
 template <int G>
-__device__ __forceinline__ void chain_step(const ModelDev &m, int fp, bool in_range, bool l0,
+__device__ __forceinline__ void chain_step(const ModelDev &m, unsigned long long own_bits, bool in_range, bool l0,
                                            const ChainTouch &f, const float (&vp)[G],
                                            const bool (&act)[G], const float (&w)[G],
                                            float (&nc)[G], float (&zc)[G]) {
   const int fl = f.fl;
-  const bool smp = in_range && owns_pair(m, fl >> 8, fp) && (fl & HF_SIMPLE) != 0;
+  const bool smp = in_range && owns_bit(own_bits, fl >> 8) && (fl & HF_SIMPLE) != 0;
   const bool first = (fl & HF_FIRST) || m.h.learn;
   const float tg = f.tg;
   const float x = f.xm * f.xo;  // x_own*x_other or x_other*x_own: same product
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
     if (fp < 0) continue;
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     if (s.gmask && !((s.gmask[start] >> fp) & 1ull)) continue;  // no row of the block touches the slot
+    const unsigned long long own_bits = owner_bits(m, fp);  // (no loads inside the step loops)
     const bool chainy = !s.cmask || ((s.cmask[start] >> fp) & 1ull) != 0ull;  // multi-valued partner field
     const int i = wave_uniform(s.uniq[u]);
     float *rec = lat_row(m, i, fa) + sc * k;  // the slot's n row; z and w rows follow at RL, 2 RL
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
 #pragma unroll
         for (int j = 0; j < CH; j++) {
           const int st = ch * CH + j;
-          if (st < steps) chain_step<G>(m, fp, st * kChainT + tl < c, l0, fC[j], vpC[j], act, w, nc, zc);
+          if (st < steps) chain_step<G>(m, own_bits, st * kChainT + tl < c, l0, fC[j], vpC[j], act, w, nc, zc);
         }
 #pragma unroll
         for (int j = 0; j < CH; j++) {
@@ -309,9 +313,9 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
         const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
         const float2 mtNN = mcol[tNN];
         const int fl = ax.y;
-        const bool live = t < c && owns_pair(m, fl >> 8, fp);
+        const bool live = t < c && owns_bit(own_bits, fl >> 8);
         if (!__any(live & ((fl & HF_CHAIN) != 0))) {
-          chain_step<G>(m, fp, t < c, l0, ChainTouch{mt.x, mt.y, __int_as_float(ax.x), fl}, vp, act, w, nc, zc);
+          chain_step<G>(m, own_bits, t < c, l0, ChainTouch{mt.x, mt.y, __int_as_float(ax.x), fl}, vp, act, w, nc, zc);
         } else {
           // its 16 touches one after another, every lane of the row applying them to its own copy
           // of the running (n, z)
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
 #pragma unroll
             for (int g = 0; g < G; g++) vpt[g] = __shfl(vp[g], src, 64);
             const int fm = flt >> 8;
-            if (st * kChainT + tt >= c || !owns_pair(m, fm, fp)) continue;
+            if (st * kChainT + tt >= c || !owns_bit(own_bits, fm)) continue;
             if (flt & HF_SIMPLE) {
 #pragma unroll
               for (int g = 0; g < G; g++)

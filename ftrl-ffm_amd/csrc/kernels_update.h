@@ -290,6 +290,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     float *rec = lat_row(m, i, fa);
     float n = rec[LAT_N * RL + ee], z = rec[LAT_Z * RL + ee];
     const float w = rec[LAT_W * RL + ee];
+    const unsigned long long own_bits = owner_bits(m, fp);  // (no loads inside the touch loop)
     const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;     // + t*F
     const float2 *mcol = s.hmeta + start;                                 // + t
     bool touched = false;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
       bool simple[kUnroll], any_chain = false;
 #pragma unroll
       for (int j = 0; j < kUnroll; j++) {
-        const bool live = t0 + j < c && active && owns_pair(m, fC.fl[j] >> 8, fp);
+        const bool live = t0 + j < c && active && owns_bit(own_bits, fC.fl[j] >> 8);
         simple[j] = live && (fC.fl[j] & HF_SIMPLE);
         any_chain = any_chain || (live && (fC.fl[j] & HF_CHAIN));
       }
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {
           const int fm = fC.fl[j] >> 8;
-          if (t0 + j < c && active && owns_pair(m, fm, fp)) {
+          if (t0 + j < c && active && owns_bit(own_bits, fm)) {
             if (fC.fl[j] & HF_SIMPLE) {
               ffm_touch(m.h, fC.fl[j] & HF_FIRST, tgj[j], xmj[j], fC.xo[j], vpC[j], w, n, z);
               touched = true;
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
       const int fp = walk_field(m, fa, sl);  // partner field of this lane's slot
       if (fp < 0) continue;
       const int kq = l - sl * k4;  // which 16-byte quarter of the slot
+      const unsigned long long own_bits = owner_bits(m, fp);
       float4 n4 = rec4[LAT_N * RL4 + l], z4 = rec4[LAT_Z * RL4 + l];
       const float4 w4 = rec4[LAT_W * RL4 + l];
       bool touched = false;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
         const int2 pr = s.occ2[start + j];  // wave-uniform
         const int p = pr.x, r = pr.y;
         const int fm = rows.field[p];
-        if (!owns_pair(m, fm, fp)) continue;
+        if (!owns_bit(own_bits, fm)) continue;
         const float xm = rows.val[p], tg = s.tg[r];
         const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
         const int q = rt.z;
@@ -529,6 +531,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev
     const int fa = wave_uniform(d.w);
     const float xm = rows.val[p], tg = s.tg[r];
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
+    const unsigned long long own_fa = owner_bits(m, fa);
     const int4 *rtab = s.rowtab + static_cast<int64_t>(r) * F;
     for (int l0 = 0; l0 < span4; l0 += 64 * kSingleTrips) {
       int l[kSingleTrips], fp[kSingleTrips], kq[kSingleTrips];
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev
         int sl = static_cast<int>((ll + 0.5f) * inv_k4);  // its slot
         sl += (sl + 1) * k4 <= ll ? 1 : (sl * k4 > ll ? -1 : 0);
         int f = lc < span4 ? walk_field(m, fa, sl) : -1;  // partner field of this vector's slot
-        if (f >= 0 && !owns_pair(m, fa, f)) f = -1;
+        if (f >= 0 && !owns_bit(own_fa, f)) f = -1;
         l[t] = f >= 0 ? ll : -1;
         kq[t] = ll - sl * k4;
         f = f < 0 ? 0 : f;

@@ -424,6 +424,7 @@ struct ffm_engine {
   // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
   // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
   int grid_small = 768, grid_hot = 2048, grid_huge = 2048, grid_single = 768;
+  int grid_giant = 512;  // workgroups of the chain launch that walk the giant features (FFM_GRID_GIANT)
   // FFM_WAIT_GROUPING=1: hold the update kernels until the look-ahead grouping in flight is done
   bool wait_grouping = false;
   bool single_kernel = true;  // FFM_SINGLE_KERNEL=0: once-only features through the small kernel
@@ -493,9 +494,10 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // 4 factors of a slot handled by one wave): 1, 2 or 4.
 static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows) {
   const int groups = e->m.n_factors / 4;
-  if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-  else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, e->grid_huge, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+  const int gb = e->grid_giant, grid = e->grid_huge + gb;
+  if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb);
+  else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb);
+  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb);
 }
 
 extern "C" {
@@ -603,6 +605,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_GRID_GIANT")) e->grid_giant = std::max(0, std::atoi(sv));
   {
     const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
     const int64_t per = cfg->n_factors % 4 == 0 ? static_cast<int64_t>(cfg->n_fields) * cfg->n_factors / 4
@@ -693,6 +696,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.sdesc, E));
   TRY_ALLOC(e->alloc(&s.big, E));
   TRY_ALLOC(e->alloc(&s.huge, E));
+  TRY_ALLOC(e->alloc(&s.giant, E / kGiantMin + 1));
   TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
   TRY_ALLOC(e->alloc(&e->d_err, 1));
   TRY_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), e->stream));
@@ -784,6 +788,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.sdesc, E));
     TRY_ALLOC(e->alloc(&t.big, E));
     TRY_ALLOC(e->alloc(&t.huge, E));
+    TRY_ALLOC(e->alloc(&t.giant, E / kGiantMin + 1));
     TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
     TRY_ALLOC(e->alloc(&t.occpos, E));
     if (masks) {

@@ -124,7 +124,8 @@ struct Scratch {
   int *few;       // [nnz] ... with 2..kSmallMax occurrences (the small list minus the features
                   //      that occur once, which ffm_update_single_kernel owns)
   int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
-  int *huge;      // [nnz] ... with more ("very hot": present in a large share of the rows)
+  int *huge;      // [nnz] ... with more, below kGiantMin ("very hot": present in many rows)
+  int *giant;     // [nnz] ... with kGiantMin or more
   int *counters;  // [kNumCounters] CNT_* below
   int *err;       // [1] sticky ERR_* flags, shared by all sets: what ffm_engine_sync reports
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
@@ -154,13 +155,19 @@ struct Scratch {
 };
 
 enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5,
-       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NSINGLE = 9 };
+       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NSINGLE = 9, CNT_NGIANT = 10 };
 constexpr int kNumCounters = 16;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 #ifndef FFM_HUGE_MIN
 #define FFM_HUGE_MIN 96
 #endif
 constexpr int kHugeMin = FFM_HUGE_MIN;  // occurrences per block above which a feature takes the lane-parallel path
+#ifndef FFM_GIANT_MIN
+#define FFM_GIANT_MIN 1024
+#endif
+// ... and from which its chains are so long that their LATENCY sets the update phase's span: such
+// "giant" features are listed apart (s.giant) and walked one group of 4 factors per wave
+constexpr int kGiantMin = FFM_GIANT_MIN;
 enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
                                                      // first / several entries share the field
 #ifndef FFM_SMALL_MAX

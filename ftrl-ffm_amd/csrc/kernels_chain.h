@@ -151,7 +151,7 @@ __device__ __forceinline__ void chain_sigma_w(const Hyper &h, const float (&nb)[
 // behind one counted wait.  Slots with a multi-valued partner field somewhere in the block
 // (s.cmask) take the plain one-step-ahead loop with the sequential fallback inside.
 #ifndef FFM_CHAIN_CHUNK
-#define FFM_CHAIN_CHUNK 4
+#define FFM_CHAIN_CHUNK 1
 #endif
 constexpr int kChainChunk = FFM_CHAIN_CHUNK;
 
@@ -203,26 +203,27 @@ __device__ __forceinline__ void chain_step(const ModelDev &m, unsigned long long
   for (int g = 0; g < G; g++) zc[g] = row_mirror(Z[g]);
 }
 
+// The items of one list of features (s.huge or s.giant), G interleaved chains per wave; `wave` of
+// `n_waves` waves share the list.
 template <int G>
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev m, Rows rows,
-                                                                       Scratch s) {
+__device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &rows, const Scratch &s,
+                                                const int *list, int n_list, unsigned wave,
+                                                unsigned n_waves) {
   constexpr int CH = kChainChunk;
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int lane = threadIdx.x & 63;
   const int tl = lane & (kChainT - 1), el = lane >> 4;
   const bool l0 = tl == 0;
   const int groups = k >> 2;                    // groups of 4 factors per slot
-  const int passes = (groups + G - 1) / G;      // 1 for k <= 16
+  const int passes = (groups + G - 1) / G;      // 1 for k <= 16 at G = 4
   const int slots = record_span(m, 1);          // slots walked per record
   const unsigned per_feat = static_cast<unsigned>(slots) * passes;
-  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const unsigned n_waves = gridDim.x * kUpdWaves;
-  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * per_feat;
+  const unsigned n_items = static_cast<unsigned>(n_list) * per_feat;
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned li = item / per_feat;
     const int rem = static_cast<int>(item - li * per_feat);
     const int sc = rem / passes, pass = rem - sc * passes;
-    const int u = wave_uniform(s.huge[li]);
+    const int u = wave_uniform(list[li]);
     const int fa = wave_uniform(s.ufield[u]);
     const int fp = wave_uniform(walk_field(m, fa, sc));  // partner field of slot sc
     if (fp < 0) continue;
@@ -367,6 +368,25 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
   }
 }
 
+// One launch for all very hot features.  The first giant_blocks workgroups take the GIANT ones
+// (kGiantMin occurrences or more) ONE chain per wave: a wave issues at most one VALU instruction
+// every four cycles, so a wave carrying four interleaved chains needs ~2.4 us per 16-touch step --
+// for the 8600-touch chains of an 8-GPU job's 65536-row blocks that alone was 1.3 ms, the span of
+// the whole update phase; one chain per wave is four times shorter, and there are few enough giant
+// features for the extra s_nop slots not to matter.  Dispatched first, the long chains also start
+// first.  The other workgroups take the rest, G chains per wave.
+template <int G>
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev m, Rows rows,
+                                                                       Scratch s, int giant_blocks) {
+  const unsigned w = wave_uniform(threadIdx.x >> 6);
+  if (static_cast<int>(blockIdx.x) < giant_blocks)
+    ffm_chain_items<1>(m, rows, s, s.giant, s.counters[CNT_NGIANT], blockIdx.x * kUpdWaves + w,
+                       giant_blocks * kUpdWaves);
+  else
+    ffm_chain_items<G>(m, rows, s, s.huge, s.counters[CNT_NHUGE],
+                       (blockIdx.x - giant_blocks) * kUpdWaves + w, (gridDim.x - giant_blocks) * kUpdWaves);
+}
+
 // ---- FM -------------------------------------------------------------------------------------
 // The same shape for FM::update_vector_nz (fm.cpp:80-101): work item = (very hot feature, pass over
 // 16 of its factors); the per-touch inputs are the row's value, tmp_grad and factor sum (s.svx).
@@ -381,11 +401,12 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m
   const unsigned passes = (groups + G - 1) / G;
   const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const unsigned n_waves = gridDim.x * kUpdWaves;
-  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NHUGE]) * passes;
+  const unsigned n_huge = static_cast<unsigned>(s.counters[CNT_NHUGE]);
+  const unsigned n_items = (n_huge + static_cast<unsigned>(s.counters[CNT_NGIANT])) * passes;
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned li = item / passes;
     const int pass = static_cast<int>(item - li * passes);
-    const int u = wave_uniform(s.huge[li]);
+    const int u = wave_uniform(li < n_huge ? s.huge[li] : s.giant[li - n_huge]);
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
     float *rec = lat_row(m, i, 0);

@@ -179,21 +179,23 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
   }
   // distinct features and their owner lists: slots handed out per workgroup (one atomic per
   // list per workgroup -- per-wave atomics on five shared counters would be a serial chain)
-  __shared__ int wave_cnt[kFinishThreads / 64][6];
-  __shared__ int wave_base[kFinishThreads / 64][6];
+  constexpr int kLists = 7;
+  __shared__ int wave_cnt[kFinishThreads / 64][kLists];
+  __shared__ int wave_base[kFinishThreads / 64][kLists];
   const int wv = threadIdx.x >> 6;
-  const bool pred[6] = {head, head && c <= kSmallMax, head && c > 1 && c <= kSmallMax,
-                        head && c > kSmallMax && c <= kHugeMin, head && c > kHugeMin,
-                        head && c == 1};
-  const int which[6] = {CNT_NUNIQ, CNT_NSMALL, CNT_NFEW, CNT_NBIG, CNT_NHUGE, CNT_NSINGLE};
-  unsigned long long pm[6];
+  const bool pred[kLists] = {head, head && c <= kSmallMax, head && c > 1 && c <= kSmallMax,
+                             head && c > kSmallMax && c <= kHugeMin,
+                             head && c > kHugeMin && c < kGiantMin, head && c == 1,
+                             head && c > kHugeMin && c >= kGiantMin};
+  const int which[kLists] = {CNT_NUNIQ, CNT_NSMALL, CNT_NFEW, CNT_NBIG, CNT_NHUGE, CNT_NSINGLE, CNT_NGIANT};
+  unsigned long long pm[kLists];
 #pragma unroll
-  for (int q = 0; q < 6; q++) {
+  for (int q = 0; q < kLists; q++) {
     pm[q] = __ballot(pred[q]);
     if (lane == 0) wave_cnt[wv][q] = __popcll(pm[q]);
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < kLists) {
     const int q = threadIdx.x;
     int total = 0;
     for (int w = 0; w < kFinishThreads / 64; w++) { wave_base[w][q] = total; total += wave_cnt[w][q]; }
@@ -201,10 +203,10 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
     for (int w = 0; w < kFinishThreads / 64; w++) wave_base[w][q] += base;
   }
   __syncthreads();
-  int slot[6];
+  int slot[kLists];
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int q = 0; q < 6; q++) slot[q] = wave_base[wv][q] + __popcll(pm[q] & below);
+  for (int q = 0; q < kLists; q++) slot[q] = wave_base[wv][q] + __popcll(pm[q] & below);
   const int u = slot[0], is = slot[1], iw = slot[2], ib = slot[3], ih = slot[4];
   if (head) {
     s.uniq[u] = static_cast<int>(K);
@@ -216,7 +218,8 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
     if (c > 1 && c <= kSmallMax) s.few[iw] = u;
     if (c <= kSmallMax) s.small[is] = u;
     else if (c <= kHugeMin) s.big[ib] = u;
-    else s.huge[ih] = u;
+    else if (c < kGiantMin) s.huge[ih] = u;
+    else s.giant[slot[6]] = u;
   }
   // slots of the feature that p's row touches: slot fp is touched when the row holds ANOTHER
   // entry of field fp (FFM::update_vector_w refreshes exactly those, ffm.cpp:72-88), within the

@@ -169,9 +169,10 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
   const int lane = threadIdx.x & 63;
   const int wave = block * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const int n_waves = n_blocks * kUpdWaves;
-  const int n_huge = s.counters[CNT_NHUGE];
-  for (int li = wave; li < n_big + n_huge; li += n_waves) {
-    const int u = wave_uniform(li < n_big ? s.big[li] : s.huge[li - n_big]);
+  const int n_huge = s.counters[CNT_NHUGE], n_giant = s.counters[CNT_NGIANT];
+  for (int li = wave; li < n_big + n_huge + n_giant; li += n_waves) {
+    const int u = wave_uniform(li < n_big ? s.big[li]
+                               : li < n_big + n_huge ? s.huge[li - n_big] : s.giant[li - n_big - n_huge]);
     if (!owns_linear(m, wave_uniform(s.ufield[u]))) continue;
     const int i = wave_uniform(s.uniq[u]);
     const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);

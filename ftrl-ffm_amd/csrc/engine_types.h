@@ -163,7 +163,7 @@ enum { OCC_FEW = -1, OCC_ONCE = -2 };
 #endif
 constexpr int kHugeMin = FFM_HUGE_MIN;  // occurrences per block above which a feature takes the lane-parallel path
 #ifndef FFM_GIANT_MIN
-#define FFM_GIANT_MIN 1024
+#define FFM_GIANT_MIN 2048
 #endif
 // ... and from which its chains are so long that their LATENCY sets the update phase's span: such
 // "giant" features are listed apart (s.giant) and walked one group of 4 factors per wave

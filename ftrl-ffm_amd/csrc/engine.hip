@@ -595,6 +595,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_PREP_WINDOW")) e->prep_window = sv[0] != '0';
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
+  // a shard's row holds ~1/n_shards of the pairs: one wave per row, so that (with the small LDS
+  // footprint of short rows) many more rows are in flight per CU
+  if (cfg->n_shards > 1) e->row_threads = 64;
   if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::min(kRowThreads, std::max(64, std::atoi(sv) / 64 * 64));
   if (const char *sv = std::getenv("FFM_WAIT_GROUPING")) e->wait_grouping = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
@@ -602,6 +605,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   // a sharded rank's very hot list holds n_shards times the rows' worth of features, each with
   // 1/n_shards of its slots: more, shorter items (measured under bench.py --emulate-shards 8)
   if (cfg->n_shards > 1) e->grid_huge = 4096;
+
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
@@ -839,7 +843,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   }
   {
     // the row kernels stage one row in dynamic LDS: opt in to what the longest admissible row needs
-    const size_t lds = row_lds_bytes(e->max_row_nnz, m.n_fields);
+    const size_t lds = row_lds_bytes(e->max_row_nnz, m.n_fields, kTermsCap);
     if (lds > 150 * 1024) {
       ffm_engine_destroy(e);
       return fail(FFM_E_UNSUPPORTED, "max_row_nnz too large for the 160 KB of LDS per workgroup");
@@ -1086,7 +1090,10 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
   const int row_cap = e->staged_row_cap > 0 ? e->staged_row_cap : e->max_row_nnz;
   e->staged_row_cap = 0;
   if (rows.n_rows == 0) return;
-  const size_t shmem = row_lds_bytes(row_cap, e->m.n_fields);
+  // (the kernels recompute the same terms capacity from the same arguments)
+  const int terms_cap = e->m.type == FFM_MODEL_FM ? row_terms_cap(2, 0, e->m.n_factors)
+                        : row_terms_cap(row_cap, e->m.n_shards > 1 ? e->m.rec_slots : 0, 0);
+  const size_t shmem = row_lds_bytes(row_cap, e->m.n_fields, terms_cap);
   const int kid = train ? K_ROW : K_PREDICT_ROW;
   if (e->m.type == FFM_MODEL_FM) {
     if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], row_cap, out, output_prob);

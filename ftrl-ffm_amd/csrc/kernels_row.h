@@ -19,12 +19,23 @@
 namespace ftrl_dev {
 
 constexpr int kRowThreads = 256;
-constexpr int kTermsCap = 2048;  // pair terms staged in LDS per pass
+constexpr int kTermsCap = 2048;  // most pair terms staged in LDS per pass
+// Terms buffer a row kernel actually needs (a multiple of 4, at most kTermsCap): all pairs of the
+// longest admissible row -- or, on a shard, its entries times the slots of a record -- or the
+// FM factor count.  Short rows then cost little LDS and many more of them are resident per CU.
+__host__ __device__ inline int row_terms_cap(int max_row_nnz, int sharded_span, int fm_factors) {
+  long long need = static_cast<long long>(max_row_nnz) * (max_row_nnz - 1) / 2;
+  if (sharded_span > 0) need = static_cast<long long>(max_row_nnz) * sharded_span;
+  if (fm_factors > need) need = fm_factors;
+  if (need < 64) need = 64;
+  if (need > kTermsCap) need = kTermsCap;
+  return static_cast<int>((need + 3) & ~3ll);
+}
 
 // Dynamic LDS carve of the row kernels (16-byte aligned base, guide G17).  All per-entry arrays
 // are indexed by the COMPACT index a of the surviving entries (remove_out_range applied).
 struct RowLds {
-  float *terms;  // [kTermsCap]           (first: keeps 16-byte alignment for b128 reads)
+  float *terms;  // [terms_cap]           (first: keeps 16-byte alignment for b128 reads)
   int *pos;      // [max_row_nnz] position of entry a inside the row
   int *field;    // [max_row_nnz]
   int *feat;     // [max_row_nnz]
@@ -34,15 +45,15 @@ struct RowLds {
   int *fcnt;     // [n_fields] surviving entries per field
   int *ffirst;   // [n_fields] compact index of the first entry of the field, -1 if none
 };
-__host__ __device__ inline size_t row_lds_bytes(int max_row_nnz, int n_fields) {
+__host__ __device__ inline size_t row_lds_bytes(int max_row_nnz, int n_fields, int terms_cap) {
   const size_t M = (size_t)((max_row_nnz + 3) & ~3), Fp = (size_t)((n_fields + 3) & ~3);
-  return sizeof(float) * kTermsCap + 6 * 4 * M + 2 * 4 * (Fp ? Fp : 4);
+  return sizeof(float) * terms_cap + 6 * 4 * M + 2 * 4 * (Fp ? Fp : 4);
 }
-__device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int n_fields) {
+__device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int n_fields, int terms_cap) {
   const int M = (max_row_nnz + 3) & ~3, Fp = ((n_fields + 3) & ~3) ? ((n_fields + 3) & ~3) : 4;
   RowLds l;
   l.terms = reinterpret_cast<float *>(base);
-  l.pos = reinterpret_cast<int *>(l.terms + kTermsCap);
+  l.pos = reinterpret_cast<int *>(l.terms + terms_cap);
   l.field = l.pos + M;
   l.feat = l.field + M;
   l.val = reinterpret_cast<float *>(l.feat + M);
@@ -230,7 +241,8 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   __shared__ uint64_t s_tab[32];  // expf's table, staged so the row's last step waits on no load
   if (TRAIN && own_tg && threadIdx.x < 32) s_tab[threadIdx.x] = kExpTab[threadIdx.x];
   const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
-  RowLds lds = carve_row_lds(smem, max_row_nnz, F);
+  const int terms_cap = row_terms_cap(max_row_nnz, m.n_shards > 1 ? record_span(m, 1) : 0, 0);
+  RowLds lds = carve_row_lds(smem, max_row_nnz, F, terms_cap);
   const int r = blockIdx.x;
   const int b = rows.row_ptr[r];
   const int nnz = rows.row_ptr[r + 1] - b;
@@ -357,8 +369,8 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
   }
   if (shard_walk) {
     const int om = record_span(m, 1), items = nv * om;
-    for (int q0 = 0; q0 < items; q0 += kTermsCap) {
-      const int q1 = min(q0 + kTermsCap, items);
+    for (int q0 = 0; q0 < items; q0 += terms_cap) {
+      const int q1 = min(q0 + terms_cap, items);
       for (int t = q0 + threadIdx.x; t < q1; t += blockDim.x) {
         const int a = t / om, j = t - a * om;
         const int fa = lds.field[a];
@@ -394,8 +406,8 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     }
   } else if (is_ffm && nv > 1) {
     const int n_pairs = nv * (nv - 1) / 2;
-    for (int q0 = 0; q0 < n_pairs; q0 += kTermsCap) {
-      const int q1 = min(q0 + kTermsCap, n_pairs);
+    for (int q0 = 0; q0 < n_pairs; q0 += terms_cap) {
+      const int q1 = min(q0 + terms_cap, n_pairs);
       for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
         int a, bb;
         unrank_pair(q, nv, a, bb);
@@ -531,7 +543,7 @@ __global__ __launch_bounds__(kRowThreads) void fm_row_kernel(ModelDev m, Rows ro
                                                              int output_prob) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv;
-  RowLds lds = carve_row_lds(smem, max_row_nnz, 1);
+  RowLds lds = carve_row_lds(smem, max_row_nnz, 1, row_terms_cap(2, 0, m.n_factors));
   const int r = blockIdx.x;
   const int b = rows.row_ptr[r];
   const int nnz = rows.row_ptr[r + 1] - b;

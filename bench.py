@@ -169,6 +169,9 @@ def main():
                          "job (1/N of the field pairs, no all-reduce) and print what the N-GPU "
                          "job's rate would be if the exchange were free")
     ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--all-columns", action="store_true",
+                    help="sharded runs: hand every rank all columns of every row (the engine drops "
+                         "the ones it owns nothing of) instead of only the rank's own columns")
     ap.add_argument("--no-field-map", action="store_true",
                     help="sharded runs: do not tell the engine the per-field id ranges (every shard "
                          "then keeps full-length records and all columns)")
@@ -263,13 +266,28 @@ def main():
     # identical synthetic blocks on every rank, parsed and resident in HOST memory
     n_blocks = args.n_blocks or max(8, min(64, (1 << 19) // rows))
     gen = synth.Generator(N_FIELDS, n_feats, **gen_kwargs)
+    keep = None
+    if compact and not args.all_columns:
+        # a compact shard never looks at the columns of fields it owns nothing of: its loader hands
+        # the engine only the kept columns (about half of them at 8 shards), which halves the
+        # rank's PCIe traffic and the entries its grouping sorts
+        plan = fa.shard_plan(N_FIELDS, n_shards, field_map=True)
+        me = args.emulate_rank if emu else rank
+        keep = (plan["pair_owner"] == me).any(axis=1) | (plan["lin_owner"] == me)
     host_blocks = []
+    blocks_feat = []
     for _ in range(n_blocks):
         b = gen.block(rows)
         if model != "FFM":
             b.field[:] = 0  # libsvm rows
+        if len(blocks_feat) < 8:
+            blocks_feat.append(b.feat)
+        if keep is not None:
+            sel = keep[b.field]
+            per_row = np.add.reduceat(sel.astype(np.int64), b.row_ptr[:-1].astype(np.int64))
+            b = synth.Block(np.concatenate([[0], np.cumsum(per_row)]).astype(np.int32), b.field[sel].copy(),
+                            b.feat[sel].copy(), b.val[sel].copy(), b.label)
         host_blocks.append(b)
-    blocks_feat = [b.feat for b in host_blocks[:8]]
     total_steps = args.steps + args.warmup + 1
     logit = torch.zeros(rows, dtype=torch.float32, device="cuda")
     loss_sum = torch.zeros(2 * total_steps, dtype=torch.float64, device="cuda")

@@ -114,16 +114,20 @@ __device__ __forceinline__ float dpp_row_shr1(float keep, float v) {
 // finalises lane t (S_t = S_{t-1} + a_t through a whole-wave shift-right-by-one DPP move); lanes
 // already final recompute the same value, so no predication is needed.  Idle lanes pass -0.0f
 // (x + -0.0f == x bit for bit, for every x including both zeros).
+// Each of the 63 steps is ONE in-place `v_add_f32_dpp s, s, a wave_shr:1`: lane t adds its a to
+// its left neighbour's running value; lane 0 has no source lane, so the hardware leaves it alone
+// (bound_ctrl off) and it keeps carry + a_0.  (As a DPP move followed by an add this chain was two
+// dependent instructions per touch: the bias chain of a 65536-row block took 1.65 ms that way.)
 __device__ __forceinline__ float wave_sequential_prefix(float carry, float a) {
   const int lane = threadIdx.x & 63;
   float s = lane == 0 ? carry + a : a;
-  const float step = lane == 0 ? -0.0f : a;
-#pragma unroll
-  for (int t = 1; t < 64; t++) {
-    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(
-        __float_as_int(s), __float_as_int(s), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-    s = prev + step;
-  }
+#define FTRL_WSHR "s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define FTRL_REP7(x) x x x x x x x
+  asm volatile(FTRL_REP7(FTRL_REP7(FTRL_WSHR)) FTRL_REP7(FTRL_WSHR) FTRL_REP7(FTRL_WSHR)
+               : "+v"(s)
+               : "v"(a));
+#undef FTRL_REP7
+#undef FTRL_WSHR
   return s;
 }
 

@@ -131,6 +131,24 @@ __device__ __forceinline__ float wave_sequential_prefix(float carry, float a) {
   return s;
 }
 
+// Two such prefixes at once, interleaved instruction by instruction: each chain's add fills the
+// other's DPP wait state, so two chains cost what one costs (measured, tools/dpp_probe2.hip:
+// 3.5 ns per dependent step for either).  sa / sb in, running prefixes out.
+__device__ __forceinline__ void wave_sequential_prefix2(float carry_a, float a, float &sa,
+                                                        float carry_b, float b, float &sb) {
+  const int lane = threadIdx.x & 63;
+  sa = lane == 0 ? carry_a + a : a;
+  sb = lane == 0 ? carry_b + b : b;
+#define FTRL_WSHR2 "v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+                   "v_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+#define FTRL_REP7(x) x x x x x x x
+  asm volatile("s_nop 1\n\t" FTRL_REP7(FTRL_REP7(FTRL_WSHR2)) FTRL_REP7(FTRL_WSHR2) FTRL_REP7(FTRL_WSHR2)
+               : "+v"(sa), "+v"(sb)
+               : "v"(a), "v"(b));
+#undef FTRL_REP7
+#undef FTRL_WSHR2
+}
+
 // The linear/bias accumulator chain over up to 64 gradients held one per lane (lane j = the j-th
 // touch, in order; lanes >= count idle).  Sequential semantics of nz_step_linear, evaluated as:
 // (1) running n by a strictly sequential prefix sum, (2) every touch's z increment in parallel,
@@ -209,12 +227,32 @@ __device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, 
   const int lane = threadIdx.x & 63;
   float n = m.bias3[1], z = m.bias3[2];
   const float w = m.bias3[0];
-  float g_next = lane < n_rows ? s.tg[lane] : 0.0f;
+  // 64 rows per pass; the two serial recurrences are software-pipelined against each other: the
+  // running n of rows r0+64.. is computed together with the running z of rows r0.. (two
+  // interleaved DPP chains cost what one costs).  Same operations on the same values in the same
+  // order as linear_chain64 / the one-thread loop.
+  float g = lane < n_rows ? s.tg[lane] : 0.0f;
+  float g_next = (64 + lane) < n_rows ? s.tg[64 + lane] : 0.0f;
+  float n_after = n_rows > 0 ? wave_sequential_prefix(n, lane < n_rows ? g * g : -0.0f) : n;
   for (int r0 = 0; r0 < n_rows; r0 += 64) {
-    const int cnt = min(64, n_rows - r0);
-    const float g = g_next;
-    g_next = (r0 + 64 + lane) < n_rows ? s.tg[r0 + 64 + lane] : 0.0f;  // prefetch the next 64
-    linear_chain64(m.h, w, lane < cnt ? g : 0.0f, cnt, n, z);
+    const bool live = r0 + lane < n_rows;
+    const float g_nn = (r0 + 128 + lane) < n_rows ? s.tg[r0 + 128 + lane] : 0.0f;  // two passes ahead
+    float n_before = __int_as_float(__builtin_amdgcn_update_dpp(
+        __float_as_int(n), __float_as_int(n_after), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    if (lane == 0) n_before = n;
+    n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n_after), 63));
+    const float sgm = div_alpha(m.h, sqrt_cr(n_after) - sqrt_cr(n_before));
+    const float inc = live ? g - sgm * w : -0.0f;
+    float z_run;
+    if (r0 + 64 < n_rows) {
+      const float q_next = (r0 + 64 + lane) < n_rows ? g_next * g_next : -0.0f;
+      wave_sequential_prefix2(z, inc, z_run, n, q_next, n_after);
+    } else {
+      z_run = wave_sequential_prefix(z, inc);
+    }
+    z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_run), 63));
+    g = g_next;
+    g_next = g_nn;
   }
   if (lane == 0) {
     m.bias3[1] = n;

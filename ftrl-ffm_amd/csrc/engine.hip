@@ -698,10 +698,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.row_of, E));
   TRY_ALLOC(e->alloc(&s.occ, E));
   TRY_ALLOC(e->alloc(&s.occ2, E));
-  TRY_ALLOC(e->alloc(&s.uniq, E));
-  TRY_ALLOC(e->alloc(&s.ustart, E));
-  TRY_ALLOC(e->alloc(&s.ucount, E));
-  TRY_ALLOC(e->alloc(&s.ufield, E));
+  TRY_ALLOC(e->alloc(&s.udesc, E));
   TRY_ALLOC(e->alloc(&s.small, E));
   TRY_ALLOC(e->alloc(&s.few, E));
   TRY_ALLOC(e->alloc(&s.sdesc, E));
@@ -790,10 +787,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.row_of, E));
     TRY_ALLOC(e->alloc(&t.occ, E));
     TRY_ALLOC(e->alloc(&t.occ2, E));
-    TRY_ALLOC(e->alloc(&t.uniq, E));
-    TRY_ALLOC(e->alloc(&t.ustart, E));
-    TRY_ALLOC(e->alloc(&t.ucount, E));
-    TRY_ALLOC(e->alloc(&t.ufield, E));
+    TRY_ALLOC(e->alloc(&t.udesc, E));
     TRY_ALLOC(e->alloc(&t.small, E));
     TRY_ALLOC(e->alloc(&t.few, E));
     TRY_ALLOC(e->alloc(&t.sdesc, E));

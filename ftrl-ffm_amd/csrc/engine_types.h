@@ -115,10 +115,10 @@ struct Scratch {
   int *row_of;    // [nnz] row of each entry
   int *occ;       // [nnz] entry indices grouped by feature; ascending inside a group
   int2 *occ2;     // [nnz] the same groups as {entry, row of the entry}
-  int *uniq;      // [nnz] distinct features of the block (arbitrary order)
-  int *ustart;    // [nnz] start of each distinct feature's group in occ
-  int *ucount;    // [nnz] its number of occurrences
-  int *ufield;    // [nnz] the field its first occurrence carries (FFM)
+  int4 *udesc;    // [nnz] the block's distinct features (arbitrary order), one 16-byte descriptor
+                  //      each -- ONE load per owner instead of four dependent ones:
+                  //      {feature id, start of its group in occ, number of occurrences, the field
+                  //      its first occurrence carries (FFM)}
   int *small;     // [nnz] indices into uniq of the features with <= kSmallMax occurrences
   int4 *sdesc;    // [nnz] one descriptor per feature that occurs once: {feature, entry, row, field}
   int *few;       // [nnz] ... with 2..kSmallMax occurrences (the small list minus the features

@@ -224,14 +224,15 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
     const int rem = static_cast<int>(item - li * per_feat);
     const int sc = rem / passes, pass = rem - sc * passes;
     const int u = wave_uniform(list[li]);
-    const int fa = wave_uniform(s.ufield[u]);
+    const int4 ud = s.udesc[u];  // {feature, start, count, field}
+    const int fa = wave_uniform(ud.w);
     const int fp = wave_uniform(walk_field(m, fa, sc));  // partner field of slot sc
     if (fp < 0) continue;
-    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     if (s.gmask && !((s.gmask[start] >> fp) & 1ull)) continue;  // no row of the block touches the slot
     const unsigned long long own_bits = owner_bits(m, fp);  // (no loads inside the step loops)
     const bool chainy = !s.cmask || ((s.cmask[start] >> fp) & 1ull) != 0ull;  // multi-valued partner field
-    const int i = wave_uniform(s.uniq[u]);
+    const int i = wave_uniform(ud.x);
     float *rec = lat_row(m, i, fa) + sc * k;  // the slot's n row; z and w rows follow at RL, 2 RL
     int kk[G];
     bool act[G];
@@ -407,8 +408,9 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m
     const unsigned li = item / passes;
     const int pass = static_cast<int>(item - li * passes);
     const int u = wave_uniform(li < n_huge ? s.huge[li] : s.giant[li - n_huge]);
-    const int i = wave_uniform(s.uniq[u]);
-    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    const int4 ud = s.udesc[u];
+    const int i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     float *rec = lat_row(m, i, 0);
     int kk[G];
     bool act[G];

@@ -209,11 +209,8 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
   for (int q = 0; q < kLists; q++) slot[q] = wave_base[wv][q] + __popcll(pm[q] & below);
   const int u = slot[0], is = slot[1], iw = slot[2], ib = slot[3], ih = slot[4];
   if (head) {
-    s.uniq[u] = static_cast<int>(K);
-    s.ustart[u] = t;
-    s.ucount[u] = c;
     const int fld = rows.field ? rows.field[p] : 0;
-    s.ufield[u] = fld;
+    s.udesc[u] = make_int4(static_cast<int>(K), t, c, fld);
     if (c == 1) s.sdesc[slot[5]] = make_int4(static_cast<int>(K), p, s.row_of[p], fld);
     if (c > 1 && c <= kSmallMax) s.few[iw] = u;
     if (c <= kSmallMax) s.small[is] = u;

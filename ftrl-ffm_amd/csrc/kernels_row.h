@@ -507,9 +507,10 @@ __global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s)
     int u = static_cast<int>((static_cast<double>(t) + 0.5) * inv_per);
     u += static_cast<unsigned>(u + 1) * per <= t ? 1 : (static_cast<unsigned>(u) * per > t ? -1 : 0);
     const int lc = static_cast<int>(t - static_cast<unsigned>(u) * per);
-    const int fa = s.ufield[u];
+    const int4 ud = s.udesc[u];  // {feature, start, count, field}
+    const int fa = ud.w;
     if (lc == 0 && owns_linear(m, fa)) {
-      const int i0 = s.uniq[u];
+      const int i0 = ud.x;
       m.lin_w[i0] = ftrl_weight(m.h, m.lin_n[i0], m.lin_z[i0]);
     }
     const int l = lc;  // walk position = element of the stored record
@@ -517,8 +518,8 @@ __global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s)
     sl += (sl + 1) * kv <= l ? 1 : (sl * kv > l ? -1 : 0);
     const int fp = walk_field(m, fa, sl);
     if (fp < 0) continue;
-    const int i = s.uniq[u];
-    const unsigned long long mask = s.gmask[s.ustart[u]];
+    const int i = ud.x;
+    const unsigned long long mask = s.gmask[ud.y];
     if (!((mask >> fp) & 1ull)) continue;
     if (VEC4) {
       const int RL4 = RL >> 2;

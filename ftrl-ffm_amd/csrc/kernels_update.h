@@ -176,9 +176,10 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
   const int gtid = block * blockDim.x + threadIdx.x;
   for (int li = gtid; li < n_small; li += n_blocks * blockDim.x) {
     const int u = s.small[li];
-    if (!owns_linear(m, s.ufield[u])) continue;  // another shard's linear terms
-    const int i = s.uniq[u];
-    const int start = s.ustart[u], c = s.ucount[u];
+    const int4 ud = s.udesc[u];  // {feature, start, count, field}
+    if (!owns_linear(m, ud.w)) continue;  // another shard's linear terms
+    const int i = ud.x;
+    const int start = ud.y, c = ud.z;
     float n = m.lin_n[i], z = m.lin_z[i];
     const float w = m.lin_w[i];
     for (int t = 0; t < c; t++) {
@@ -195,9 +196,10 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
   for (int li = wave; li < n_big + n_huge + n_giant; li += n_waves) {
     const int u = wave_uniform(li < n_big ? s.big[li]
                                : li < n_big + n_huge ? s.huge[li - n_big] : s.giant[li - n_big - n_huge]);
-    if (!owns_linear(m, wave_uniform(s.ufield[u]))) continue;
-    const int i = wave_uniform(s.uniq[u]);
-    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    const int4 ud = s.udesc[u];
+    if (!owns_linear(m, wave_uniform(ud.w))) continue;
+    const int i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     float n = m.lin_n[i], z = m.lin_z[i];
     const float w = m.lin_w[i];
     for (int t0 = 0; t0 < c; t0 += 64) {
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned li = item / chunks;
     const int u = wave_uniform(s.big[li]);
-    const int fa = wave_uniform(s.ufield[u]);
+    const int4 ud = s.udesc[u];  // {feature, start, count, field}
+    const int fa = wave_uniform(ud.w);
     const int epos = static_cast<int>(item - li * chunks) * 64 + lane;  // element of the stored record
     const int eb = epos < span ? epos : 0;
     int sl = static_cast<int>((eb + 0.5f) * inv_k);  // this lane's slot
@@ -328,8 +331,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     const int ee = active ? eb : 0;
     const int fp = active ? fpw : 0;  // (idle lanes still form valid fact addresses)
     const int kk = active ? eb - sl * k : 0;  // and factor
-    const int i = wave_uniform(s.uniq[u]);
-    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    const int i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     float *rec = lat_row(m, i, fa);
     float n = rec[LAT_N * RL + ee], z = rec[LAT_Z * RL + ee];
     const float w = rec[LAT_W * RL + ee];
@@ -451,12 +454,13 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
     const unsigned u = item / chunks;
     const int e = static_cast<int>(item - u * chunks) * 64 + lane;
     if (e >= RL) continue;
-    const int fa = s.ufield[u];
+    const int4 ud = s.udesc[u];
+    const int fa = ud.w;
     const int sl = e / k, kk = e - sl * k;
     const int fp = walk_field(m, fa, sl);
     if (fp < 0) continue;
-    const int i = s.uniq[u];
-    const int start = s.ustart[u], c = s.ucount[u];
+    const int i = ud.x;
+    const int start = ud.y, c = ud.z;
     float *rec = lat_row(m, i, fa);
     float n = rec[LAT_N * RL + e], z = rec[LAT_Z * RL + e];
     const float w = rec[LAT_W * RL + e];
@@ -498,9 +502,10 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
   const int span4 = record_span(m, k4);
   for (int li = wave; li < n_small; li += n_waves) {
     const int u = wave_uniform(list[li]);
-    const int i = wave_uniform(s.uniq[u]);
-    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
-    const int fa = wave_uniform(s.ufield[u]);
+    const int4 ud = s.udesc[u];
+    const int i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    const int fa = wave_uniform(ud.w);
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
     for (int l0 = 0; l0 < span4; l0 += 64) {
       const int l = l0 + lane;  // 16-byte vector of the stored record
@@ -647,8 +652,9 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     const int u = static_cast<int>(item / chunks);
     const int e = static_cast<int>(item - static_cast<int64_t>(u) * chunks) * 64 + lane;
     if (e >= k) continue;
-    const int i = wave_uniform(s.uniq[u]);
-    const int start = wave_uniform(s.ustart[u]), c = wave_uniform(s.ucount[u]);
+    const int4 ud = s.udesc[u];
+    const int i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     if (skip_huge && c > kHugeMin) continue;
     float *rec = lat_row(m, i, 0);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];

@@ -154,6 +154,9 @@ __device__ __forceinline__ void chain_sigma_w(const Hyper &h, const float (&nb)[
 #define FFM_CHAIN_CHUNK 1
 #endif
 constexpr int kChainChunk = FFM_CHAIN_CHUNK;
+#ifndef FFM_CHAIN_PIPELINE
+#define FFM_CHAIN_PIPELINE 1
+#endif
 
 struct ChainTouch {  // what a step needs of one touch once its partner weights are requested
   float tg, xm, xo;
@@ -250,7 +253,7 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
     const float2 *mcol = s.hmeta + start;                              // + t
     const int steps = (c + kChainT - 1) / kChainT;
 
-    if (!chainy) {
+    if (!chainy && FFM_CHAIN_PIPELINE) {
       // ---- three-stage pipeline over chunks of CH steps ----
       const int n_chunks = (steps + CH - 1) / CH;
       int4 axA[CH], axB[CH];

@@ -1518,7 +1518,10 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   const int this_slot = e->slot_next;
   if (sl.used) {
     ScopedTimer tm("stage:slot_wait");
-    if (!sl.zero_copy) HIP_TRY(hipEventSynchronize(sl.ev_copied));  // its pinned image is free again
+    // the block staged kSlots calls ago has been pulled off its host image -- the slot's own pinned
+    // buffer, or (zero_copy) the caller's arrays, which the caller may therefore reuse once kSlots
+    // further ffm_engine_stage_batch calls have returned
+    HIP_TRY(hipEventSynchronize(sl.ev_copied));
     HIP_TRY(hipStreamWaitEvent(e->copy, sl.ev_trained, 0));        // and nothing reads its device arrays
   }
   // host arrays -> pinned image (the caller may reuse its buffers on return) -> device, prep stream

@@ -225,8 +225,8 @@ int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out);
  * oldest staged block of an unsharded engine.  So rows stream host -> HBM inside the training loop
  * on every rank, overlapped with the previous block's training.
  *   zero_copy != 0: the five arrays are page-locked host memory (hipHostMalloc, hipHostRegister or
- * ffm_engine_pin_host) and the caller leaves them untouched until the block has been trained (two
- * further ffm_engine_stage_batch calls have returned, or ffm_engine_sync), each 16-byte aligned:
+ * ffm_engine_pin_host) and the caller leaves them untouched until FOUR further
+ * ffm_engine_stage_batch calls have returned (or ffm_engine_sync has), each 16-byte aligned:
  * the device pulls them straight from there (a kernel reading the mapped host memory), without the
  * copy into the engine's own staging slot -- the host's share of one 8192 x 39 block drops from a
  * 3.9 MB memcpy to one kernel launch. */

@@ -16,7 +16,8 @@ import os
 import shutil
 import sys
 
-WIDE_READERS = ("ffm_refresh_kernel", "ffm_update_small_kernel")
+# kernels whose reads are dominated by whole records streamed as 16 B per lane
+WIDE_READERS = ("ffm_refresh_kernel", "ffm_update_small_kernel", "ffm_update_single_kernel")
 
 
 def short(name):
@@ -35,7 +36,7 @@ def per_kernel(path, counter):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join("gpurun_out", "prof_" + rnd)
     os.makedirs("profiles", exist_ok=True)
     shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"),
@@ -65,6 +66,11 @@ def main():
                           hbm_GBps=round((rd * corr + wr) / (st["avg_us"] * 1e-6) / 1e9, 1))
     with open(os.path.join("profiles", rnd + "_pmc_hbm_summary.json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
+    # the other artefacts of tools/profile_round.sh, as they are
+    for name in ("timeline.txt", "step_gaps.txt", "sq_summary.txt", "sq_summary_emu8.txt", "c2.json", "c3.json",
+                 "c4.json", "emu8_strong_rank3.json") + tuple("emu8_rank%d.json" % r for r in range(8)):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join("profiles", rnd + "_" + name))
     for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["avg_us"]):
         print("%-36s avg %9.1f us  hbm %8.1f MB/launch  %7.1f GB/s" % (
             k, v["avg_us"], v["hbm_bytes_per_launch"] / 1e6, v["hbm_GBps"]))

@@ -75,6 +75,7 @@ ABI = [
     ("ffm_engine_train_batch_async", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
     ("ffm_engine_train_flush", ctypes.c_int, [_vp, _f64p]),
     ("ffm_engine_stage_batch", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR + [ctypes.c_int32]),
+    ("ffm_engine_blocks_pulled", ctypes.c_int64, [_vp]),
     ("ffm_engine_train_forward_staged", ctypes.c_int, [_vp, _vp]),
     ("ffm_engine_train_staged", ctypes.c_int, [_vp, _vp, _vp]),
     ("ffm_engine_pin_host", ctypes.c_int, [_vp, ctypes.c_size_t]),
@@ -271,6 +272,10 @@ class Engine:
         """Host block -> (pinned slot ->) HBM + grouping on the side stream (returns at once).
         zero_copy: the block's arrays are page-locked (pin_block) and stay untouched until trained."""
         self._check(self.lib.ffm_engine_stage_batch(self.h, *self._csr(c), int(zero_copy)))
+
+    def blocks_pulled(self):
+        """How many staged blocks have been uploaded so far (their host arrays may be reused)."""
+        return int(self.lib.ffm_engine_blocks_pulled(self.h))
 
     def train_staged(self, logit_out=None, loss_sum_out=None):
         """The whole step on the oldest staged block (unsharded engines; device outputs)."""

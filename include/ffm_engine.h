@@ -225,14 +225,16 @@ int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out);
  * oldest staged block of an unsharded engine.  So rows stream host -> HBM inside the training loop
  * on every rank, overlapped with the previous block's training.
  *   zero_copy != 0: the five arrays are page-locked host memory (hipHostMalloc, hipHostRegister or
- * ffm_engine_pin_host) and the caller leaves them untouched until FOUR further
- * ffm_engine_stage_batch calls have returned (or ffm_engine_sync has), each 16-byte aligned:
+ * ffm_engine_pin_host), each 16-byte aligned, and the caller leaves them untouched until the
+ * block has been uploaded -- ffm_engine_blocks_pulled() (non-blocking) has reached the block's
+ * 1-based staging number, or ffm_engine_sync has returned:
  * the device pulls them straight from there (a kernel reading the mapped host memory), without the
  * copy into the engine's own staging slot -- the host's share of one 8192 x 39 block drops from a
  * 3.9 MB memcpy to one kernel launch. */
 int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
                            const int32_t *field, const int32_t *feat, const float *val,
                            const int32_t *label, int32_t zero_copy);
+int64_t ffm_engine_blocks_pulled(ffm_engine *e);
 int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit);
 int ffm_engine_train_staged(ffm_engine *e, float *logit_out, double *loss_sum_out);
 /* hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime themselves. */

@@ -809,7 +809,13 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
   // (a high-priority queue for the look-ahead grouping was tried: the whole step got 45% slower)
-  TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
+  if (const char *sv = std::getenv("FFM_PREP_PRIORITY")) {  // experiment: the look-ahead stream above / below normal
+    int lo = 0, hi = 0;
+    TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    TRY_HIP(hipStreamCreateWithPriority(&e->prep, hipStreamNonBlocking, sv[0] == '1' ? hi : lo));
+  } else {
+    TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
+  }
   e->copy = e->prep;
   TRY_HIP(hipEventCreateWithFlags(&e->ev_rows_done, hipEventDisableTiming));
   for (int i = 0; i < ffm_engine::kSets; i++) {

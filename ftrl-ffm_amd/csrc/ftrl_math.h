@@ -179,8 +179,9 @@ __device__ __forceinline__ void nz_step_latent_jside(const Hyper &h, float w, fl
 // ARM optimized-routines: x*N/ln2 = k + r, 2^(k/N) from a 32-entry table, cubic in r, all in
 // double, one rounding to float) is NOT correctly rounded in ~8e-5 of inputs, so a "more accurate"
 // device exp would differ from the reference in those.  This is that algorithm, with the fused
-// multiply-adds x86-64 glibc's FMA build performs; checked on the host against glibc 2.35 expf on
-// all 2^32 float inputs (tests/test_expf_port.py keeps the same statement in C under test).
+// multiply-adds x86-64 glibc's FMA build performs; checked on the device against the host C
+// library's 1/(1+expf(-x)) on 300 k inputs including the tails
+// (tests/test_gpu_parity.py::test_device_sigmoid_is_the_c_library_sigmoid).
 // 2^(i/32) for i = 0..31, bits of the double with the exponent's low bits folded in (glibc's
 // __exp2f_data.tab).  Callers on a latency-critical path stage it in LDS and pass that copy.
 static __device__ const uint64_t kExpTab[32] = {

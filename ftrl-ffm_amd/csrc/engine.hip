@@ -773,11 +773,11 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   auto alloc_sort = [&](Scratch &t) -> int {
     // counters, hist and cursor share one allocation: one memset per block clears them all
     int *cc = nullptr;
-    int r2 = e->alloc(&cc, static_cast<size_t>(kNumCounters) + 2 * static_cast<size_t>(e->n_buckets) * kLineInts);
+    int r2 = e->alloc(&cc, static_cast<size_t>(kNumCounters) + 2 * static_cast<size_t>(e->n_buckets));
     if (r2) return r2;
     t.counters = cc;
     t.hist = cc + kNumCounters;
-    t.cursor = t.hist + static_cast<size_t>(e->n_buckets) * kLineInts;
+    t.cursor = t.hist + e->n_buckets;
     if ((r2 = e->alloc(&t.bbase, static_cast<size_t>(e->n_buckets) + 1))) return r2;
     if ((r2 = e->alloc(&t.pairs, E))) return r2;
     if ((r2 = e->alloc(&t.bigb, static_cast<size_t>(e->n_buckets)))) return r2;
@@ -1137,7 +1137,7 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
   Scratch &sc = e->sc[set];
   ScopedTimer tm_all("grouping:all");
   // counters, histogram and cursors of the set in one go
-  HIP_TRY(hipMemsetAsync(sc.counters, 0, (kNumCounters + 2 * static_cast<size_t>(e->n_buckets) * kLineInts) * sizeof(int), st));
+  HIP_TRY(hipMemsetAsync(sc.counters, 0, (kNumCounters + 2 * static_cast<size_t>(e->n_buckets)) * sizeof(int), st));
   if (rows.nnz > 0) {
     const int nnz = rows.nnz;
     if (sc.rowmask)

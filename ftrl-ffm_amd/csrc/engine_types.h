@@ -113,8 +113,8 @@ struct Scratch {
   unsigned *key;  // [nnz] sort key per entry: feature id, n_feats for entries remove_out_range erases
   unsigned *skey; // [n surviving] their keys sorted ascending (s.occ: the entries in the same order)
   // the sort (kernels_group.h): bucket = key >> bucket_shift
-  int *hist;      // [n_buckets * kLineInts] surviving entries per bucket, one per 64-byte line
-  int *cursor;    // [n_buckets * kLineInts] positions handed out so far inside each bucket's range
+  int *hist;      // [n_buckets] surviving entries per bucket (zeroed with the counters)
+  int *cursor;    // [n_buckets] positions handed out so far inside each bucket's range
   int *bbase;     // [n_buckets + 1] start of each bucket's range; [n_buckets] = surviving entries
   unsigned long long *pairs;  // [nnz] (key << 32 | entry), bucket by bucket, unsorted inside
   int *bigb;      // [n_buckets] buckets too large for the small sort's LDS (CNT_NBIGB of them)
@@ -161,16 +161,9 @@ struct Scratch {
   float *svx;     // [n_rows*n_factors] FM per-row factor sums (sum_vx, fm.h:24)
 };
 
-// Every counter that takes atomics sits on a 64-byte line of its own (kLineInts apart), and so do
-// the sort's per-bucket histogram and cursor entries: device-scope atomics are performed at the
-// memory side, one line at a time -- with 16 counters per line the grouping's ~400 k atomics
-// queued on ~30 lines (the key kernel alone took 130 us that way).
-constexpr int kLineInts = 16;
-enum { CNT_NUNIQ = 0, CNT_CURSOR = 1 * kLineInts, CNT_NMULTI = 2 * kLineInts, CNT_ERROR = 3 * kLineInts,
-       CNT_NSMALL = 4 * kLineInts, CNT_NBIG = 5 * kLineInts, CNT_NHUGE = 6 * kLineInts,
-       CNT_NFEW = 7 * kLineInts, CNT_NSINGLE = 9 * kLineInts, CNT_NGIANT = 10 * kLineInts,
-       CNT_NBIGB = 11 * kLineInts };
-constexpr int kNumCounters = 12 * kLineInts;
+enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5,
+       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NSINGLE = 9, CNT_NGIANT = 10, CNT_NBIGB = 11 };
+constexpr int kNumCounters = 16;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 #ifndef FFM_HUGE_MIN
 #define FFM_HUGE_MIN 96

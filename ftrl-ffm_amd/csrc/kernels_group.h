@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, R
   if (in) {
     s.row_of[p] = lo;
     s.key[p] = valid ? static_cast<unsigned>(i) : static_cast<unsigned>(m.n_feats);
-    if (valid) atomicAdd(&s.hist[(static_cast<unsigned>(i) >> s.bucket_shift) * kLineInts], 1);  // (fire and forget)
+    if (valid) atomicAdd(&s.hist[static_cast<unsigned>(i) >> s.bucket_shift], 1);  // (result unused: fire and forget)
     s.occpos[p] = OCC_FEW;
     if (s.gmask) { s.gmask[p] = 0ull; s.cmask[p] = 0ull; }
   }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kScatterThreads) void group_scatter_kernel(Rows row
   int local = 0;
   for (int j = 0; j < per; j++) {
     const int b = tid * per + j;
-    if (b < nb) local += s.hist[b * kLineInts];
+    if (b < nb) local += s.hist[b];
   }
   int incl = local;
 #pragma unroll
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kScatterThreads) void group_scatter_kernel(Rows row
       base[b] = run;
       cnt[b] = 0;
       if (blockIdx.x == 0) s.bbase[b] = run;
-      run += s.hist[b * kLineInts];
+      run += s.hist[b];
     }
   }
   if (blockIdx.x == 0 && tid == kScatterThreads - 1) s.bbase[nb] = run;  // = number of surviving entries
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kScatterThreads) void group_scatter_kernel(Rows row
   __syncthreads();
   for (int b = tid; b < nb; b += kScatterThreads) {
     const int c = cnt[b];
-    if (c) base[b] += atomicAdd(&s.cursor[b * kLineInts], c);
+    if (c) base[b] += atomicAdd(&s.cursor[b], c);
   }
   __syncthreads();
 #pragma unroll

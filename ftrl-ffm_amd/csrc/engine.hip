@@ -767,7 +767,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     e->bucket_shift = 0;
     while (((static_cast<uint64_t>(cfg->n_feats) - 1) >> e->bucket_shift) + 1 > static_cast<uint64_t>(target)) e->bucket_shift++;
     e->n_buckets = static_cast<int>(((static_cast<uint64_t>(cfg->n_feats) - 1) >> e->bucket_shift) + 1);
-    TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&group_bucket_sort_kernel<16384, true>),
+    TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&group_bucket_sort_kernel<16384, 2048>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
   }
   auto alloc_sort = [&](Scratch &t) -> int {
@@ -780,7 +780,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     t.cursor = t.hist + e->n_buckets;
     if ((r2 = e->alloc(&t.bbase, static_cast<size_t>(e->n_buckets) + 1))) return r2;
     if ((r2 = e->alloc(&t.pairs, E))) return r2;
-    if ((r2 = e->alloc(&t.bigb, static_cast<size_t>(e->n_buckets)))) return r2;
     t.n_buckets = e->n_buckets;
     t.bucket_shift = e->bucket_shift;
     return FFM_OK;
@@ -1148,8 +1147,8 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
     e->prof_begin(K_GROUP_SORT, st);
     hipLaunchKernelGGL(group_scatter_kernel, dim3(cdiv(nnz, kScatterThreads * kScatterPer)), dim3(kScatterThreads), 0, st,
                        rows, sc, static_cast<unsigned>(e->m.n_feats));
-    hipLaunchKernelGGL((group_bucket_sort_kernel<2048, false>), dim3(e->n_buckets), dim3(kSortThreads), 2048 * 8, st, sc);
-    hipLaunchKernelGGL((group_bucket_sort_kernel<16384, true>), dim3(kBigSortBlocks), dim3(kSortThreads), 16384 * 8, st, sc);
+    hipLaunchKernelGGL((group_bucket_sort_kernel<2048, 0>), dim3(e->n_buckets), dim3(kSortThreads), 2048 * 8, st, sc);
+    hipLaunchKernelGGL((group_bucket_sort_kernel<16384, 2048>), dim3(e->n_buckets), dim3(kSortThreads), 16384 * 8, st, sc);
     e->prof_end(st);
     LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, e->m, rows, sc);
   }

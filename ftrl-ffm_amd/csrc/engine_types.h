@@ -117,7 +117,6 @@ struct Scratch {
   int *cursor;    // [n_buckets] positions handed out so far inside each bucket's range
   int *bbase;     // [n_buckets + 1] start of each bucket's range; [n_buckets] = surviving entries
   unsigned long long *pairs;  // [nnz] (key << 32 | entry), bucket by bucket, unsorted inside
-  int *bigb;      // [n_buckets] buckets too large for the small sort's LDS (CNT_NBIGB of them)
   int n_buckets, bucket_shift;
   int *row_of;    // [nnz] row of each entry
   int *occ;       // [nnz] entry indices grouped by feature; ascending inside a group
@@ -162,7 +161,7 @@ struct Scratch {
 };
 
 enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5,
-       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NSINGLE = 9, CNT_NGIANT = 10, CNT_NBIGB = 11 };
+       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NSINGLE = 9, CNT_NGIANT = 10 };
 constexpr int kNumCounters = 16;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 #ifndef FFM_HUGE_MIN

@@ -199,24 +199,16 @@ __global__ __launch_bounds__(kScatterThreads) void group_scatter_kernel(Rows row
 // network whose every compare is ascending (each merge starts with the "flip" i <-> i ^ (k-1)), so
 // a bucket of any size sorts with virtual +inf padding: partners past the end are simply skipped.
 // Buckets up to CAP pairs are sorted in LDS; a larger one (one feature in more than CAP rows of a
-// block) in place in global memory by the same workgroup -- slow, correct, rare.  Two launches:
-// BIG = false, one workgroup per bucket with 16 KB of LDS, sorts the buckets up to its CAP and
-// lists the larger ones (s.bigb); BIG = true, a few workgroups with 128 KB of LDS each, walks
-// that list -- so only as many CUs give up their LDS as there are large buckets.
+// block) in place in global memory by the same workgroup -- slow, correct, rare.  The launch with
+// LO > 0 takes only the buckets above LO (two launches: most buckets are small and should not pay
+// for the big buckets' LDS).
 constexpr int kSortThreads = 256;
-constexpr int kBigSortBlocks = 64;
-template <int CAP, bool BIG>
+template <int CAP, int LO>
 __global__ __launch_bounds__(kSortThreads) void group_bucket_sort_kernel(Scratch s) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sort_buf[];
-  for (int w = blockIdx.x; w < (BIG ? s.counters[CNT_NBIGB] : s.n_buckets); w += gridDim.x) {
-  const int b = BIG ? s.bigb[w] : w;
+  const int b = blockIdx.x;
   const int start = s.bbase[b], n = s.bbase[b + 1] - start;
-  if (!BIG && n > CAP) {
-    if (threadIdx.x == 0) s.bigb[atomicAdd(&s.counters[CNT_NBIGB], 1)] = b;
-    continue;
-  }
-  if (n == 0) continue;
-  __syncthreads();  // (BIG: the previous bucket's LDS image is done with)
+  if (n <= LO || (LO == 0 && n > CAP)) return;
   unsigned long long *a = n <= CAP ? sort_buf : s.pairs + start;
   if (n <= CAP)
     for (int j = threadIdx.x; j < n; j += kSortThreads) sort_buf[j] = s.pairs[start + j];
@@ -247,7 +239,6 @@ __global__ __launch_bounds__(kSortThreads) void group_bucket_sort_kernel(Scratch
     const unsigned long long v = a[j];
     s.skey[start + j] = static_cast<unsigned>(v >> 32);
     s.occ[start + j] = static_cast<int>(v & 0xffffffffu);
-  }
   }
 }
 

@@ -13,6 +13,8 @@
 
 #include <cstring>
 
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -32,6 +34,11 @@
 #include "kernels_chain.h"
 
 using namespace ftrl_dev;
+
+// The grouping's sort: always the Onesweep radix sort (a few passes over the key bits), never
+// rocPRIM's merge-sort variant (about twenty small launches at this size).
+using GroupSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                  rocprim::default_config, 0>;
 
 namespace {
 
@@ -87,7 +94,7 @@ enum KernelId {
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
-    "group_keys_kernel", "group_bucket_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
+    "group_keys_kernel", "group_radix_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
     "linear_update_kernel", "bias_update_kernel", "latent_update_kernel", "latent_update_hot_kernel",
     "latent_update_huge_kernel",
     "row_kernel<predict>", "refresh_kernel", "latent_update_single_kernel"};
@@ -398,7 +405,9 @@ struct ffm_engine {
   int cur_slot = -1;        // slot of the block between train_forward_staged and train_update
   int64_t n_staged_total = 0, n_pulled = 0;  // blocks staged so far / known to be uploaded
   double *d_loss_acc = nullptr;  // [1] sum of the async blocks' losses since the last flush
-  int n_buckets = 1, bucket_shift = 0;  // the grouping's sort: bucket = feature id >> bucket_shift
+  void *d_sort_tmp[kSets] = {};  // rocPRIM radix sort workspace per scratch set
+  size_t sort_tmp_bytes = 0;
+  unsigned sort_bits = 32;
   float *d_stage = nullptr;  // dense staging for get/set
   int64_t stage_floats = 0;
   int *d_ids = nullptr;      // feature ids of one ffm_engine_get_rows / set_rows chunk
@@ -698,6 +707,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.big, E));
   TRY_ALLOC(e->alloc(&s.huge, E));
   TRY_ALLOC(e->alloc(&s.giant, E / kGiantMin + 1));
+  TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
   TRY_ALLOC(e->alloc(&e->d_err, 1));
   TRY_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), e->stream));
   s.err = e->d_err;
@@ -761,30 +771,16 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.loss, R));
   TRY_ALLOC(e->alloc(&s.svx, R * static_cast<size_t>(m.type == FFM_MODEL_FM ? m.n_factors : 1)));
   {
-    // the grouping's sort: buckets of ~512 entries of a full block, at most kMaxBuckets of them,
-    // bucket = feature id >> shift (so bucket order is key order)
-    const int target = static_cast<int>(std::min<size_t>(std::max<size_t>(E / 512, 64), kMaxBuckets));
-    e->bucket_shift = 0;
-    while (((static_cast<uint64_t>(cfg->n_feats) - 1) >> e->bucket_shift) + 1 > static_cast<uint64_t>(target)) e->bucket_shift++;
-    e->n_buckets = static_cast<int>(((static_cast<uint64_t>(cfg->n_feats) - 1) >> e->bucket_shift) + 1);
-    TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&group_bucket_sort_kernel<16384, 2048>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+    // stable LSD radix sort of (feature id, entry) pairs: key bits = those of the sentinel n_feats
+    e->sort_bits = 1;
+    while (e->sort_bits < 32 && (static_cast<uint64_t>(cfg->n_feats) >> e->sort_bits) != 0) e->sort_bits++;
+    TRY_HIP(rocprim::radix_sort_pairs<GroupSortConfig>(nullptr, e->sort_tmp_bytes, s.key, s.skey,
+                                      rocprim::counting_iterator<int>(0), s.occ, E, 0u, e->sort_bits,
+                                      e->stream));
+    unsigned char *tmp = nullptr;
+    TRY_ALLOC(e->alloc(&tmp, e->sort_tmp_bytes));
+    e->d_sort_tmp[0] = tmp;
   }
-  auto alloc_sort = [&](Scratch &t) -> int {
-    // counters, hist and cursor share one allocation: one memset per block clears them all
-    int *cc = nullptr;
-    int r2 = e->alloc(&cc, static_cast<size_t>(kNumCounters) + 2 * static_cast<size_t>(e->n_buckets));
-    if (r2) return r2;
-    t.counters = cc;
-    t.hist = cc + kNumCounters;
-    t.cursor = t.hist + e->n_buckets;
-    if ((r2 = e->alloc(&t.bbase, static_cast<size_t>(e->n_buckets) + 1))) return r2;
-    if ((r2 = e->alloc(&t.pairs, E))) return r2;
-    t.n_buckets = e->n_buckets;
-    t.bucket_shift = e->bucket_shift;
-    return FFM_OK;
-  };
-  TRY_ALLOC(alloc_sort(s));
   for (int si = 1; si < ffm_engine::kSets; si++) {
     Scratch &t = e->sc[si];
     t = s;  // shared: head/next/rowtab/haux/hmeta/logit/tg/loss/svx
@@ -800,13 +796,16 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.big, E));
     TRY_ALLOC(e->alloc(&t.huge, E));
     TRY_ALLOC(e->alloc(&t.giant, E / kGiantMin + 1));
-    TRY_ALLOC(alloc_sort(t));
+    TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
     TRY_ALLOC(e->alloc(&t.occpos, E));
     if (masks) {
       TRY_ALLOC(e->alloc(&t.rowmask, 2 * R));
       TRY_ALLOC(e->alloc(&t.gmask, E));
       TRY_ALLOC(e->alloc(&t.cmask, E));
     }
+    unsigned char *tmp = nullptr;
+    TRY_ALLOC(e->alloc(&tmp, e->sort_tmp_bytes));
+    e->d_sort_tmp[si] = tmp;
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
   // (a high-priority queue for the look-ahead grouping was tried: the whole step got 45% slower)
@@ -1135,20 +1134,18 @@ static bool same_block(const Rows &a, const Rows &b) {
 static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st) {
   Scratch &sc = e->sc[set];
   ScopedTimer tm_all("grouping:all");
-  // counters, histogram and cursors of the set in one go
-  HIP_TRY(hipMemsetAsync(sc.counters, 0, (kNumCounters + 2 * static_cast<size_t>(e->n_buckets)) * sizeof(int), st));
+  HIP_TRY(hipMemsetAsync(sc.counters, 0, kNumCounters * sizeof(int), st));
   if (rows.nnz > 0) {
     const int nnz = rows.nnz;
     if (sc.rowmask)
       HIP_TRY(hipMemsetAsync(sc.rowmask, 0, sizeof(unsigned long long) * 2 * rows.n_rows, st));
     LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->max_row_nnz);
-    // scatter into buckets, then every bucket sorted by (feature, entry): small buckets in 16 KB
-    // of LDS each, the few large ones in 128 KB
     e->prof_begin(K_GROUP_SORT, st);
-    hipLaunchKernelGGL(group_scatter_kernel, dim3(cdiv(nnz, kScatterThreads * kScatterPer)), dim3(kScatterThreads), 0, st,
-                       rows, sc, static_cast<unsigned>(e->m.n_feats));
-    hipLaunchKernelGGL((group_bucket_sort_kernel<2048, 0>), dim3(e->n_buckets), dim3(kSortThreads), 2048 * 8, st, sc);
-    hipLaunchKernelGGL((group_bucket_sort_kernel<16384, 2048>), dim3(e->n_buckets), dim3(kSortThreads), 16384 * 8, st, sc);
+    ScopedTimer tm_sort("grouping:sort");
+    size_t bytes = e->sort_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
+                                      rocprim::counting_iterator<int>(0), sc.occ,
+                                      static_cast<size_t>(nnz), 0u, e->sort_bits, st));
     e->prof_end(st);
     LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, e->m, rows, sc);
   }

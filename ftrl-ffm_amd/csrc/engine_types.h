@@ -111,13 +111,7 @@ __device__ __forceinline__ int walk_field(const ModelDev &m, int fa, int c) {
 // Per-block scratch: the block grouped by feature ("postings"), per-row field chains, outputs.
 struct Scratch {
   unsigned *key;  // [nnz] sort key per entry: feature id, n_feats for entries remove_out_range erases
-  unsigned *skey; // [n surviving] their keys sorted ascending (s.occ: the entries in the same order)
-  // the sort (kernels_group.h): bucket = key >> bucket_shift
-  int *hist;      // [n_buckets] surviving entries per bucket (zeroed with the counters)
-  int *cursor;    // [n_buckets] positions handed out so far inside each bucket's range
-  int *bbase;     // [n_buckets + 1] start of each bucket's range; [n_buckets] = surviving entries
-  unsigned long long *pairs;  // [nnz] (key << 32 | entry), bucket by bucket, unsorted inside
-  int n_buckets, bucket_shift;
+  unsigned *skey; // [nnz] the keys sorted ascending (s.occ holds the entries in the same order)
   int *row_of;    // [nnz] row of each entry
   int *occ;       // [nnz] entry indices grouped by feature; ascending inside a group
   int2 *occ2;     // [nnz] the same groups as {entry, row of the entry}

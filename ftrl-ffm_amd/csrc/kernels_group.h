@@ -1,8 +1,7 @@
 // kernels_group.h -- groups one block of rows by feature ("postings"): the mini-batch scheduler's
-// device half.  group_keys_kernel (one sort key per entry + a histogram over key buckets) ->
-// group_scatter_kernel (entries into their bucket's range) -> group_bucket_sort_kernel (each bucket
-// sorted by (feature id, entry index) in LDS: the concatenation is the stable sort of the block by
-// feature) -> group_finish_kernel (group boundaries, owner lists, touched-slot masks).  No per-feature arrays and no same-address atomic
+// device half.  Three steps: group_keys_kernel (one sort key per entry) -> a stable LSD radix sort
+// of (feature id, entry index) pairs (rocPRIM device primitive) -> group_finish_kernel (group
+// boundaries, owner lists, touched-slot masks).  No per-feature arrays and no same-address atomic
 // chains: a feature present in a thousand rows costs what a thousand distinct features cost.  Replaces the per-feature std::mutex / std::shared_mutex arbitration of the
 // reference (src/include/model/ftrl_model.h:49, ffm.h:32): instead of N threads racing for a
 // feature's lock, every distinct feature of the block gets ONE owner that applies all of the
@@ -56,12 +55,6 @@ __device__ __forceinline__ int wave_reserve(int *counter, int amount) {
 // ERR_ROW_TOO_LONG here, before anything has touched the model, and every later kernel of the
 // block then does nothing (CNT_ERROR) -- the block is a no-op and the caller learns about it from
 // the next ffm_engine_sync / check_errors / flush.
-//
-// The sort.  A key's bucket is its high bits (key >> s.bucket_shift; the shift is chosen at create
-// so that a full block averages ~512 entries per bucket), so bucket order is key order.  Three
-// small kernels instead of a radix-sort library's ~10 launches: beside the persistent update
-// kernels every launch of the look-ahead grouping waits for wave slots, and that wait -- not the
-// work, ~40 us alone -- is what the grouping costs.
 __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, Rows rows, Scratch s,
                                                                    int max_row_nnz) {
   const int pp = blockIdx.x * blockDim.x + threadIdx.x;  // the grid covers whole waves
@@ -90,7 +83,6 @@ __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, R
   if (in) {
     s.row_of[p] = lo;
     s.key[p] = valid ? static_cast<unsigned>(i) : static_cast<unsigned>(m.n_feats);
-    if (valid) atomicAdd(&s.hist[static_cast<unsigned>(i) >> s.bucket_shift], 1);  // (result unused: fire and forget)
     s.occpos[p] = OCC_FEW;
     if (s.gmask) { s.gmask[p] = 0ull; s.cmask[p] = 0ull; }
   }
@@ -127,121 +119,6 @@ __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, R
   }
 }
 
-// Entries into their bucket's range of s.pairs as (key << 32 | entry).  One workgroup takes 4096
-// entries: ranks inside the workgroup by LDS atomics, then ONE global atomic per (workgroup,
-// non-empty bucket) reserves the bucket's next positions -- the order inside a bucket is
-// arbitrary, the bucket sort fixes it.  Every workgroup recomputes the exclusive prefix of the
-// histogram (the buckets' starts) in LDS; workgroup 0 also publishes it (s.bbase) for the sort.
-constexpr int kScatterThreads = 1024;
-constexpr int kScatterPer = 4;
-constexpr int kMaxBuckets = 4096;
-__global__ __launch_bounds__(kScatterThreads) void group_scatter_kernel(Rows rows, Scratch s,
-                                                                        unsigned sentinel) {
-  __shared__ int cnt[kMaxBuckets];
-  __shared__ int base[kMaxBuckets];
-  __shared__ int wsum[kScatterThreads / 64];
-  const int nb = s.n_buckets, tid = threadIdx.x;
-  // exclusive prefix of s.hist over the buckets: thread t owns buckets [t*per, (t+1)*per)
-  const int per = (nb + kScatterThreads - 1) / kScatterThreads;
-  int local = 0;
-  for (int j = 0; j < per; j++) {
-    const int b = tid * per + j;
-    if (b < nb) local += s.hist[b];
-  }
-  int incl = local;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int v = __shfl_up(incl, d, 64);
-    if ((tid & 63) >= d) incl += v;
-  }
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-  __syncthreads();
-  int wbase = 0;
-  for (int w = 0; w < (tid >> 6); w++) wbase += wsum[w];
-  int run = wbase + incl - local;
-  for (int j = 0; j < per; j++) {
-    const int b = tid * per + j;
-    if (b < nb) {
-      base[b] = run;
-      cnt[b] = 0;
-      if (blockIdx.x == 0) s.bbase[b] = run;
-      run += s.hist[b];
-    }
-  }
-  if (blockIdx.x == 0 && tid == kScatterThreads - 1) s.bbase[nb] = run;  // = number of surviving entries
-  __syncthreads();
-  unsigned k[kScatterPer];
-  int r[kScatterPer];
-  const int p0 = blockIdx.x * (kScatterThreads * kScatterPer);
-#pragma unroll
-  for (int it = 0; it < kScatterPer; it++) {
-    const int p = p0 + it * kScatterThreads + tid;
-    k[it] = p < rows.nnz ? s.key[p] : sentinel;
-    r[it] = k[it] < sentinel ? atomicAdd(&cnt[k[it] >> s.bucket_shift], 1) : 0;
-  }
-  __syncthreads();
-  for (int b = tid; b < nb; b += kScatterThreads) {
-    const int c = cnt[b];
-    if (c) base[b] += atomicAdd(&s.cursor[b], c);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < kScatterPer; it++) {
-    const int p = p0 + it * kScatterThreads + tid;
-    if (k[it] < sentinel)
-      s.pairs[base[k[it] >> s.bucket_shift] + r[it]] =
-          (static_cast<unsigned long long>(k[it]) << 32) | static_cast<unsigned>(p);
-  }
-}
-
-// One workgroup per bucket: its (key, entry) pairs sorted ascending -- equal keys end up in entry
-// order, i.e. row order then position in the row -- and written out as s.skey / s.occ.  A bitonic
-// network whose every compare is ascending (each merge starts with the "flip" i <-> i ^ (k-1)), so
-// a bucket of any size sorts with virtual +inf padding: partners past the end are simply skipped.
-// Buckets up to CAP pairs are sorted in LDS; a larger one (one feature in more than CAP rows of a
-// block) in place in global memory by the same workgroup -- slow, correct, rare.  The launch with
-// LO > 0 takes only the buckets above LO (two launches: most buckets are small and should not pay
-// for the big buckets' LDS).
-constexpr int kSortThreads = 256;
-template <int CAP, int LO>
-__global__ __launch_bounds__(kSortThreads) void group_bucket_sort_kernel(Scratch s) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long sort_buf[];
-  const int b = blockIdx.x;
-  const int start = s.bbase[b], n = s.bbase[b + 1] - start;
-  if (n <= LO || (LO == 0 && n > CAP)) return;
-  unsigned long long *a = n <= CAP ? sort_buf : s.pairs + start;
-  if (n <= CAP)
-    for (int j = threadIdx.x; j < n; j += kSortThreads) sort_buf[j] = s.pairs[start + j];
-  __syncthreads();
-  int npad = 1;
-  while (npad < n) npad <<= 1;
-  for (int k = 2; k <= npad; k <<= 1) {
-    for (int i = threadIdx.x; i < n; i += kSortThreads) {  // flip: i <-> i ^ (k - 1)
-      const int q = i ^ (k - 1);
-      if (q > i && q < n) {
-        const unsigned long long x = a[i], y = a[q];
-        if (x > y) { a[i] = y; a[q] = x; }
-      }
-    }
-    __syncthreads();
-    for (int j = k >> 2; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < n; i += kSortThreads) {
-        const int q = i ^ j;
-        if (q > i && q < n) {
-          const unsigned long long x = a[i], y = a[q];
-          if (x > y) { a[i] = y; a[q] = x; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int j = threadIdx.x; j < n; j += kSortThreads) {
-    const unsigned long long v = a[j];
-    s.skey[start + j] = static_cast<unsigned>(v >> 32);
-    s.occ[start + j] = static_cast<int>(v & 0xffffffffu);
-  }
-}
-
 // first index in skey[0, n) whose key is >= k (strict = false) or > k (strict = true)
 __device__ __forceinline__ int sorted_bound(const unsigned *skey, int n, unsigned k, bool strict) {
   int lo = 0, hi = n;
@@ -263,7 +140,7 @@ __device__ __forceinline__ int sorted_bound(const unsigned *skey, int n, unsigne
 __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m, Rows rows,
                                                                      Scratch s) {
   if (s.counters[CNT_ERROR]) return;  // untrainable block: no groups, no owners, nothing runs
-  const int nnz = s.bbase[s.n_buckets];  // the surviving entries: what the bucket sort wrote
+  const int nnz = rows.nnz;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // the grid covers whole waves
   const bool in = t < nnz;

@@ -154,9 +154,14 @@ struct Scratch {
   float *svx;     // [n_rows*n_factors] FM per-row factor sums (sum_vx, fm.h:24)
 };
 
-enum { CNT_NUNIQ = 0, CNT_CURSOR = 1, CNT_NMULTI = 2, CNT_ERROR = 3, CNT_NSMALL = 4, CNT_NBIG = 5,
-       CNT_NHUGE = 6, CNT_NFEW = 7, CNT_NSINGLE = 9, CNT_NGIANT = 10 };
-constexpr int kNumCounters = 16;
+// Every counter that takes atomics sits on a 64-byte line of its own (kLineInts apart):
+// device-scope atomics are performed at the memory side, one line at a time, and the grouping's
+// per-workgroup list reservations (seven lists, ~1250 workgroups) used to queue on ONE line.
+constexpr int kLineInts = 16;
+enum { CNT_NUNIQ = 0, CNT_CURSOR = 1 * kLineInts, CNT_NMULTI = 2 * kLineInts, CNT_ERROR = 3 * kLineInts,
+       CNT_NSMALL = 4 * kLineInts, CNT_NBIG = 5 * kLineInts, CNT_NHUGE = 6 * kLineInts,
+       CNT_NFEW = 7 * kLineInts, CNT_NSINGLE = 9 * kLineInts, CNT_NGIANT = 10 * kLineInts };
+constexpr int kNumCounters = 11 * kLineInts;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 #ifndef FFM_HUGE_MIN
 #define FFM_HUGE_MIN 96

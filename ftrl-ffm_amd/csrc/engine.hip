@@ -425,6 +425,7 @@ struct ffm_engine {
   // the block's lazy refresh as one pass over its distinct features (ffm_refresh_kernel) instead
   // of per occurrence inside the row kernel; FFM_ENGINE_ROW_REFRESH=1 keeps it in the row kernel
   bool pre_refresh = false;
+  int refresh_mode = 2;  // 1: every distinct feature in ffm_refresh_kernel; 2: the single ones by their row
   unsigned long long *d_ownmask = nullptr;
   bool lin_any = true;          // this shard owns the linear terms of at least one field
   int logical_len = 0;          // n_fields * n_factors (FFM), n_factors (FM), 0 (LR): the reference's row
@@ -433,6 +434,11 @@ struct ffm_engine {
   // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
   // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
   int grid_small = 768, grid_hot = 2048, grid_huge = 2048, grid_single = 768;
+  // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
+  // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
+  // slowed the HBM-bound kernels they ran beside up to 4x (refresh of a 65536-row block 70 -> 330 us),
+  // 24 (96 KB, about the link's bandwidth-delay product) still move the block at link rate.
+  int grid_pull = 24;
   int grid_giant = 512;  // workgroups of the chain launch that walk the giant features (FFM_GRID_GIANT)
   // FFM_WAIT_GROUPING=1: hold the update kernels until the look-ahead grouping in flight is done
   bool wait_grouping = false;
@@ -615,6 +621,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   // 1/n_shards of its slots: more, shorter items (measured under bench.py --emulate-shards 8)
   if (cfg->n_shards > 1) e->grid_huge = 4096;
 
+  if (const char *sv = std::getenv("FFM_GRID_PULL")) e->grid_pull = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
@@ -625,6 +632,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
                                                 : static_cast<int64_t>(cfg->n_fields) * cfg->n_factors;
     e->pre_refresh = cfg->model_type == FFM_MODEL_FFM && cfg->n_fields <= 64 &&
                      static_cast<int64_t>(e->max_nnz) * per < (1ll << 31) && !(rr && rr[0] == '1');
+    if (rr && rr[0] == '0') e->refresh_mode = 1;
+    if (rr && rr[0] == '2') e->refresh_mode = 2;
   }
   ModelDev &m = e->m;
   m.type = cfg->model_type;
@@ -1110,13 +1119,13 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
   } else {
     const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
     const int mr = row_cap;
-    const int refreshed = train && e->pre_refresh ? 1 : 0;
+    const int refreshed = train && e->pre_refresh ? e->refresh_mode : 0;
     if (refreshed && rows.nnz > 0) {
       const int per = vec4 ? e->m.row_len / 4 : e->m.row_len;
       const int64_t items = static_cast<int64_t>(std::min(rows.nnz, e->max_nnz)) * per;
       const int grid = static_cast<int>(std::min<int64_t>((items + 255) / 256, 8192));
-      if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur]);
-      else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur]);
+      if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], refreshed == 2);
+      else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], refreshed == 2);
     }
     if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg);
     else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg);
@@ -1564,7 +1573,7 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
     HIP_TRY(put(feat, 4 * E, sl.feat));
     HIP_TRY(put(val, 4 * E, sl.val));
     HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
-    hipLaunchKernelGGL(pull_block_kernel, dim3(128), dim3(256), 0, e->copy, job);
+    hipLaunchKernelGGL(pull_block_kernel, dim3(e->grid_pull), dim3(256), 0, e->copy, job);
     HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
   }
   // group it ahead, behind its own upload on the prep stream

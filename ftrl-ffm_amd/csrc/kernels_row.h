@@ -42,12 +42,13 @@ struct RowLds {
   float *val;    // [max_row_nnz]
   float *linw;   // [max_row_nnz] linear weight
   int *opos;     // [max_row_nnz] occurrence position when the entry's feature is hot, else -1
+  int *slist;    // [max_row_nnz] the entries this row refreshes itself (compact indices)
   int *fcnt;     // [n_fields] surviving entries per field
   int *ffirst;   // [n_fields] compact index of the first entry of the field, -1 if none
 };
 __host__ __device__ inline size_t row_lds_bytes(int max_row_nnz, int n_fields, int terms_cap) {
   const size_t M = (size_t)((max_row_nnz + 3) & ~3), Fp = (size_t)((n_fields + 3) & ~3);
-  return sizeof(float) * terms_cap + 6 * 4 * M + 2 * 4 * (Fp ? Fp : 4);
+  return sizeof(float) * terms_cap + 7 * 4 * M + 2 * 4 * (Fp ? Fp : 4);
 }
 __device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int n_fields, int terms_cap) {
   const int M = (max_row_nnz + 3) & ~3, Fp = ((n_fields + 3) & ~3) ? ((n_fields + 3) & ~3) : 4;
@@ -59,7 +60,8 @@ __device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int
   l.val = reinterpret_cast<float *>(l.feat + M);
   l.linw = l.val + M;
   l.opos = reinterpret_cast<int *>(l.linw + M);
-  l.fcnt = l.opos + M;
+  l.slist = l.opos + M;
+  l.fcnt = l.slist + M;
   l.ffirst = l.fcnt + Fp;
   return l;
 }
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
                                                               int output_prob, int refreshed,
                                                               int own_tg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_nv;
+  __shared__ int s_nv, s_ns;
   __shared__ float s_tg;
   __shared__ uint64_t s_tab[32];  // expf's table, staged so the row's last step waits on no load
   if (TRAIN && own_tg && threadIdx.x < 32) s_tab[threadIdx.x] = kExpTab[threadIdx.x];
@@ -273,7 +275,8 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     const int i = lds.feat[a];
     if (!owns_linear(m, lds.field[a])) return 0.0f;
     float lw;
-    if (TRAIN && !refreshed) {
+    // refreshed == 2: the features that occur once in the block are refreshed here, by their row
+    if (TRAIN && (refreshed == 0 || (refreshed == 2 && s.occpos[b + lds.pos[a]] == OCC_ONCE))) {
       lw = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
       m.lin_w[i] = lw;
     } else {
@@ -295,31 +298,62 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     publish_row_tables(m, rows, s, lds, r, b, nv, F);
     // lazy refresh of every slot (feature a, partner field fp) that a pair of this row touches:
     // FFM::update_vector_w, ffm.cpp:72-88 -- unless ffm_refresh_kernel did it for the whole block
-    if (refreshed) {
+    if (refreshed == 1) {
     } else if (VEC4) {
-      const int RL4 = RL >> 2, k4 = k >> 2;
-      const float inv_RL4 = 1.0f / static_cast<float>(RL4), inv_k4 = 1.0f / static_cast<float>(k4);
-      const int total = nv * RL4;
-      for (int t = threadIdx.x; t < total; t += blockDim.x) {
-        int a = static_cast<int>((t + 0.5f) * inv_RL4);
-        a += (a + 1) * RL4 <= t ? 1 : (a * RL4 > t ? -1 : 0);  // exact for any size
-        const int c4 = t - a * RL4;
-        int sl = static_cast<int>((c4 + 0.5f) * inv_k4);  // slot of the record
-        sl += (sl + 1) * k4 <= c4 ? 1 : (sl * k4 > c4 ? -1 : 0);
-        const int fa = lds.field[a];
-        const int fp = walk_field(m, fa, sl);
-        const bool touched = fp >= 0 && (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
-        if (touched) {
-          float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a], fa));
-          const float4 n4 = row[LAT_N * RL4 + c4], z4 = row[LAT_Z * RL4 + c4];
-          const float4 w4 = m.h.learn ? row[LAT_W * RL4 + c4] : n4;
-          row[LAT_W * RL4 + c4] = latent_weight4(m.h, n4, z4, w4);
+      // the entries refreshed here (all of them, or with refreshed == 2 those whose feature occurs
+      // nowhere else in the block), compacted by wave 0; then kRefreshFly 16-byte vectors of (n, z)
+      // per thread in flight at a time
+      if (threadIdx.x < 64) {
+        int ns = 0;
+        for (int base = 0; base < nv; base += 64) {
+          const int a = base + threadIdx.x;
+          const bool mine = a < nv && (refreshed == 0 || lds.opos[a] == OCC_ONCE);
+          const unsigned long long mask = __ballot(mine);
+          if (mine) lds.slist[ns + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = a;
+          ns += __popcll(mask);
         }
+        if (threadIdx.x == 0) s_ns = ns;
+      }
+      __syncthreads();
+      constexpr int kRefreshFly = 4;
+      const int RL4 = RL >> 2, k4 = k >> 2;
+      const int per = record_span(m, k4);  // vectors walked per record
+      const float inv_per = 1.0f / static_cast<float>(per), inv_k4 = 1.0f / static_cast<float>(k4);
+      const int total = s_ns * per;
+      for (int t0 = threadIdx.x; t0 < total; t0 += kRefreshFly * blockDim.x) {
+        float4 *wp[kRefreshFly];
+        float4 n4[kRefreshFly], z4[kRefreshFly], w4[kRefreshFly];
+#pragma unroll
+        for (int u = 0; u < kRefreshFly; u++) {
+          const int t = t0 + u * blockDim.x;
+          wp[u] = nullptr;
+          if (t >= total) continue;
+          int j = static_cast<int>((t + 0.5f) * inv_per);
+          j += (j + 1) * per <= t ? 1 : (j * per > t ? -1 : 0);  // exact for any size
+          const int a = lds.slist[j];
+          const int c4 = t - j * per;
+          int sl = static_cast<int>((c4 + 0.5f) * inv_k4);  // slot of the record
+          sl += (sl + 1) * k4 <= c4 ? 1 : (sl * k4 > c4 ? -1 : 0);
+          const int fa = lds.field[a];
+          const int fp = walk_field(m, fa, sl);
+          const bool touched = fp >= 0 && (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
+          if (touched) {
+            float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a], fa));
+            n4[u] = row[LAT_N * RL4 + c4];
+            z4[u] = row[LAT_Z * RL4 + c4];
+            w4[u] = m.h.learn ? row[LAT_W * RL4 + c4] : n4[u];
+            wp[u] = row + LAT_W * RL4 + c4;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kRefreshFly; u++)
+          if (wp[u]) *wp[u] = latent_weight4(m.h, n4[u], z4[u], w4[u]);
       }
     } else {
       const int total = nv * RL;
       for (int t = threadIdx.x; t < total; t += blockDim.x) {
         const int a = t / RL, e = t - a * RL;
+        if (refreshed == 2 && lds.opos[a] != OCC_ONCE) continue;
         const int fa = lds.field[a];
         const int fp = walk_field(m, fa, e / k);
         const bool touched = fp >= 0 && (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
@@ -492,9 +526,14 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
 // the block touches (s.gmask, from the grouping) -- and the row kernel is left with the forward.
 // Work item = (distinct feature u, 16-byte vector l of its record); VEC4 as in the row kernel.
 // ------------------------------------------------------------------------------------------
+// skip_single: the features that occur once in the block are refreshed by their row (the row
+// kernel with refreshed == 2: their w then reaches the pair phase through L2 instead of a second
+// trip to HBM); this pass walks the few / big / huge / giant lists only.
 template <bool VEC4>
-__global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s) {
-  const int n_uniq = s.counters[CNT_NUNIQ];
+__global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s, int skip_single) {
+  const int n_few = s.counters[CNT_NFEW], n_big = s.counters[CNT_NBIG];
+  const int n_huge = s.counters[CNT_NHUGE], n_giant = s.counters[CNT_NGIANT];
+  const int n_uniq = skip_single ? n_few + n_big + n_huge + n_giant : s.counters[CNT_NUNIQ];
   const int k = m.n_factors, RL = m.row_len;
   const int kv = VEC4 ? (k >> 2) : k;          // items per slot
   const int per = record_span(m, kv);          // items walked per record
@@ -507,6 +546,10 @@ __global__ __launch_bounds__(256) void ffm_refresh_kernel(ModelDev m, Scratch s)
     int u = static_cast<int>((static_cast<double>(t) + 0.5) * inv_per);
     u += static_cast<unsigned>(u + 1) * per <= t ? 1 : (static_cast<unsigned>(u) * per > t ? -1 : 0);
     const int lc = static_cast<int>(t - static_cast<unsigned>(u) * per);
+    if (skip_single)
+      u = u < n_few ? s.few[u]
+          : u < n_few + n_big ? s.big[u - n_few]
+          : u < n_few + n_big + n_huge ? s.huge[u - n_few - n_big] : s.giant[u - n_few - n_big - n_huge];
     const int4 ud = s.udesc[u];  // {feature, start, count, field}
     const int fa = ud.w;
     if (lc == 0 && owns_linear(m, fa)) {

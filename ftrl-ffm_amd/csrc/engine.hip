@@ -425,7 +425,10 @@ struct ffm_engine {
   // the block's lazy refresh as one pass over its distinct features (ffm_refresh_kernel) instead
   // of per occurrence inside the row kernel; FFM_ENGINE_ROW_REFRESH=1 keeps it in the row kernel
   bool pre_refresh = false;
-  int refresh_mode = 2;  // 1: every distinct feature in ffm_refresh_kernel; 2: the single ones by their row
+  // 1: every distinct feature in ffm_refresh_kernel; 2: the once-only ones by their row; 3: and
+  // updated there too when the row kernel has the whole logit (FFM_ENGINE_ROW_REFRESH=0/2/3)
+  int refresh_mode = 3;
+  bool singles_in_row = false;  // the block in flight had its once-only features updated by the row kernel
   unsigned long long *d_ownmask = nullptr;
   bool lin_any = true;          // this shard owns the linear terms of at least one field
   int logical_len = 0;          // n_fields * n_factors (FFM), n_factors (FM), 0 (LR): the reference's row
@@ -634,6 +637,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
                      static_cast<int64_t>(e->max_nnz) * per < (1ll << 31) && !(rr && rr[0] == '1');
     if (rr && rr[0] == '0') e->refresh_mode = 1;
     if (rr && rr[0] == '2') e->refresh_mode = 2;
+    if (rr && rr[0] == '3') e->refresh_mode = 3;
   }
   ModelDev &m = e->m;
   m.type = cfg->model_type;
@@ -1119,13 +1123,15 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
   } else {
     const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
     const int mr = row_cap;
-    const int refreshed = train && e->pre_refresh ? e->refresh_mode : 0;
+    int refreshed = train && e->pre_refresh ? e->refresh_mode : 0;
+    if (refreshed == 3 && !(own_tg && vec4 && e->single_kernel)) refreshed = 2;
+    if (train) e->singles_in_row = refreshed == 3;
     if (refreshed && rows.nnz > 0) {
       const int per = vec4 ? e->m.row_len / 4 : e->m.row_len;
       const int64_t items = static_cast<int64_t>(std::min(rows.nnz, e->max_nnz)) * per;
       const int grid = static_cast<int>(std::min<int64_t>((items + 255) / 256, 8192));
-      if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], refreshed == 2);
-      else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], refreshed == 2);
+      if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
+      else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
     }
     if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg);
     else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg);
@@ -1283,7 +1289,8 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   // small features on the main stream: the once-only ones through their descriptor kernel
   auto launch_small = [&]() {
     const bool single = e->single_kernel;
-    if (single) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    if (single && !e->singles_in_row)  // (else: already applied by the row kernel)
+      LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
   };
   if (ffm && vec4 && e->serial) {

@@ -166,6 +166,28 @@ __device__ __forceinline__ void nz_step_latent(const Hyper &h, float w, float g,
   n = n + g * g;
 }
 
+// The same two steps for a chain of touches of one accumulator: sqrt(n + g*g) of a touch is
+// sqrt(n) of the next, so the caller carries it (sqn = sqrt_cr(n) on entry; both square roots are
+// correctly rounded, so the bits are those of the two-root form).
+__device__ __forceinline__ void nz_step_latent_carry(const Hyper &h, float w, float g, float &n,
+                                                     float &z, float &sqn) {
+  const float na = n + g * g;
+  const float sa = sqrt_cr(na);
+  const float s = div_alpha(h, sa - sqn);
+  z = (z + g) - s * w;
+  n = na;
+  sqn = sa;
+}
+__device__ __forceinline__ void nz_step_linear_carry(const Hyper &h, float w, float g, float &n,
+                                                     float &z, float &sqn) {
+  const float na = n + g * g;
+  const float sa = sqrt_cr(na);
+  const float s = div_alpha(h, sa - sqn);
+  z = z + (g - s * w);
+  n = na;
+  sqn = sa;
+}
+
 // FFM j-side, src/model/ffm.cpp:117-120 -- INCLUDING the :118 quirk: the square root takes
 // n + g2*g1 (product of the two different gradients), which is NaN when that is negative.
 __device__ __forceinline__ void nz_step_latent_jside(const Hyper &h, float w, float g2, float g1,

@@ -135,6 +135,37 @@ __device__ __forceinline__ void chain_sigma_w(const Hyper &h, const float (&nb)[
   }
 }
 
+// The same when every live touch of the step puts its own g*g under the root (FFM touches whose own
+// entry is the pair's first, every FM touch): sqrt(n + g*g) of touch t IS sqrt(n-before) of touch
+// t+1, so one square root per touch serves both -- the second comes from the left neighbour by the
+// DPP move that already brings its running n (lane 0: from the previous step, through sqc).
+// S = running n after each touch; nc_in = the carry the step started from (lane 0 of a row).
+// Returns false (nothing written) when an operand is outside the short forms' range.
+template <int G>
+__device__ __forceinline__ bool chain_sigma_w_forward(const Hyper &h, const float (&S)[G],
+                                                      const float (&nc_in)[G], const bool (&simple)[G],
+                                                      const float (&w)[G], float (&sqc)[G],
+                                                      bool sq_valid, float (&mm)[G]) {
+  bool ok = h.fast_div != 0;
+#pragma unroll
+  for (int g = 0; g < G; g++) ok = ok && chain_operand_ok(S[g]) && (sq_valid || chain_operand_ok(nc_in[g]));
+  if (!__all(ok)) return false;
+  if (!sq_valid) {
+    // (a real branch: as a select the compiler evaluates this root in every step)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < G; g++) sqc[g] = sqrt_fast(nc_in[g]);
+  }
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const float sq = sqrt_fast(S[g]);
+    const float d = sq - row_left(sqc[g], sq);
+    mm[g] = div_alpha_fast(h, simple[g] ? d : 0.0f) * w[g];
+    sqc[g] = row_mirror(sq);  // lane 0: sqrt of the carry the next step starts from
+  }
+  return true;
+}
+
 // ---- FFM ------------------------------------------------------------------------------------
 // Work item = (very hot feature, slot of its record, pass over G groups of 4 factors of the slot);
 // one wave per item.  Lane: tl = touch inside the step (DPP row position), el = factor inside a
@@ -168,16 +199,18 @@ template <int G>
 __device__ __forceinline__ void chain_step(const ModelDev &m, unsigned long long own_bits, bool in_range, bool l0,
                                            const ChainTouch &f, const float (&vp)[G],
                                            const bool (&act)[G], const float (&w)[G],
-                                           float (&nc)[G], float (&zc)[G]) {
+                                           float (&nc)[G], float (&zc)[G], float (&sqc)[G],
+                                           bool &sq_valid) {
   const int fl = f.fl;
   const bool smp = in_range && owns_bit(own_bits, fl >> 8) && (fl & HF_SIMPLE) != 0;
   const bool first = (fl & HF_FIRST) || m.h.learn;
   const float tg = f.tg;
   const float x = f.xm * f.xo;  // x_own*x_other or x_other*x_own: same product
-  float g1v[G], q[G], S[G], ga[G], arg0[G], nb[G], mm[G], mc[G], Z[G];
+  float g1v[G], q[G], S[G], ga[G], arg0[G], nb[G], mm[G], mc[G], Z[G], nc_in[G];
   bool simple[G];
 #pragma unroll
   for (int g = 0; g < G; g++) {
+    nc_in[g] = nc[g];
     simple[g] = smp && act[g];
     const float gr = tg * vp[g] * x;  // own slot's gradient (g1 if own entry first, else g2)
     const float g1 = tg * w[g] * x;   // second-entry case: the first entry's gradient
@@ -189,12 +222,20 @@ __device__ __forceinline__ void chain_step(const ModelDev &m, unsigned long long
   }
   row_chain_add<G>(S, q);
 #pragma unroll
-  for (int g = 0; g < G; g++) {
-    nb[g] = row_left(nc[g], S[g]);    // n before this touch
-    arg0[g] = nb[g] + g1v[g];
-    nc[g] = row_mirror(S[g]);         // lane 0: the row's last running n
+  for (int g = 0; g < G; g++) nc[g] = row_mirror(S[g]);  // lane 0: the row's last running n
+  // all live touches on the g*g side: one square root per touch (see chain_sigma_w_forward)
+  const bool fwd = __all(first || !smp);
+  if (!fwd || !chain_sigma_w_forward<G>(m.h, S, nc_in, simple, w, sqc, sq_valid, mm)) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      nb[g] = row_left(nc_in[g], S[g]);  // n before this touch
+      arg0[g] = nb[g] + g1v[g];
+    }
+    chain_sigma_w<G>(m.h, nb, arg0, simple, w, mm);
+    sq_valid = false;
+  } else {
+    sq_valid = true;
   }
-  chain_sigma_w<G>(m.h, nb, arg0, simple, w, mm);
 #pragma unroll
   for (int g = 0; g < G; g++) {
     const float ms = simple[g] ? mm[g] : 0.0f;
@@ -240,8 +281,11 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
     int kk[G];
     bool act[G];
     float nc[G], zc[G], w[G];  // carries: valid in lane 0 of every row
+    float sqc[G];              // sqrt(nc) while sq_valid (chain_sigma_w_forward)
+    bool sq_valid = false;
 #pragma unroll
     for (int g = 0; g < G; g++) {
+      sqc[g] = 0.0f;
       const int grp = pass * G + g;
       act[g] = grp < groups;
       kk[g] = (act[g] ? grp : 0) * 4 + el;
@@ -289,7 +333,8 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
 #pragma unroll
         for (int j = 0; j < CH; j++) {
           const int st = ch * CH + j;
-          if (st < steps) chain_step<G>(m, own_bits, st * kChainT + tl < c, l0, fC[j], vpC[j], act, w, nc, zc);
+          if (st < steps)
+            chain_step<G>(m, own_bits, st * kChainT + tl < c, l0, fC[j], vpC[j], act, w, nc, zc, sqc, sq_valid);
         }
 #pragma unroll
         for (int j = 0; j < CH; j++) {
@@ -320,8 +365,10 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
         const int fl = ax.y;
         const bool live = t < c && owns_bit(own_bits, fl >> 8);
         if (!__any(live & ((fl & HF_CHAIN) != 0))) {
-          chain_step<G>(m, own_bits, t < c, l0, ChainTouch{mt.x, mt.y, __int_as_float(ax.x), fl}, vp, act, w, nc, zc);
+          chain_step<G>(m, own_bits, t < c, l0, ChainTouch{mt.x, mt.y, __int_as_float(ax.x), fl}, vp, act, w, nc, zc,
+                        sqc, sq_valid);
         } else {
+          sq_valid = false;
           // its 16 touches one after another, every lane of the row applying them to its own copy
           // of the running (n, z)
 #pragma unroll
@@ -417,9 +464,11 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m
     float *rec = lat_row(m, i, 0);
     int kk[G];
     bool act[G];
-    float nc[G], zc[G], w[G];
+    float nc[G], zc[G], w[G], sqc[G];
+    bool sq_valid = false;
 #pragma unroll
     for (int g = 0; g < G; g++) {
+      sqc[g] = 0.0f;
       const int e = (pass * G + g) * 4 + el;
       act[g] = e < k;
       kk[g] = act[g] ? e : 0;
@@ -444,10 +493,11 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m
       for (int g = 0; g < G; g++) svN[g] = s.svx[static_cast<int64_t>(prN.y) * k + kk[g]];
       const int2 prNN = ocol[min((st + 2) * kChainT + tl, c - 1)];
       const bool live = t < c;
-      float q[G], S[G], ga[G], arg0[G], nb[G], mm[G], mc[G], Z[G];
+      float q[G], S[G], ga[G], arg0[G], nb[G], mm[G], mc[G], Z[G], nc_in[G];
       bool simple[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
+        nc_in[g] = nc[g];
         simple[g] = live && act[g];
         const float gr = tg * (x * sv[g] - w[g] * x * x);  // fm.cpp:84-95
         const float gg = gr * gr;
@@ -458,12 +508,19 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m
       }
       row_chain_add<G>(S, q);
 #pragma unroll
-      for (int g = 0; g < G; g++) {
-        nb[g] = row_left(nc[g], S[g]);
-        arg0[g] = nb[g] + arg0[g];
-        nc[g] = row_mirror(S[g]);
+      for (int g = 0; g < G; g++) nc[g] = row_mirror(S[g]);
+      // every FM touch has its own g*g under the root: one square root per touch
+      if (!chain_sigma_w_forward<G>(m.h, S, nc_in, simple, w, sqc, sq_valid, mm)) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          nb[g] = row_left(nc_in[g], S[g]);
+          arg0[g] = nb[g] + arg0[g];
+        }
+        chain_sigma_w<G>(m.h, nb, arg0, simple, w, mm);
+        sq_valid = false;
+      } else {
+        sq_valid = true;
       }
-      chain_sigma_w<G>(m.h, nb, arg0, simple, w, mm);
 #pragma unroll
       for (int g = 0; g < G; g++) {
         const float ms = simple[g] ? mm[g] : 0.0f;

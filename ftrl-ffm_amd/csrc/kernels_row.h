@@ -15,6 +15,7 @@
 // pair phase re-reads the freshly written w slots (64 B each at k = 16) out of L2.
 #pragma once
 #include "engine_types.h"
+#include "kernels_touch.h"
 
 namespace ftrl_dev {
 
@@ -232,8 +233,13 @@ __device__ __forceinline__ float wave_add_terms_in_order(const float *terms, int
 // !TRAIN: logit from the stored weights; out = logit or sigmoid(logit); per-row loss if labelled.
 // VEC4: n_factors is a multiple of 4, so every slot is a whole number of 16-byte vectors.
 // ------------------------------------------------------------------------------------------
+#ifdef FFM_ROW_WAVES
+#define FFM_ROW_OCC __attribute__((amdgpu_waves_per_eu(FFM_ROW_WAVES, FFM_ROW_WAVES)))
+#else
+#define FFM_ROW_OCC
+#endif
 template <bool TRAIN, bool VEC4>
-__global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
+__global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
                                                               int output_prob, int refreshed,
                                                               int own_tg) {
@@ -275,8 +281,8 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     const int i = lds.feat[a];
     if (!owns_linear(m, lds.field[a])) return 0.0f;
     float lw;
-    // refreshed == 2: the features that occur once in the block are refreshed here, by their row
-    if (TRAIN && (refreshed == 0 || (refreshed == 2 && s.occpos[b + lds.pos[a]] == OCC_ONCE))) {
+    // refreshed >= 2: the features that occur once in the block are refreshed here, by their row
+    if (TRAIN && (refreshed == 0 || (refreshed >= 2 && s.occpos[b + lds.pos[a]] == OCC_ONCE))) {
       lw = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
       m.lin_w[i] = lw;
     } else {
@@ -315,7 +321,10 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
         if (threadIdx.x == 0) s_ns = ns;
       }
       __syncthreads();
-      constexpr int kRefreshFly = 4;
+#ifndef FFM_REFRESH_FLY
+#define FFM_REFRESH_FLY 4
+#endif
+      constexpr int kRefreshFly = FFM_REFRESH_FLY;
       const int RL4 = RL >> 2, k4 = k >> 2;
       const int per = record_span(m, k4);  // vectors walked per record
       const float inv_per = 1.0f / static_cast<float>(per), inv_k4 = 1.0f / static_cast<float>(k4);
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
       const int total = nv * RL;
       for (int t = threadIdx.x; t < total; t += blockDim.x) {
         const int a = t / RL, e = t - a * RL;
-        if (refreshed == 2 && lds.opos[a] != OCC_ONCE) continue;
+        if (refreshed >= 2 && lds.opos[a] != OCC_ONCE) continue;
         const int fa = lds.field[a];
         const int fp = walk_field(m, fa, e / k);
         const bool touched = fp >= 0 && (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
@@ -514,6 +523,70 @@ __global__ __launch_bounds__(kRowThreads) void ffm_row_kernel(ModelDev m, Rows r
     for (int a = threadIdx.x; a < nv; a += blockDim.x) {
       const int op = lds.opos[a];
       if (op >= 0) s.hmeta[op] = make_float2(tg, lds.val[a]);
+    }
+    // refreshed == 3: the (n, z) update of the features that occur nowhere else in the block
+    // (FFM::update_vector_nz, ffm.cpp:90-136, for their slots), right here: this row is their only
+    // touch, tmp_grad is known, and their records and the partners' weights were read moments ago
+    // (refresh and pair phase above), so the second read comes out of the caches instead of HBM.
+    // Same touches in the same order as ffm_update_single_kernel, which then has nothing to do.
+    if (VEC4 && refreshed == 3) {
+#ifndef FFM_UPD_FLY
+#define FFM_UPD_FLY 1
+#endif
+      constexpr int kUpdFly = FFM_UPD_FLY;
+      const int RL4 = RL >> 2, k4 = k >> 2;
+      const int per = record_span(m, k4);
+      const float inv_per = 1.0f / static_cast<float>(per), inv_k4 = 1.0f / static_cast<float>(k4);
+      const int total = s_ns * per;
+      for (int t0 = threadIdx.x; t0 < total; t0 += kUpdFly * blockDim.x) {
+        float4 *rp[kUpdFly];
+        float4 n4[kUpdFly], z4[kUpdFly], w4[kUpdFly], vp[kUpdFly];
+        int ia[kUpdFly], ifp[kUpdFly], ikq[kUpdFly];
+#pragma unroll
+        for (int u = 0; u < kUpdFly; u++) {
+          const int t = t0 + u * blockDim.x;
+          rp[u] = nullptr;
+          if (t >= total) continue;
+          int j = static_cast<int>((t + 0.5f) * inv_per);
+          j += (j + 1) * per <= t ? 1 : (j * per > t ? -1 : 0);
+          const int a = lds.slist[j];
+          const int c4 = t - j * per;
+          int sl = static_cast<int>((c4 + 0.5f) * inv_k4);
+          sl += (sl + 1) * k4 <= c4 ? 1 : (sl * k4 > c4 ? -1 : 0);
+          const int fa = lds.field[a];
+          const int fp = walk_field(m, fa, sl);
+          if (fp < 0 || (lds.fcnt[fp] - (fa == fp ? 1 : 0)) <= 0) continue;
+          float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a], fa));
+          n4[u] = row[LAT_N * RL4 + c4];
+          z4[u] = row[LAT_Z * RL4 + c4];
+          w4[u] = row[LAT_W * RL4 + c4];
+          rp[u] = row + c4;
+          ia[u] = a;
+          ifp[u] = fp;
+          ikq[u] = c4 - sl * k4;
+          if (lds.fcnt[fp] == 1)  // (then fa != fp: the only entry of that field is the partner)
+            vp[u] = reinterpret_cast<const float4 *>(lat_row(m, lds.feat[lds.ffirst[fp]], fp))
+                [LAT_W * RL4 + slot_of(m, fp, fa) * k4 + ikq[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kUpdFly; u++) {
+          if (!rp[u]) continue;
+          const int a = ia[u], fp = ifp[u], fa = lds.field[a];
+          if (lds.fcnt[fp] == 1) {
+            const int bb = lds.ffirst[fp];
+            ffm_touch4(m.h, a < bb, tg, lds.val[a], lds.val[bb], vp[u], w4[u], n4[u], z4[u]);
+          } else {  // several entries of that field in the row: one touch each, in row order
+            for (int bb = lds.ffirst[fp]; bb < nv; bb++) {
+              if (bb == a || lds.field[bb] != fp) continue;
+              const float4 vq = reinterpret_cast<const float4 *>(lat_row(m, lds.feat[bb], fp))
+                  [LAT_W * RL4 + slot_of(m, fp, fa) * k4 + ikq[u]];
+              ffm_touch4(m.h, a < bb, tg, lds.val[a], lds.val[bb], vq, w4[u], n4[u], z4[u]);
+            }
+          }
+          rp[u][LAT_N * RL4] = n4[u];
+          rp[u][LAT_Z * RL4] = z4[u];
+        }
+      }
     }
   }
 }

@@ -18,6 +18,7 @@
 //    long sequential chains of a hot feature spread over many waves.
 #pragma once
 #include "engine_types.h"
+#include "kernels_touch.h"
 
 namespace ftrl_dev {
 
@@ -31,75 +32,6 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 // the 64-bit float offset a haux entry carries in its .z (lo) and .w (hi)
 __device__ __forceinline__ int64_t haux_offset(int lo, int hi) {
   return (static_cast<int64_t>(hi) << 32) | static_cast<unsigned>(lo);
-}
-
-// One touch of slot (own feature, partner field fp) by the pair {own entry, other entry}.
-__device__ __forceinline__ void ffm_touch(const Hyper &h, bool own_first, float tg, float x_own,
-                                          float x_other, float vp, float w, float &n, float &z) {
-  if (own_first) {
-    // own entry is the pair's first: slot (i, field2), ffm.cpp:112-115
-    const float x = x_own * x_other;
-    const float g1 = tg * vp * x;
-    nz_step_latent(h, w, g1, n, z);
-  } else {
-    // own entry is the pair's second: slot (j, field1), ffm.cpp:117-120 with the :118 quirk
-    const float x = x_other * x_own;
-    const float g2 = tg * vp * x;  // tmp_grad * vif1 * x
-    const float g1 = tg * w * x;   // tmp_grad * vif2 * x (the first entry's gradient)
-    nz_step_latent_jside(h, w, g2, g1, n, z);
-  }
-}
-
-// The same touch on N factors of one slot held by one lane, votes hoisted (sqrt_cr_n /
-// div_alpha_n): one wave vote per stage instead of one per factor.
-template <int N>
-__device__ __forceinline__ void ffm_touch_n(const Hyper &h, bool own_first, float tg, float x_own,
-                                            float x_other, const float (&vp)[N],
-                                            const float (&w)[N], float (&n)[N], float (&z)[N]) {
-  float g[N], arg[2 * N], sq[2 * N], d[N], sg[N];
-  const float x = own_first ? x_own * x_other : x_other * x_own;
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    g[i] = tg * vp[i] * x;              // own slot's gradient
-    const float g1 = tg * w[i] * x;     // second-entry case: the first entry's gradient
-    arg[i] = n[i] + ((own_first || h.learn) ? g[i] * g[i] : g[i] * g1);  // ffm.cpp:113 / :118
-    arg[N + i] = n[i];
-  }
-  // both square roots and the alpha divide in their short exact forms when every operand of the
-  // wave is comfortably normal (one vote; ftrl_math.h: chain_operand_ok), else IEEE
-  bool ok = h.fast_div != 0;
-#pragma unroll
-  for (int i = 0; i < 2 * N; i++) ok = ok && chain_operand_ok(arg[i]);
-  if (__all(ok)) {
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) sq[i] = sqrt_fast(arg[i]);
-#pragma unroll
-    for (int i = 0; i < N; i++) d[i] = sq[i] - sq[N + i];
-#pragma unroll
-    for (int i = 0; i < N; i++) sg[i] = div_alpha_fast(h, d[i]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) sq[i] = sqrtf(arg[i]);
-#pragma unroll
-    for (int i = 0; i < N; i++) d[i] = sq[i] - sq[N + i];
-#pragma unroll
-    for (int i = 0; i < N; i++) sg[i] = d[i] / h.alpha;
-  }
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    z[i] = (z[i] + g[i]) - sg[i] * w[i];
-    n[i] = n[i] + g[i] * g[i];
-  }
-}
-
-__device__ __forceinline__ void ffm_touch4(const Hyper &h, bool own_first, float tg, float x_own,
-                                           float x_other, float4 vp4, float4 w4, float4 &n4,
-                                           float4 &z4) {
-  const float vp[4] = {vp4.x, vp4.y, vp4.z, vp4.w}, w[4] = {w4.x, w4.y, w4.z, w4.w};
-  float n[4] = {n4.x, n4.y, n4.z, n4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w};
-  ffm_touch_n<4>(h, own_first, tg, x_own, x_other, vp, w, n, z);
-  n4 = make_float4(n[0], n[1], n[2], n[3]);
-  z4 = make_float4(z[0], z[1], z[2], z[3]);
 }
 
 // (Very hot features -- more than kHugeMin occurrences -- are kernels_chain.h's.)
@@ -182,9 +114,10 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
     const int start = ud.y, c = ud.z;
     float n = m.lin_n[i], z = m.lin_z[i];
     const float w = m.lin_w[i];
+    float sqn = sqrt_cr(n);
     for (int t = 0; t < c; t++) {
       const int2 pr = s.occ2[start + t];
-      nz_step_linear(m.h, w, s.tg[pr.y] * rows.val[pr.x], n, z);
+      nz_step_linear_carry(m.h, w, s.tg[pr.y] * rows.val[pr.x], n, z, sqn);
     }
     m.lin_n[i] = n;
     m.lin_z[i] = z;
@@ -341,6 +274,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     const float2 *mcol = s.hmeta + start;                                 // + t
     bool touched = false;
     const int nb = (c + kUnroll - 1) / kUnroll;
+    float sqn = 0.0f;       // sqrt(n) while sq_valid: the last touch's sqrt(n + g*g), forwarded
+    bool sq_valid = false;  // (wave-uniform)
 
     HotFacts fA, fB, fC;          // facts of groups b+2, b+1, b
     int peA[kUnroll], peB[kUnroll], peC[kUnroll];
@@ -367,12 +302,13 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
         tgj[j] = mt.x;
         xmj[j] = mt.y;
       }
-      bool simple[kUnroll], any_chain = false;
+      bool simple[kUnroll], any_chain = false, gg_side = true;
 #pragma unroll
       for (int j = 0; j < kUnroll; j++) {
         const bool live = t0 + j < c && active && owns_bit(own_bits, fC.fl[j] >> 8);
         simple[j] = live && (fC.fl[j] & HF_SIMPLE);
         any_chain = any_chain || (live && (fC.fl[j] & HF_CHAIN));
+        gg_side = gg_side && (!simple[j] || (fC.fl[j] & HF_FIRST) || m.h.learn);
       }
       if (!__any(any_chain)) {
         float gj[kUnroll], aj[kUnroll], nbv[kUnroll], mj[kUnroll];
@@ -385,33 +321,63 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
           gj[j] = g;
           aj[j] = (first || m.h.learn) ? g * g : g * g1;  // what the square root sees added to n (:118)
         }
+        float naf[kUnroll];  // n after touch j
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {
           nbv[j] = n;
           if (simple[j]) n = n + gj[j] * gj[j];
+          naf[j] = n;
         }
-        // the group's square roots and alpha divides in their short exact forms when every
-        // operand of the wave is comfortably normal (one vote; ftrl_math.h), else IEEE
-        float arg[kUnroll];
-        bool ok = m.h.fast_div != 0;
+        // Every live touch of the group on the g*g side (own entry first): sqrt(n + g*g) of a touch
+        // IS sqrt(n-before) of the next, so one square root per touch, the last one carried into the
+        // next group.  In their short exact forms (ftrl_math.h) behind one wave vote.
+        bool done = false;
+        if (__all(gg_side)) {
+          bool ok = m.h.fast_div != 0 && (sq_valid || chain_operand_ok(nbv[0]));
 #pragma unroll
-        for (int j = 0; j < kUnroll; j++) {
-          arg[j] = nbv[j] + aj[j];
-          ok = ok && chain_operand_ok(arg[j]) && chain_operand_ok(nbv[j]);
+          for (int j = 0; j < kUnroll; j++) ok = ok && chain_operand_ok(naf[j]);
+          if (__all(ok)) {
+            float sq = sqn;
+            if (!sq_valid) {
+              asm volatile("" ::: "memory");  // (a real branch, not a select with the root always evaluated)
+              sq = sqrt_fast(nbv[0]);
+            }
+#pragma unroll
+            for (int j = 0; j < kUnroll; j++) {
+              const float sa = sqrt_fast(naf[j]);
+              mj[j] = div_alpha_fast(m.h, sa - sq) * w;
+              sq = sa;
+            }
+            sqn = sq;
+            done = true;
+          }
         }
-        if (__all(ok)) {
+        sq_valid = done;
+        if (!done) {
+          // the group's square roots and alpha divides in their short exact forms when every
+          // operand of the wave is comfortably normal (one vote), else IEEE
+          float arg[kUnroll];
+          bool ok = m.h.fast_div != 0;
 #pragma unroll
-          for (int j = 0; j < kUnroll; j++)
-            mj[j] = div_alpha_fast(m.h, sqrt_fast(arg[j]) - sqrt_fast(nbv[j])) * w;
-        } else {
+          for (int j = 0; j < kUnroll; j++) {
+            arg[j] = nbv[j] + aj[j];
+            ok = ok && chain_operand_ok(arg[j]) && chain_operand_ok(nbv[j]);
+          }
+          if (__all(ok)) {
 #pragma unroll
-          for (int j = 0; j < kUnroll; j++) mj[j] = ((sqrtf(arg[j]) - sqrtf(nbv[j])) / m.h.alpha) * w;
+            for (int j = 0; j < kUnroll; j++)
+              mj[j] = div_alpha_fast(m.h, sqrt_fast(arg[j]) - sqrt_fast(nbv[j])) * w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < kUnroll; j++) mj[j] = ((sqrtf(arg[j]) - sqrtf(nbv[j])) / m.h.alpha) * w;
+          }
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; j++)
           if (simple[j]) { z = (z + gj[j]) - mj[j]; touched = true; }
       } else {
         // a multi-valued field somewhere in the group: one touch after another, chains walked
+        sq_valid = false;
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {
           const int fm = fC.fl[j] >> 8;
@@ -659,6 +625,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     float *rec = lat_row(m, i, 0);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
     const float w = rec[LAT_W * k + e];
+    float sqn = sqrt_cr(n);
     for (int t0 = 0; t0 < c; t0 += kFmUnroll) {
       float xj[kFmUnroll], tgj[kFmUnroll], sj[kFmUnroll];
 #pragma unroll
@@ -674,7 +641,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
         if (t0 + j >= c) break;
         const float x = xj[j];
         const float g = tgj[j] * (x * sj[j] - w * x * x);
-        nz_step_latent(m.h, w, g, n, z);
+        nz_step_latent_carry(m.h, w, g, n, z, sqn);
       }
     }
     rec[LAT_N * k + e] = n;

@@ -1145,15 +1145,27 @@ static bool same_block(const Rows &a, const Rows &b) {
          a.feat == b.feat && a.val == b.val;
 }
 
+// Zeroes the grouping's counters and per-row field masks (a kernel: hipMemsetAsync costs the
+// submitting thread ~100 us per call here, a launch ~5).
+__global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_counters,
+                                                          unsigned long long *rowmask, int n_mask) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int i = tid; i < n_counters; i += stride) counters[i] = 0;
+  for (int i = tid; i < n_mask; i += stride) rowmask[i] = 0ull;
+}
+
 // Groups `rows` by feature into scratch set `set` on stream `st`.
 static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st) {
   Scratch &sc = e->sc[set];
   ScopedTimer tm_all("grouping:all");
-  HIP_TRY(hipMemsetAsync(sc.counters, 0, kNumCounters * sizeof(int), st));
+  {
+    ScopedTimer tm_clear("grouping:clear");
+    const int n_mask = rows.nnz > 0 && sc.rowmask ? 2 * rows.n_rows : 0;
+    hipLaunchKernelGGL(group_clear_kernel, dim3(std::max(1, std::min(64, cdiv(n_mask, 1024)))), dim3(256), 0, st,
+                       sc.counters, kNumCounters, sc.rowmask, n_mask);
+  }
   if (rows.nnz > 0) {
     const int nnz = rows.nnz;
-    if (sc.rowmask)
-      HIP_TRY(hipMemsetAsync(sc.rowmask, 0, sizeof(unsigned long long) * 2 * rows.n_rows, st));
     LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->max_row_nnz);
     e->prof_begin(K_GROUP_SORT, st);
     ScopedTimer tm_sort("grouping:sort");
@@ -1204,6 +1216,7 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
                                     const int32_t *row_ptr, const int32_t *field,
                                     const int32_t *feat, const float *val, const int32_t *label,
                                     float *partial_logit) {
+  ScopedTimer tm_fwd("train:forward");
   int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
   if (rc) return rc;
   if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
@@ -1249,6 +1262,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
                                    double *loss_sum_out) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
   if (!e->has_pending) return fail(FFM_E_INVALID, "train_update without a preceding train_forward");
+  ScopedTimer tm_upd("train:update");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   const Rows rows = e->pending;
   e->has_pending = false;

@@ -37,6 +37,9 @@ using namespace ftrl_dev;
 
 // The grouping's sort: always the Onesweep radix sort (a few passes over the key bits), never
 // rocPRIM's merge-sort variant (about twenty small launches at this size).
+// (Its default tuning -- 1024-thread workgroups, twenty of them for a block -- only finds room when a
+// kernel beside it drains; 256-thread configurations do find room and were measured slower for the
+// step: the sort then takes wave slots from the kernels on the critical path.)
 using GroupSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                                   rocprim::default_config, 0>;
 

@@ -135,6 +135,44 @@ def test_ragged_empty_and_multivalued_rows():
         e.close()
 
 
+@pytest.mark.parametrize("mode", ["0", "2", "3", "1"])
+def test_refresh_modes_are_bit_identical(mode, monkeypatch):
+    """Where the lazy weight refresh and the once-only features' update run is a scheduling choice
+    (FFM_ENGINE_ROW_REFRESH: 0 = one pass over the block's distinct features, 2 = once-only
+    features refreshed by their row, 3 = and updated there, 1 = everything per occurrence in the
+    row kernel): every choice must give the oracle's bits, on Zipf blocks (features repeat) and on
+    ragged rows with several features per field."""
+    monkeypatch.setenv("FFM_ENGINE_ROW_REFRESH", mode)
+    rng = np.random.default_rng(23)
+    F, k, per = 10, 8, 40
+    nf = F * per
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o)  # n near 0: the ffm.cpp:118 NaNs included
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=512, **STRESS_HP)
+    e.set_state(st)
+    blk = synth.Generator(F, nf, "zipf", seed=5).block(512)
+    for r0 in range(0, 512, 128):
+        sub = blk.rows(r0, r0 + 128)
+        lo, _ = o.train_batch(sub)
+        lg, _ = e.train_batch(sub)
+        assert_bitwise(lg, lo, "mode %s logits at %d" % (mode, r0))
+    rows, labels = [], []
+    for r in range(96):  # several features per field, fields out of order, once-only ids among them
+        row = []
+        for f in rng.permutation(F)[: int(rng.integers(2, F + 1))]:
+            for i in rng.choice(per, size=int(rng.integers(1, 3)), replace=False):
+                row.append((int(f), int(f) * per + int(i), float(np.float32(rng.random() + 0.2))))
+        rows.append(row)
+        labels.append(int(rng.integers(0, 2)))
+    csr = Csr.from_rows(rows, labels)
+    lo, _ = o.train_batch(csr)
+    lg, _ = e.train_batch(csr)
+    assert_bitwise(lg, lo, "mode %s ragged logits" % mode)
+    assert_state_bitwise(e.get_state(), o.get_state(), "mode %s" % mode)
+    e.close()
+
+
 def test_empty_block_and_capacity_errors():
     e = fa.Engine("FFM", 100, 4, 4, max_batch_rows=8, max_batch_nnz=64, max_row_nnz=16)
     empty = Csr(np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32),

@@ -54,25 +54,45 @@ def algorithmic_bytes_per_row(nnz, k):
     return nnz * (nnz - 1) * k * 20 + nnz * 20 + 20 + (nnz * 12 + 8) + 12
 
 
+def refresh_mode(n_shards):
+    """Where the engine refreshes / updates the features that occur once in a block
+    (csrc/engine.hip refresh_mode; FFM_ENGINE_ROW_REFRESH overrides): 1 = refresh kernel + single
+    kernel, 2 = refreshed by their row, 3 = and updated there (one shard: the row kernel has tmp_grad)."""
+    env = os.environ.get("FFM_ENGINE_ROW_REFRESH", "")[:1]
+    mode = {"0": 1, "2": 2, "3": 3}.get(env, 3)
+    return 2 if mode == 3 and n_shards > 1 else mode
+
+
 def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
     """Algorithmic bytes ONE launch of `kernel` is responsible for, averaged over the bench's
     blocks.  SURVEY.md 8(d)'s per-row total (20 B per touched slot-factor: read n,z + write w,n,z)
     is apportioned to the kernels that move those bytes, so the shares add up to it:
-      refresh kernel       : read (n,z) + write w = 12 B per touched slot-factor of the block's
+      refresh              : read (n,z) + write w = 12 B per touched slot-factor of the block's
                              DISTINCT features (with (n,z) frozen over the block every occurrence
                              would compute the same w, so once per distinct feature is all the
                              block algorithm needs; the per-row figure of 8(d) counts it per
-                             occurrence, and step_algorithmic_GBps keeps that accounting)
-      row kernel           : CSR in, linear weights, logit / tmp_grad / loss out
-      update kernels       : write (n,z) = 8 B per slot-factor of the occurrences each owns
+                             occurrence, and step_algorithmic_GBps keeps that accounting) -- the
+                             refresh kernel's, except (modes 2, 3) for the features that occur once
+                             in the block, whose 12 B belong to the row kernel
+      row kernel           : CSR in, linear weights, logit / tmp_grad / loss out (+ the above; + in
+                             mode 3 the once-only features' update)
+      update               : write (n,z) = 8 B per slot-factor of the occurrences each kernel owns
                              (features with 1, 2..4, 5..96, > 96 occurrences in the block)
     Under field-pair sharding every rank moves 1/n_shards of the slot-factors."""
     per_occ = (nnz - 1) * k  # slot-factors one occurrence of a feature touches
     rows = [len(f) // nnz for f in blocks_feat]
+    mode = refresh_mode(n_shards)
+    counts = [np.unique(f, return_counts=True)[1] for f in blocks_feat]
+    once = [int((c == 1).sum()) for c in counts]
     if "refresh" in kernel:
-        return float(np.mean([len(np.unique(f)) * per_occ * 12 / n_shards for f in blocks_feat]))
+        return float(np.mean([(len(c) - (o if mode >= 2 else 0)) * per_occ * 12 / n_shards
+                              for c, o in zip(counts, once)]))
     if "row_kernel" in kernel:
-        return float(np.mean([r * (nnz * 12 + 12 + (nnz * 12 + 8) + 4 + 16) for r in rows]))
+        per_once = (12 if mode >= 2 else 0) + (8 if mode == 3 else 0)
+        return float(np.mean([r * (nnz * 12 + 12 + (nnz * 12 + 8) + 4 + 16) + o * per_occ * per_once / n_shards
+                              for r, o in zip(rows, once)]))
+    if "single" in kernel and mode == 3:
+        return 0.0
     shares = []
     for f in blocks_feat:
         _, c = np.unique(f, return_counts=True)

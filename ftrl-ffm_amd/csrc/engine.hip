@@ -432,6 +432,15 @@ struct ffm_engine {
   // updated there too when the row kernel has the whole logit (FFM_ENGINE_ROW_REFRESH=0/2/3)
   int refresh_mode = 3;
   bool singles_in_row = false;  // the block in flight had its once-only features updated by the row kernel
+  // Row phases (engine_types.h): the rows of a block cut into `phases` ranges, the hot / very hot
+  // update of one range beside the forward pass of the next (FFM_PHASES=2..4).  Off by default:
+  // bit-identical, but measured 5 % (2 phases) to 16 % (4) SLOWER per step -- the row kernel of
+  // the next phase reaches the chip first and keeps every wave slot refilled, the update kernels
+  // of the previous phase (112 VGPRs per wave against the row kernel's 80) find room only when it
+  // drains, so nothing overlaps and the per-launch fixed costs double.  cur_phases: of the block
+  // in flight.
+  int phases = 1, cur_phases = 1;
+  hipEvent_t ev_row[kMaxPhases] = {};
   unsigned long long *d_ownmask = nullptr;
   bool lin_any = true;          // this shard owns the linear terms of at least one field
   int logical_len = 0;          // n_fields * n_factors (FFM), n_factors (FM), 0 (LR): the reference's row
@@ -513,12 +522,20 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // The very-hot-feature chain kernels are instantiated per number of interleaved chains (groups of
 // 4 factors of a slot handled by one wave): 1, 2 or 4.
-static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows) {
+static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows, int ph = 0, int phases = 1) {
   const int groups = e->m.n_factors / 4;
   const int gb = e->grid_giant, grid = e->grid_huge + gb;
-  if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb);
-  else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb);
-  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb);
+  if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
+  else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
+  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
+}
+
+// Row phases a block of n_rows rows is grouped for (and trained in, when the row kernel has the
+// whole logit): only where the forward pass and the hot features' update are both long enough.
+static int phases_for(const ffm_engine *e, int n_rows) {
+  const bool ok = e->m.type == FFM_MODEL_FFM && e->m.n_shards == 1 && e->m.n_factors % 4 == 0 &&
+                  e->pre_refresh && !e->serial && n_rows >= 1024 * e->phases;
+  return ok ? e->phases : 1;
 }
 
 extern "C" {
@@ -568,6 +585,7 @@ void ffm_engine_destroy(ffm_engine *e) {
     if (e->ev_set_free[i]) (void)hipEventDestroy(e->ev_set_free[i]);
   }
   if (e->ev_rows_done) (void)hipEventDestroy(e->ev_rows_done);
+  for (auto &ev : e->ev_row) if (ev) (void)hipEventDestroy(ev);
   if (e->prep) (void)hipStreamDestroy(e->prep);
 
   if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
@@ -628,6 +646,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (cfg->n_shards > 1) e->grid_huge = 4096;
 
   if (const char *sv = std::getenv("FFM_GRID_PULL")) e->grid_pull = std::max(1, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_PHASES")) e->phases = std::min(kMaxPhases, std::max(1, std::atoi(sv)));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
@@ -696,9 +715,15 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
   }
-  TRY_HIP(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
+  if (std::getenv("FFM_AUX_PRIORITY")) {  // experiment: the hot / very hot update streams above normal (measured: +45 % per step)
+    int lo = 0, hi = 0;
+    TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    TRY_HIP(hipStreamCreateWithPriority(&e->aux2, hipStreamNonBlocking, hi));
+    TRY_HIP(hipStreamCreateWithPriority(&e->aux3, hipStreamNonBlocking, hi));
+  }
+  if (!e->aux2) TRY_HIP(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
-  TRY_HIP(hipStreamCreateWithFlags(&e->aux3, hipStreamNonBlocking));
+  if (!e->aux3) TRY_HIP(hipStreamCreateWithFlags(&e->aux3, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join3, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
@@ -732,6 +757,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.next, E));
   TRY_ALLOC(e->alloc(&s.rowtab, R * static_cast<size_t>(m.n_fields)));
   TRY_ALLOC(e->alloc(&s.occpos, E));
+  TRY_ALLOC(e->alloc(&s.usplit, E));
   const bool ffm_model = m.type == FFM_MODEL_FFM;
   const bool masks = ffm_model && m.n_fields <= 64;
   if (masks) {
@@ -814,6 +840,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.giant, E / kGiantMin + 1));
     TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
     TRY_ALLOC(e->alloc(&t.occpos, E));
+    TRY_ALLOC(e->alloc(&t.usplit, E));
     if (masks) {
       TRY_ALLOC(e->alloc(&t.rowmask, 2 * R));
       TRY_ALLOC(e->alloc(&t.gmask, E));
@@ -834,6 +861,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   }
   e->copy = e->prep;
   TRY_HIP(hipEventCreateWithFlags(&e->ev_rows_done, hipEventDisableTiming));
+  for (auto &ev : e->ev_row) TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   for (int i = 0; i < ffm_engine::kSets; i++) {
     TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&e->ev_set_free[i], hipEventDisableTiming));
@@ -1136,10 +1164,19 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
       if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
       else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
     }
-    if (train && vec4) LAUNCH(e, kid, (ffm_row_kernel<true, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg);
-    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg);
-    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0);
-    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0);
+    if (train) e->cur_phases = own_tg && vec4 ? phases_for(e, rows.n_rows) : 1;
+    if (train && vec4) {
+      // one launch per row phase; the update streams pick each phase up at its event
+      for (int ph = 0; ph < e->cur_phases; ph++) {
+        const int r0 = phase_row(rows.n_rows, e->cur_phases, ph), r1 = phase_row(rows.n_rows, e->cur_phases, ph + 1);
+        if (r1 > r0)
+          LAUNCH(e, kid, (ffm_row_kernel<true, true>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, r0);
+        if (e->cur_phases > 1) (void)hipEventRecord(e->ev_row[ph], e->stream);
+      }
+    }
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, 0);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
   }
 }
 
@@ -1177,7 +1214,8 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
                                       rocprim::counting_iterator<int>(0), sc.occ,
                                       static_cast<size_t>(nnz), 0u, e->sort_bits, st));
     e->prof_end(st);
-    LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, e->m, rows, sc);
+    LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, e->m, rows, sc,
+              phases_for(e, rows.n_rows));
   }
   HIP_TRY(hipGetLastError());
   return FFM_OK;
@@ -1312,16 +1350,23 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   };
   if (ffm && vec4 && e->serial) {
     launch_ffm_chain(e, e->stream, rows);
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks);
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, 0, 1);
     launch_small();
   } else if (ffm && vec4) {
     // the three owner shapes touch disjoint features: run them side by side (long sequential
-    // chains of the hot ones beside the bandwidth-shaped small-feature pass)
-    HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-    launch_ffm_chain(e, e->aux3, rows);
+    // chains of the hot ones beside the bandwidth-shaped small-feature pass).  With row phases the
+    // two side streams take each phase's touches as soon as its rows are done -- beside the forward
+    // pass of the next phase (which reads w; the update writes n and z).
+    const int P = own_tg ? e->cur_phases : 1;
+    for (int ph = 0; ph < P; ph++) {
+      HIP_TRY(hipStreamWaitEvent(e->aux3, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
+      launch_ffm_chain(e, e->aux3, rows, ph, P);
+    }
     HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
-    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
-    LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks);
+    for (int ph = 0; ph < P; ph++) {
+      HIP_TRY(hipStreamWaitEvent(e->aux2, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
+      LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, P);
+    }
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
     launch_small();
     if (loss_sum_out)

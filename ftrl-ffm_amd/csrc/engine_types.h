@@ -142,6 +142,8 @@ struct Scratch {
                                 //      some row of the block touches slot fp of the feature
   unsigned long long *cmask;    // [nnz] the same for slots whose partner field is MULTI-VALUED in some
                                 //      row of the feature (the row holds >= 2 entries of field fp)
+  int *usplit;    // [nnz] row phases (see phase_row): for a hot feature whose group starts at `start`,
+                  //      usplit[start + j] = how many of its occurrences lie in rows before phase j+1
   int *occpos;    // [nnz] entry -> its position t in occ when its feature is hot, else
                   //      OCC_FEW (2..kSmallMax occurrences) or OCC_ONCE (this entry only)
   int4 *haux;     // [nnz*n_fields] per (occurrence t, partner field): {partner value bits,
@@ -153,6 +155,21 @@ struct Scratch {
   double *loss;   // [n_rows] logloss per row
   float *svx;     // [n_rows*n_factors] FM per-row factor sums (sum_vx, fm.h:24)
 };
+
+// Row phases: a block's rows may be cut into P consecutive ranges ("phases") so that the update of
+// the hot features' touches from one range runs beside the forward pass of the next (the forward
+// reads w, the update writes n and z: no hazard inside a block).  Phase j covers rows
+// [phase_row(j), phase_row(j + 1)); a hot feature's occurrences are in row order, so a phase owns
+// a contiguous run [lo, hi) of them.
+constexpr int kMaxPhases = 4;
+__host__ __device__ inline int phase_row(int n_rows, int phases, int j) {
+  return static_cast<int>(static_cast<long long>(n_rows) * j / phases);
+}
+__device__ __forceinline__ void phase_touches(const Scratch &s, int start, int c, int ph, int phases,
+                                              int &lo, int &hi) {
+  lo = ph == 0 ? 0 : s.usplit[start + ph - 1];
+  hi = ph == phases - 1 ? c : s.usplit[start + ph];
+}
 
 // Every counter that takes atomics sits on a 64-byte line of its own (kLineInts apart):
 // device-scope atomics are performed at the memory side, one line at a time, and the grouping's

@@ -252,7 +252,7 @@ __device__ __forceinline__ void chain_step(const ModelDev &m, unsigned long long
 template <int G>
 __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &rows, const Scratch &s,
                                                 const int *list, int n_list, unsigned wave,
-                                                unsigned n_waves) {
+                                                unsigned n_waves, int ph, int phases) {
   constexpr int CH = kChainChunk;
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int lane = threadIdx.x & 63;
@@ -272,7 +272,12 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
     const int fa = wave_uniform(ud.w);
     const int fp = wave_uniform(walk_field(m, fa, sc));  // partner field of slot sc
     if (fp < 0) continue;
-    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    const int start = wave_uniform(ud.y);
+    int t_lo, c;  // this row phase's touches [t_lo, c) of the feature's occurrences
+    phase_touches(s, start, wave_uniform(ud.z), ph, phases, t_lo, c);
+    t_lo = wave_uniform(t_lo);
+    c = wave_uniform(c);
+    if (t_lo >= c) continue;
     if (s.gmask && !((s.gmask[start] >> fp) & 1ull)) continue;  // no row of the block touches the slot
     const unsigned long long own_bits = owner_bits(m, fp);  // (no loads inside the step loops)
     const bool chainy = !s.cmask || ((s.cmask[start] >> fp) & 1ull) != 0ull;  // multi-valued partner field
@@ -295,7 +300,7 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
     }
     const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;  // + t*F
     const float2 *mcol = s.hmeta + start;                              // + t
-    const int steps = (c + kChainT - 1) / kChainT;
+    const int steps = (c - t_lo + kChainT - 1) / kChainT;
 
     if (!chainy && FFM_CHAIN_PIPELINE) {
       // ---- three-stage pipeline over chunks of CH steps ----
@@ -307,7 +312,7 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
       auto load_raw = [&](int chunk, int4 (&ax)[CH], float2 (&mt)[CH]) {
 #pragma unroll
         for (int j = 0; j < CH; j++) {
-          const int t = min((chunk * CH + j) * kChainT + tl, c - 1);  // past the end: repeats, unused
+          const int t = min(t_lo + (chunk * CH + j) * kChainT + tl, c - 1);  // past the end: repeats, unused
           ax[j] = acol[static_cast<int64_t>(t) * F];
           mt[j] = mcol[t];
         }
@@ -334,7 +339,7 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
         for (int j = 0; j < CH; j++) {
           const int st = ch * CH + j;
           if (st < steps)
-            chain_step<G>(m, own_bits, st * kChainT + tl < c, l0, fC[j], vpC[j], act, w, nc, zc, sqc, sq_valid);
+            chain_step<G>(m, own_bits, t_lo + st * kChainT + tl < c, l0, fC[j], vpC[j], act, w, nc, zc, sqc, sq_valid);
         }
 #pragma unroll
         for (int j = 0; j < CH; j++) {
@@ -347,19 +352,19 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
       }
     } else {
       // ---- a multi-valued partner field somewhere: facts two steps ahead, weights one ----
-      int4 ax = acol[static_cast<int64_t>(min(tl, c - 1)) * F];
-      float2 mt = mcol[min(tl, c - 1)];
-      int4 axN = acol[static_cast<int64_t>(min(kChainT + tl, c - 1)) * F];
-      float2 mtN = mcol[min(kChainT + tl, c - 1)];
+      int4 ax = acol[static_cast<int64_t>(min(t_lo + tl, c - 1)) * F];
+      float2 mt = mcol[min(t_lo + tl, c - 1)];
+      int4 axN = acol[static_cast<int64_t>(min(t_lo + kChainT + tl, c - 1)) * F];
+      float2 mtN = mcol[min(t_lo + kChainT + tl, c - 1)];
       float vp[G];
 #pragma unroll
       for (int g = 0; g < G; g++) vp[g] = m.lat[haux_offset(ax.z, ax.w) + kk[g]];
       for (int st = 0; st < steps; st++) {
-        const int t = st * kChainT + tl;
+        const int t = t_lo + st * kChainT + tl;
         float vpN[G];
 #pragma unroll
         for (int g = 0; g < G; g++) vpN[g] = m.lat[haux_offset(axN.z, axN.w) + kk[g]];  // step st+1
-        const int tNN = min((st + 2) * kChainT + tl, c - 1);                              // step st+2
+        const int tNN = min(t_lo + (st + 2) * kChainT + tl, c - 1);                       // step st+2
         const int4 axNN = acol[static_cast<int64_t>(tNN) * F];
         const float2 mtNN = mcol[tNN];
         const int fl = ax.y;
@@ -382,13 +387,13 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
 #pragma unroll
             for (int g = 0; g < G; g++) vpt[g] = __shfl(vp[g], src, 64);
             const int fm = flt >> 8;
-            if (st * kChainT + tt >= c || !owns_bit(own_bits, fm)) continue;
+            if (t_lo + st * kChainT + tt >= c || !owns_bit(own_bits, fm)) continue;
             if (flt & HF_SIMPLE) {
 #pragma unroll
               for (int g = 0; g < G; g++)
                 ffm_touch(m.h, flt & HF_FIRST, tgt, xmt, xot, vpt[g], w[g], nc[g], zc[g]);
             } else if (flt & HF_CHAIN) {
-              const int pt = s.occ2[start + st * kChainT + tt].x;  // the touch's own entry
+              const int pt = s.occ2[start + t_lo + st * kChainT + tt].x;  // the touch's own entry
               const int r = s.row_of[pt];
               for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
                 if (qq == pt) continue;
@@ -426,16 +431,19 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
 // the whole update phase; one chain per wave is four times shorter, and there are few enough giant
 // features for the extra s_nop slots not to matter.  Dispatched first, the long chains also start
 // first.  The other workgroups take the rest, G chains per wave.
+// ph of `phases`: the touches that come from the rows of one row phase (engine_types.h).
 template <int G>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev m, Rows rows,
-                                                                       Scratch s, int giant_blocks) {
+                                                                       Scratch s, int giant_blocks,
+                                                                       int ph, int phases) {
   const unsigned w = wave_uniform(threadIdx.x >> 6);
   if (static_cast<int>(blockIdx.x) < giant_blocks)
     ffm_chain_items<1>(m, rows, s, s.giant, s.counters[CNT_NGIANT], blockIdx.x * kUpdWaves + w,
-                       giant_blocks * kUpdWaves);
+                       giant_blocks * kUpdWaves, ph, phases);
   else
     ffm_chain_items<G>(m, rows, s, s.huge, s.counters[CNT_NHUGE],
-                       (blockIdx.x - giant_blocks) * kUpdWaves + w, (gridDim.x - giant_blocks) * kUpdWaves);
+                       (blockIdx.x - giant_blocks) * kUpdWaves + w, (gridDim.x - giant_blocks) * kUpdWaves,
+                       ph, phases);
 }
 
 // ---- FM -------------------------------------------------------------------------------------

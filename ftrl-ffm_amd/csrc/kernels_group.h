@@ -138,7 +138,7 @@ __device__ __forceinline__ int sorted_bound(const unsigned *skey, int n, unsigne
 // position publishes {entry, row}, its entry's occurrence class, and ORs its touched-slot mask
 // into the group's (one atomic per group piece per wave).
 __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m, Rows rows,
-                                                                     Scratch s) {
+                                                                     Scratch s, int phases) {
   if (s.counters[CNT_ERROR]) return;  // untrainable block: no groups, no owners, nothing runs
   const int nnz = rows.nnz;
   const int lane = threadIdx.x & 63;
@@ -176,6 +176,17 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
     p = s.occ[t];
     s.occ2[t] = make_int2(p, s.row_of[p]);
     s.occpos[p] = c > kSmallMax ? t : (c == 1 ? OCC_ONCE : OCC_FEW);
+    if (phases > 1 && c > kSmallMax) {
+      // where the row phases cut this hot feature's occurrences: for boundary row b the position
+      // whose row is the last one before b writes the count (or the head writes 0): one writer each
+      const int r = s.row_of[p];
+      const int rn = last ? 0x7fffffff : s.row_of[s.occ[t + 1]];
+      for (int j = 1; j < phases; j++) {
+        const int b = phase_row(rows.n_rows, phases, j);
+        if (r < b && rn >= b) s.usplit[lower + j - 1] = t + 1 - lower;
+        if (head && r >= b) s.usplit[lower + j - 1] = 0;
+      }
+    }
   }
   // distinct features and their owner lists: slots handed out per workgroup (one atomic per
   // list per workgroup -- per-wave atomics on five shared counters would be a serial chain)

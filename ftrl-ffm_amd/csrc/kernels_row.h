@@ -242,7 +242,7 @@ template <bool TRAIN, bool VEC4>
 __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
                                                               int output_prob, int refreshed,
-                                                              int own_tg) {
+                                                              int own_tg, int row0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv, s_ns;
   __shared__ float s_tg;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
   const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
   const int terms_cap = row_terms_cap(max_row_nnz, m.n_shards > 1 ? record_span(m, 1) : 0, 0);
   RowLds lds = carve_row_lds(smem, max_row_nnz, F, terms_cap);
-  const int r = blockIdx.x;
+  const int r = blockIdx.x + row0;  // (row0: first row of this launch's row phase)
   const int b = rows.row_ptr[r];
   const int nnz = rows.row_ptr[r + 1] - b;
   // a row beyond the LDS capacity: the grouping has flagged the whole training block (no kernel

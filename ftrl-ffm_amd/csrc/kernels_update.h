@@ -102,9 +102,12 @@ __device__ __forceinline__ void linear_chain64(const Hyper &h, float w, float g,
 
 // Linear update (update_linear_nz, ftrl_model.cpp:66-77).  Small features: one thread each,
 // touches applied one after another; hot features: one wave each, 64 touches per pass.
+// ph of `phases` (row phases, engine_types.h): a hot feature's touches of this phase's rows; the
+// small features' few touches all in the last phase.
 __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows &rows,
-                                                   const Scratch &s, int block, int n_blocks) {
-  const int n_small = s.counters[CNT_NSMALL], n_big = s.counters[CNT_NBIG];
+                                                   const Scratch &s, int block, int n_blocks,
+                                                   int ph = 0, int phases = 1) {
+  const int n_small = ph == phases - 1 ? s.counters[CNT_NSMALL] : 0, n_big = s.counters[CNT_NBIG];
   const int gtid = block * blockDim.x + threadIdx.x;
   for (int li = gtid; li < n_small; li += n_blocks * blockDim.x) {
     const int u = s.small[li];
@@ -132,10 +135,15 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
     const int4 ud = s.udesc[u];
     if (!owns_linear(m, wave_uniform(ud.w))) continue;
     const int i = wave_uniform(ud.x);
-    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    const int start = wave_uniform(ud.y);
+    int t_lo, c;  // this phase's touches [t_lo, c)
+    phase_touches(s, start, wave_uniform(ud.z), ph, phases, t_lo, c);
+    t_lo = wave_uniform(t_lo);
+    c = wave_uniform(c);
+    if (t_lo >= c) continue;
     float n = m.lin_n[i], z = m.lin_z[i];
     const float w = m.lin_w[i];
-    for (int t0 = 0; t0 < c; t0 += 64) {
+    for (int t0 = t_lo; t0 < c; t0 += 64) {
       const int cnt = min(64, c - t0);
       float g = 0.0f;
       if (lane < cnt) {
@@ -156,9 +164,12 @@ __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, 
 }
 
 // Bias update: one wave walks all rows of the block in order (update_bias_nz, :79-85).
-__device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, const Scratch &s) {
-  if (!m.bias_own) return;            // another shard's
-  if (s.counters[CNT_ERROR]) return;  // untrainable block (ERR_ROW_TOO_LONG): a no-op
+// Rows [row_lo, row_hi) of the block (one row phase, or all of them).
+__device__ __forceinline__ void bias_update_body(const ModelDev &m, int row_lo, int row_hi, const Scratch &sc) {
+  if (!m.bias_own) return;             // another shard's
+  if (sc.counters[CNT_ERROR]) return;  // untrainable block (ERR_ROW_TOO_LONG): a no-op
+  struct { const float *tg; } s{sc.tg + row_lo};
+  const int n_rows = row_hi - row_lo;
   const int lane = threadIdx.x & 63;
   float n = m.bias3[1], z = m.bias3[2];
   const float w = m.bias3[0];
@@ -195,7 +206,7 @@ __device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, 
   }
 }
 __global__ __launch_bounds__(64) void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
-  bias_update_body(m, n_rows, s);
+  bias_update_body(m, 0, n_rows, s);
 }
 
 // ---- hot features, moderate counts: work item = (feature from the big list, 64 elements) ----
@@ -230,15 +241,19 @@ __device__ __forceinline__ void hot_issue_weights(const float *wcol, const HotFa
 // side_blocks > 0: the first workgroups of the launch carry the block's two short serial jobs --
 // workgroup 0 the bias chain, workgroups 1..side_blocks-1 the linear update -- so that they run
 // beside the latent chains without a stream (and a hardware queue) of their own.
+// ph of `phases`: the touches that come from the rows of one row phase (engine_types.h).
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m, Rows rows,
-                                                                     Scratch s, int side_blocks) {
+                                                                     Scratch s, int side_blocks,
+                                                                     int ph, int phases) {
   if (static_cast<int>(blockIdx.x) < side_blocks) {
     if (blockIdx.x == 0) {
       // one wave, 8192 dependent touches: let it win the issue arbitration on its SIMD
       __builtin_amdgcn_s_setprio(3);
-      if (threadIdx.x < 64) bias_update_body(m, rows.n_rows, s);
+      // (the whole chain in the last row phase: the row kernel of a later phase still derives the
+      // bias weight from the block-start bias_n / bias_z)
+      if (threadIdx.x < 64 && ph == phases - 1) bias_update_body(m, 0, rows.n_rows, s);
     } else {
-      linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1);
+      linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, ph, phases);
     }
     return;
   }
@@ -265,7 +280,12 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     const int fp = active ? fpw : 0;  // (idle lanes still form valid fact addresses)
     const int kk = active ? eb - sl * k : 0;  // and factor
     const int i = wave_uniform(ud.x);
-    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    const int start = wave_uniform(ud.y);
+    int t_lo, c;  // this phase's touches [t_lo, c) of the feature's occurrences
+    phase_touches(s, start, wave_uniform(ud.z), ph, phases, t_lo, c);
+    t_lo = wave_uniform(t_lo);
+    c = wave_uniform(c);
+    if (t_lo >= c) continue;
     float *rec = lat_row(m, i, fa);
     float n = rec[LAT_N * RL + ee], z = rec[LAT_Z * RL + ee];
     const float w = rec[LAT_W * RL + ee];
@@ -273,18 +293,18 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
     const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;     // + t*F
     const float2 *mcol = s.hmeta + start;                                 // + t
     bool touched = false;
-    const int nb = (c + kUnroll - 1) / kUnroll;
+    const int nb = (c - t_lo + kUnroll - 1) / kUnroll;
     float sqn = 0.0f;       // sqrt(n) while sq_valid: the last touch's sqrt(n + g*g), forwarded
     bool sq_valid = false;  // (wave-uniform)
 
     HotFacts fA, fB, fC;          // facts of groups b+2, b+1, b
     int peA[kUnroll], peB[kUnroll], peC[kUnroll];
     float vpB[kUnroll], vpC[kUnroll];
-    hot_load_facts(acol, F, c, 0, fB, peB);
-    if (nb > 1) hot_load_facts(acol, F, c, kUnroll, fA, peA);
+    hot_load_facts(acol, F, c, t_lo, fB, peB);
+    if (nb > 1) hot_load_facts(acol, F, c, t_lo + kUnroll, fA, peA);
     hot_issue_weights(m.lat + kk, fB, peB, vpB);
     for (int b = 0; b < nb; b++) {
-      const int t0 = b * kUnroll;
+      const int t0 = t_lo + b * kUnroll;
       fC = fB;
 #pragma unroll
       for (int j = 0; j < kUnroll; j++) { vpC[j] = vpB[j]; peC[j] = peB[j]; }

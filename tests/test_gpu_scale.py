@@ -126,6 +126,32 @@ def test_quirk_nans_flow_through_the_chain_kernels(F, k, per, B):
     e.close()
 
 
+@pytest.mark.parametrize("phases", [2, 3, 4])
+def test_row_phases_are_bit_identical(phases, monkeypatch):
+    """FFM_PHASES cuts a block's rows into ranges and runs the hot / very hot update of one range
+    beside the forward pass of the next (off by default: measured slower).  Same touches in the
+    same order, so the oracle's bits -- NaNs of ffm.cpp:118 included -- on blocks where every
+    feature is hot or very hot and the ranges cut through all of their chains."""
+    monkeypatch.setenv("FFM_PHASES", str(phases))
+    rng = np.random.default_rng(29)
+    F, k, per, B = 12, 16, 50, 4096
+    nf = F * per
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o, n_hi=0.02)
+    st["vec_n"][rng.random(st["vec_n"].shape) < 0.2] = 0.0
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=B, **STRESS_HP)
+    e.set_state(st)
+    blk = synth.Generator(F, nf, "zipf", seed=12).block(B + 1500)
+    for r0, r1 in ((0, B), (B, B + 1500)):  # (the short block trains unphased)
+        sub = blk.rows(r0, r1)
+        lo, _ = o.train_batch(sub)
+        lg, _ = e.train_batch(sub)
+        assert_bitwise(lg, lo, "phases=%d logits of block at %d" % (phases, r0))
+    assert_state_bitwise(e.get_state(), o.get_state(), "phases=%d" % phases)
+    e.close()
+
+
 @pytest.mark.parametrize("compact", [False, True], ids=["full_records", "compact"])
 def test_eight_shards_at_39x16_on_one_gpu(compact):
     """n_shards = 8 at the headline shape: eight engines on this GPU, each owning 1/8 of the field

@@ -478,6 +478,8 @@ def main():
             out["resident"] = resident
         if kname and model == "FFM":
             share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, n_shards)
+            per_step = max(1, round(klaunches / max(args.steps, 1)))  # (FFM_PHASES > 1: several launches per block)
+            share /= per_step
             avg_s = kms / 1000.0 / max(klaunches, 1)
             achieved = share / avg_s / 1e9
             traffic = None
@@ -497,10 +499,11 @@ def main():
                 "whole_step": {"achieved": out["step_algorithmic_GBps"],
                                "frac": round(out["step_algorithmic_GBps"] / PEAK_HBM_GBPS, 4),
                                "bytes_per_row": int(bytes_row)},
-                "note": "the update kernels run side by side on separate streams, so a kernel's span "
-                        "includes waiting for CUs; the chain kernels are bound by VALU issue and "
-                        "dependent-load latency, not HBM (DESIGN.md); warm-up spans of all kernels "
-                        "are in other_kernels",
+                "note": "traffic = bytes leaving the L2 (Infinity-Cache hits included, FETCH_SIZE x2 for "
+                        "float4 record streams: tools/summarize_profile.py); the update kernels run side "
+                        "by side on separate streams, so their spans include waiting for CUs, and they "
+                        "are bound by dependent-load latency and wave slots, not HBM (DESIGN.md 6); "
+                        "warm-up spans of all kernels are in other_kernels",
             }
             # the other big kernels, from the fully timed warm-up launches (same accounting)
             others = []

@@ -543,6 +543,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev 
 }
 
 // ---- features that occur ONCE in the block (most of the distinct features) ----------------------
+// (On one shard the row kernel applies these touches itself -- kernels_row.h, refreshed == 3 --
+// and this kernel is not launched; a shard of several only has tmp_grad after the all-reduce.)
 // One wave per feature, driven by a 16-byte descriptor {feature, entry, row, field} the grouping
 // wrote for it, so the dependent-load chain is three deep instead of six (descriptor -> record
 // vectors + the row's per-field table -> partner weights): each lane takes up to kSingleTrips

@@ -55,7 +55,7 @@ def build_host(force=False, verbose=False):
         if (not force and os.path.exists(out)
                 and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps)):
             continue
-        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-o", out,
+        cmd = ["g++", "-std=c++17", "-O3", "-fopenmp", "-Wall", "-pthread", "-o", out,
                os.path.join(HOST, main)] + srcs + [LIB, "-ldl", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
         if verbose:
             print(" ".join(cmd))

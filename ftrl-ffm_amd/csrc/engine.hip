@@ -407,6 +407,11 @@ struct ffm_engine {
   int n_staged = 0;
   int cur_slot = -1;        // slot of the block between train_forward_staged and train_update
   int64_t n_staged_total = 0, n_pulled = 0;  // blocks staged so far / known to be uploaded
+  // upload of block number b (1-based) -> ev_pulled[b % kPullRing].  (Per staging slot it would not
+  // do: a slot is refilled -- on the HOST's timeline -- while the GPU may still be several blocks
+  // behind, so "its slot carries a later block" does not mean "uploaded".)
+  static constexpr int kPullRing = 16;
+  hipEvent_t ev_pulled[kPullRing] = {};
   double *d_loss_acc = nullptr;  // [1] sum of the async blocks' losses since the last flush
   void *d_sort_tmp[kSets] = {};  // rocPRIM radix sort workspace per scratch set
   size_t sort_tmp_bytes = 0;
@@ -586,6 +591,7 @@ void ffm_engine_destroy(ffm_engine *e) {
   }
   if (e->ev_rows_done) (void)hipEventDestroy(e->ev_rows_done);
   for (auto &ev : e->ev_row) if (ev) (void)hipEventDestroy(ev);
+  for (auto &ev : e->ev_pulled) if (ev) (void)hipEventDestroy(ev);
   if (e->prep) (void)hipStreamDestroy(e->prep);
 
   if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
@@ -1541,18 +1547,28 @@ __global__ void loss_accumulate_kernel(double *acc, const double *one) { *acc +=
 // A hipMemcpyAsync here makes the SUBMITTING THREAD wait until the stream's earlier kernels have
 // finished (measured: mean 0.38 ms, up to 16 ms per call) -- the host then cannot run ahead of the
 // GPU and every other step starts ~230 us late; a kernel launch never blocks.
+// The host reads are SYSTEM-scope loads: memory page-locked with hipHostRegister is cacheable in
+// the L2s, and a caller that refills a block buffer it has used before (the trainers' ring) would
+// otherwise be served the previous block's lines that are still on-die -- a stale row_ptr then
+// shows up as "row longer than max_row_nnz", or worse, as plausible rows of the wrong block.
 struct PullJob { const char *src[5]; char *dst[5]; unsigned bytes[5]; };
 __global__ __launch_bounds__(256) void pull_block_kernel(PullJob job) {
   const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
 #pragma unroll
   for (int a = 0; a < 5; a++) {
     const unsigned n16 = job.bytes[a] >> 4;
-    const int4 *s = reinterpret_cast<const int4 *>(job.src[a]);
-    int4 *d = reinterpret_cast<int4 *>(job.dst[a]);
-    for (unsigned i = tid; i < n16; i += stride) d[i] = s[i];
+    const unsigned long long *s = reinterpret_cast<const unsigned long long *>(job.src[a]);
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(job.dst[a]);
+    for (unsigned i = tid; i < n16; i += stride) {
+      ulonglong2 v;
+      v.x = __hip_atomic_load(s + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v.y = __hip_atomic_load(s + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      d[i] = v;
+    }
     const unsigned tail = job.bytes[a] & 15u;  // sizes are multiples of 4
     if (tid < (tail >> 2))
-      reinterpret_cast<int *>(job.dst[a])[(n16 << 2) + tid] = reinterpret_cast<const int *>(job.src[a])[(n16 << 2) + tid];
+      reinterpret_cast<int *>(job.dst[a])[(n16 << 2) + tid] = __hip_atomic_load(
+          reinterpret_cast<const int *>(job.src[a]) + (n16 << 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1569,6 +1585,7 @@ static int slots_init(ffm_engine *e) {
     HIP_TRY(hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&sl.ev_trained, hipEventDisableTiming));
   }
+  for (auto &ev : e->ev_pulled) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   int rc = e->alloc(&e->d_loss_acc, 1);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(e->d_loss_acc, 0, sizeof(double), e->stream));
@@ -1644,6 +1661,17 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
     HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
     hipLaunchKernelGGL(pull_block_kernel, dim3(e->grid_pull), dim3(256), 0, e->copy, job);
     HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
+    {
+      // this block's entry of the upload ring; the block that had it kPullRing blocks ago is
+      // long uploaded (the wait returns at once unless the GPU is that far behind the host)
+      const int64_t ordinal = e->n_staged_total + 1;
+      hipEvent_t ev = e->ev_pulled[ordinal % ffm_engine::kPullRing];
+      if (ordinal > ffm_engine::kPullRing) {
+        HIP_TRY(hipEventSynchronize(ev));
+        e->n_pulled = std::max(e->n_pulled, ordinal - ffm_engine::kPullRing);
+      }
+      HIP_TRY(hipEventRecord(ev, e->copy));
+    }
   }
   // group it ahead, behind its own upload on the prep stream
   {
@@ -1666,16 +1694,11 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
 // How many of the blocks staged so far have been uploaded (their host arrays are free again).
 int64_t ffm_engine_blocks_pulled(ffm_engine *e) {
   if (!e || !e->slots_ready) return 0;
-  // blocks are pulled in staging order: advance over the slots whose upload event has fired
-  for (;;) {
-    const int64_t next = e->n_pulled + 1;
-    if (next > e->n_staged_total) break;
-    const ffm_engine::Slot *hit = nullptr;
-    for (const auto &sl : e->slots)
-      if (sl.used && sl.seq == next) hit = &sl;
-    if (hit && hipEventQuery(hit->ev_copied) != hipSuccess) break;  // (a slot already refilled: that block is long pulled)
-    e->n_pulled = next;
-  }
+  // blocks are uploaded in staging order: advance over the ring entries whose event has fired
+  // (entries are re-recorded only kPullRing blocks later, after n_pulled has passed them)
+  while (e->n_pulled < e->n_staged_total &&
+         hipEventQuery(e->ev_pulled[(e->n_pulled + 1) % ffm_engine::kPullRing]) == hipSuccess)
+    e->n_pulled++;
   return e->n_pulled;
 }
 
@@ -1727,6 +1750,20 @@ int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *r
   // train what the previous call staged; the block staged just now keeps uploading and grouping
   // beside it (and beside the caller's preparation of the next one)
   while (e->n_staged > 1)
+    if ((rc = train_one_staged(e))) return rc;
+  return FFM_OK;
+}
+
+int ffm_engine_train_batch_async_pinned(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                        const int32_t *field, const int32_t *feat, const float *val,
+                                        const int32_t *label) {
+  if (e && e->m.n_shards > 1)
+    return fail(FFM_E_INVALID, "sharded engines train with stage_batch + train_forward_staged + all-reduce + train_update");
+  int rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label, 1);
+  if (rc) return rc;
+  // block t+2 is staged: train block t (bench.py's schedule; the grouping of t+2 then has its
+  // window beside block t and until block t+1 ends)
+  while (e->n_staged > 2)
     if ((rc = train_one_staged(e))) return rc;
   return FFM_OK;
 }

@@ -73,6 +73,7 @@ ABI = [
     ("ffm_engine_predict_finish_device", ctypes.c_int,
      [_vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     ("ffm_engine_train_batch_async", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
+    ("ffm_engine_train_batch_async_pinned", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
     ("ffm_engine_train_flush", ctypes.c_int, [_vp, _f64p]),
     ("ffm_engine_stage_batch", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR + [ctypes.c_int32]),
     ("ffm_engine_blocks_pulled", ctypes.c_int64, [_vp]),
@@ -267,6 +268,11 @@ class Engine:
     def train_batch_async(self, c):
         """Pipelined: stages and groups this block, trains the one passed by the previous call."""
         self._check(self.lib.ffm_engine_train_batch_async(self.h, *self._csr(c)))
+
+    def train_batch_async_pinned(self, c):
+        """The same for a block in page-locked memory (pin_block): no host copy, three blocks in
+        flight; the block stays untouched until blocks_pulled() has reached its ordinal."""
+        self._check(self.lib.ffm_engine_train_batch_async_pinned(self.h, *self._csr(c)))
 
     def stage_batch(self, c, zero_copy=False):
         """Host block -> (pinned slot ->) HBM + grouping on the side stream (returns at once).

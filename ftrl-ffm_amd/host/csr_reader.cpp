@@ -1,5 +1,6 @@
 #include "csr_reader.h"
 
+#include <cstring>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -106,15 +107,35 @@ void CsrData::slice(size_t r0, size_t r1, CsrBlock &out) const {
   for (size_t r = r0; r <= r1; r++) out.row_ptr[r - r0] = static_cast<int32_t>(row_ptr[r] - b);
 }
 
-void CsrData::gather(const int *idx, size_t n, CsrBlock &out) const {
-  out.clear();
+size_t CsrData::gather_nnz(const int *idx, size_t n) const {
+  size_t total = 0;
+  for (size_t j = 0; j < n; j++) total += static_cast<size_t>(row_ptr[idx[j] + 1] - row_ptr[idx[j]]);
+  return total;
+}
+
+void CsrData::gather(const int *idx, size_t n, CsrBlock &out, int n_threads) const {
+  out.row_ptr.resize(n + 1);
+  out.label.resize(n);
+  out.row_ptr[0] = 0;
+  int32_t total = 0;
   for (size_t j = 0; j < n; j++) {
-    const int64_t b = row_ptr[idx[j]], e = row_ptr[idx[j] + 1];
-    out.field.insert(out.field.end(), field.begin() + b, field.begin() + e);
-    out.feat.insert(out.feat.end(), feat.begin() + b, feat.begin() + e);
-    out.val.insert(out.val.end(), val.begin() + b, val.begin() + e);
-    out.row_ptr.push_back(static_cast<int32_t>(out.feat.size()));
-    out.label.push_back(label[idx[j]]);
+    total += static_cast<int32_t>(row_ptr[idx[j] + 1] - row_ptr[idx[j]]);
+    out.row_ptr[j + 1] = total;
+  }
+  out.field.resize(static_cast<size_t>(total));
+  out.feat.resize(static_cast<size_t>(total));
+  out.val.resize(static_cast<size_t>(total));
+  int32_t *of = out.field.data(), *oi = out.feat.data(), *ol = out.label.data();
+  float *ov = out.val.data();
+  const int32_t *orp = out.row_ptr.data();
+#pragma omp parallel for schedule(static) num_threads(n_threads) if (n_threads > 1 && n >= 1024)
+  for (size_t j = 0; j < n; j++) {
+    const int64_t b = row_ptr[idx[j]];
+    const size_t len = static_cast<size_t>(row_ptr[idx[j] + 1] - b);
+    std::memcpy(of + orp[j], field.data() + b, 4 * len);
+    std::memcpy(oi + orp[j], feat.data() + b, 4 * len);
+    std::memcpy(ov + orp[j], val.data() + b, 4 * len);
+    ol[j] = label[idx[j]];
   }
 }
 

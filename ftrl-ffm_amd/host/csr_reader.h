@@ -21,7 +21,10 @@ struct CsrData {
   // rows [r0, r1) as one block
   void slice(size_t r0, size_t r1, CsrBlock &out) const;
   // rows idx[0..n) (any order) as one block -- the offline trainer's shuffled visit
-  void gather(const int *idx, size_t n, CsrBlock &out) const;
+  // (n_threads > 1: the rows are copied by that many OpenMP threads -- a shuffled visit is a
+  // random walk over the file image, bound by memory latency, not bandwidth)
+  void gather(const int *idx, size_t n, CsrBlock &out, int n_threads = 1) const;
+  size_t gather_nnz(const int *idx, size_t n) const;  // entries that block will hold
 };
 
 CsrData load_csr(const std::string &path, const std::string &file_type, int n_threads);

@@ -144,8 +144,48 @@ void FtrlModel::train_block_async(const CsrBlock &blk) {
     check(ffm_engine_train_batch_async(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(),
                                        b.feat.data(), b.val.data(), b.label.data()),
           "ffm_engine_train_batch_async");
+    handed_over_++;
   });
 }
+
+bool FtrlModel::pin_block(CsrBlock &blk) {
+  blk.row_ptr.reserve(static_cast<size_t>(max_rows_) + 1);
+  blk.label.reserve(static_cast<size_t>(max_rows_));
+  blk.field.reserve(static_cast<size_t>(max_nnz_));
+  blk.feat.reserve(static_cast<size_t>(max_nnz_));
+  blk.val.reserve(static_cast<size_t>(max_nnz_));
+  void *ptr[5] = {blk.row_ptr.data(), blk.label.data(), blk.field.data(), blk.feat.data(), blk.val.data()};
+  auto pages = [](size_t n) { return (4 * n + 4095) & ~static_cast<size_t>(4095); };  // (PageAllocator's)
+  const size_t bytes[5] = {pages(blk.row_ptr.capacity()), pages(blk.label.capacity()), pages(blk.field.capacity()),
+                           pages(blk.feat.capacity()), pages(blk.val.capacity())};
+  for (int i = 0; i < 5; i++)
+    if (ffm_engine_pin_host(ptr[i], bytes[i]) != FFM_OK) {
+      for (int j = 0; j < i; j++) ffm_engine_unpin_host(ptr[j]);
+      return false;
+    }
+  return true;
+}
+
+void FtrlModel::unpin_block(CsrBlock &blk) {
+  void *ptr[5] = {blk.row_ptr.data(), blk.label.data(), blk.field.data(), blk.feat.data(), blk.val.data()};
+  for (void *p : ptr) ffm_engine_unpin_host(p);
+}
+
+long long FtrlModel::train_block_pinned(const CsrBlock &blk) {
+  const int n = blk.n_rows();
+  bool fits = n <= max_rows_ && blk.row_ptr[n] <= max_nnz_;
+  for (int r = 0; r < n && fits; r++) fits = blk.row_ptr[r + 1] - blk.row_ptr[r] <= max_row_nnz_;
+  if (!fits) {  // (split into several calls, each copied: its arrays are free again on return)
+    train_block_async(blk);
+    return handed_over_;
+  }
+  check(ffm_engine_train_batch_async_pinned(eng_, n, blk.row_ptr.data(), blk.field.data(), blk.feat.data(),
+                                            blk.val.data(), blk.label.data()),
+        "ffm_engine_train_batch_async_pinned");
+  return ++handed_over_;
+}
+
+long long FtrlModel::blocks_pulled() { return ffm_engine_blocks_pulled(eng_); }
 
 double FtrlModel::train_flush() {
   double loss_sum = 0.0;

@@ -40,6 +40,15 @@ class FtrlModel {
   // The block's arrays may be reused as soon as train_block_async returns.
   void train_block_async(const CsrBlock &blk);
   double train_flush();
+  // The same without the host copy, for blocks gathered in page-locked memory: pin_block() sizes a
+  // block's arrays for one engine call and page-locks them (false: could not, use the copying
+  // path); train_block_pinned() hands such a block over -- it must then stay untouched until
+  // blocks_pulled() has reached the number it returns (blocks handed over so far).  A block that
+  // does not fit one engine call goes through the copying path instead.
+  bool pin_block(CsrBlock &blk);
+  void unpin_block(CsrBlock &blk);
+  long long train_block_pinned(const CsrBlock &blk);
+  long long blocks_pulled();
 
   // Model files in the reference's formats (ffm.cpp:138-200, lr.cpp:26-39); available for every
   // model type here (the reference has none for FM).  save_state/load_state add the FTRL
@@ -71,6 +80,7 @@ class FtrlModel {
   // engine capacities chosen at construction; blocks beyond max_nnz_ are split into several
   // engine calls (each still a block in row order), a single row beyond max_row_nnz_ is an error
   int max_rows_ = 0, max_nnz_ = 0, max_row_nnz_ = 0;
+  long long handed_over_ = 0;  // blocks passed to the engine's pipelined entry points so far
   CsrBlock part_;
   // calls `fn(sub-block)` for consecutive row ranges of blk that fit the engine
   template <typename Fn> void for_each_fitting(const CsrBlock &blk, Fn fn);

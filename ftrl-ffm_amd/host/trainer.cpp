@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <random>
+#include <thread>
 
 namespace ftrl {
 
@@ -34,6 +35,25 @@ FtrlOffline::FtrlOffline(const config_options &opt)
   }
 }
 
+FtrlOffline::~FtrlOffline() {
+  for (auto &b : ring_) model_ptr->unpin_block(b);
+}
+
+bool FtrlOffline::ensure_ring() {
+  if (ring_tried_) return !ring_.empty();
+  ring_tried_ = true;
+  if (std::getenv("FTRL_NO_PINNED_RING")) return false;  // (A/B aid: the copying path)
+  ring_.resize(kRing);
+  ring_seq_.assign(kRing, 0);
+  for (int i = 0; i < kRing; i++)
+    if (!model_ptr->pin_block(ring_[i])) {  // no page-locked memory to be had: the copying path
+      for (int j = 0; j < i; j++) model_ptr->unpin_block(ring_[j]);
+      ring_.clear();
+      return false;
+    }
+  return true;
+}
+
 // One pass over a CSR file image: training visits the rows in a seeded shuffle, block by block;
 // evaluation in file order.  Mean of loss(y, logit) over all rows.
 double FtrlOffline::csr_epoch(const CsrData &d, bool train) {
@@ -47,13 +67,27 @@ double FtrlOffline::csr_epoch(const CsrData &d, bool train) {
   }
   double total_loss = 0.0;
   CsrBlock blk;
+  const bool ring = train && ensure_ring();
+  int slot = 0;
   size_t pos = 0;
   while (pos < total) {
     const size_t rows = std::min<size_t>(train ? sched_.next_block_rows() : sched_.max_block_rows(), total - pos);
-    if (train) d.gather(indices.data() + pos, rows, blk); else d.slice(pos, pos + rows, blk);
-    // training is pipelined: this block is uploaded and grouped while the previous one trains
-    // and the next one is gathered here
-    if (train) model_ptr->train_block_async(blk); else total_loss += model_ptr->predict_block(blk, false);
+    // training is pipelined: this block is uploaded and grouped while the previous ones train
+    // and the next one is gathered here -- straight into page-locked memory when there is a ring
+    // entry it fits (the device then pulls it from there; the entry is reused once it has)
+    if (train && ring && rows < ring_[slot].row_ptr.capacity() &&
+        d.gather_nnz(indices.data() + pos, rows) <= ring_[slot].feat.capacity()) {
+      while (model_ptr->blocks_pulled() < ring_seq_[slot]) std::this_thread::yield();
+      d.gather(indices.data() + pos, rows, ring_[slot], n_threads);
+      ring_seq_[slot] = model_ptr->train_block_pinned(ring_[slot]);
+      slot = (slot + 1) % kRing;
+    } else if (train) {
+      d.gather(indices.data() + pos, rows, blk, n_threads);
+      model_ptr->train_block_async(blk);
+    } else {
+      d.slice(pos, pos + rows, blk);
+      total_loss += model_ptr->predict_block(blk, false);
+    }
     if (train) sched_.consumed(static_cast<int>(rows));
     pos += rows;
   }

@@ -42,6 +42,7 @@ class BlockScheduler {
 class FtrlOffline {
  public:
   explicit FtrlOffline(const config_options &opt);
+  ~FtrlOffline();
   void train();
   void evaluate(int epoch = 0);
   double one_epoch(std::vector<Sample> &samples, bool train, bool use_pool);
@@ -59,6 +60,13 @@ class FtrlOffline {
   CsrData train_csr_, eval_csr_;                                // what train()/evaluate() walk
   bool has_eval_ = false;
   double csr_epoch(const CsrData &d, bool train);
+  // Training blocks are gathered straight into a ring of page-locked blocks which the device
+  // pulls from (FtrlModel::train_block_pinned): no host copy, three blocks in flight.
+  static constexpr int kRing = 6;
+  std::vector<CsrBlock> ring_;
+  std::vector<long long> ring_seq_;  // ordinal of the block each ring entry carried last
+  bool ring_tried_ = false;
+  bool ensure_ring();
 };
 
 class FtrlOnline {

@@ -2,6 +2,8 @@
 // src/include/utils/types.h:18-25 and src/include/data/sample.h:6-9 so callers port unchanged.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
+#include <new>
 #include <tuple>
 #include <vector>
 
@@ -15,10 +17,28 @@ struct Sample {
   int y;
 };
 
+// Whole pages per array: a block's arrays can then be page-locked one by one (hipHostRegister
+// works on pages: two small arrays sharing a heap page cannot both be registered).
+template <typename T>
+struct PageAllocator {
+  using value_type = T;
+  PageAllocator() = default;
+  template <typename U> PageAllocator(const PageAllocator<U> &) {}
+  T *allocate(size_t n) {
+    const size_t bytes = (n * sizeof(T) + 4095) & ~static_cast<size_t>(4095);
+    void *p = std::aligned_alloc(4096, bytes ? bytes : 4096);
+    if (!p) throw std::bad_alloc();
+    return static_cast<T *>(p);
+  }
+  void deallocate(T *p, size_t) { std::free(p); }
+  template <typename U> bool operator==(const PageAllocator<U> &) const { return true; }
+  template <typename U> bool operator!=(const PageAllocator<U> &) const { return false; }
+};
+
 // A block of rows in the engine's CSR wire format (include/ffm_engine.h).
 struct CsrBlock {
-  std::vector<int32_t> row_ptr{0}, field, feat, label;
-  std::vector<float> val;
+  std::vector<int32_t, PageAllocator<int32_t>> row_ptr{0}, field, feat, label;
+  std::vector<float, PageAllocator<float>> val;
   int32_t n_rows() const { return static_cast<int32_t>(row_ptr.size()) - 1; }
   void clear() {
     row_ptr.assign(1, 0);

@@ -213,6 +213,16 @@ int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *r
                                  const int32_t *field, const int32_t *feat, const float *val,
                                  const int32_t *label);
 int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out);
+/* The same for a trainer that gathers its blocks in PAGE-LOCKED memory (hipHostMalloc, or
+ * ffm_engine_pin_host on its own buffers; every array 16-byte aligned): nothing is copied on the
+ * host, the device pulls the rows straight out of the caller's arrays, and the pipeline is three
+ * blocks deep -- block t+2 uploads and is grouped while block t trains.  The price: the arrays of a
+ * block must stay untouched until it has been uploaded, i.e. until ffm_engine_blocks_pulled() has
+ * reached the block's ordinal (blocks handed over so far, through this call or the copying one,
+ * counted from 1) -- a ring of five or six blocks never waits.  Same results, same flush. */
+int ffm_engine_train_batch_async_pinned(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                        const int32_t *field, const int32_t *feat, const float *val,
+                                        const int32_t *label);
 
 /* The two halves of ffm_engine_train_batch_async, for callers that put something between forward
  * and update -- the sharded trainer's all-reduce: ffm_engine_stage_batch copies the host block into

@@ -568,3 +568,39 @@ def test_staged_host_blocks_equal_block_by_block(zero_copy):
     if zero_copy:
         for blk in blocks:
             b_.unpin_block(blk)
+
+
+def test_pinned_async_training_equals_block_by_block():
+    """ffm_engine_train_batch_async_pinned (what the offline trainer calls: blocks gathered in
+    page-locked memory, no host copy, three blocks in flight) mixed with the copying
+    ffm_engine_train_batch_async: the bits and the loss sum of ffm_engine_train_batch block by
+    block, and blocks_pulled() reaches every block's ordinal."""
+    F, k, per = 8, 16, 50
+    nf = F * per
+    g = synth.Generator(F, nf, "zipf", seed=16)
+    blocks = [g.block(n) for n in (256, 17, 256, 256, 3, 256, 128, 256)]
+
+    def make():
+        e = fa.Engine("FFM", nf, F, k, max_batch_rows=256, seed=3, **STRESS_HP)
+        e.fill_state(seed=9)
+        return e
+
+    a = make()
+    ref_loss = sum(a.train_batch(b)[1] for b in blocks)
+    sa = a.get_state()
+    a.close()
+    e = make()
+    for blk in blocks:
+        e.pin_block(blk)
+    for i, blk in enumerate(blocks):
+        if i == 4:
+            e.train_batch_async(blk)  # a copied block in between keeps its place in the order
+        else:
+            e.train_batch_async_pinned(blk)
+    got_loss = e.train_flush()
+    assert e.blocks_pulled() == len(blocks)
+    assert abs(got_loss - ref_loss) <= 1e-9 * abs(ref_loss)
+    assert_state_bitwise(e.get_state(), sa, "pinned async training")
+    for blk in blocks:
+        e.unpin_block(blk)
+    e.close()

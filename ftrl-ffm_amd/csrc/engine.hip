@@ -410,7 +410,11 @@ struct ffm_engine {
   // upload of block number b (1-based) -> ev_pulled[b % kPullRing].  (Per staging slot it would not
   // do: a slot is refilled -- on the HOST's timeline -- while the GPU may still be several blocks
   // behind, so "its slot carries a later block" does not mean "uploaded".)
-  static constexpr int kPullRing = 16;
+  // (1024: the submitting thread of an asynchronous trainer runs hundreds of blocks ahead of the
+  // GPU; an entry is only waited for -- hipEventSynchronize stalls that thread for the whole
+  // backlog, 0.7 ms per block measured with 16 entries -- if it is still pending when its turn
+  // comes again, which the hardware queues' own depth rules out)
+  static constexpr int kPullRing = 1024;
   hipEvent_t ev_pulled[kPullRing] = {};
   double *d_loss_acc = nullptr;  // [1] sum of the async blocks' losses since the last flush
   void *d_sort_tmp[kSets] = {};  // rocPRIM radix sort workspace per scratch set
@@ -1547,28 +1551,23 @@ __global__ void loss_accumulate_kernel(double *acc, const double *one) { *acc +=
 // A hipMemcpyAsync here makes the SUBMITTING THREAD wait until the stream's earlier kernels have
 // finished (measured: mean 0.38 ms, up to 16 ms per call) -- the host then cannot run ahead of the
 // GPU and every other step starts ~230 us late; a kernel launch never blocks.
-// The host reads are SYSTEM-scope loads: memory page-locked with hipHostRegister is cacheable in
-// the L2s, and a caller that refills a block buffer it has used before (the trainers' ring) would
-// otherwise be served the previous block's lines that are still on-die -- a stale row_ptr then
-// shows up as "row longer than max_row_nnz", or worse, as plausible rows of the wrong block.
+// Every wave starts with a system-scope acquire (it drops the non-coherent lines of its L2): a
+// caller that refills a block buffer it has used before (the trainers' ring) must not be served
+// lines of the previous block that are still on-die, should the runtime map its page-locked memory
+// cacheable.  (System-scope LOADS instead -- 8 bytes per lane -- halved the upload rate.)
 struct PullJob { const char *src[5]; char *dst[5]; unsigned bytes[5]; };
 __global__ __launch_bounds__(256) void pull_block_kernel(PullJob job) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
 #pragma unroll
   for (int a = 0; a < 5; a++) {
     const unsigned n16 = job.bytes[a] >> 4;
-    const unsigned long long *s = reinterpret_cast<const unsigned long long *>(job.src[a]);
-    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(job.dst[a]);
-    for (unsigned i = tid; i < n16; i += stride) {
-      ulonglong2 v;
-      v.x = __hip_atomic_load(s + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      v.y = __hip_atomic_load(s + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      d[i] = v;
-    }
+    const int4 *s = reinterpret_cast<const int4 *>(job.src[a]);
+    int4 *d = reinterpret_cast<int4 *>(job.dst[a]);
+    for (unsigned i = tid; i < n16; i += stride) d[i] = s[i];
     const unsigned tail = job.bytes[a] & 15u;  // sizes are multiples of 4
     if (tid < (tail >> 2))
-      reinterpret_cast<int *>(job.dst[a])[(n16 << 2) + tid] = __hip_atomic_load(
-          reinterpret_cast<const int *>(job.src[a]) + (n16 << 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      reinterpret_cast<int *>(job.dst[a])[(n16 << 2) + tid] = reinterpret_cast<const int *>(job.src[a])[(n16 << 2) + tid];
   }
 }
 
@@ -1663,11 +1662,13 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
     HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
     {
       // this block's entry of the upload ring; the block that had it kPullRing blocks ago is
-      // long uploaded (the wait returns at once unless the GPU is that far behind the host)
+      // long uploaded
       const int64_t ordinal = e->n_staged_total + 1;
       hipEvent_t ev = e->ev_pulled[ordinal % ffm_engine::kPullRing];
       if (ordinal > ffm_engine::kPullRing) {
-        HIP_TRY(hipEventSynchronize(ev));
+        // (query first: hipEventSynchronize costs the submitting thread ~0.5 ms even when the
+        // event fired long ago)
+        if (hipEventQuery(ev) != hipSuccess) HIP_TRY(hipEventSynchronize(ev));
         e->n_pulled = std::max(e->n_pulled, ordinal - ffm_engine::kPullRing);
       }
       HIP_TRY(hipEventRecord(ev, e->copy));

@@ -69,18 +69,21 @@ __device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int
 
 // Stages the surviving entries of the row (remove_out_range: ftrl_model.cpp:36-42, ffm.cpp:30-36)
 // into LDS, in row order.  Executed by wave 0; the count goes to *nv_out.
+// occpos (training FFM rows): the entries' occurrence classes ride along, so nothing later in the
+// row waits on a load of its own for them.
 __device__ __forceinline__ void stage_row(const ModelDev &m, const Rows &rows, int b, int nnz,
-                                          RowLds &lds, int *nv_out) {
+                                          RowLds &lds, int *nv_out, const int *occpos = nullptr) {
   if (threadIdx.x < 64) {
     int nv = 0;
     for (int base = 0; base < nnz; base += 64) {
       const int p = base + threadIdx.x;
       bool valid = false;
-      int i = 0, f = 0;
+      int i = 0, f = 0, op = 0;
       float x = 0.0f;
       if (p < nnz) {
         i = rows.feat[b + p];
         x = rows.val[b + p];
+        if (occpos) op = occpos[b + p];
         valid = i >= 0 && i < m.n_feats;
         if (m.type == 2) {
           f = rows.field[b + p];
@@ -95,6 +98,7 @@ __device__ __forceinline__ void stage_row(const ModelDev &m, const Rows &rows, i
         lds.field[a] = f;
         lds.feat[a] = i;
         lds.val[a] = x;
+        if (occpos) lds.opos[a] = op;
       }
       nv += __popcll(mask);
     }
@@ -131,8 +135,7 @@ __device__ __forceinline__ float add_terms_in_order(const float *terms, int cnt,
 __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows &rows,
                                                    const Scratch &s, RowLds &lds, int r, int b,
                                                    int nv, int F) {
-  for (int a = threadIdx.x; a < nv; a += blockDim.x) lds.opos[a] = s.occpos[b + lds.pos[a]];
-  __syncthreads();
+  // (lds.opos: staged with the row)
   // For entries of hot features: what each partner field contributes to their touches
   // ({partner value, flags | own field, offset of the partner's weights lo, hi}), laid out by occurrence position
   // for the hot update kernel.
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
   const bool is_ffm = m.type == 2;
 
   for (int f = threadIdx.x; f < F; f += blockDim.x) { lds.fcnt[f] = 0; lds.ffirst[f] = -1; }
-  stage_row(m, rows, b, nnz, lds, &s_nv);
+  stage_row(m, rows, b, nnz, lds, &s_nv, TRAIN && is_ffm ? s.occpos : nullptr);
   __syncthreads();
   const int nv = s_nv;
 
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
     if (!owns_linear(m, lds.field[a])) return 0.0f;
     float lw;
     // refreshed >= 2: the features that occur once in the block are refreshed here, by their row
-    if (TRAIN && (refreshed == 0 || (refreshed >= 2 && s.occpos[b + lds.pos[a]] == OCC_ONCE))) {
+    if (TRAIN && (refreshed == 0 || (refreshed >= 2 && lds.opos[a] == OCC_ONCE))) {
       lw = ftrl_weight(m.h, m.lin_n[i], m.lin_z[i]);
       m.lin_w[i] = lw;
     } else {

@@ -604,3 +604,51 @@ def test_pinned_async_training_equals_block_by_block():
     for blk in blocks:
         e.unpin_block(blk)
     e.close()
+
+
+def test_ring_of_pinned_buffers_refilled_as_soon_as_blocks_pulled_allows():
+    """A trainer's ring: five page-locked block buffers, each refilled with the next block's rows
+    the moment blocks_pulled() has passed the block it carried -- with the host submitting faster
+    than the GPU trains (blocks_pulled() once counted a block as uploaded when its staging slot had
+    been handed to a later block, which on a busy GPU it had not been).  Must equal block by block."""
+    F, k, per, R = 16, 8, 400, 5
+    nf = F * per
+    g = synth.Generator(F, nf, "zipf", seed=21)
+    rows = 1024
+    blocks = [g.block(rows) for _ in range(24)] * 5  # 120 blocks through the ring
+
+    def make():
+        e = fa.Engine("FFM", nf, F, k, max_batch_rows=rows, seed=3, **STRESS_HP)
+        e.fill_state(seed=9)
+        return e
+
+    a = make()
+    ref_loss = sum(a.train_batch(b)[1] for b in blocks)
+    sa = a.get_state()
+    a.close()
+    e = make()
+    cap = rows * F
+    ring = [Csr(np.zeros(rows + 1, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32),
+                np.zeros(cap, np.float32), np.zeros(rows, np.int32)) for _ in range(R)]
+    for r in ring:
+        e.pin_block(r)
+    carried = [0] * R
+    for i, b in enumerate(blocks):
+        s = i % R
+        while e.blocks_pulled() < carried[s]:
+            pass
+        r = ring[s]
+        r.row_ptr[:] = b.row_ptr
+        r.field[:b.nnz] = b.field
+        r.feat[:b.nnz] = b.feat
+        r.val[:b.nnz] = b.val
+        r.label[:] = b.label
+        e.train_batch_async_pinned(Csr(r.row_ptr, r.field[:b.nnz], r.feat[:b.nnz], r.val[:b.nnz], r.label))
+        carried[s] = i + 1
+    got_loss = e.train_flush()
+    assert e.blocks_pulled() == len(blocks)
+    assert abs(got_loss - ref_loss) <= 1e-9 * abs(ref_loss)
+    assert_state_bitwise(e.get_state(), sa, "ring of pinned buffers")
+    for r in ring:
+        e.unpin_block(r)
+    e.close()

@@ -241,8 +241,20 @@ __device__ __forceinline__ void hot_issue_weights(const float *wcol, const HotFa
 // side_blocks > 0: the first workgroups of the launch carry the block's two short serial jobs --
 // workgroup 0 the bias chain, workgroups 1..side_blocks-1 the linear update -- so that they run
 // beside the latent chains without a stream (and a hardware queue) of their own.
+// Five waves per SIMD (at most 96 VGPRs): the kernel waits on gathers half of the time, and the
+// fifth wave is worth 1.5 % of the step.  It fits without spilling only WITHOUT the square-root
+// forwarding below (94 VGPRs; with it 105, or 96 + 20 bytes of scratch), whose 6 % fewer
+// instructions did not show in the step time -- so the forwarding is compiled out here
+// (FFM_HOT_FWD=1 -DFFM_HOT_WAVES=4 brings it back); the chain kernels keep theirs.
+#ifndef FFM_HOT_WAVES
+#define FFM_HOT_WAVES 5
+#endif
+#define FFM_HOT_OCC __attribute__((amdgpu_waves_per_eu(FFM_HOT_WAVES, FFM_HOT_WAVES)))
+#ifndef FFM_HOT_FWD
+#define FFM_HOT_FWD 0
+#endif
 // ph of `phases`: the touches that come from the rows of one row phase (engine_types.h).
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m, Rows rows,
+__global__ __launch_bounds__(kUpdThreads) FFM_HOT_OCC void ffm_update_hot_kernel(ModelDev m, Rows rows,
                                                                      Scratch s, int side_blocks,
                                                                      int ph, int phases) {
   if (static_cast<int>(blockIdx.x) < side_blocks) {
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_hot_kernel(ModelDev m,
         // IS sqrt(n-before) of the next, so one square root per touch, the last one carried into the
         // next group.  In their short exact forms (ftrl_math.h) behind one wave vote.
         bool done = false;
-        if (__all(gg_side)) {
+        if (FFM_HOT_FWD && __all(gg_side)) {
           bool ok = m.h.fast_div != 0 && (sq_valid || chain_operand_ok(nbv[0]));
 #pragma unroll
           for (int j = 0; j < kUnroll; j++) ok = ok && chain_operand_ok(naf[j]);
@@ -475,7 +487,12 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
 // Requires n_factors % 4 == 0.  c <= kSmallMax occurrences.  Kept lean in registers: the
 // bandwidth comes from many resident waves, each with its record's loads in flight.
 // few_only: the features that occur once are ffm_update_single_kernel's
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_small_kernel(ModelDev m, Rows rows,
+#ifdef FFM_SMALL_WAVES
+#define FFM_SMALL_OCC __attribute__((amdgpu_waves_per_eu(FFM_SMALL_WAVES, FFM_SMALL_WAVES)))
+#else
+#define FFM_SMALL_OCC
+#endif
+__global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_kernel(ModelDev m, Rows rows,
                                                                        Scratch s, int few_only) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int RL4 = RL >> 2, k4 = k >> 2;

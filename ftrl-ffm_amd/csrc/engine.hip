@@ -532,7 +532,11 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // The very-hot-feature chain kernels are instantiated per number of interleaved chains (groups of
 // 4 factors of a slot handled by one wave): 1, 2 or 4.
 static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows, int ph = 0, int phases = 1) {
+#ifdef FFM_CHAIN_G
+  const int groups = FFM_CHAIN_G == 4 ? 4 : FFM_CHAIN_G;  // (experiment: fewer interleaved chains per wave)
+#else
   const int groups = e->m.n_factors / 4;
+#endif
   const int gb = e->grid_giant, grid = e->grid_huge + gb;
   if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
   else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);

@@ -417,6 +417,7 @@ struct ffm_engine {
   static constexpr int kPullRing = 1024;
   hipEvent_t ev_pulled[kPullRing] = {};
   double *d_loss_acc = nullptr;  // [1] sum of the async blocks' losses since the last flush
+  double *d_loss_part = nullptr; // [kLossParts + 1] loss_sum_kernel's partial sums and ticket
   void *d_sort_tmp[kSets] = {};  // rocPRIM radix sort workspace per scratch set
   size_t sort_tmp_bytes = 0;
   unsigned sort_bits = 32;
@@ -528,6 +529,7 @@ struct ffm_engine {
   LAUNCH_ON(e, (e)->stream, kid, kernel, grid, block, shmem, __VA_ARGS__)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int loss_grid(int n_rows) { return std::max(1, std::min(kLossParts, cdiv(n_rows, 1024))); }
 
 // The very-hot-feature chain kernels are instantiated per number of interleaved chains (groups of
 // 4 factors of a slot handled by one wave): 1, 2 or 4.
@@ -582,6 +584,11 @@ int64_t ffm_engine_row_len(const ffm_engine *e) { return e ? e->logical_len : 0;
 void ffm_engine_destroy(ffm_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device_id);
+  // everything the engine has in flight -- uploads still reading the caller's page-locked arrays
+  // (staged, never trained), look-ahead groupings, the side streams -- ends before anything is freed
+  if (e->prep) (void)hipStreamSynchronize(e->prep);
+  if (e->aux2) (void)hipStreamSynchronize(e->aux2);
+  if (e->aux3) (void)hipStreamSynchronize(e->aux3);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &r : e->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
@@ -887,6 +894,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&e->d_label, R));
   TRY_ALLOC(e->alloc(&e->d_out, R));
   TRY_ALLOC(e->alloc(&e->d_loss_sum, 2));
+  TRY_ALLOC(e->alloc(&e->d_loss_part, kLossParts + 1));
+  TRY_HIP(hipMemsetAsync(e->d_loss_part, 0, sizeof(double) * (kLossParts + 1), e->stream));
   e->stage_floats = 16 << 20;  // 64 MiB dense staging for get/set
   if (static_cast<int64_t>(e->logical_len) > e->stage_floats) e->stage_floats = e->logical_len;
   TRY_ALLOC(e->alloc(&e->d_stage, static_cast<size_t>(e->stage_floats)));
@@ -1384,7 +1393,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
     launch_small();
     if (loss_sum_out)
-      LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
+      LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   } else if (ffm) {
@@ -1402,7 +1411,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   }
   if (loss_sum_out && !(ffm && vec4 && !e->serial))
-    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out);
+    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
   if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
   HIP_TRY(hipEventRecord(e->ev_set_free[e->cur], e->stream));
   e->trained_set[1] = e->trained_set[0];
@@ -1441,7 +1450,7 @@ int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
   launch_row_kernel(e, rows, false, out ? out : e->d_out, output_prob);
   if (loss_sum_out && label)
-    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out);
+    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(n_rows), 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }
@@ -1456,7 +1465,7 @@ int ffm_engine_predict_finish_device(ffm_engine *e, int32_t n_rows, const float 
   if (n_rows > 0)
     LAUNCH(e, K_TMP_GRAD, predict_finish_kernel, cdiv(n_rows, 256), 256, 0, n_rows, logit, label, output_prob, out, e->sc[e->cur].loss);
   if (loss_sum_out) {
-    if (label) LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, 1, 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out);
+    if (label) LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(n_rows), 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
     else HIP_TRY(hipMemsetAsync(loss_sum_out, 0, sizeof(double), e->stream));
   }
   HIP_TRY(hipGetLastError());

@@ -764,18 +764,40 @@ __global__ void predict_finish_kernel(int n_rows, const float *logit, const int 
 }
 
 // Deterministic sum of the per-row losses (fixed order: 256 strided partials, then a tree).
+// Several workgroups, each over a contiguous range of rows; the one that finishes last adds the
+// partial sums in workgroup order -- a fixed order of additions whatever the timing.  (One
+// workgroup took 110-150 us for the 65536 rows of an 8-GPU rank's block, at the end of the main
+// stream.)  scratch: [kLossParts] partial sums, then the ticket counter.
+constexpr int kLossParts = 64;
 __global__ __launch_bounds__(256) void loss_sum_kernel(int n_rows, const double *loss,
-                                                       double *out) {
+                                                       double *out, double *scratch) {
   __shared__ double part[256];
+  __shared__ bool last;
+  const int per = (n_rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * per, r1 = min(n_rows, r0 + per);
   double acc = 0.0;
-  for (int r = threadIdx.x; r < n_rows; r += 256) acc += loss[r];
+  for (int r = r0 + threadIdx.x; r < r1; r += 256) acc += loss[r];
   part[threadIdx.x] = acc;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
     if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out = part[0];
+  unsigned *ticket = reinterpret_cast<unsigned *>(scratch + kLossParts);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&scratch[blockIdx.x], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    double total = 0.0;
+    for (unsigned b = 0; b < gridDim.x; b++)
+      total += __hip_atomic_load(&scratch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *out = total;
+    *ticket = 0u;
+  }
 }
 
 // Evaluates sigmoid_ref on an array (self-test entry point: lets the parity tests compare the

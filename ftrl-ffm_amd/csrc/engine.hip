@@ -407,15 +407,14 @@ struct ffm_engine {
   int n_staged = 0;
   int cur_slot = -1;        // slot of the block between train_forward_staged and train_update
   int64_t n_staged_total = 0, n_pulled = 0;  // blocks staged so far / known to be uploaded
-  // upload of block number b (1-based) -> ev_pulled[b % kPullRing].  (Per staging slot it would not
-  // do: a slot is refilled -- on the HOST's timeline -- while the GPU may still be several blocks
-  // behind, so "its slot carries a later block" does not mean "uploaded".)
-  // (1024: the submitting thread of an asynchronous trainer runs hundreds of blocks ahead of the
-  // GPU; an entry is only waited for -- hipEventSynchronize stalls that thread for the whole
-  // backlog, 0.7 ms per block measured with 16 entries -- if it is still pending when its turn
-  // comes again, which the hardware queues' own depth rules out)
-  static constexpr int kPullRing = 1024;
-  hipEvent_t ev_pulled[kPullRing] = {};
+  // The upload kernel of block number b (1-based; uploads run in staging order) writes b into a
+  // word of page-locked host memory when its last workgroup is done: ffm_engine_blocks_pulled is a
+  // plain read.  (Per staging slot would not do -- a slot is refilled, on the HOST's timeline, while
+  // the GPU may still be several blocks behind --, and an event per block costs the submitting
+  // thread a query per poll and the runtime a signal per block.)
+  long long *h_pulled = nullptr;       // hipHostMalloc
+  long long *d_pulled = nullptr;       // the same word as the device sees it
+  unsigned *d_pull_ticket = nullptr;   // workgroups of the running upload kernel that are done
   double *d_loss_acc = nullptr;  // [1] sum of the async blocks' losses since the last flush
   double *d_loss_part = nullptr; // [kLossParts + 1] loss_sum_kernel's partial sums and ticket
   void *d_sort_tmp[kSets] = {};  // rocPRIM radix sort workspace per scratch set
@@ -606,7 +605,7 @@ void ffm_engine_destroy(ffm_engine *e) {
   }
   if (e->ev_rows_done) (void)hipEventDestroy(e->ev_rows_done);
   for (auto &ev : e->ev_row) if (ev) (void)hipEventDestroy(ev);
-  for (auto &ev : e->ev_pulled) if (ev) (void)hipEventDestroy(ev);
+  if (e->h_pulled) (void)hipHostFree(e->h_pulled);
   if (e->prep) (void)hipStreamDestroy(e->prep);
 
   if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
@@ -1568,7 +1567,10 @@ __global__ void loss_accumulate_kernel(double *acc, const double *one) { *acc +=
 // caller that refills a block buffer it has used before (the trainers' ring) must not be served
 // lines of the previous block that are still on-die, should the runtime map its page-locked memory
 // cacheable.  (System-scope LOADS instead -- 8 bytes per lane -- halved the upload rate.)
-struct PullJob { const char *src[5]; char *dst[5]; unsigned bytes[5]; };
+struct PullJob {
+  const char *src[5]; char *dst[5]; unsigned bytes[5];
+  long long ordinal; long long *pulled; unsigned *ticket;  // completion word (host memory), see h_pulled
+};
 __global__ __launch_bounds__(256) void pull_block_kernel(PullJob job) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
@@ -1581,6 +1583,15 @@ __global__ __launch_bounds__(256) void pull_block_kernel(PullJob job) {
     const unsigned tail = job.bytes[a] & 15u;  // sizes are multiples of 4
     if (tid < (tail >> 2))
       reinterpret_cast<int *>(job.dst[a])[(n16 << 2) + tid] = reinterpret_cast<const int *>(job.src[a])[(n16 << 2) + tid];
+  }
+  // the workgroup that finishes last publishes the block's number to the host
+  __syncthreads();  // (every load of this workgroup has returned: its stores were issued after them)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(job.ticket, 1u) == gridDim.x - 1) {
+      *job.ticket = 0u;
+      __hip_atomic_store(job.pulled, job.ordinal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1597,7 +1608,11 @@ static int slots_init(ffm_engine *e) {
     HIP_TRY(hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&sl.ev_trained, hipEventDisableTiming));
   }
-  for (auto &ev : e->ev_pulled) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_pulled), 64, hipHostMallocDefault));
+  *e->h_pulled = 0;
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_pulled), e->h_pulled, 0));
+  if (int rc_t = e->alloc(&e->d_pull_ticket, 1)) return rc_t;
+  HIP_TRY(hipMemsetAsync(e->d_pull_ticket, 0, sizeof(unsigned), e->copy));
   int rc = e->alloc(&e->d_loss_acc, 1);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(e->d_loss_acc, 0, sizeof(double), e->stream));
@@ -1671,21 +1686,11 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
     HIP_TRY(put(feat, 4 * E, sl.feat));
     HIP_TRY(put(val, 4 * E, sl.val));
     HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
+    job.ordinal = e->n_staged_total + 1;
+    job.pulled = e->d_pulled;
+    job.ticket = e->d_pull_ticket;
     hipLaunchKernelGGL(pull_block_kernel, dim3(e->grid_pull), dim3(256), 0, e->copy, job);
     HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
-    {
-      // this block's entry of the upload ring; the block that had it kPullRing blocks ago is
-      // long uploaded
-      const int64_t ordinal = e->n_staged_total + 1;
-      hipEvent_t ev = e->ev_pulled[ordinal % ffm_engine::kPullRing];
-      if (ordinal > ffm_engine::kPullRing) {
-        // (query first: hipEventSynchronize costs the submitting thread ~0.5 ms even when the
-        // event fired long ago)
-        if (hipEventQuery(ev) != hipSuccess) HIP_TRY(hipEventSynchronize(ev));
-        e->n_pulled = std::max(e->n_pulled, ordinal - ffm_engine::kPullRing);
-      }
-      HIP_TRY(hipEventRecord(ev, e->copy));
-    }
   }
   // group it ahead, behind its own upload on the prep stream
   {
@@ -1708,11 +1713,7 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
 // How many of the blocks staged so far have been uploaded (their host arrays are free again).
 int64_t ffm_engine_blocks_pulled(ffm_engine *e) {
   if (!e || !e->slots_ready) return 0;
-  // blocks are uploaded in staging order: advance over the ring entries whose event has fired
-  // (entries are re-recorded only kPullRing blocks later, after n_pulled has passed them)
-  while (e->n_pulled < e->n_staged_total &&
-         hipEventQuery(e->ev_pulled[(e->n_pulled + 1) % ffm_engine::kPullRing]) == hipSuccess)
-    e->n_pulled++;
+  e->n_pulled = std::max<int64_t>(e->n_pulled, __atomic_load_n(e->h_pulled, __ATOMIC_ACQUIRE));
   return e->n_pulled;
 }
 

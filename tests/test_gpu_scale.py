@@ -97,11 +97,11 @@ def test_headline_size_model_matches_remapped_oracle(name, mt, F, k, n_feats, ne
     e.close()
 
 
-@pytest.mark.parametrize("F,k,per,B", [(8, 16, 40, 512), (39, 16, 60, 2048), (6, 4, 3, 1500)])
+@pytest.mark.parametrize("F,k,per,B", [(8, 16, 40, 1024), (39, 16, 60, 2048), (6, 4, 3, 1500)])
 def test_quirk_nans_flow_through_the_chain_kernels(F, k, per, B):
     """No +0.05 on n here: with n near 0 the reference's sqrt(n + g2*g1) (ffm.cpp:118) goes NaN for
-    many j-side touches, and with so few ids per field every feature is hot (5..96 occurrences)
-    or very hot (> 96): the NaNs must propagate through the DPP chains exactly as through the
+    many j-side touches, and with so few ids per field every feature is hot (5..192 occurrences)
+    or very hot (> 192): the NaNs must propagate through the DPP chains exactly as through the
     oracle's sequential loop -- same positions in n, z, w and in the next block's logits."""
     rng = np.random.default_rng(23)
     nf = F * per
@@ -121,8 +121,8 @@ def test_quirk_nans_flow_through_the_chain_kernels(F, k, per, B):
     assert np.isnan(so["vec_z"]).any(), "the case must actually produce NaNs"
     assert_state_bitwise(se, so, "NaN chains F=%d" % F)
     _, cnt = np.unique(blk.rows(0, B).feat, return_counts=True)
-    assert (cnt > 96).any()  # very hot chains are exercised ...
-    assert F == 6 or ((cnt > 4) & (cnt <= 96)).any()  # ... and (but for the tiny case) hot ones
+    assert (cnt > 192).any()  # very hot chains are exercised ...
+    assert F == 6 or ((cnt > 4) & (cnt <= 192)).any()  # ... and (but for the tiny case) hot ones
     e.close()
 
 

@@ -45,7 +45,7 @@ CONFIGS = {
     "c4": dict(model="FM", fields=39, factors=64, rows=8192, feats=10_000_000),
 }
 PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-SMALL_MAX, HUGE_MIN = 4, 192  # occurrence classes of the update kernels (csrc/engine_types.h)
+SMALL_MAX, HUGE_MIN = 8, 192  # occurrence classes of the update kernels (csrc/engine_types.h)
 
 
 def algorithmic_bytes_per_row(nnz, k):
@@ -77,7 +77,7 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
       row kernel           : CSR in, linear weights, logit / tmp_grad / loss out (+ the above; + in
                              mode 3 the once-only features' update)
       update               : write (n,z) = 8 B per slot-factor of the occurrences each kernel owns
-                             (features with 1, 2..4, 5..192, > 192 occurrences in the block)
+                             (features with 1, 2..8, 9..192, > 192 occurrences in the block)
     Under field-pair sharding every rank moves 1/n_shards of the slot-factors."""
     per_occ = (nnz - 1) * k  # slot-factors one occurrence of a feature touches
     rows = [len(f) // nnz for f in blocks_feat]

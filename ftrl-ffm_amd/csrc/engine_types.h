@@ -194,8 +194,9 @@ constexpr int kHugeMin = FFM_HUGE_MIN;  // occurrences per block above which a f
 constexpr int kGiantMin = FFM_GIANT_MIN;
 enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
                                                      // first / several entries share the field
+// (4 until the once-only features left the update phase; re-swept since: 8)
 #ifndef FFM_SMALL_MAX
-#define FFM_SMALL_MAX 4
+#define FFM_SMALL_MAX 8
 #endif
 constexpr int kSmallMax = FFM_SMALL_MAX;  // occurrences per block up to which a feature takes the "small" path
 enum { ERR_ROW_TOO_LONG = 1, ERR_FIELD_MAP = 2 };

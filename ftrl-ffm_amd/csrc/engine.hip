@@ -1366,8 +1366,12 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   // small features on the main stream: the once-only ones through their descriptor kernel
   auto launch_small = [&]() {
     const bool single = e->single_kernel;
-    if (single && !e->singles_in_row)  // (else: already applied by the row kernel)
-      LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    if (single && !e->singles_in_row) {  // (else: already applied by the row kernel)
+      const int span4 = e->m.rec_slots * (e->m.n_factors / 4);  // 16-byte vectors of a stored record
+      if (span4 <= 64) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<1>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      else if (span4 <= 128) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    }
     LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
   };
   if (ffm && vec4 && e->serial) {

@@ -566,8 +566,10 @@ __global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_ke
 // wrote for it, so the dependent-load chain is three deep instead of six (descriptor -> record
 // vectors + the row's per-field table -> partner weights): each lane takes up to kSingleTrips
 // 16-byte vectors of the record and has all their loads in flight together.
-constexpr int kSingleTrips = 3;
-
+// (kSingleTrips: 3 covers a full 39x16 record in one pass; a compact shard's record is a quarter
+// of that, and the vectors it would never use cost registers -- 125 against 73 -- and wave slots:
+// the engine picks the instantiation by the stored record's length)
+template <int kSingleTrips>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev m, Rows rows,
                                                                         Scratch s) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;

@@ -463,7 +463,8 @@ struct ffm_engine {
   // slowed the HBM-bound kernels they ran beside up to 4x (refresh of a 65536-row block 70 -> 330 us),
   // 24 (96 KB, about the link's bandwidth-delay product) still move the block at link rate.
   int grid_pull = 24;
-  int grid_giant = 512;  // workgroups of the chain launch that walk the giant features (FFM_GRID_GIANT)
+  int grid_giant = 512;  // workgroups that walk the giant features (FFM_GRID_GIANT)
+  bool giant_apart = false;  // ... in a launch of their own on the hot kernel's stream (FFM_GIANT_APART=0: inside the chain launch)
   // FFM_WAIT_GROUPING=1: hold the update kernels until the look-ahead grouping in flight is done
   bool wait_grouping = false;
   bool single_kernel = true;  // FFM_SINGLE_KERNEL=0: once-only features through the small kernel
@@ -538,10 +539,22 @@ static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows, in
 #else
   const int groups = e->m.n_factors / 4;
 #endif
-  const int gb = e->grid_giant, grid = e->grid_huge + gb;
+  // giant_apart: the giant features have a launch of their own (launch_ffm_giant)
+  const int gb = e->giant_apart ? 0 : e->grid_giant, grid = e->grid_huge + gb;
   if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
   else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
   else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
+}
+
+// Experiment (FFM_GIANT_APART=1, off): the giant features (kGiantMin occurrences or more: the
+// 65536-row blocks of a multi-GPU job have them) in a launch of their own on the hot kernel's
+// stream -- the one-chain-per-wave instantiation needs 57 VGPRs against the 122 of the four-chain
+// kernel it rides in.  Measured 5 % slower per step: the giant launch lasts as long as its longest
+// chain (0.5 ms alone on the chip) whatever the occupancy, and the hot kernel queues behind it.
+static void launch_ffm_giant(ffm_engine *e, hipStream_t st, const Rows &rows, int ph = 0, int phases = 1) {
+  if (!e->giant_apart || e->grid_giant <= 0 || rows.n_rows < kGiantMin) return;
+  LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, e->grid_giant, kUpdThreads, 0, e->m, rows,
+            e->sc[e->cur], e->grid_giant, ph, phases);
 }
 
 // Row phases a block of n_rows rows is grouped for (and trained in, when the row kernel has the
@@ -674,6 +687,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_GIANT")) e->grid_giant = std::max(0, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_GIANT_APART")) e->giant_apart = sv[0] != '0';
   {
     const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
     const int64_t per = cfg->n_factors % 4 == 0 ? static_cast<int64_t>(cfg->n_fields) * cfg->n_factors / 4
@@ -1378,6 +1392,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
   };
   if (ffm && vec4 && e->serial) {
+    launch_ffm_giant(e, e->stream, rows);
     launch_ffm_chain(e, e->stream, rows);
     LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, 0, 1);
     launch_small();
@@ -1394,6 +1409,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     for (int ph = 0; ph < P; ph++) {
       HIP_TRY(hipStreamWaitEvent(e->aux2, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
+      launch_ffm_giant(e, e->aux2, rows, ph, P);
       LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, P);
     }
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));

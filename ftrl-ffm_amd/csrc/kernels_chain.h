@@ -253,7 +253,15 @@ template <int G>
 __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &rows, const Scratch &s,
                                                 const int *list, int n_list, unsigned wave,
                                                 unsigned n_waves, int ph, int phases) {
-  constexpr int CH = kChainChunk;
+  // One chain per wave (the giant features) takes 0.9 us per 16-touch step even alone on the
+  // chip, three times its issue cost; deeper prefetch for it (FFM_GIANT_CHUNK = 2, 4, 8: facts and
+  // weights up to 16 / 8 steps ahead, 107 VGPRs) measured 0 to 5 % SLOWER per step on an 8-GPU
+  // rank's blocks, a launch of its own at twice the occupancy (FFM_GIANT_APART) 5 % slower, issue
+  // priority (FFM_GIANT_PRIO) the same: kept as knobs, off.
+#ifndef FFM_GIANT_CHUNK
+#define FFM_GIANT_CHUNK 1
+#endif
+  constexpr int CH = G == 1 ? FFM_GIANT_CHUNK : kChainChunk;
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int lane = threadIdx.x & 63;
   const int tl = lane & (kChainT - 1), el = lane >> 4;
@@ -437,10 +445,13 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
                                                                        Scratch s, int giant_blocks,
                                                                        int ph, int phases) {
   const unsigned w = wave_uniform(threadIdx.x >> 6);
-  if (static_cast<int>(blockIdx.x) < giant_blocks)
+  if (static_cast<int>(blockIdx.x) < giant_blocks) {
+#ifdef FFM_GIANT_PRIO
+    __builtin_amdgcn_s_setprio(FFM_GIANT_PRIO);  // (experiment: no measurable effect)
+#endif
     ffm_chain_items<1>(m, rows, s, s.giant, s.counters[CNT_NGIANT], blockIdx.x * kUpdWaves + w,
                        giant_blocks * kUpdWaves, ph, phases);
-  else
+  } else
     ffm_chain_items<G>(m, rows, s, s.huge, s.counters[CNT_NHUGE],
                        (blockIdx.x - giant_blocks) * kUpdWaves + w, (gridDim.x - giant_blocks) * kUpdWaves,
                        ph, phases);

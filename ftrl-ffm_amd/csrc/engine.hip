@@ -468,6 +468,7 @@ struct ffm_engine {
   // FFM_WAIT_GROUPING=1: hold the update kernels until the look-ahead grouping in flight is done
   bool wait_grouping = false;
   bool single_kernel = true;  // FFM_SINGLE_KERNEL=0: once-only features through the small kernel
+  bool single_flat = true;    // FFM_SINGLE_FLAT=0: one wave per feature also for short stored records
   int row_threads = kRowThreads;  // workgroup size of the FFM row kernel (FFM_ROW_THREADS)
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // profiling
@@ -673,6 +674,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::min(kRowThreads, std::max(64, std::atoi(sv) / 64 * 64));
   if (const char *sv = std::getenv("FFM_WAIT_GROUPING")) e->wait_grouping = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
+  if (const char *sv = std::getenv("FFM_SINGLE_FLAT")) e->single_flat = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_GRID_SINGLE")) e->grid_single = std::max(1, std::atoi(sv));
   // a sharded rank's very hot list holds n_shards times the rows' worth of features, each with
   // 1/n_shards of its slots: more, shorter items (measured under bench.py --emulate-shards 8)
@@ -1385,11 +1387,15 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     const bool single = e->single_kernel;
     if (single && !e->singles_in_row) {  // (else: already applied by the row kernel)
       const int span4 = e->m.rec_slots * (e->m.n_factors / 4);  // 16-byte vectors of a stored record
-      if (span4 <= 64) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<1>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      if (span4 < 64 && e->single_flat) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_flat_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      else if (span4 <= 64) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<1>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else if (span4 <= 128) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     }
-    LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
+    if (e->m.rec_slots * (e->m.n_factors / 4) < 64 && e->single_flat)
+      LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
+    else
+      LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
   };
   if (ffm && vec4 && e->serial) {
     launch_ffm_giant(e, e->stream, rows);

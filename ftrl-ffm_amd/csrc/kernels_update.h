@@ -559,6 +559,66 @@ __global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_ke
   }
 }
 
+// The same for SHORT stored records (a compact shard's), a lane = one (feature, vector) of a flat
+// index space -- see ffm_update_single_flat_kernel below.
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_small_flat_kernel(ModelDev m, Rows rows,
+                                                                            Scratch s, int few_only) {
+  const int RL4 = m.row_len >> 2, k4 = m.n_factors >> 2, F = m.n_fields;
+  const int span4 = record_span(m, k4);
+  const int *list = few_only ? s.few : s.small;
+  const unsigned total =
+      static_cast<unsigned>(s.counters[few_only ? CNT_NFEW : CNT_NSMALL]) * static_cast<unsigned>(span4);
+  const double inv_span = 1.0 / static_cast<double>(span4);
+  const float inv_k4 = 1.0f / static_cast<float>(k4);
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    int li = static_cast<int>((static_cast<double>(t) + 0.5) * inv_span);  // t / span4, corrected
+    li += static_cast<unsigned>(li + 1) * span4 <= t ? 1 : (static_cast<unsigned>(li) * span4 > t ? -1 : 0);
+    const int l = static_cast<int>(t - static_cast<unsigned>(li) * span4);  // vector of the stored record
+    int sl = static_cast<int>((l + 0.5f) * inv_k4);                         // its slot
+    sl += (sl + 1) * k4 <= l ? 1 : (sl * k4 > l ? -1 : 0);
+    const int kq = l - sl * k4;
+    const int4 ud = s.udesc[list[li]];  // {feature, start, count, field}
+    const int i = ud.x, start = ud.y, c = ud.z, fa = ud.w;
+    const int fp = walk_field(m, fa, sl);  // partner field of this vector's slot
+    if (fp < 0) continue;
+    const unsigned long long own_bits = owner_bits(m, fp);
+    float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
+    float4 n4 = rec4[LAT_N * RL4 + l], z4 = rec4[LAT_Z * RL4 + l];
+    const float4 w4 = rec4[LAT_W * RL4 + l];
+    bool touched = false;
+    for (int j = 0; j < c; j++) {
+      const int2 pr = s.occ2[start + j];
+      const int p = pr.x, r = pr.y;
+      const int fm = rows.field[p];
+      if (!owns_bit(own_bits, fm)) continue;
+      const float xm = rows.val[p], tg = s.tg[r];
+      const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
+      const int q = rt.z;
+      if (q >= 0) {
+        if (q != p) {
+          const float4 vp = reinterpret_cast<const float4 *>(
+              lat_row(m, rt.x, fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
+          ffm_touch4(m.h, p < q, tg, xm, __int_as_float(rt.y), vp, w4, n4, z4);
+          touched = true;
+        }
+      } else if (q == -2) {
+        for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+          if (qq == p) continue;
+          const float4 vp = reinterpret_cast<const float4 *>(
+              lat_row(m, rows.feat[qq], fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
+          ffm_touch4(m.h, p < qq, tg, xm, rows.val[qq], vp, w4, n4, z4);
+          touched = true;
+        }
+      }
+    }
+    if (touched) {
+      rec4[LAT_N * RL4 + l] = n4;
+      rec4[LAT_Z * RL4 + l] = z4;
+    }
+  }
+}
+
 // ---- features that occur ONCE in the block (most of the distinct features) ----------------------
 // (On one shard the row kernel applies these touches itself -- kernels_row.h, refreshed == 3 --
 // and this kernel is not launched; a shard of several only has tmp_grad after the all-reduce.)
@@ -641,6 +701,59 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev
           rec4[LAT_Z * RL4 + l[t]] = z4[t];
         }
       }
+    }
+  }
+}
+
+// The same for SHORT stored records (a compact shard's: 40 vectors at 10 slots x 16 factors): one
+// wave per feature would leave a third of its lanes idle, so here a lane is one (feature, vector)
+// of a flat index space and a wave covers the end of one record and the start of the next.  What
+// was wave-uniform (descriptor, row table, tmp_grad) becomes a broadcast load per lane.
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_single_flat_kernel(ModelDev m, Rows rows,
+                                                                             Scratch s) {
+  const int RL4 = m.row_len >> 2, k4 = m.n_factors >> 2, F = m.n_fields;
+  const int span4 = record_span(m, k4);
+  const unsigned total = static_cast<unsigned>(s.counters[CNT_NSINGLE]) * static_cast<unsigned>(span4);
+  const double inv_span = 1.0 / static_cast<double>(span4);
+  const float inv_k4 = 1.0f / static_cast<float>(k4);
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    // li = t / span4 through the double reciprocal (exact after one correction for t < 2^31)
+    int li = static_cast<int>((static_cast<double>(t) + 0.5) * inv_span);
+    li += static_cast<unsigned>(li + 1) * span4 <= t ? 1 : (static_cast<unsigned>(li) * span4 > t ? -1 : 0);
+    const int ll = static_cast<int>(t - static_cast<unsigned>(li) * span4);  // vector of the stored record
+    int sl = static_cast<int>((ll + 0.5f) * inv_k4);                         // its slot
+    sl += (sl + 1) * k4 <= ll ? 1 : (sl * k4 > ll ? -1 : 0);
+    const int kq = ll - sl * k4;
+    const int4 d = s.sdesc[li];  // {feature, entry, row, field}
+    const int i = d.x, p = d.y, r = d.z, fa = d.w;
+    const int f = walk_field(m, fa, sl);  // partner field of this vector's slot
+    if (f < 0 || !owns_bit(owner_bits(m, fa), f)) continue;
+    const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + f];
+    const int q = rt.z;
+    if (q == -1 || q == p) continue;  // no entry of that field in the row (or only this one)
+    float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
+    float4 n4 = rec4[LAT_N * RL4 + ll], z4 = rec4[LAT_Z * RL4 + ll];
+    const float4 w4 = rec4[LAT_W * RL4 + ll];
+    const float xm = rows.val[p], tg = s.tg[r];
+    bool touched = false;
+    if (q >= 0) {
+      const float4 vp = reinterpret_cast<const float4 *>(
+          lat_row(m, rt.x, f))[LAT_W * RL4 + slot_of(m, f, fa) * k4 + kq];
+      ffm_touch4(m.h, p < q, tg, xm, __int_as_float(rt.y), vp, w4, n4, z4);
+      touched = true;
+    } else {  // several entries of that field in the row: walk them in row order
+      for (int qq = s.head[static_cast<int64_t>(r) * F + f]; qq >= 0; qq = s.next[qq]) {
+        if (qq == p) continue;
+        const float4 vq = reinterpret_cast<const float4 *>(
+            lat_row(m, rows.feat[qq], f))[LAT_W * RL4 + slot_of(m, f, fa) * k4 + kq];
+        ffm_touch4(m.h, p < qq, tg, xm, rows.val[qq], vq, w4, n4, z4);
+        touched = true;
+      }
+    }
+    if (touched) {
+      rec4[LAT_N * RL4 + ll] = n4;
+      rec4[LAT_Z * RL4 + ll] = z4;
     }
   }
 }

@@ -469,6 +469,7 @@ struct ffm_engine {
   bool wait_grouping = false;
   bool single_kernel = true;  // FFM_SINGLE_KERNEL=0: once-only features through the small kernel
   bool single_flat = true;    // FFM_SINGLE_FLAT=0: one wave per feature also for short stored records
+  bool small_flat_always = false;  // FFM_SMALL_FLAT=1 (experiment): the flat few-occurrence kernel for long records too
   int row_threads = kRowThreads;  // workgroup size of the FFM row kernel (FFM_ROW_THREADS)
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // profiling
@@ -675,6 +676,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_WAIT_GROUPING")) e->wait_grouping = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_SINGLE_FLAT")) e->single_flat = sv[0] != '0';
+  if (const char *sv = std::getenv("FFM_SMALL_FLAT")) e->small_flat_always = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_GRID_SINGLE")) e->grid_single = std::max(1, std::atoi(sv));
   // a sharded rank's very hot list holds n_shards times the rows' worth of features, each with
   // 1/n_shards of its slots: more, shorter items (measured under bench.py --emulate-shards 8)
@@ -1392,7 +1394,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       else if (span4 <= 128) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     }
-    if (e->m.rec_slots * (e->m.n_factors / 4) < 64 && e->single_flat)
+    if ((e->m.rec_slots * (e->m.n_factors / 4) < 64 && e->single_flat) || e->small_flat_always)
       LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
     else
       LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);

@@ -559,6 +559,16 @@ static void launch_ffm_giant(ffm_engine *e, hipStream_t st, const Rows &rows, in
             e->sc[e->cur], e->grid_giant, ph, phases);
 }
 
+// The once-only / few-occurrence kernels over a flat (feature, vector) index space instead of a
+// wave per feature: when a wave per feature would leave more than a sixth of its lanes idle on a
+// compact shard's records (40 vectors at 8 shards, 80 at 2 or 4).  For full-length records (156
+// vectors, 81 % lane use) the flat shape measured no better.
+static bool flat_pays(const ffm_engine *e, int span4) {
+  if (!e->single_flat || e->m.n_shards <= 1 || span4 <= 0) return false;
+  const int lanes = (span4 + 63) / 64 * 64;
+  return span4 * 6 < lanes * 5;
+}
+
 // Row phases a block of n_rows rows is grouped for (and trained in, when the row kernel has the
 // whole logit): only where the forward pass and the hot features' update are both long enough.
 static int phases_for(const ffm_engine *e, int n_rows) {
@@ -1389,12 +1399,12 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     const bool single = e->single_kernel;
     if (single && !e->singles_in_row) {  // (else: already applied by the row kernel)
       const int span4 = e->m.rec_slots * (e->m.n_factors / 4);  // 16-byte vectors of a stored record
-      if (span4 < 64 && e->single_flat) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_flat_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      if (flat_pays(e, span4)) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_flat_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else if (span4 <= 64) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<1>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else if (span4 <= 128) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     }
-    if ((e->m.rec_slots * (e->m.n_factors / 4) < 64 && e->single_flat) || e->small_flat_always)
+    if (flat_pays(e, e->m.rec_slots * (e->m.n_factors / 4)) || e->small_flat_always)
       LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
     else
       LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);

@@ -1020,6 +1020,10 @@ int ffm_engine_eval_sigmoid(ffm_engine *e, int32_t n, const float *x, float *y) 
 // that a block could not be trained.
 static int check_device_errors(ffm_engine *e) {
   int flags = 0;
+  // the uploads of blocks that are staged but not trained yet run on the prep stream: the
+  // zero-copy contract (include/ffm_engine.h) lets the caller reuse its page-locked arrays once
+  // this returns, so they must have been pulled too
+  for (int i = 0; i < e->n_staged; i++) HIP_TRY(hipEventSynchronize(e->slots[e->staged[i]].ev_copied));
   HIP_TRY(hipMemcpyAsync(&flags, e->d_err, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (flags) HIP_TRY(hipMemsetAsync(e->d_err, 0, sizeof(int), e->stream));
@@ -1690,6 +1694,10 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
   if (e->n_staged >= ffm_engine::kSlots - 1) return fail(FFM_E_CAPACITY, "three staged blocks are already waiting");
   if (e->has_pending) return fail(FFM_E_INVALID, "stage between train_forward and train_update");
+  // everything ffm_engine_prepare_device can refuse is refused HERE, before the upload kernel is
+  // launched: that kernel publishes the block's ordinal to ffm_engine_blocks_pulled, and a block
+  // that then failed to stage would leave the count one ahead for good
+  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "three prepared blocks are already waiting");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   if ((rc = slots_init(e))) return rc;
   ffm_engine::Slot &sl = e->slots[e->slot_next];

@@ -75,6 +75,7 @@ __device__ __forceinline__ void stage_row(const ModelDev &m, const Rows &rows, i
                                           RowLds &lds, int *nv_out, const int *occpos = nullptr) {
   if (threadIdx.x < 64) {
     int nv = 0;
+    bool bad = false;
     for (int base = 0; base < nnz; base += 64) {
       const int p = base + threadIdx.x;
       bool valid = false;
@@ -88,6 +89,9 @@ __device__ __forceinline__ void stage_row(const ModelDev &m, const Rows &rows, i
         if (m.type == 2) {
           f = rows.field[b + p];
           valid = valid && f >= 0 && f < m.n_fields;
+          // compact shard: an id outside its field's id range has no record here (group_keys_kernel
+          // voids a TRAINING block for it; predict rows are caught here -- ADVICE r02)
+          if (valid && m.field_start && (i < m.field_start[f] || i >= m.field_start[f + 1])) bad = true;
           if (valid) valid = keeps_field(m, f);  // a compact shard drops the columns it owns nothing of
         }
       }
@@ -102,7 +106,8 @@ __device__ __forceinline__ void stage_row(const ModelDev &m, const Rows &rows, i
       }
       nv += __popcll(mask);
     }
-    if (threadIdx.x == 0) *nv_out = nv;
+    const bool any_bad = __any(bad);
+    if (threadIdx.x == 0) *nv_out = any_bad ? -1 : nv;  // -1: an id outside its field's range
   }
 }
 
@@ -275,6 +280,16 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
   stage_row(m, rows, b, nnz, lds, &s_nv, TRAIN && is_ffm ? s.occpos : nullptr);
   __syncthreads();
   const int nv = s_nv;
+  if (nv < 0) {  // compact shard, an id outside its field's range: no record to read -- NaN row
+    if (threadIdx.x == 0) {
+      atomicOr(s.err, ERR_FIELD_MAP);
+      const float nan = __int_as_float(0x7fc00000);
+      if (TRAIN) { s.logit[r] = nan; s.tg[r] = 0.0f; }
+      s.loss[r] = static_cast<double>(nan);
+      if (out) out[r] = nan;
+    }
+    return;
+  }
 
   // linear weights of the surviving entries (update_linear_w, ftrl_model.cpp:52-59).  The first
   // blockDim.x of them are fetched now into a register each, so that the loads fly while the row's

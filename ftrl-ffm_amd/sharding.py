@@ -59,8 +59,19 @@ class ShardedStep:
         if cur is not None:
             self._ext.wait_stream(cur)          # and summed before the engine consumes them
 
+    def _inputs_ready(self):
+        """Device CSR arrays are usually produced on torch's current stream (non-blocking H2D,
+        preprocessing kernels); the engine reads them on ITS stream, so that stream first waits for
+        what the current stream has enqueued so far (read-before-write otherwise)."""
+        if self._ext is None:
+            return
+        cur = self._torch.cuda.current_stream(self.logit.device)
+        if cur.cuda_stream != self._ext.cuda_stream:
+            self._ext.wait_stream(cur)
+
     def __call__(self, n_rows, nnz, row_ptr, field, feat, val, label, loss_sum_out=None):
         ptr = self.logit.data_ptr()
+        self._inputs_ready()
         self.engine.train_forward_device(n_rows, nnz, row_ptr, field, feat, val, label, ptr)
         self._exchange(n_rows)
         self.engine.train_update_device(ptr, None, loss_sum_out)
@@ -81,6 +92,7 @@ class ShardedStep:
                 out=None, loss_sum_out=None):
         """predict() on the sharded model: partial logits -> all-reduce -> value / logloss."""
         ptr = self.logit.data_ptr()
+        self._inputs_ready()
         self.engine.predict_batch_device(n_rows, nnz, row_ptr, field, feat, val, None, False, ptr)
         self._exchange(n_rows)
         self.engine.predict_finish_device(n_rows, ptr, label, output_prob, out if out else ptr,

@@ -250,6 +250,24 @@ def test_compact_shard_rejects_ids_outside_their_field_range():
         e.sync()
     assert ei.value.code == -1
     assert_state_bitwise(e.get_state(), before, "voided block")
+    # predict() on the same rows: no grouping runs for it, so the row kernel itself
+    # must refuse the entry -- NaN for that row, FFM_E_INVALID at the next sync, the other rows'
+    # partial logits what they are without the bad row in the block
+    e.predict_batch_device(8, int(bad.row_ptr[-1]), d["row_ptr"].data_ptr(), d["field"].data_ptr(),
+                           d["feat"].data_ptr(), d["val"].data_ptr(), None, False, out.data_ptr())
+    with pytest.raises(fa.EngineError) as ei:
+        e.sync()
+    assert ei.value.code == -1
+    got = out.cpu().numpy()
+    assert np.isnan(got[3]) and not np.isnan(np.delete(got, 3)).any()
+    good_rows = [r for i, r in enumerate(rows) if i != 3]
+    good = Csr.from_rows(good_rows, [0] * 7)
+    dg = {k_: torch.from_numpy(getattr(good, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val")}
+    out7 = torch.zeros(7, device="cuda")
+    e.predict_batch_device(7, int(good.row_ptr[-1]), dg["row_ptr"].data_ptr(), dg["field"].data_ptr(),
+                           dg["feat"].data_ptr(), dg["val"].data_ptr(), None, False, out7.data_ptr())
+    e.sync()
+    assert np.array_equal(np.delete(got, 3).view(np.uint32), out7.cpu().numpy().view(np.uint32))
     e.close()
 
 

@@ -46,8 +46,10 @@ class ShardedStep:
             self._ext = torch.cuda.ExternalStream(engine.stream, device=logit.device)
 
     def _exchange(self, n_rows):
-        if self.dist is None or self.dist.get_world_size() <= 1:
+        if self.dist is None:
             return
+        # (a process group of ONE rank still runs the collective: a sum over one rank, but RCCL, its
+        # stream and the event ordering below are then the ones an N-rank job uses)
         cur = None
         if self._ext is not None:
             cur = self._torch.cuda.current_stream(self.logit.device)

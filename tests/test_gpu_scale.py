@@ -229,6 +229,66 @@ def test_eight_shards_at_39x16_on_one_gpu(compact):
     del free0
 
 
+def test_eight_shards_train_from_their_own_summed_logits():
+    """The end-to-end sharded step: eight compact shard engines, every block
+    forward on each shard -> the shards' OWN partial logits summed (float32, shard order: what the
+    all-reduce delivers, up to its own association order) -> every shard updates from that sum.
+    The summed logit differs from the oracle's by the association order of ~740 terms (rtol 1e-5),
+    tmp_grad and every (n, z) step inherit that: merged state within rtol 2e-4 / atol 2e-6 of the
+    oracle after three 1024-row blocks, stress hyper-parameters (weights move), no NaN."""
+    F, k, per, B, S = 39, 16, 40, 1024, 8
+    nf = F * per
+    rng = np.random.default_rng(15)
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o)
+    st["vec_n"] += np.float32(0.05)
+    st["lin_n"] += np.float32(0.05)
+    o.set_state(st)
+    g = synth.Generator(F, nf, "zipf", seed=19)
+    blocks = [g.block(B) for _ in range(3)]
+    fs = (np.arange(F + 1) * per).astype(np.int32)
+    shards = [fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=B, max_batch_nnz=B * F,
+                        n_shards=S, shard_rank=r, max_row_nnz=F, field_start=fs, **STRESS_HP)
+              for r in range(S)]
+    for e in shards:
+        e.set_state(st)
+    plan = fa.shard_plan(F, S, field_map=True)
+    for blk in blocks:
+        lo, _ = o.train_batch(blk)
+        dev = {k_: torch.from_numpy(getattr(blk, k_)).cuda() for k_ in ("row_ptr", "field", "feat", "val", "label")}
+        parts = torch.zeros(S, B, device="cuda")
+        for r, e in enumerate(shards):
+            e.train_forward_device(B, blk.nnz, dev["row_ptr"].data_ptr(), dev["field"].data_ptr(),
+                                   dev["feat"].data_ptr(), dev["val"].data_ptr(), dev["label"].data_ptr(),
+                                   parts[r].data_ptr())
+            e.sync()
+        total = parts.sum(0).contiguous()  # the shards' own sum
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(total.cpu().numpy(), lo, rtol=1e-5, atol=2e-6)
+        for e in shards:
+            e.train_update_device(total.data_ptr())
+            e.sync()
+    want = o.get_state()
+    states = [e.get_state() for e in shards]
+    fld = np.arange(nf) // per
+    owner = np.repeat(plan["pair_owner"][fld], k, axis=1)
+    for key in ("vec_n", "vec_z", "vec_w"):
+        merged = np.zeros_like(want[key])
+        for r in range(S):
+            merged = np.where(owner == r, states[r][key], merged)
+        assert not np.isnan(merged).any()
+        np.testing.assert_allclose(merged, want[key], rtol=2e-4, atol=2e-6, err_msg="own-sum " + key)
+    lin_owner = plan["lin_owner"][fld]
+    for key in ("lin_n", "lin_z", "lin_w"):
+        merged = np.zeros_like(want[key])
+        for r in range(S):
+            merged = np.where(lin_owner == r, states[r][key], merged)
+        np.testing.assert_allclose(merged, want[key], rtol=2e-4, atol=2e-6, err_msg="own-sum " + key)
+    np.testing.assert_allclose(states[plan["bias_owner"]]["bias3"], want["bias3"], rtol=2e-4, atol=2e-6)
+    for e in shards:
+        e.close()
+
+
 def test_compact_shard_rejects_ids_outside_their_field_range():
     """With per-field id ranges an entry whose id belongs to another field voids its block:
     FFM_E_INVALID at the next sync, model untouched."""

@@ -332,6 +332,8 @@ def main():
                 pinned_keep.append(t)
                 setattr(b, name, t.numpy())
 
+    STAGE_AHEAD = int(os.environ.get("BENCH_STAGE_AHEAD", "2"))  # blocks staged ahead of the one in training
+
     def run_host(first, count):
         """`count` steps; returns the sum of the steps' losses (all enqueued work is flushed)."""
         if count == 0:
@@ -345,7 +347,7 @@ def main():
         # scheduled into block t's refresh / row window with until the end of block t+1 to finish
         staged = 0
         for i in range(count):
-            while staged < min(i + 3, count):
+            while staged < min(i + 1 + STAGE_AHEAD, count):
                 eng.stage_batch(host_blocks[(first + staged) % n_blocks], zero_copy)
                 staged += 1
             if sharded:
@@ -395,11 +397,19 @@ def main():
             step_resident(first + i, dev_blocks[(first + i) % len(dev_blocks)])
 
     def timed(run, first, count):
+        # the interpreter's cyclic garbage collector stays out of the timed region (BENCH_GC=1 lets it
+        # run): a full collection over torch's and numpy's module graphs takes tens of milliseconds
+        # -- one of them inside 20 steps of 1.1 ms would be most of the measurement
+        import gc
+        gc.collect()
+        if os.environ.get("BENCH_GC", "0") != "1":
+            gc.disable()
         fence()
         t0 = time.perf_counter()
         out = run(first, count)
         fence()
         el = time.perf_counter() - t0
+        gc.enable()
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -18,6 +18,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +37,7 @@
 #include "kernels_row.h"
 #include "kernels_update.h"
 #include "kernels_chain.h"
+#include "kernels_fm.h"
 
 using namespace ftrl_dev;
 
@@ -71,6 +77,8 @@ struct ScopedTimer {
   ~ScopedTimer() {
     if (!g_timers.on) return;
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    static std::mutex mu;  // (the staging thread times its sections too)
+    std::lock_guard<std::mutex> lock(mu);
     auto &a = g_timers.get(name);
     a.total += s; a.n++; if (s > a.worst) a.worst = s;
   }
@@ -479,6 +487,84 @@ struct ffm_engine {
   bool small_flat_always = false;  // FFM_SMALL_FLAT=1 (experiment): the flat few-occurrence kernel for long records too
   int row_threads = kRowThreads;  // workgroup size of the FFM row kernel (FFM_ROW_THREADS)
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
+  // ---- staging thread ------------------------------------------------------------------------
+  // The GPU submissions of a staged block (its upload kernel and the ~10 launches of its grouping,
+  // all on the prep stream) are issued by a thread of the engine's own, two blocks ahead of the
+  // training launches that the caller's thread issues.  Why: rocPRIM's radix sort calls
+  // hipMemsetAsync inside, which on this runtime can hold the submitting thread until earlier work
+  // of the stream has retired -- measured 30 us per sort call on most boxes of the pool but 240 us
+  // mean / 31 ms worst on others (profiles/r03_host_leg_diag.txt), during which the caller's thread
+  // did not enqueue the NEXT training block and the H2D-inclusive step grew from 1.13 to 1.32 ms
+  // with the resident step unchanged.  All bookkeeping stays on the caller's thread; the worker only
+  // replays closures in order.  staged_issued: ordinal of the last staged block whose launches are
+  // out (a training call waits for ITS block only, never for the look-ahead's).
+  bool stage_thread_on = true;  // FFM_STAGE_THREAD=0: the caller's thread submits everything
+  std::thread worker;
+  std::mutex wmu;
+  std::condition_variable wcv_job, wcv_done;
+  std::deque<std::function<int()>> wjobs;
+  bool wstop = false, wbusy = false;
+  int64_t staged_issued = 0;
+  int worker_rc = 0;
+  std::string worker_msg;
+  void worker_main() {
+    (void)hipSetDevice(cfg.device_id);
+    for (;;) {
+      std::function<int()> job;
+      {
+        std::unique_lock<std::mutex> lock(wmu);
+        wcv_job.wait(lock, [&] { return wstop || !wjobs.empty(); });
+        if (wjobs.empty()) return;
+        job = std::move(wjobs.front());
+        wjobs.pop_front();
+        wbusy = true;
+      }
+      const int rc = job();
+      {
+        std::lock_guard<std::mutex> lock(wmu);
+        if (rc != 0 && worker_rc == 0) { worker_rc = rc; worker_msg = g_last_error; }
+        wbusy = false;
+      }
+      wcv_done.notify_all();
+    }
+  }
+  // Runs `job` on the staging thread (or right here when it is off / while kernels are being timed).
+  int submit(std::function<int()> job) {
+    if (!stage_thread_on || prof_on) return job();
+    {
+      std::lock_guard<std::mutex> lock(wmu);
+      if (!worker.joinable()) worker = std::thread([this] { worker_main(); });
+      wjobs.push_back(std::move(job));
+    }
+    wcv_job.notify_one();
+    return 0;
+  }
+  int worker_error() {  // an error of an earlier deferred submission surfaces at the next wait
+    if (worker_rc == 0) return 0;
+    const int rc = worker_rc;
+    worker_rc = 0;
+    return fail(rc, "staging thread: " + worker_msg);
+  }
+  // Until everything submitted so far is issued (before the caller's thread touches the prep stream).
+  int drain() {
+    std::unique_lock<std::mutex> lock(wmu);
+    wcv_done.wait(lock, [&] { return wjobs.empty() && !wbusy; });
+    return worker_error();
+  }
+  // Until the launches of staged block number `seq` are issued.
+  int wait_issued(int64_t seq) {
+    std::unique_lock<std::mutex> lock(wmu);
+    wcv_done.wait(lock, [&] { return staged_issued >= seq || (wjobs.empty() && !wbusy); });
+    return worker_error();
+  }
+  void stop_worker() {
+    {
+      std::lock_guard<std::mutex> lock(wmu);
+      wstop = true;
+    }
+    wcv_job.notify_all();
+    if (worker.joinable()) worker.join();
+  }
   // profiling
   bool prof_on = false;
   int prof_only = -1;  // >= 0: record only this kernel id (ffm_engine_profile_focus)
@@ -615,6 +701,7 @@ int64_t ffm_engine_row_len(const ffm_engine *e) { return e ? e->logical_len : 0;
 void ffm_engine_destroy(ffm_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device_id);
+  e->stop_worker();  // (issues what is still queued, then joins)
   // everything the engine has in flight -- uploads still reading the caller's page-locked arrays
   // (staged, never trained), look-ahead groupings, the side streams -- ends before anything is freed
   if (e->prep) (void)hipStreamSynchronize(e->prep);
@@ -709,6 +796,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_GIANT")) e->grid_giant = std::max(0, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GIANT_APART")) e->giant_apart = sv[0] != '0';
+  if (const char *sv = std::getenv("FFM_STAGE_THREAD")) e->stage_thread_on = sv[0] != '0';
   {
     const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
     const int64_t per = cfg->n_factors % 4 == 0 ? static_cast<int64_t>(cfg->n_fields) * cfg->n_factors / 4
@@ -1020,6 +1108,7 @@ int ffm_engine_eval_sigmoid(ffm_engine *e, int32_t n, const float *x, float *y) 
 // that a block could not be trained.
 static int check_device_errors(ffm_engine *e) {
   int flags = 0;
+  if (int rc_w = e->drain()) return rc_w;
   // the uploads of blocks that are staged but not trained yet run on the prep stream: the
   // zero-copy contract (include/ffm_engine.h) lets the caller reuse its page-locked arrays once
   // this returns, so they must have been pulled too
@@ -1212,7 +1301,14 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
                         : row_terms_cap(row_cap, e->m.n_shards > 1 ? e->m.rec_slots : 0, 0);
   const size_t shmem = row_lds_bytes(row_cap, e->m.n_fields, terms_cap);
   const int kid = train ? K_ROW : K_PREDICT_ROW;
-  if (e->m.type == FFM_MODEL_FM) {
+  if (e->m.type == FFM_MODEL_FM && e->m.n_factors <= 64) {
+    // one wave per row, lane = factor (kernels_fm.h)
+    if (train) e->singles_in_row = own_tg != 0;
+    const int grid = cdiv(rows.n_rows, kFmRowsPerBlock);
+    if (train) LAUNCH(e, kid, fm_row_wave_kernel<true>, grid, 64 * kFmRowsPerBlock, 0, e->m, rows, e->sc[e->cur], row_cap, out, output_prob, own_tg);
+    else LAUNCH(e, kid, fm_row_wave_kernel<false>, grid, 64 * kFmRowsPerBlock, 0, e->m, rows, e->sc[e->cur], row_cap, out, output_prob, 0);
+  } else if (e->m.type == FFM_MODEL_FM) {
+    if (train) e->singles_in_row = false;
     if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], row_cap, out, output_prob);
     else LAUNCH(e, kid, fm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], row_cap, out, output_prob);
   } else {
@@ -1259,7 +1355,8 @@ __global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_c
 }
 
 // Groups `rows` by feature into scratch set `set` on stream `st`.
-static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st) {
+// timed = false: from the staging thread (no HIP-event bookkeeping of the profiler there).
+static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st, bool timed = true) {
   Scratch &sc = e->sc[set];
   ScopedTimer tm_all("grouping:all");
   {
@@ -1270,43 +1367,52 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
   }
   if (rows.nnz > 0) {
     const int nnz = rows.nnz;
-    LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->max_row_nnz);
-    e->prof_begin(K_GROUP_SORT, st);
-    ScopedTimer tm_sort("grouping:sort");
-    size_t bytes = e->sort_tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
-                                      rocprim::counting_iterator<int>(0), sc.occ,
-                                      static_cast<size_t>(nnz), 0u, e->sort_bits, st));
-    e->prof_end(st);
-    LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, e->m, rows, sc,
-              phases_for(e, rows.n_rows));
+    if (timed) LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->max_row_nnz);
+    else hipLaunchKernelGGL(group_keys_kernel, dim3(cdiv(nnz, kGroupThreads)), dim3(kGroupThreads), 0, st, e->m, rows, sc, e->max_row_nnz);
+    if (timed) e->prof_begin(K_GROUP_SORT, st);
+    {
+      ScopedTimer tm_sort("grouping:sort");
+      size_t bytes = e->sort_tmp_bytes;
+      HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
+                                        rocprim::counting_iterator<int>(0), sc.occ,
+                                        static_cast<size_t>(nnz), 0u, e->sort_bits, st));
+    }
+    if (timed) e->prof_end(st);
+    if (timed) LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, e->m, rows, sc,
+                         phases_for(e, rows.n_rows));
+    else hipLaunchKernelGGL(group_finish_kernel, dim3(cdiv(nnz, kFinishThreads)), dim3(kFinishThreads), 0, st, e->m, rows, sc,
+                            phases_for(e, rows.n_rows));
   }
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }
 
-int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
-                              const int32_t *field, const int32_t *feat, const float *val) {
-  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
-  if (rc) return rc;
+// A look-ahead grouping in two halves: the bookkeeping (caller's thread, in call order) and the
+// stream operations (whoever submits: the caller's thread or the staging thread, in the same order).
+struct PrepPlan {
+  int set = 0;
+  bool wait_free = false;  // the set carried an earlier block: wait for its ev_set_free
+  bool wait_rows = false;  // FFM_PREP_AFTER_ROWS
+  int ws = -1;             // prep_window: start when this set's block has trained (-1: at once)
+  Rows rows{};
+};
+static int prepare_plan(ffm_engine *e, const Rows &rows, PrepPlan *pl) {
   if (e->has_pending) return fail(FFM_E_INVALID, "prepare between train_forward and train_update");
   if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "three prepared blocks are already waiting");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
   const int set = (e->last_set + 1) % ffm_engine::kSets;
-  Rows rows{n_rows, nnz, row_ptr, field, feat, val, nullptr};
-  if (e->set_used[set]) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[set], 0));
+  pl->set = set;
+  pl->rows = rows;
+  pl->wait_free = e->set_used[set];
   // Optionally group beside the UPDATE phase of the block enqueued last instead of beside its
   // refresh + row phase (measured: the grouping's atomics slow whichever phase they share).
-  if (e->prep_after_rows && e->rows_done_recorded) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_rows_done, 0));
+  pl->wait_rows = e->prep_after_rows && e->rows_done_recorded;
+  pl->ws = -1;
   if (e->prep_window) {
     // n_prepared == 1: the predecessor is prepared but not enqueued yet -> wait for the block
     // enqueued last; n_prepared == 0: the predecessor IS the block enqueued last -> the one before
     const int ws = e->trained_set[e->n_prepared >= 1 ? 0 : 1];
-    if (ws >= 0 && ws != set) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[ws], 0));
+    if (ws >= 0 && ws != set) pl->ws = ws;
   }
-  rc = launch_grouping(e, set, rows, e->prep);
-  if (rc) return rc;
-  HIP_TRY(hipEventRecord(e->ev_grouped[set], e->prep));
   // the set is in use from now on, also when this look-ahead ends up discarded: whoever takes the
   // set next must wait for ev_set_free (recorded when the block trains or the look-ahead is dropped)
   e->set_used[set] = true;
@@ -1315,6 +1421,26 @@ int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const 
   e->prepared_rows[e->n_prepared] = rows;
   e->n_prepared++;
   return FFM_OK;
+}
+static int prepare_submit(ffm_engine *e, const PrepPlan &pl, bool timed) {
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if (pl.wait_free) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.set], 0));
+  if (pl.wait_rows) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_rows_done, 0));
+  if (pl.ws >= 0) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.ws], 0));
+  int rc = launch_grouping(e, pl.set, pl.rows, e->prep, timed);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(e->ev_grouped[pl.set], e->prep));
+  return FFM_OK;
+}
+
+int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
+                              const int32_t *field, const int32_t *feat, const float *val) {
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  if (rc) return rc;
+  if ((rc = e->drain())) return rc;  // (staged blocks' submissions come first on the prep stream)
+  PrepPlan pl;
+  if ((rc = prepare_plan(e, Rows{n_rows, nnz, row_ptr, field, feat, val, nullptr}, &pl))) return rc;
+  return prepare_submit(e, pl, true);
 }
 
 int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
@@ -1330,11 +1456,13 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   e->pending = rows;
   e->has_pending = true;
   // only train_batch_device has the whole logit in its row kernel (one shard, FFM / LR)
-  e->own_tg_cur = e->whole_step && e->m.n_shards == 1 && e->m.type != FFM_MODEL_FM;
+  e->own_tg_cur = e->whole_step && e->m.n_shards == 1 &&
+                  (e->m.type != FFM_MODEL_FM || e->m.n_factors <= 64);  // (FM: fm_row_wave_kernel)
   e->whole_step = false;
   const bool use_prepared = e->n_prepared > 0 && same_block(e->prepared_rows[0], rows);
   if (e->n_prepared > 0 && !use_prepared) {
     // groupings made ahead for some other block: forget them all
+    if ((rc = e->drain())) return rc;
     for (int i = 0; i < e->n_prepared; i++) HIP_TRY(hipEventRecord(e->ev_set_free[e->prepared_set[i]], e->prep));
     e->n_prepared = 0;
   }
@@ -1378,6 +1506,8 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0 && !own_tg)
     LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
   // this shard runs the bias chain / a linear update when it owns the bias / any field's linear terms
+  // FM, whole step: fm_row_wave_kernel has applied the touches of the once-only features itself
+  const int fm_in_row = e->m.type == FFM_MODEL_FM && own_tg && e->singles_in_row ? 1 : 0;
   const bool lin_owner = e->m.bias_own != 0 || e->lin_any;
   const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
   const bool vec4 = e->m.n_factors % 4 == 0;
@@ -1390,7 +1520,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   if (rows.n_rows > 0 && lin_owner && e->serial && !side_in_hot) {
     LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
     if (rows.nnz > 0)
-      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
   }
   // The update kernels are persistent and fill the chip: a look-ahead grouping still in flight on
   // the prep queue makes little progress beside them.  Optionally let it finish first (measured
@@ -1402,7 +1532,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
     LAUNCH_ON(e, e->aux2, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
     if (rows.nnz > 0)
-      LAUNCH_ON(e, e->aux2, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      LAUNCH_ON(e, e->aux2, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
     HIP_TRY(hipEventRecord(e->ev_join, e->aux2));
   }
   // small features on the main stream: the once-only ones through their descriptor kernel
@@ -1458,7 +1588,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     } else {
       LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     }
-    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1);
+    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1, fm_in_row);
     if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   }
   if (loss_sum_out && !(ffm && vec4 && !e->serial))
@@ -1702,13 +1832,14 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   if ((rc = slots_init(e))) return rc;
   ffm_engine::Slot &sl = e->slots[e->slot_next];
   const int this_slot = e->slot_next;
-  if (sl.used) {
+  const bool slot_was_used = sl.used;
+  if (sl.used && !sl.zero_copy) {
     ScopedTimer tm("stage:slot_wait");
     // the slot's own pinned image must have been pulled before it is overwritten.  (Not so for a
     // zero_copy block, whose image is the caller's: blocking the submitting thread here costs
     // ~0.2 ms per step; such callers ask ffm_engine_blocks_pulled before reusing their memory.)
-    if (!sl.zero_copy) HIP_TRY(hipEventSynchronize(sl.ev_copied));
-    HIP_TRY(hipStreamWaitEvent(e->copy, sl.ev_trained, 0));        // and nothing reads its device arrays
+    if ((rc = e->wait_issued(sl.seq))) return rc;
+    HIP_TRY(hipEventSynchronize(sl.ev_copied));
   }
   // host arrays -> pinned image (the caller may reuse its buffers on return) -> device, prep stream
   const size_t R1 = static_cast<size_t>(n_rows) + 1, E = static_cast<size_t>(nnz);
@@ -1745,14 +1876,32 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
     job.ordinal = e->n_staged_total + 1;
     job.pulled = e->d_pulled;
     job.ticket = e->d_pull_ticket;
-    hipLaunchKernelGGL(pull_block_kernel, dim3(e->grid_pull), dim3(256), 0, e->copy, job);
-    HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
   }
-  // group it ahead, behind its own upload on the prep stream
-  {
-    ScopedTimer tm("stage:prepare");
-    rc = ffm_engine_prepare_device(e, n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val);
-  }
+  // its grouping, behind its own upload on the prep stream: planned here, submitted with the upload
+  PrepPlan plan;
+  if ((rc = prepare_plan(e, Rows{n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val, nullptr}, &plan)))
+    return rc;
+  const int64_t seq = e->n_staged_total + 1;
+  const int grid_pull = e->grid_pull;
+  const bool timed = !e->stage_thread_on || e->prof_on;
+  rc = e->submit([e, this_slot, slot_was_used, job, plan, seq, grid_pull, timed]() -> int {
+    ScopedTimer tm("stage:submit");
+    ffm_engine::Slot &s2 = e->slots[this_slot];
+    int rc2 = FFM_OK;
+    auto body = [&]() -> int {
+      HIP_TRY(hipSetDevice(e->cfg.device_id));
+      if (slot_was_used) HIP_TRY(hipStreamWaitEvent(e->copy, s2.ev_trained, 0));  // nothing reads its device arrays
+      hipLaunchKernelGGL(pull_block_kernel, dim3(grid_pull), dim3(256), 0, e->copy, job);
+      HIP_TRY(hipEventRecord(s2.ev_copied, e->copy));
+      return prepare_submit(e, plan, timed);
+    };
+    rc2 = body();
+    {
+      std::lock_guard<std::mutex> lock(e->wmu);
+      e->staged_issued = seq;  // (also after a failure: nobody may wait for it forever)
+    }
+    return rc2;
+  });
   if (rc) return rc;
   sl.used = true;
   sl.zero_copy = zero_copy != 0;
@@ -1782,6 +1931,7 @@ int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit) {
   ffm_engine::Slot &sl = e->slots[slot];
   e->staged_row_cap = sl.row_cap;
   HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if (int rc_w = e->wait_issued(sl.seq)) return rc_w;  // its upload + grouping launches are out
   HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));  // (also when its grouping was discarded)
   int rc = ffm_engine_train_forward_device(e, sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr,
                                            sl.feat, sl.val, sl.label, partial_logit);
@@ -1860,6 +2010,7 @@ int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out) {
 
 int ffm_engine_profile_enable(ffm_engine *e, int32_t on) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (int rc_w = e->drain()) return rc_w;
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   HIP_TRY(hipDeviceSynchronize());
   for (auto &r : e->prof) { e->event_pool.push_back(r.e0); e->event_pool.push_back(r.e1); }

@@ -104,9 +104,11 @@ __device__ __forceinline__ void linear_chain64(const Hyper &h, float w, float g,
 // touches applied one after another; hot features: one wave each, 64 touches per pass.
 // ph of `phases` (row phases, engine_types.h): a hot feature's touches of this phase's rows; the
 // small features' few touches all in the last phase.
+// skip_once: the linear terms of the features that occur once in the block were updated by their
+// row (fm_row_wave_kernel)
 __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows &rows,
                                                    const Scratch &s, int block, int n_blocks,
-                                                   int ph = 0, int phases = 1) {
+                                                   int ph = 0, int phases = 1, int skip_once = 0) {
   const int n_small = ph == phases - 1 ? s.counters[CNT_NSMALL] : 0, n_big = s.counters[CNT_NBIG];
   const int gtid = block * blockDim.x + threadIdx.x;
   for (int li = gtid; li < n_small; li += n_blocks * blockDim.x) {
@@ -115,6 +117,7 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
     if (!owns_linear(m, ud.w)) continue;  // another shard's linear terms
     const int i = ud.x;
     const int start = ud.y, c = ud.z;
+    if (skip_once && c == 1) continue;
     float n = m.lin_n[i], z = m.lin_z[i];
     const float w = m.lin_w[i];
     float sqn = sqrt_cr(n);
@@ -159,8 +162,8 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
   }
 }
 __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, Rows rows,
-                                                                    Scratch s) {
-  linear_update_body(m, rows, s, blockIdx.x, gridDim.x);
+                                                                    Scratch s, int skip_once) {
+  linear_update_body(m, rows, s, blockIdx.x, gridDim.x, 0, 1, skip_once);
 }
 
 // Bias update: one wave walks all rows of the block in order (update_bias_nz, :79-85).
@@ -760,22 +763,28 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_flat_kernel(Mod
 
 // FM latent update.  Work item = (distinct feature u, chunk of 64 factors).
 // skip_huge: the features with more than kHugeMin occurrences belong to fm_update_huge_kernel
+// skip_once: the features that occur once in the block were updated by their row (fm_row_wave_kernel)
 __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s,
-                                                                int skip_huge) {
+                                                                int skip_huge, int skip_once) {
   const int k = m.n_factors;
   const int chunks = (k + 63) / 64;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const int n_waves = gridDim.x * kUpdWaves;
-  const int64_t n_items = static_cast<int64_t>(s.counters[CNT_NUNIQ]) * chunks;
+  // skip_once: only the features with 2 .. kHugeMin occurrences are left -- the `few` and `big`
+  // lists -- instead of a walk over every distinct feature of the block
+  const int n_few = s.counters[CNT_NFEW], n_big = s.counters[CNT_NBIG];
+  const int64_t n_items = static_cast<int64_t>(skip_once && skip_huge ? n_few + n_big : s.counters[CNT_NUNIQ]) * chunks;
   for (int64_t item = wave; item < n_items; item += n_waves) {
-    const int u = static_cast<int>(item / chunks);
+    int u = static_cast<int>(item / chunks);
     const int e = static_cast<int>(item - static_cast<int64_t>(u) * chunks) * 64 + lane;
     if (e >= k) continue;
+    if (skip_once && skip_huge) u = wave_uniform(u < n_few ? s.few[u] : s.big[u - n_few]);
     const int4 ud = s.udesc[u];
     const int i = wave_uniform(ud.x);
     const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     if (skip_huge && c > kHugeMin) continue;
+    if (skip_once && c == 1) continue;
     float *rec = lat_row(m, i, 0);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
     const float w = rec[LAT_W * k + e];

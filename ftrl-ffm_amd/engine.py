@@ -254,8 +254,21 @@ class Engine:
 
     # ---- blocks of rows in host memory ----
     def _csr(self, c):
+        # numpy's .ctypes.data_as builds a fresh ctypes object per call (several microseconds each):
+        # for a block that is handed over again and again (a trainer's ring of page-locked blocks)
+        # the argument tuple is kept on the block, keyed by the identity of its arrays
         fld = c.field if (self.model_type == FFM or c.field is not None) else None
-        return (c.n_rows, _i(c.row_ptr), _i(fld), _i(c.feat), _f(c.val), _i(c.label))
+        key = (c.n_rows, id(c.row_ptr), id(fld), id(c.feat), id(c.val), id(c.label))
+        cached = getattr(c, "_ffm_csr_args", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        args = (c.n_rows, _i(c.row_ptr), _i(fld), _i(c.feat), _f(c.val), _i(c.label))
+        try:
+            # (the arrays ride along: while they are referenced here their ids cannot be reused)
+            c._ffm_csr_args = (key, args, (c.row_ptr, fld, c.feat, c.val, c.label))
+        except AttributeError:  # (a block type without a __dict__)
+            pass
+        return args
 
     def train_batch(self, c):
         """One block with the engine's batch semantics.  Returns (logits, loss_sum)."""

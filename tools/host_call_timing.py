@@ -7,13 +7,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ftrl_ffm_amd as fa
 from ftrl_ffm_amd import synth
-F, K, B = 39, 16, 8192
+F, K, B = int(os.environ.get("F", 39)), int(os.environ.get("K", 16)), int(os.environ.get("B", 8192))
 nf = int(os.environ.get("NF", 3_000_000)); nf -= nf % F
 ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
 e = fa.Engine("FFM", nf, F, K, max_batch_rows=B, max_batch_nnz=B * F, stream=ts.cuda_stream, max_row_nnz=F)
 e.fill_state()
 g = synth.Generator(F, nf, "zipf", seed=42)
-blocks = [g.block(B) for _ in range(16)]
+NB = int(os.environ.get('NB', 16))
+blocks = [g.block(B) for _ in range(NB)]
 keep = []
 for b in blocks:
     for name in ("row_ptr", "field", "feat", "val", "label"):
@@ -27,7 +28,7 @@ e.stage_batch(blocks[0], True)
 for i in range(N):
     t0 = time.perf_counter()
     if i + 1 < N:
-        e.stage_batch(blocks[(i + 1) % 16], True)
+        e.stage_batch(blocks[(i + 1) % NB], True)
     t1 = time.perf_counter()
     e.train_staged(None, loss.data_ptr() + 8 * (i % 4096))
     t2 = time.perf_counter()

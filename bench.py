@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_FIELDS, N_FACTORS = 39, 16
+MODEL = "FFM"
 FEATS_C5 = 33_000_000
 # BASELINE.json configs; only c5's single-GPU slice is the bench line, the others are for DESIGN.md
 CONFIGS = {
@@ -79,6 +80,8 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
       update               : write (n,z) = 8 B per slot-factor of the occurrences each kernel owns
                              (features with 1, 2..8, 9..192, > 192 occurrences in the block)
     Under field-pair sharding every rank moves 1/n_shards of the slot-factors."""
+    if MODEL == "FM":
+        return fm_kernel_share_bytes(kernel, blocks_feat, nnz, k)
     per_occ = (nnz - 1) * k  # slot-factors one occurrence of a feature touches
     rows = [len(f) // nnz for f in blocks_feat]
     mode = refresh_mode(n_shards)
@@ -104,6 +107,23 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
     return float(np.mean(shares))
 
 
+def fm_kernel_share_bytes(kernel, blocks_feat, nnz, k):
+    """The same apportioning for FM (nnz*k*20 + nnz*20 + 20 + nnz*8 + 8 + 12 B per
+    row; a feature's record is k slot-factors).  fm_row_wave_kernel (csrc/kernels_fm.h) refreshes
+    every OCCURRENCE's record (read n,z + write w = 12 B per factor), reads the CSR entries, the
+    linear terms, writes logit / tmp_grad / loss / the row's k factor sums, and applies the (n, z)
+    step (8 B per factor) of the features that occur once in the block; fm_update_kernel owns the
+    features with 2..192 occurrences, fm_update_chain_kernel the rest (8 B per factor-occurrence)."""
+    rows = [len(f) // nnz for f in blocks_feat]
+    counts = [np.unique(f, return_counts=True)[1] for f in blocks_feat]
+    if "row_kernel" in kernel:
+        return float(np.mean([r * (nnz * k * 12 + nnz * 12 + (nnz * 8 + 8) + 4 + 16 + 4 * k) + int((c == 1).sum()) * (k * 8 + 8)
+                              for r, c in zip(rows, counts)]))
+    if "chain" in kernel or "huge" in kernel:
+        return float(np.mean([c[c > HUGE_MIN].sum() * k * 8 for c in counts]))
+    return float(np.mean([c[(c > 1) & (c <= HUGE_MIN)].sum() * k * 8 for c in counts]))
+
+
 def cpu_baseline(args, gen_kwargs):
     """The reference's own multi-thread CPU path timed on this host on a bounded sample of the same
     workload: oracle/_ref (the unmodified reference model classes compiled from /root/reference by
@@ -118,6 +138,8 @@ def cpu_baseline(args, gen_kwargs):
     rows = args.cpu_rows
     g = synth.Generator(N_FIELDS, n_feats, **gen_kwargs)
     blk = g.block(rows)
+    if MODEL != "FFM":
+        blk.field[:] = 0  # libsvm rows
     kind = "ref" if pyoracle.have_ref() else "oracle"
     if kind == "ref":
         try:
@@ -131,7 +153,7 @@ def cpu_baseline(args, gen_kwargs):
     st = None
     tried = {}
     for threads in sorted({1, min(8, ncpu), ncpu}):
-        m = CpuModel(kind, "FFM", n_feats, N_FIELDS, N_FACTORS)
+        m = CpuModel(kind, MODEL, n_feats, N_FIELDS if MODEL == "FFM" else 1, N_FACTORS)
         if st is None:
             st = m.zero_state()
             st["vec_w"][...] = rng.normal(0, 0.02, st["vec_w"].shape).astype(np.float32)
@@ -144,10 +166,10 @@ def cpu_baseline(args, gen_kwargs):
     best_t = max(tried, key=tried.get)
     return {"value": round(tried[best_t], 1), "unit": "samples/s", "cores": best_t,
             "kind": "reference" if kind == "ref" else "port",
-            "sample": "%d rows, FFM F=%d k=%d nnz=%d Zipf(1.1), n_feats=%d, warm state; %s at n_threads in "
+            "sample": "%d rows, %s F=%d k=%d nnz=%d Zipf(1.1), n_feats=%d, warm state; %s at n_threads in "
                       "{1, 8, all}: %s; best reported; host has %d cores" % (
-                          rows, N_FIELDS, N_FACTORS, N_FIELDS, n_feats,
-                          "the reference's FtrlOffline::one_epoch loop over its own FFM model "
+                          rows, MODEL, N_FIELDS, N_FACTORS, N_FIELDS, n_feats,
+                          "the reference's FtrlOffline::one_epoch loop over its own model "
                           "(oracle/_ref)" if kind == "ref" else "oracle fo_train_rows_threaded",
                           ", ".join("%dT=%.0f/s" % kv for kv in sorted(tried.items())), ncpu)}
 
@@ -225,9 +247,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     fa.build()
 
-    global N_FIELDS, N_FACTORS
+    global N_FIELDS, N_FACTORS, MODEL
     cfgw = CONFIGS[args.config]
-    model = cfgw["model"]
+    model = MODEL = cfgw["model"]
     N_FIELDS, N_FACTORS = cfgw["fields"], cfgw["factors"]
     emu = args.emulate_shards if world == 1 else 0
     n_shards = emu or world
@@ -486,7 +508,7 @@ def main():
         }
         if resident:
             out["resident"] = resident
-        if kname and model == "FFM":
+        if kname:
             share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, n_shards)
             per_step = max(1, round(klaunches / max(args.steps, 1)))  # (FFM_PHASES > 1: several launches per block)
             share /= per_step
@@ -520,7 +542,9 @@ def main():
             for line in table.splitlines():
                 parts = line.split()
                 nm = parts[0]
-                full = {"row_kernel<train>": "ffm_row_kernel<train>",
+                full = {"row_kernel<train>": "fm_row_kernel<train>", "latent_update_kernel": "fm_update_kernel",
+                        "latent_update_huge_kernel": "fm_update_chain_kernel"}.get(nm) if model == "FM" else \
+                       {"row_kernel<train>": "ffm_row_kernel<train>",
                         "refresh_kernel": "ffm_refresh_kernel",
                         "latent_update_single_kernel": "ffm_update_single_kernel",
                         "latent_update_kernel": "ffm_update_small_kernel",
@@ -535,7 +559,7 @@ def main():
                                "achieved": round(sh / (us * 1e-6) / 1e9, 1),
                                "frac": round(sh / (us * 1e-6) / 1e9 / PEAK_HBM_GBPS, 4)})
             out["roofline"]["other_kernels"] = others
-        if n_gpus == 1 and not emu and not args.no_cpu_baseline and args.config == "c5":
+        if n_gpus == 1 and not emu and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, gen_kwargs)
         print(json.dumps(out), flush=True)
         if table:

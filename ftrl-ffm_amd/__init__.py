@@ -3,7 +3,7 @@ include/ffm_engine.h (csrc/), plus the host-side mirror of the reference's model
 (host/) and this thin ctypes binding (engine.py).  No CPU fallback: importing is cheap, but
 creating an Engine without libffm_engine.so or without a GPU raises."""
 from . import build as _build
-from .engine import (ABI, FFM, FM, LR, Config, Engine, EngineError, LIB_PATH,  # noqa: F401
+from .engine import (ABI, FFM, FM, LR, Config, Engine, EngineError, Group, LIB_PATH,  # noqa: F401
                      init_weights_host, load_library, shard_plan)
 
 

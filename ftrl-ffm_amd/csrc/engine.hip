@@ -1813,26 +1813,17 @@ int ffm_engine_unpin_host(void *p) {
   return FFM_OK;
 }
 
-// Stage one block of host rows: (pinned image ->) HBM -> grouping, all on the prep stream.
-int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
-                           const int32_t *field, const int32_t *feat, const float *val,
-                           const int32_t *label, int32_t zero_copy) {
-  int32_t nnz = 0;
-  int longest = 1;
-  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
-  if (rc) return rc;
-  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
-  if (e->n_staged >= ffm_engine::kSlots - 1) return fail(FFM_E_CAPACITY, "three staged blocks are already waiting");
-  if (e->has_pending) return fail(FFM_E_INVALID, "stage between train_forward and train_update");
-  // everything ffm_engine_prepare_device can refuse is refused HERE, before the upload kernel is
-  // launched: that kernel publishes the block's ordinal to ffm_engine_blocks_pulled, and a block
-  // that then failed to stage would leave the count one ahead for good (ADVICE r02)
-  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "three prepared blocks are already waiting");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
+// The next staging slot for a host block: waits until the slot's own pinned image is free, copies
+// the caller's arrays into it (unless zero_copy) and describes the upload (pull_block_kernel's
+// argument; the block's ordinal is n_staged_total + 1).  Bookkeeping of the slot is the caller's.
+static int claim_slot(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
+                      const int32_t *field, const int32_t *feat, const float *val, const int32_t *label,
+                      int32_t zero_copy, int *slot_out, bool *was_used, PullJob *job_out) {
+  int rc;
   if ((rc = slots_init(e))) return rc;
   ffm_engine::Slot &sl = e->slots[e->slot_next];
-  const int this_slot = e->slot_next;
-  const bool slot_was_used = sl.used;
+  *slot_out = e->slot_next;
+  *was_used = sl.used;
   if (sl.used && !sl.zero_copy) {
     ScopedTimer tm("stage:slot_wait");
     // the slot's own pinned image must have been pulled before it is overwritten.  (Not so for a
@@ -1844,12 +1835,12 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   // host arrays -> pinned image (the caller may reuse its buffers on return) -> device, prep stream
   const size_t R1 = static_cast<size_t>(n_rows) + 1, E = static_cast<size_t>(nnz);
   char *p = sl.pinned;
-  PullJob job{};
+  PullJob &job = *job_out;
   int n_job = 0;
   // page-locked source of each array: the caller's own (zero_copy: untouched until the block has
   // trained) or its image in the slot's pinned buffer; the device then pulls it (pull_block_kernel)
   auto put = [&](const void *src, size_t bytes, void *dst) -> hipError_t {
-    if (!bytes) return hipSuccess;
+    if (!bytes || !src) return hipSuccess;
     const void *host = src;
     if (!zero_copy) {
       std::memcpy(p, src, bytes);
@@ -1866,17 +1857,40 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
     n_job++;
     return hipSuccess;
   };
-  {
-    ScopedTimer tm("stage:copies");
-    HIP_TRY(put(row_ptr, 4 * R1, sl.row_ptr));
-    if (field) HIP_TRY(put(field, 4 * E, sl.field));
-    HIP_TRY(put(feat, 4 * E, sl.feat));
-    HIP_TRY(put(val, 4 * E, sl.val));
-    HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
-    job.ordinal = e->n_staged_total + 1;
-    job.pulled = e->d_pulled;
-    job.ticket = e->d_pull_ticket;
-  }
+  ScopedTimer tm("stage:copies");
+  HIP_TRY(put(row_ptr, 4 * R1, sl.row_ptr));
+  if (field) HIP_TRY(put(field, 4 * E, sl.field));
+  HIP_TRY(put(feat, 4 * E, sl.feat));
+  HIP_TRY(put(val, 4 * E, sl.val));
+  HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
+  job.ordinal = e->n_staged_total + 1;
+  job.pulled = e->d_pulled;
+  job.ticket = e->d_pull_ticket;
+  return FFM_OK;
+}
+
+// Stage one block of host rows: (pinned image ->) HBM -> grouping, all on the prep stream.
+int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                           const int32_t *field, const int32_t *feat, const float *val,
+                           const int32_t *label, int32_t zero_copy) {
+  int32_t nnz = 0;
+  int longest = 1;
+  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
+  if (rc) return rc;
+  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
+  if (e->n_staged >= ffm_engine::kSlots - 1) return fail(FFM_E_CAPACITY, "three staged blocks are already waiting");
+  if (e->has_pending) return fail(FFM_E_INVALID, "stage between train_forward and train_update");
+  // everything ffm_engine_prepare_device can refuse is refused HERE, before the upload kernel is
+  // launched: that kernel publishes the block's ordinal to ffm_engine_blocks_pulled, and a block
+  // that then failed to stage would leave the count one ahead for good (ADVICE r02)
+  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "three prepared blocks are already waiting");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  int this_slot = 0;
+  bool slot_was_used = false;
+  PullJob job{};
+  if ((rc = claim_slot(e, n_rows, nnz, row_ptr, field, feat, val, label, zero_copy, &this_slot, &slot_was_used, &job)))
+    return rc;
+  ffm_engine::Slot &sl = e->slots[this_slot];
   // its grouping, behind its own upload on the prep stream: planned here, submitted with the upload
   PrepPlan plan;
   if ((rc = prepare_plan(e, Rows{n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val, nullptr}, &plan)))
@@ -1986,6 +2000,50 @@ int ffm_engine_train_batch_async_pinned(ffm_engine *e, int32_t n_rows, const int
   // window beside block t and until block t+1 ends)
   while (e->n_staged > 2)
     if ((rc = train_one_staged(e))) return rc;
+  return FFM_OK;
+}
+
+// Pipelined evaluation: upload through a staging slot on the side stream, predict on the main one.
+int ffm_engine_predict_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                   const int32_t *field, const int32_t *feat, const float *val,
+                                   const int32_t *label, int32_t zero_copy) {
+  int32_t nnz = 0;
+  int longest = 1;
+  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
+  if (rc) return rc;
+  if (e->m.n_shards > 1) return fail(FFM_E_INVALID, "a sharded engine predicts through predict_batch_device + predict_finish_device");
+  if (e->n_staged > 0 || e->has_pending) return fail(FFM_E_INVALID, "staged training blocks are still waiting");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if ((rc = e->drain())) return rc;
+  int this_slot = 0;
+  bool slot_was_used = false;
+  PullJob job{};
+  if ((rc = claim_slot(e, n_rows, nnz, row_ptr, field, feat, val, label, zero_copy, &this_slot, &slot_was_used, &job)))
+    return rc;
+  ffm_engine::Slot &sl = e->slots[this_slot];
+  if (slot_was_used) HIP_TRY(hipStreamWaitEvent(e->copy, sl.ev_trained, 0));  // nothing reads its device arrays
+  hipLaunchKernelGGL(pull_block_kernel, dim3(e->grid_pull), dim3(256), 0, e->copy, job);
+  HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
+  sl.used = true;
+  sl.zero_copy = zero_copy != 0;
+  sl.n_rows = n_rows;
+  sl.nnz = nnz;
+  sl.row_cap = longest;
+  sl.has_field = field != nullptr;
+  sl.seq = ++e->n_staged_total;
+  {
+    std::lock_guard<std::mutex> lock(e->wmu);
+    e->staged_issued = sl.seq;
+  }
+  e->slot_next = (e->slot_next + 1) % ffm_engine::kSlots;
+  HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));
+  e->staged_row_cap = longest;
+  rc = ffm_engine_predict_batch_device(e, n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val,
+                                       label ? sl.label : nullptr, 0, e->d_out, label ? e->d_loss_sum : nullptr);
+  if (rc) return rc;
+  if (label) hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
+  HIP_TRY(hipEventRecord(sl.ev_trained, e->stream));  // the slot's device arrays are free again
+  HIP_TRY(hipGetLastError());
   return FFM_OK;
 }
 
@@ -2105,3 +2163,5 @@ int ffm_engine_profile_dump(ffm_engine *e, char *buf, size_t cap) {
 }
 
 }  // extern "C"
+
+#include "engine_group.h"

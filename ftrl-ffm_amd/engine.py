@@ -75,6 +75,7 @@ ABI = [
     ("ffm_engine_train_batch_async", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
     ("ffm_engine_train_batch_async_pinned", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR),
     ("ffm_engine_train_flush", ctypes.c_int, [_vp, _f64p]),
+    ("ffm_engine_predict_batch_async", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR + [ctypes.c_int32]),
     ("ffm_engine_stage_batch", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR + [ctypes.c_int32]),
     ("ffm_engine_blocks_pulled", ctypes.c_int64, [_vp]),
     ("ffm_engine_train_forward_staged", ctypes.c_int, [_vp, _vp]),
@@ -97,6 +98,18 @@ ABI = [
      [_vp, _i32p, _f64p, ctypes.c_char_p, ctypes.c_size_t]),
     ("ffm_engine_profile_focus", ctypes.c_int, [_vp]),
     ("ffm_engine_profile_dump", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+    # several GPUs in one process (ffm_group_*)
+    ("ffm_group_create", ctypes.c_int, [ctypes.POINTER(Config), ctypes.c_int32, _i32p, ctypes.POINTER(_vp)]),
+    ("ffm_group_destroy", None, [_vp]),
+    ("ffm_group_size", ctypes.c_int32, [_vp]),
+    ("ffm_group_engine", ctypes.c_void_p, [_vp, ctypes.c_int32]),
+    ("ffm_group_collective", ctypes.c_char_p, [_vp]),
+    ("ffm_group_train_batch", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR + [_f32p, _f64p]),
+    ("ffm_group_train_batch_async", ctypes.c_int, [_vp, ctypes.c_int32] + _CSR + [ctypes.c_int32]),
+    ("ffm_group_train_flush", ctypes.c_int, [_vp, _f64p]),
+    ("ffm_group_blocks_pulled", ctypes.c_int64, [_vp]),
+    ("ffm_group_predict_batch", ctypes.c_int,
+     [_vp, ctypes.c_int32] + _CSR + [ctypes.c_int32, _f32p, _f64p]),
 ]
 
 _lib = None
@@ -321,6 +334,11 @@ class Engine:
         self._check(self.lib.ffm_engine_train_flush(self.h, ctypes.byref(loss)))
         return float(loss.value)
 
+    def predict_batch_async(self, c, zero_copy=False):
+        """Pipelined evaluation: uploads the block on the side stream and predicts it; the loss sum
+        of all blocks since the last flush comes back from train_flush()."""
+        self._check(self.lib.ffm_engine_predict_batch_async(self.h, *self._csr(c), int(zero_copy)))
+
     def train_rows(self, c):
         """Row after row (n_rows == 1 per call): the reference's sequential train() loop."""
         logits = np.zeros(c.n_rows, np.float32)
@@ -411,3 +429,91 @@ class Engine:
         buf = ctypes.create_string_buffer(4096)
         self._check(self.lib.ffm_engine_profile_dump(self.h, buf, 4096))
         return buf.value.decode()
+
+
+class Group:
+    """Several field-pair shard engines in ONE process (ffm_group_*): one engine per entry of
+    `devices`, one RCCL all-reduce of the partial logits per block when the devices are distinct
+    (a kernel sum when they share a device: one-GPU dry run of the orchestration)."""
+
+    def __init__(self, devices, model_type="FFM", n_feats=10000, n_fields=8, n_factors=16, w_alpha=1e-4,
+                 w_beta=1.0, w_l1=0.1, w_l2=5.0, init_mean=0.0, init_stddev=0.02, seed=42,
+                 max_batch_rows=8192, max_batch_nnz=None, skip_init=False, max_row_nnz=0,
+                 field_start=None):
+        self.lib = load_library()
+        cfg = Config()
+        self.lib.ffm_engine_default_config(ctypes.byref(cfg))
+        cfg.model_type = MODEL_TYPES[model_type] if isinstance(model_type, str) else int(model_type)
+        cfg.n_feats, cfg.n_fields, cfg.n_factors = int(n_feats), int(n_fields), int(n_factors)
+        cfg.w_alpha, cfg.w_beta, cfg.w_l1, cfg.w_l2 = w_alpha, w_beta, w_l1, w_l2
+        cfg.init_mean, cfg.init_stddev, cfg.seed = init_mean, init_stddev, int(seed)
+        cfg.max_batch_rows = int(max_batch_rows)
+        cfg.max_batch_nnz = int(max_batch_nnz if max_batch_nnz else max_batch_rows * 64)
+        cfg.flags = FLAG_SKIP_INIT if skip_init else 0
+        cfg.max_row_nnz = int(max_row_nnz)
+        self._field_start = None
+        if field_start is not None:
+            self._field_start = np.ascontiguousarray(field_start, np.int32)
+            cfg.field_start = _i(self._field_start)
+        dev = np.ascontiguousarray(devices, np.int32)
+        self.h = _vp()
+        rc = self.lib.ffm_group_create(ctypes.byref(cfg), dev.size, _i(dev), ctypes.byref(self.h))
+        if rc != 0:
+            raise EngineError(rc, self.lib.ffm_engine_last_error().decode())
+        self.size = int(self.lib.ffm_group_size(self.h))
+        self.collective = self.lib.ffm_group_collective(self.h).decode()
+        # borrowed handles to the shards (for set_state / get_state in tests); the group owns them
+        self.engines = []
+        for r in range(self.size):
+            e = Engine.__new__(Engine)
+            e.lib, e.cfg, e.model_type = self.lib, cfg, cfg.model_type
+            e.h = _vp(self.lib.ffm_group_engine(self.h, r))
+            e._field_start = self._field_start
+            e.n_feats, e.n_fields, e.n_factors = cfg.n_feats, cfg.n_fields, cfg.n_factors
+            e.row_len = int(self.lib.ffm_engine_row_len(e.h))
+            e.close = lambda: None  # noqa: E731  (never destroys: the group does)
+            self.engines.append(e)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.lib.ffm_engine_last_error().decode())
+
+    def _csr(self, c):
+        return self.engines[0]._csr(c)
+
+    def train_batch(self, c):
+        out = np.zeros(max(c.n_rows, 1), np.float32)
+        loss = ctypes.c_double(0.0)
+        self._check(self.lib.ffm_group_train_batch(self.h, *self._csr(c), _f(out), ctypes.byref(loss)))
+        return out[:c.n_rows], float(loss.value)
+
+    def train_batch_async(self, c, zero_copy=False):
+        self._check(self.lib.ffm_group_train_batch_async(self.h, *self._csr(c), int(zero_copy)))
+
+    def train_flush(self):
+        loss = ctypes.c_double(0.0)
+        self._check(self.lib.ffm_group_train_flush(self.h, ctypes.byref(loss)))
+        return float(loss.value)
+
+    def blocks_pulled(self):
+        return int(self.lib.ffm_group_blocks_pulled(self.h))
+
+    def predict_batch(self, c, output_prob=False, with_loss=True):
+        out = np.zeros(max(c.n_rows, 1), np.float32)
+        loss = ctypes.c_double(0.0)
+        n, rp, fld, ft, v, lab = self._csr(c)
+        self._check(self.lib.ffm_group_predict_batch(self.h, n, rp, fld, ft, v, lab if with_loss else None,
+                                                     int(output_prob), _f(out), ctypes.byref(loss)))
+        return out[:c.n_rows], float(loss.value)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.ffm_group_destroy(self.h)
+            self.h = _vp()
+            self.engines = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -9,7 +9,7 @@
 #include <stdexcept>
 #include <vector>
 
-const char *const cmd_help =
+const std::string_view cmd_help =
     "\nUsage: ./ftrl_ffm_main [<options>]\n\noptions:\n"
     "--model_path <model_path>: set the output model path\n"
     "--train_data <data_path>: set the train data path\n"
@@ -31,6 +31,10 @@ const char *const cmd_help =
     "--batch_ramp <r>: block size grows as rows_seen/r (0 disables)\tdefault:32\n"
     "--seed <seed>: seed of the weight init and the offline shuffle\tdefault:42\n"
     "--device <id>: HIP device ordinal\tdefault:0\n"
+    "--n_gpus <n>: shard the field pairs over n devices (one engine each, RCCL all-reduce of the\n"
+    "              partial logits per block)\tdefault:1\n"
+    "--field_ranges <uniform|none>: uniform = field f owns ids [f*n_feats/n_fields, (f+1)*n_feats/n_fields),\n"
+    "              shards then store only their own slots\tdefault:none\n"
     "--learn <bool>: keep initial latent weights until their first gradient and use g2*g2 at\n"
     "                ffm.cpp:118, so FM/FFM factors train (NOT the reference's results)\tdefault:false\n";
 
@@ -88,6 +92,8 @@ void config_options::parse_option(int argc, char *argv[]) {
     else if (k == "--seed") seed = std::stoull(v);
     else if (k == "--device") device = std::stoi(v);
     else if (k == "--learn") learn = assign_bool(v);
+    else if (k == "--n_gpus") n_gpus = std::stoi(v);
+    else if (k == "--field_ranges") field_ranges = v;
     else throw std::invalid_argument("unknown argument: " + k + "\n");
   }
   file_type = detect_file_type(train_path);

@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <string_view>
 
 struct config_options {
   std::string model_path, train_path, eval_path;
@@ -21,9 +22,13 @@ struct config_options {
   uint64_t seed = 42;      // --seed: weight init and the offline shuffle (the reference is unseeded)
   int device = 0;          // --device: HIP device ordinal
   bool learn = false;      // --learn: FFM_FLAG_LEARN, the opt-in variant in which the factors train
+  int n_gpus = 1;          // --n_gpus: field-pair shards, one engine per device, RCCL all-reduce per block
+  std::string field_ranges = "none";  // --field_ranges uniform: field f owns ids [f*n_feats/F, (f+1)*n_feats/F)
+                                      //   (the layout of python/generate_data.py:272-306): shards then store
+                                      //   only their slots; none: every shard keeps whole records
 
   void parse_option(int argc, char *argv[]);  // throws std::invalid_argument like the reference
 };
 
 std::string detect_file_type(const std::string &file_path);  // cmd_option.cpp:35-59
-extern const char *const cmd_help;
+extern const std::string_view cmd_help;

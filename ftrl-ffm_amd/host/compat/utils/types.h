@@ -1,0 +1,5 @@
+// utils/types.h -- the reference's include path for this header (src/include/utils/types.h:7-25); forwards to the host mirror.
+// Source-level drop-in: /root/reference/src/main.cpp and tests/test_*.cpp compile against this tree
+// where they lie (tests/test_compat_compile.py).
+#pragma once
+#include "../../types.h"

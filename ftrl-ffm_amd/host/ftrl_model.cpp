@@ -52,9 +52,10 @@ FtrlModel::FtrlModel(const config_options &opt, int mt)
   check(rc, "ffm_engine_create");
   row_len_ = ffm_engine_row_len(eng_);
   lin_w.resize(static_cast<size_t>(n_feats));
-  if (row_len_ > 0)
-    vec_w.assign(static_cast<size_t>(n_feats), std::vector<float>(static_cast<size_t>(row_len_)));
-  pull_weights();
+  vec_w.owner_ = this;
+  vec_w.row_len_ = static_cast<size_t>(row_len_);
+  vec_w.n_ = row_len_ > 0 ? static_cast<size_t>(n_feats) : 0;
+  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
 }
 
 FtrlModel::~FtrlModel() { ffm_engine_destroy(eng_); }
@@ -206,75 +207,208 @@ double FtrlModel::predict_block(const CsrBlock &blk, bool output_prob, float *ou
   return total;
 }
 
+// ---- the lazy latent mirror --------------------------------------------------------------------
+
+size_t FtrlModel::stream_chunk() const {  // ~64 MB of floats per component and chunk
+  const size_t per = static_cast<size_t>(std::max<int64_t>(row_len_, 1));
+  return std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(n_feats), (16u << 20) / per));
+}
+
+void FtrlModel::get_latent_rows(int component, size_t first, size_t count, float *out) {
+  std::vector<int32_t> ids(count);
+  for (size_t j = 0; j < count; j++) ids[j] = static_cast<int32_t>(first + j);
+  check(ffm_engine_get_rows(eng_, static_cast<int32_t>(count), ids.data(), nullptr, nullptr, nullptr,
+                            component == 0 ? out : nullptr, component == 1 ? out : nullptr,
+                            component == 2 ? out : nullptr),
+        "ffm_engine_get_rows");
+}
+void FtrlModel::set_latent_rows(int component, size_t first, size_t count, const float *in) {
+  std::vector<int32_t> ids(count);
+  for (size_t j = 0; j < count; j++) ids[j] = static_cast<int32_t>(first + j);
+  check(ffm_engine_set_rows(eng_, static_cast<int32_t>(count), ids.data(), nullptr, nullptr, nullptr,
+                            component == 0 ? in : nullptr, component == 1 ? in : nullptr,
+                            component == 2 ? in : nullptr),
+        "ffm_engine_set_rows");
+}
+
+LatentMirror::row &LatentMirror::operator[](size_t i) {
+  if (dense_ready_) return dense_[i];
+  auto it = cache_.find(i);
+  if (it != cache_.end()) return it->second;
+  row r(row_len_);
+  owner_->get_latent_rows(0, i, 1, r.data());
+  return cache_.emplace(i, std::move(r)).first->second;
+}
+LatentMirror::row &LatentMirror::at(size_t i) {
+  if (i >= n_) throw std::out_of_range("vec_w");
+  return (*this)[i];
+}
+void LatentMirror::pull_all() {
+  if (dense_ready_) return;
+  dense_.assign(n_, row(row_len_));
+  const size_t chunk = owner_->stream_chunk();
+  std::vector<float> buf(chunk * row_len_);
+  for (size_t f0 = 0; f0 < n_; f0 += chunk) {
+    const size_t nf = std::min(chunk, n_ - f0);
+    owner_->get_latent_rows(0, f0, nf, buf.data());
+    for (size_t j = 0; j < nf; j++) std::copy(buf.begin() + j * row_len_, buf.begin() + (j + 1) * row_len_, dense_[f0 + j].begin());
+  }
+  for (auto &kv : cache_) dense_[kv.first] = std::move(kv.second);  // (rows edited before the pull win)
+  cache_.clear();
+  dense_ready_ = true;
+}
+
 void FtrlModel::pull_weights() {
-  std::vector<float> flat(static_cast<size_t>(n_feats) * static_cast<size_t>(row_len_));
-  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), flat.empty() ? nullptr : flat.data()),
-        "ffm_engine_get_weights");
-  for (size_t i = 0; i < vec_w.size(); i++)
-    std::copy(flat.begin() + i * row_len_, flat.begin() + (i + 1) * row_len_, vec_w[i].begin());
+  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
+  if (vec_w.dense_ready_) {
+    vec_w.dense_ready_ = false;
+    vec_w.cache_.clear();
+    vec_w.pull_all();
+  } else {
+    for (auto &kv : vec_w.cache_) get_latent_rows(0, kv.first, 1, kv.second.data());
+  }
 }
 
 void FtrlModel::push_weights() {
-  std::vector<float> flat(static_cast<size_t>(n_feats) * static_cast<size_t>(row_len_));
-  for (size_t i = 0; i < vec_w.size(); i++)
-    std::copy(vec_w[i].begin(), vec_w[i].end(), flat.begin() + i * row_len_);
-  check(ffm_engine_set_weights(eng_, &bias, lin_w.data(), flat.empty() ? nullptr : flat.data()),
-        "ffm_engine_set_weights");
+  check(ffm_engine_set_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_set_weights");
+  if (vec_w.dense_ready_) {
+    const size_t chunk = stream_chunk(), rl = static_cast<size_t>(row_len_);
+    std::vector<float> buf(chunk * rl);
+    for (size_t f0 = 0; f0 < vec_w.n_; f0 += chunk) {
+      const size_t nf = std::min(chunk, vec_w.n_ - f0);
+      for (size_t j = 0; j < nf; j++) std::copy(vec_w.dense_[f0 + j].begin(), vec_w.dense_[f0 + j].end(), buf.begin() + j * rl);
+      set_latent_rows(0, f0, nf, buf.data());
+    }
+  } else {
+    for (auto &kv : vec_w.cache_) set_latent_rows(0, kv.first, 1, kv.second.data());
+  }
 }
 
-static ModelWeights gather(FtrlModel &m, int64_t row_len) {
-  m.pull_weights();
-  ModelWeights w;
-  w.bias = m.bias;
-  w.lin_w = m.lin_w;
-  w.vec_w.reserve(m.vec_w.size() * static_cast<size_t>(row_len));
-  for (const auto &v : m.vec_w) w.vec_w.insert(w.vec_w.end(), v.begin(), v.end());
-  return w;
+// ---- model files, streamed (persist.h) -----------------------------------------------------------
+
+void FtrlModel::save_model(std::string_view file_name) {  // ffm.cpp:163-180
+  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
+  TextModelWriter w{std::string(file_name)};
+  w.scalar(bias);
+  for (float v : lin_w) w.scalar(v);
+  const size_t chunk = stream_chunk(), rl = static_cast<size_t>(row_len_), nf = rl ? static_cast<size_t>(n_feats) : 0;
+  std::vector<float> buf(chunk * rl);
+  for (size_t f0 = 0; f0 < nf; f0 += chunk) {
+    const size_t n = std::min(chunk, nf - f0);
+    get_latent_rows(0, f0, n, buf.data());
+    w.rows(buf.data(), n, rl);
+  }
+  w.finish();
+}
+void FtrlModel::load_model(std::string_view file_name) {  // ffm.cpp:182-200
+  TextModelReader r{std::string(file_name)};
+  bias = r.scalar();
+  for (auto &v : lin_w) v = r.scalar();
+  check(ffm_engine_set_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_set_weights");
+  const size_t chunk = stream_chunk(), rl = static_cast<size_t>(row_len_), nf = rl ? static_cast<size_t>(n_feats) : 0;
+  std::vector<float> buf(chunk * rl);
+  for (size_t f0 = 0; f0 < nf; f0 += chunk) {
+    const size_t n = std::min(chunk, nf - f0);
+    r.rows(buf.data(), n, rl);
+    set_latent_rows(0, f0, n, buf.data());
+  }
+  vec_w.dense_ready_ = false;
+  vec_w.dense_.clear();
+  vec_w.cache_.clear();
+}
+void FtrlModel::save_compressed_model(std::string_view file_name, int compress_level) {  // ffm.cpp:138-146
+  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
+  const size_t rl = static_cast<size_t>(row_len_), nf = static_cast<size_t>(n_feats);
+  FloatFrameWriter w(std::string(file_name), 1 + nf + nf * rl, compress_level);
+  w.write(&bias, 1);
+  w.write(lin_w.data(), nf);
+  const size_t chunk = stream_chunk();
+  std::vector<float> buf(chunk * rl);
+  for (size_t f0 = 0; rl && f0 < nf; f0 += chunk) {
+    const size_t n = std::min(chunk, nf - f0);
+    get_latent_rows(0, f0, n, buf.data());
+    w.write(buf.data(), n * rl);
+  }
+  w.finish();
+}
+void FtrlModel::load_compressed_model(std::string_view file_name) {  // ffm.cpp:148-161
+  const size_t rl = static_cast<size_t>(row_len_), nf = static_cast<size_t>(n_feats);
+  FloatFrameReader r{std::string(file_name)};
+  if (r.total_floats() != 1 + nf + nf * rl) throw std::runtime_error(std::string(file_name) + ": holds a model of a different shape");
+  auto need = [&](float *p, size_t n) {
+    if (r.read(p, n) != n) throw std::runtime_error(std::string(file_name) + ": zstd frame is truncated");
+  };
+  need(&bias, 1);
+  need(lin_w.data(), nf);
+  check(ffm_engine_set_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_set_weights");
+  const size_t chunk = stream_chunk();
+  std::vector<float> buf(chunk * rl);
+  for (size_t f0 = 0; rl && f0 < nf; f0 += chunk) {
+    const size_t n = std::min(chunk, nf - f0);
+    need(buf.data(), n * rl);
+    set_latent_rows(0, f0, n, buf.data());
+  }
+  std::printf("loading from %s, floats: %zu\n", std::string(file_name).c_str(), r.total_floats());
+  vec_w.dense_ready_ = false;
+  vec_w.dense_.clear();
+  vec_w.cache_.clear();
 }
 
-static void scatter(FtrlModel &m, const ModelWeights &w, int64_t row_len) {
-  m.bias = w.bias;
-  m.lin_w = w.lin_w;
-  for (size_t i = 0; i < m.vec_w.size(); i++)
-    std::copy(w.vec_w.begin() + i * row_len, w.vec_w.begin() + (i + 1) * row_len, m.vec_w[i].begin());
-  m.push_weights();
+// [bias_n, bias_z, lin_n[], lin_z[], vec_n[], vec_z[]], one zstd frame
+void FtrlModel::save_state(std::string_view file_name, int compress_level) {
+  const size_t nf = static_cast<size_t>(n_feats), rl = static_cast<size_t>(row_len_);
+  FloatFrameWriter w(std::string(file_name), 2 + 2 * nf + 2 * nf * rl, compress_level);
+  float b2[2];
+  std::vector<float> lin(nf);
+  check(ffm_engine_get_state(eng_, &b2[0], &b2[1], lin.data(), nullptr, nullptr, nullptr), "ffm_engine_get_state");
+  w.write(b2, 2);
+  w.write(lin.data(), nf);
+  check(ffm_engine_get_state(eng_, nullptr, nullptr, nullptr, lin.data(), nullptr, nullptr), "ffm_engine_get_state");
+  w.write(lin.data(), nf);
+  const size_t chunk = stream_chunk();
+  std::vector<float> buf(chunk * rl);
+  for (int comp = 1; comp <= 2 && rl; comp++)
+    for (size_t f0 = 0; f0 < nf; f0 += chunk) {
+      const size_t n = std::min(chunk, nf - f0);
+      get_latent_rows(comp, f0, n, buf.data());
+      w.write(buf.data(), n * rl);
+    }
+  w.finish();
+}
+void FtrlModel::load_state(std::string_view file_name) {
+  const size_t nf = static_cast<size_t>(n_feats), rl = static_cast<size_t>(row_len_);
+  FloatFrameReader r{std::string(file_name)};
+  if (r.total_floats() != 2 + 2 * nf + 2 * nf * rl) throw std::runtime_error(std::string(file_name) + ": wrong shape");
+  auto need = [&](float *p, size_t n) {
+    if (r.read(p, n) != n) throw std::runtime_error(std::string(file_name) + ": zstd frame is truncated");
+  };
+  float b2[2];
+  std::vector<float> lin(nf);
+  need(b2, 2);
+  need(lin.data(), nf);
+  check(ffm_engine_set_state(eng_, &b2[0], &b2[1], lin.data(), nullptr, nullptr, nullptr), "ffm_engine_set_state");
+  need(lin.data(), nf);
+  check(ffm_engine_set_state(eng_, nullptr, nullptr, nullptr, lin.data(), nullptr, nullptr), "ffm_engine_set_state");
+  const size_t chunk = stream_chunk();
+  std::vector<float> buf(chunk * rl);
+  for (int comp = 1; comp <= 2 && rl; comp++)
+    for (size_t f0 = 0; f0 < nf; f0 += chunk) {
+      const size_t n = std::min(chunk, nf - f0);
+      need(buf.data(), n * rl);
+      set_latent_rows(comp, f0, n, buf.data());
+    }
 }
 
-void FtrlModel::save_model(const std::string &file_name) {
-  write_text_model(file_name, gather(*this, row_len_), n_feats, static_cast<size_t>(row_len_));
-}
-void FtrlModel::load_model(const std::string &file_name) {
-  scatter(*this, read_text_model(file_name, n_feats, static_cast<size_t>(row_len_)), row_len_);
-}
-void FtrlModel::save_compressed_model(const std::string &file_name, int compress_level) {
-  write_compressed_model(file_name, gather(*this, row_len_), compress_level);
-}
-void FtrlModel::load_compressed_model(const std::string &file_name) {
-  scatter(*this, read_compressed_model(file_name, n_feats, static_cast<size_t>(row_len_)), row_len_);
-}
-
-void FtrlModel::save_state(const std::string &file_name, int compress_level) {
-  const size_t nf = static_cast<size_t>(n_feats), nv = nf * static_cast<size_t>(row_len_);
-  std::vector<float> flat(2 + 2 * nf + 2 * nv);
-  check(ffm_engine_get_state(eng_, &flat[0], &flat[1], &flat[2], &flat[2 + nf],
-                             nv ? &flat[2 + 2 * nf] : nullptr, nv ? &flat[2 + 2 * nf + nv] : nullptr),
-        "ffm_engine_get_state");
-  write_compressed_floats(file_name, flat, compress_level);
-}
-void FtrlModel::load_state(const std::string &file_name) {
-  const size_t nf = static_cast<size_t>(n_feats), nv = nf * static_cast<size_t>(row_len_);
-  const std::vector<float> flat = read_compressed_floats(file_name);
-  if (flat.size() != 2 + 2 * nf + 2 * nv) throw std::runtime_error(file_name + ": wrong shape");
-  check(ffm_engine_set_state(eng_, &flat[0], &flat[1], &flat[2], &flat[2 + nf],
-                             nv ? &flat[2 + 2 * nf] : nullptr, nv ? &flat[2 + 2 * nf + nv] : nullptr),
-        "ffm_engine_set_state");
-}
-
-bool FtrlModel::has_zero_weights() {  // utils.h:63-76 over lin_w and vec_w
-  pull_weights();
+bool FtrlModel::has_zero_weights() {  // utils.h:63-76 over lin_w, then vec_w (ftrl_offline.cpp:105-119)
+  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
   if (std::any_of(lin_w.begin(), lin_w.end(), [](float w) { return w == 0.0f; })) return true;
-  for (const auto &v : vec_w)
-    if (std::any_of(v.begin(), v.end(), [](float w) { return w == 0.0f; })) return true;
+  const size_t chunk = stream_chunk(), rl = static_cast<size_t>(row_len_), nf = rl ? static_cast<size_t>(n_feats) : 0;
+  std::vector<float> buf(chunk * rl);
+  for (size_t f0 = 0; f0 < nf; f0 += chunk) {  // streamed: stops at the first chunk that holds a zero
+    const size_t n = std::min(chunk, nf - f0);
+    get_latent_rows(0, f0, n, buf.data());
+    if (std::any_of(buf.begin(), buf.begin() + n * rl, [](float w) { return w == 0.0f; })) return true;
+  }
   return false;
 }
 

@@ -8,11 +8,19 @@
 //   float predict(feat_vec&, bool)
 //   train_block / predict_block   the same for a block of rows (what the trainers call).
 //
-// bias / lin_w / vec_w are host mirrors of the device weights: call pull_weights() to refresh them
-// after training, push_weights() after editing them (the reference's tests poke them directly).
+// bias / lin_w / vec_w are host mirrors of the device weights, as public as in the reference
+// (ftrl_model.h:35-37, ffm.h:25, fm.h:20).  bias and lin_w (4 bytes per feature) are pulled at
+// construction; vec_w is LAZY: `model.vec_w.size()` and `model.vec_w[i].size()` answer without
+// moving anything, `model.vec_w[i]` pulls row i from HBM the first time it is touched, whole-model
+// walks (begin()/end(), pull_all()) pull everything -- the 33 M-feature headline model has 82 GB of
+// vec_w, which no constructor should copy.  pull_weights() refreshes what is mirrored after
+// training, push_weights() writes edited mirrors back (the reference's tests poke them directly).
+// Model files are streamed record chunk by record chunk (persist.h): host memory stays bounded.
 #pragma once
 #include <memory>
 #include <string>
+#include <string_view>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ffm_engine.h"
@@ -20,6 +28,31 @@
 #include "types.h"
 
 namespace ftrl {
+
+class FtrlModel;
+
+// std::vector<std::vector<float>>-shaped view of the latent weights in HBM (see the file comment).
+class LatentMirror {
+ public:
+  using row = std::vector<float>;
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  row &operator[](size_t i);
+  row &at(size_t i);
+  std::vector<row>::iterator begin() { pull_all(); return dense_.begin(); }
+  std::vector<row>::iterator end() { pull_all(); return dense_.end(); }
+  void pull_all();                    // every row, dense (small models, the reference's tests)
+  bool is_dense() const { return dense_ready_; }
+  size_t rows_mirrored() const { return dense_ready_ ? n_ : cache_.size(); }
+
+ private:
+  friend class FtrlModel;
+  FtrlModel *owner_ = nullptr;
+  size_t n_ = 0, row_len_ = 0;
+  bool dense_ready_ = false;
+  std::vector<row> dense_;
+  std::unordered_map<size_t, row> cache_;  // rows touched one by one
+};
 
 class FtrlModel {
  public:
@@ -53,21 +86,26 @@ class FtrlModel {
   // Model files in the reference's formats (ffm.cpp:138-200, lr.cpp:26-39); available for every
   // model type here (the reference has none for FM).  save_state/load_state add the FTRL
   // accumulators, which make a checkpoint resumable.
-  void save_model(const std::string &file_name);
-  void load_model(const std::string &file_name);
-  void save_compressed_model(const std::string &file_name, int compress_level);
-  void load_compressed_model(const std::string &file_name);
-  void save_state(const std::string &file_name, int compress_level = 3);
-  void load_state(const std::string &file_name);
+  void save_model(std::string_view file_name);
+  void load_model(std::string_view file_name);
+  void save_compressed_model(std::string_view file_name, int compress_level);
+  void load_compressed_model(std::string_view file_name);
+  void save_state(std::string_view file_name, int compress_level = 3);
+  void load_state(std::string_view file_name);
 
-  void pull_weights();  // device -> bias / lin_w / vec_w
-  void push_weights();  // bias / lin_w / vec_w -> device
+  void pull_weights();  // device -> bias, lin_w and the rows of vec_w that are mirrored
+  void push_weights();  // bias, lin_w and the mirrored rows of vec_w -> device
   bool has_zero_weights();
 
   ModelType model_type;
   float bias = 0.0f;
   std::vector<float> lin_w;
-  std::vector<std::vector<float>> vec_w;  // [n_feats][row_len]; empty for LR
+  LatentMirror vec_w;  // [n_feats][row_len], lazy; empty for LR
+
+  // features per chunk when a whole model is streamed (files, has_zero_weights, pull_all)
+  size_t stream_chunk() const;
+  void get_latent_rows(int component, size_t first, size_t count, float *out);  // 0 = w, 1 = n, 2 = z
+  void set_latent_rows(int component, size_t first, size_t count, const float *in);
 
   ffm_engine *engine() { return eng_; }
   int64_t row_len() const { return row_len_; }

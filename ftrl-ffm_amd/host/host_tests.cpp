@@ -3,6 +3,7 @@
 // tests/test_task.cpp:25-43, tests/test_utils.cpp:40-43), plus flag parsing and parser errors.
 //   host_tests cpu   -> everything that needs no GPU (reader, parsers, flags, loss)
 //   host_tests gpu   -> model shapes, remove_out_range, weight round trip, online/offline tasks
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -264,9 +265,28 @@ static int convert(int argc, char **argv) {
   const std::string in = argv[2], out = argv[3];
   const size_t nf = std::stoul(argv[4]), rl = std::stoul(argv[5]);
   auto is_zst = [](const std::string &p) { return p.size() > 4 && p.substr(p.size() - 4) == ".zst"; };
-  const ftrl::ModelWeights w = is_zst(in) ? ftrl::read_compressed_model(in, nf, rl)
-                                          : ftrl::read_text_model(in, nf, rl);
-  if (is_zst(out)) ftrl::write_compressed_model(out, w, 3); else ftrl::write_text_model(out, w, nf, rl);
+  // streamed through the file classes alone: [bias, lin_w[nf], vec_w[nf][rl]]
+  std::vector<float> lin(nf + 1), rows(nf * rl);
+  if (is_zst(in)) {
+    ftrl::FloatFrameReader r(in);
+    if (r.total_floats() != 1 + nf + nf * rl) return 3;
+    if (r.read(lin.data(), nf + 1) != nf + 1 || r.read(rows.data(), nf * rl) != nf * rl) return 4;
+  } else {
+    ftrl::TextModelReader r(in);
+    for (auto &v : lin) v = r.scalar();
+    r.rows(rows.data(), nf, rl);
+  }
+  if (is_zst(out)) {
+    ftrl::FloatFrameWriter w(out, 1 + nf + nf * rl, 3);
+    w.write(lin.data(), nf + 1);
+    for (size_t f0 = 0; f0 < nf; f0 += 7) w.write(rows.data() + f0 * rl, std::min<size_t>(7, nf - f0) * rl);  // in pieces
+    w.finish();
+  } else {
+    ftrl::TextModelWriter w(out);
+    for (float v : lin) w.scalar(v);
+    w.rows(rows.data(), nf, rl);
+    w.finish();
+  }
   return 0;
 }
 

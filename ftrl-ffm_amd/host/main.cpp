@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <string>
 
 #include "cmd_option.h"
 #include "trainer.h"
@@ -12,7 +13,7 @@ int main(int argc, char *argv[]) {
   try {
     opt.parse_option(argc, argv);
   } catch (const std::invalid_argument &e) {
-    std::fprintf(stderr, "invalid argument: %s\n%s", e.what(), cmd_help);
+    std::fprintf(stderr, "invalid argument: %s\n%s", e.what(), std::string(cmd_help).c_str());
     return EXIT_FAILURE;
   }
   try {

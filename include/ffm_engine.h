@@ -224,6 +224,19 @@ int ffm_engine_train_batch_async_pinned(ffm_engine *e, int32_t n_rows, const int
                                         const int32_t *field, const int32_t *feat, const float *val,
                                         const int32_t *label);
 
+/* Pipelined evaluation from host buffers -- Evaluator::run_task (src/eval/evaluate.cpp:23-33) and the
+ * eval branch of FtrlOffline::one_epoch (ftrl_offline.cpp:79-80) accumulate loss(y, predict(x)) and
+ * nothing else: the block is uploaded through a staging slot on the side stream (zero_copy as in
+ * ffm_engine_stage_batch: page-locked arrays pulled in place, untouched until
+ * ffm_engine_blocks_pulled() has reached the block's ordinal) and predicted on the engine's stream,
+ * so the upload of block t+1 and the caller's parsing of block t+2 overlap the forward pass of
+ * block t.  Returns at once; ffm_engine_train_flush waits and returns (and resets) the sum of the
+ * losses of all blocks since the previous flush.  Unsharded engines; not to be mixed with staged
+ * training blocks that have not trained yet. */
+int ffm_engine_predict_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                   const int32_t *field, const int32_t *feat, const float *val,
+                                   const int32_t *label, int32_t zero_copy);
+
 /* The two halves of ffm_engine_train_batch_async, for callers that put something between forward
  * and update -- the sharded trainer's all-reduce: ffm_engine_stage_batch copies the host block into
  * a pinned staging slot, uploads it and groups it on the side stream (returns at once; the
@@ -275,6 +288,43 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
                                     float *partial_logit);
 int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *logit_out,
                                    double *loss_sum_out);
+
+/* ---- several GPUs in ONE process: a group of field-pair shards --------------------------------
+ * The reference has no counterpart ("distributed communication backend: none"); this
+ * is what its caller FtrlOffline::one_epoch (src/task/ftrl_offline.cpp:63-103) drives when the
+ * model is sharded over the GPUs of a node (BASELINE.json config 5).  ffm_group_create makes one
+ * engine per entry of device_ids[n] (cfg->n_shards = n is implied, shard_rank = position; with
+ * cfg->field_start every shard stores only its own slots) and one RCCL communicator per device
+ * (librccl.so, bound at run time; ncclCommInitAll).  A training block is staged on EVERY engine
+ * (each GPU pulls it from the caller's page-locked arrays, or from its own pinned copy), every
+ * engine computes the partial logits of its field pairs, ONE ncclAllReduce(sum, float32, n_rows)
+ * per block runs on the engines' own streams (ncclGroupStart/End around the n calls), every engine
+ * updates its slots.  Same pipelining, ordinals and flush semantics as the one-engine entry points
+ * of the same names.  Results: the one-engine results up to the association order of the
+ * cross-shard logit sum (rtol 1e-5 per logit).
+ *   Engines that SHARE a device (device_ids with repeats: a one-GPU dry run of the orchestration,
+ * tests/test_gpu_group.py) cannot be RCCL ranks; their partial logits are summed by a kernel on
+ * that device instead -- ffm_group_collective() says which of the two a group uses. */
+typedef struct ffm_group ffm_group;
+int ffm_group_create(const ffm_engine_config *cfg, int32_t n, const int32_t *device_ids, ffm_group **out);
+void ffm_group_destroy(ffm_group *g);
+int32_t ffm_group_size(const ffm_group *g);
+ffm_engine *ffm_group_engine(ffm_group *g, int32_t rank);
+const char *ffm_group_collective(const ffm_group *g); /* "rccl" | "device-local sum" */
+/* one block, synchronous: logits (host, may be NULL) and the sum of loss(y, logit) */
+int ffm_group_train_batch(ffm_group *g, int32_t n_rows, const int32_t *row_ptr, const int32_t *field,
+                          const int32_t *feat, const float *val, const int32_t *label,
+                          float *logit_out, double *loss_sum_out);
+/* pipelined (ffm_engine_train_batch_async / _pinned): zero_copy != 0 for page-locked arrays */
+int ffm_group_train_batch_async(ffm_group *g, int32_t n_rows, const int32_t *row_ptr,
+                                const int32_t *field, const int32_t *feat, const float *val,
+                                const int32_t *label, int32_t zero_copy);
+int ffm_group_train_flush(ffm_group *g, double *loss_sum_out);
+int64_t ffm_group_blocks_pulled(ffm_group *g); /* blocks every engine has uploaded */
+/* predict(), synchronous: out (host, may be NULL) and the loss sum when label is given */
+int ffm_group_predict_batch(ffm_group *g, int32_t n_rows, const int32_t *row_ptr, const int32_t *field,
+                            const int32_t *feat, const float *val, const int32_t *label,
+                            int32_t output_prob, float *out, double *loss_sum_out);
 
 /* Measurement utility: overwrite ALL accumulators with a reproducible "warm" state drawn on the
  * device -- n ~ U[n_lo, n_hi), z ~ N(0, z_stddev) for bias, linear and latent -- so that

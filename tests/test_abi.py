@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     text = open(os.path.join(ROOT, "include", "ffm_engine.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ffm_engine_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(ffm_(?:engine|group)_\w+)\s*\(", text)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():

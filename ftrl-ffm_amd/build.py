@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
 
 HOST = os.path.join(HERE, "host")
 HOST_SRCS = ["cmd_option.cpp", "parser.cpp", "reader.cpp", "ftrl_model.cpp", "trainer.cpp",
-             "persist.cpp", "csr_reader.cpp"]
+             "persist.cpp", "csr_reader.cpp", "csr_stream.cpp"]
 MAIN_BIN = os.path.join(HOST, "ftrl_ffm_main")
 TEST_BIN = os.path.join(HOST, "host_tests")
 

@@ -16,10 +16,7 @@
 namespace ftrl {
 namespace {
 
-struct Part {
-  std::vector<int32_t> nnz, field, feat, label;
-  std::vector<float> val;
-};
+using Part = CsrPart;
 
 [[noreturn]] void bad_line(const char *b, const char *e) {
   const std::string line(b, e);
@@ -95,6 +92,10 @@ void parse_range(const char *p, const char *end, bool has_field, Part &out) {
 }
 
 }  // namespace
+
+void parse_csr_range(const char *begin, const char *end, bool has_field, CsrPart &out) {
+  parse_range(begin, end, has_field, out);
+}
 
 void CsrData::slice(size_t r0, size_t r1, CsrBlock &out) const {
   out.clear();

@@ -29,4 +29,13 @@ struct CsrData {
 
 CsrData load_csr(const std::string &path, const std::string &file_type, int n_threads);
 
+// The rows of a byte range of a libffm / libsvm text (whole lines), as parallel arrays: what one
+// reader thread produces (load_csr's partitions, csr_stream's chunks).
+struct CsrPart {
+  std::vector<int32_t> nnz, field, feat, label;  // nnz, label: per row
+  std::vector<float> val;
+  void clear() { nnz.clear(); field.clear(); feat.clear(); label.clear(); val.clear(); }
+};
+void parse_csr_range(const char *begin, const char *end, bool has_field, CsrPart &out);
+
 }  // namespace ftrl

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 
 namespace ftrl {
@@ -47,18 +48,72 @@ FtrlModel::FtrlModel(const config_options &opt, int mt)
   cfg.max_row_nnz = max_row_nnz_;
   cfg.device_id = opt.device;
   if (opt.learn) cfg.flags |= FFM_FLAG_LEARN;
-  const int rc = ffm_engine_create(&cfg, &eng_);
-  if (rc == FFM_E_INVALID) throw std::invalid_argument(ffm_engine_last_error());
-  check(rc, "ffm_engine_create");
+  n_gpus_ = std::max(1, opt.n_gpus);
+  int rc;
+  const char *force_group = std::getenv("FFM_GROUP_RCCL");  // (a group of one: the RCCL path on a one-GPU box)
+  if (n_gpus_ > 1 || (force_group && force_group[0] == '1' && mt == FFM_MODEL_FFM)) {
+    // field-pair sharding needs field(i): --field_ranges uniform says field f owns the ids
+    // [f * n_feats / n_fields, (f + 1) * n_feats / n_fields) (python/generate_data.py:272-306 lays
+    // ids out per field); every shard then stores only the slots it owns
+    if (mt != FFM_MODEL_FFM) throw std::invalid_argument("--n_gpus > 1 shards the FFM field pairs: model_type must be FFM");
+    if (n_gpus_ > 1 && opt.field_ranges != "uniform")
+      throw std::invalid_argument("--n_gpus > 1 needs --field_ranges uniform (per-field id ranges)");
+    std::vector<int32_t> fs(static_cast<size_t>(opt.n_fields) + 1);
+    if (opt.field_ranges == "uniform") {
+      per_field_ = opt.n_feats / opt.n_fields;
+      for (int f = 0; f <= opt.n_fields; f++) fs[f] = f == opt.n_fields ? opt.n_feats : f * per_field_;
+      if (n_gpus_ > 1) cfg.field_start = fs.data();
+    }
+    std::vector<int32_t> devs(static_cast<size_t>(n_gpus_));
+    const bool same = std::getenv("FTRL_SAME_DEVICE") != nullptr;  // one-GPU dry run of the orchestration
+    for (int r = 0; r < n_gpus_; r++) devs[r] = same ? opt.device : opt.device + r;
+    rc = ffm_group_create(&cfg, n_gpus_, devs.data(), &grp_);
+    if (rc == FFM_E_INVALID) throw std::invalid_argument(ffm_engine_last_error());
+    check(rc, "ffm_group_create");
+    eng_ = ffm_group_engine(grp_, 0);
+    lin_owner_of_field_.resize(static_cast<size_t>(opt.n_fields));
+    int32_t bo = 0;
+    check(ffm_engine_shard_plan(opt.n_fields, n_gpus_, n_gpus_ > 1 ? 1 : 0, nullptr, lin_owner_of_field_.data(), &bo), "ffm_engine_shard_plan");
+    bias_owner_ = bo;
+    std::printf("%d field-pair shards, collective: %s\n", n_gpus_, ffm_group_collective(grp_));
+  } else {
+    rc = ffm_engine_create(&cfg, &eng_);
+    if (rc == FFM_E_INVALID) throw std::invalid_argument(ffm_engine_last_error());
+    check(rc, "ffm_engine_create");
+  }
   row_len_ = ffm_engine_row_len(eng_);
   lin_w.resize(static_cast<size_t>(n_feats));
   vec_w.owner_ = this;
   vec_w.row_len_ = static_cast<size_t>(row_len_);
   vec_w.n_ = row_len_ > 0 ? static_cast<size_t>(n_feats) : 0;
-  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
+  pull_linear();
 }
 
-FtrlModel::~FtrlModel() { ffm_engine_destroy(eng_); }
+FtrlModel::~FtrlModel() {
+  if (grp_) ffm_group_destroy(grp_); else ffm_engine_destroy(eng_);
+}
+
+ffm_engine *FtrlModel::shard(int r) const { return grp_ ? ffm_group_engine(grp_, r) : eng_; }
+
+// bias and lin_w from their owners (one engine: the engine)
+void FtrlModel::pull_linear() {
+  if (!grp_) {
+    check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
+    return;
+  }
+  std::vector<float> tmp(lin_w.size());
+  for (int r = 0; r < n_gpus_; r++) {
+    float b = 0.0f;
+    check(ffm_engine_get_weights(shard(r), &b, tmp.data(), nullptr), "ffm_engine_get_weights");
+    if (r == bias_owner_) bias = b;
+    for (size_t i = 0; i < tmp.size(); i++)
+      if (lin_owner_of_field_[field_of(static_cast<int>(i))] == r) lin_w[i] = tmp[i];
+  }
+}
+void FtrlModel::push_linear() {
+  for (int r = 0; r < n_gpus_; r++)
+    check(ffm_engine_set_weights(shard(r), &bias, lin_w.data(), nullptr), "ffm_engine_set_weights");
+}
 
 void FtrlModel::remove_out_range(feat_vec &feats) {  // ftrl_model.cpp:36-42
   feats.erase(std::remove_if(feats.begin(), feats.end(),
@@ -131,10 +186,15 @@ double FtrlModel::train_block(const CsrBlock &blk, float *logit_out) {
   double total = 0.0;
   for_each_fitting(blk, [&](const CsrBlock &b, int r0) {
     double loss_sum = 0.0;
-    check(ffm_engine_train_batch(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(), b.feat.data(),
-                                 b.val.data(), b.label.data(), logit_out ? logit_out + r0 : nullptr,
-                                 &loss_sum),
-          "ffm_engine_train_batch");
+    if (grp_)
+      check(ffm_group_train_batch(grp_, b.n_rows(), b.row_ptr.data(), b.field.data(), b.feat.data(),
+                                  b.val.data(), b.label.data(), logit_out ? logit_out + r0 : nullptr, &loss_sum),
+            "ffm_group_train_batch"), handed_over_++;  // (a group stages every block: its ordinal counts)
+    else
+      check(ffm_engine_train_batch(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(), b.feat.data(),
+                                   b.val.data(), b.label.data(), logit_out ? logit_out + r0 : nullptr,
+                                   &loss_sum),
+            "ffm_engine_train_batch");
     total += loss_sum;
   });
   return total;
@@ -142,9 +202,14 @@ double FtrlModel::train_block(const CsrBlock &blk, float *logit_out) {
 
 void FtrlModel::train_block_async(const CsrBlock &blk) {
   for_each_fitting(blk, [&](const CsrBlock &b, int) {
-    check(ffm_engine_train_batch_async(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(),
-                                       b.feat.data(), b.val.data(), b.label.data()),
-          "ffm_engine_train_batch_async");
+    if (grp_)
+      check(ffm_group_train_batch_async(grp_, b.n_rows(), b.row_ptr.data(), b.field.data(), b.feat.data(),
+                                        b.val.data(), b.label.data(), 0),
+            "ffm_group_train_batch_async");
+    else
+      check(ffm_engine_train_batch_async(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(),
+                                         b.feat.data(), b.val.data(), b.label.data()),
+            "ffm_engine_train_batch_async");
     handed_over_++;
   });
 }
@@ -180,17 +245,45 @@ long long FtrlModel::train_block_pinned(const CsrBlock &blk) {
     train_block_async(blk);
     return handed_over_;
   }
-  check(ffm_engine_train_batch_async_pinned(eng_, n, blk.row_ptr.data(), blk.field.data(), blk.feat.data(),
-                                            blk.val.data(), blk.label.data()),
-        "ffm_engine_train_batch_async_pinned");
+  if (grp_)
+    check(ffm_group_train_batch_async(grp_, n, blk.row_ptr.data(), blk.field.data(), blk.feat.data(),
+                                      blk.val.data(), blk.label.data(), 1),
+          "ffm_group_train_batch_async");
+  else
+    check(ffm_engine_train_batch_async_pinned(eng_, n, blk.row_ptr.data(), blk.field.data(), blk.feat.data(),
+                                              blk.val.data(), blk.label.data()),
+          "ffm_engine_train_batch_async_pinned");
   return ++handed_over_;
 }
 
-long long FtrlModel::blocks_pulled() { return ffm_engine_blocks_pulled(eng_); }
+long long FtrlModel::blocks_pulled() { return grp_ ? ffm_group_blocks_pulled(grp_) : ffm_engine_blocks_pulled(eng_); }
 
 double FtrlModel::train_flush() {
   double loss_sum = 0.0;
-  check(ffm_engine_train_flush(eng_, &loss_sum), "ffm_engine_train_flush");
+  if (grp_) check(ffm_group_train_flush(grp_, &loss_sum), "ffm_group_train_flush");
+  else check(ffm_engine_train_flush(eng_, &loss_sum), "ffm_engine_train_flush");
+  return loss_sum;
+}
+
+long long FtrlModel::predict_block_async(const CsrBlock &blk, bool pinned) {
+  const int n = blk.n_rows();
+  bool fits = n <= max_rows_ && blk.row_ptr[n] <= max_nnz_;
+  for (int r = 0; r < n && fits; r++) fits = blk.row_ptr[r + 1] - blk.row_ptr[r] <= max_row_nnz_;
+  if (grp_ || !fits) {  // a group predicts block by block (every shard, then the sum); so do split blocks
+    eval_loss_pending_ += predict_block(blk, false);
+    return handed_over_;
+  }
+  check(ffm_engine_predict_batch_async(eng_, n, blk.row_ptr.data(), blk.field.data(), blk.feat.data(),
+                                       blk.val.data(), blk.label.data(), pinned ? 1 : 0),
+        "ffm_engine_predict_batch_async");
+  return ++handed_over_;
+}
+
+double FtrlModel::eval_flush() {
+  double loss_sum = 0.0;
+  if (!grp_) check(ffm_engine_train_flush(eng_, &loss_sum), "ffm_engine_train_flush");
+  loss_sum += eval_loss_pending_;
+  eval_loss_pending_ = 0.0;
   return loss_sum;
 }
 
@@ -198,10 +291,16 @@ double FtrlModel::predict_block(const CsrBlock &blk, bool output_prob, float *ou
   double total = 0.0;
   for_each_fitting(blk, [&](const CsrBlock &b, int r0) {
     double loss_sum = 0.0;
-    check(ffm_engine_predict_batch(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(),
-                                   b.feat.data(), b.val.data(), b.label.data(), output_prob ? 1 : 0,
-                                   out ? out + r0 : nullptr, &loss_sum),
-          "ffm_engine_predict_batch");
+    if (grp_)
+      check(ffm_group_predict_batch(grp_, b.n_rows(), b.row_ptr.data(), b.field.data(), b.feat.data(),
+                                    b.val.data(), b.label.data(), output_prob ? 1 : 0,
+                                    out ? out + r0 : nullptr, &loss_sum),
+            "ffm_group_predict_batch");
+    else
+      check(ffm_engine_predict_batch(eng_, b.n_rows(), b.row_ptr.data(), b.field.data(),
+                                     b.feat.data(), b.val.data(), b.label.data(), output_prob ? 1 : 0,
+                                     out ? out + r0 : nullptr, &loss_sum),
+            "ffm_engine_predict_batch");
     total += loss_sum;
   });
   return total;
@@ -217,18 +316,29 @@ size_t FtrlModel::stream_chunk() const {  // ~64 MB of floats per component and 
 void FtrlModel::get_latent_rows(int component, size_t first, size_t count, float *out) {
   std::vector<int32_t> ids(count);
   for (size_t j = 0; j < count; j++) ids[j] = static_cast<int32_t>(first + j);
-  check(ffm_engine_get_rows(eng_, static_cast<int32_t>(count), ids.data(), nullptr, nullptr, nullptr,
-                            component == 0 ? out : nullptr, component == 1 ? out : nullptr,
-                            component == 2 ? out : nullptr),
-        "ffm_engine_get_rows");
+  std::vector<float> part;
+  for (int r = 0; r < n_gpus_; r++) {
+    float *dst = out;
+    if (r > 0) {  // a shard stores only the slots it owns; the others read as 0: the model is the sum
+      part.resize(count * static_cast<size_t>(row_len_));
+      dst = part.data();
+    }
+    check(ffm_engine_get_rows(shard(r), static_cast<int32_t>(count), ids.data(), nullptr, nullptr, nullptr,
+                              component == 0 ? dst : nullptr, component == 1 ? dst : nullptr,
+                              component == 2 ? dst : nullptr),
+          "ffm_engine_get_rows");
+    if (r > 0)
+      for (size_t i = 0; i < part.size(); i++) out[i] += part[i];
+  }
 }
 void FtrlModel::set_latent_rows(int component, size_t first, size_t count, const float *in) {
   std::vector<int32_t> ids(count);
   for (size_t j = 0; j < count; j++) ids[j] = static_cast<int32_t>(first + j);
-  check(ffm_engine_set_rows(eng_, static_cast<int32_t>(count), ids.data(), nullptr, nullptr, nullptr,
-                            component == 0 ? in : nullptr, component == 1 ? in : nullptr,
-                            component == 2 ? in : nullptr),
-        "ffm_engine_set_rows");
+  for (int r = 0; r < n_gpus_; r++)  // (every shard keeps what it owns of them)
+    check(ffm_engine_set_rows(shard(r), static_cast<int32_t>(count), ids.data(), nullptr, nullptr, nullptr,
+                              component == 0 ? in : nullptr, component == 1 ? in : nullptr,
+                              component == 2 ? in : nullptr),
+          "ffm_engine_set_rows");
 }
 
 LatentMirror::row &LatentMirror::operator[](size_t i) {
@@ -259,7 +369,7 @@ void LatentMirror::pull_all() {
 }
 
 void FtrlModel::pull_weights() {
-  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
+  pull_linear();
   if (vec_w.dense_ready_) {
     vec_w.dense_ready_ = false;
     vec_w.cache_.clear();
@@ -270,7 +380,7 @@ void FtrlModel::pull_weights() {
 }
 
 void FtrlModel::push_weights() {
-  check(ffm_engine_set_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_set_weights");
+  push_linear();
   if (vec_w.dense_ready_) {
     const size_t chunk = stream_chunk(), rl = static_cast<size_t>(row_len_);
     std::vector<float> buf(chunk * rl);
@@ -287,7 +397,7 @@ void FtrlModel::push_weights() {
 // ---- model files, streamed (persist.h) -----------------------------------------------------------
 
 void FtrlModel::save_model(std::string_view file_name) {  // ffm.cpp:163-180
-  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
+  pull_linear();
   TextModelWriter w{std::string(file_name)};
   w.scalar(bias);
   for (float v : lin_w) w.scalar(v);
@@ -304,7 +414,7 @@ void FtrlModel::load_model(std::string_view file_name) {  // ffm.cpp:182-200
   TextModelReader r{std::string(file_name)};
   bias = r.scalar();
   for (auto &v : lin_w) v = r.scalar();
-  check(ffm_engine_set_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_set_weights");
+  push_linear();
   const size_t chunk = stream_chunk(), rl = static_cast<size_t>(row_len_), nf = rl ? static_cast<size_t>(n_feats) : 0;
   std::vector<float> buf(chunk * rl);
   for (size_t f0 = 0; f0 < nf; f0 += chunk) {
@@ -317,7 +427,7 @@ void FtrlModel::load_model(std::string_view file_name) {  // ffm.cpp:182-200
   vec_w.cache_.clear();
 }
 void FtrlModel::save_compressed_model(std::string_view file_name, int compress_level) {  // ffm.cpp:138-146
-  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
+  pull_linear();
   const size_t rl = static_cast<size_t>(row_len_), nf = static_cast<size_t>(n_feats);
   FloatFrameWriter w(std::string(file_name), 1 + nf + nf * rl, compress_level);
   w.write(&bias, 1);
@@ -340,7 +450,7 @@ void FtrlModel::load_compressed_model(std::string_view file_name) {  // ffm.cpp:
   };
   need(&bias, 1);
   need(lin_w.data(), nf);
-  check(ffm_engine_set_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_set_weights");
+  push_linear();
   const size_t chunk = stream_chunk();
   std::vector<float> buf(chunk * rl);
   for (size_t f0 = 0; rl && f0 < nf; f0 += chunk) {
@@ -360,10 +470,22 @@ void FtrlModel::save_state(std::string_view file_name, int compress_level) {
   FloatFrameWriter w(std::string(file_name), 2 + 2 * nf + 2 * nf * rl, compress_level);
   float b2[2];
   std::vector<float> lin(nf);
-  check(ffm_engine_get_state(eng_, &b2[0], &b2[1], lin.data(), nullptr, nullptr, nullptr), "ffm_engine_get_state");
+  // bias and linear accumulators from the shards that own them
+  auto linear_state = [&](bool z_row) {
+    std::vector<float> tmp(nf);
+    for (int r = 0; r < n_gpus_; r++) {
+      float bn = 0.0f, bz = 0.0f;
+      check(ffm_engine_get_state(shard(r), &bn, &bz, z_row ? nullptr : tmp.data(), z_row ? tmp.data() : nullptr, nullptr, nullptr),
+            "ffm_engine_get_state");
+      if (r == bias_owner_ || !grp_) { b2[0] = bn; b2[1] = bz; }
+      for (size_t i = 0; i < nf; i++)
+        if (!grp_ || lin_owner_of_field_[field_of(static_cast<int>(i))] == r) lin[i] = tmp[i];
+    }
+  };
+  linear_state(false);
   w.write(b2, 2);
   w.write(lin.data(), nf);
-  check(ffm_engine_get_state(eng_, nullptr, nullptr, nullptr, lin.data(), nullptr, nullptr), "ffm_engine_get_state");
+  linear_state(true);
   w.write(lin.data(), nf);
   const size_t chunk = stream_chunk();
   std::vector<float> buf(chunk * rl);
@@ -386,9 +508,11 @@ void FtrlModel::load_state(std::string_view file_name) {
   std::vector<float> lin(nf);
   need(b2, 2);
   need(lin.data(), nf);
-  check(ffm_engine_set_state(eng_, &b2[0], &b2[1], lin.data(), nullptr, nullptr, nullptr), "ffm_engine_set_state");
+  for (int r = 0; r < n_gpus_; r++)
+    check(ffm_engine_set_state(shard(r), &b2[0], &b2[1], lin.data(), nullptr, nullptr, nullptr), "ffm_engine_set_state");
   need(lin.data(), nf);
-  check(ffm_engine_set_state(eng_, nullptr, nullptr, nullptr, lin.data(), nullptr, nullptr), "ffm_engine_set_state");
+  for (int r = 0; r < n_gpus_; r++)
+    check(ffm_engine_set_state(shard(r), nullptr, nullptr, nullptr, lin.data(), nullptr, nullptr), "ffm_engine_set_state");
   const size_t chunk = stream_chunk();
   std::vector<float> buf(chunk * rl);
   for (int comp = 1; comp <= 2 && rl; comp++)
@@ -400,7 +524,7 @@ void FtrlModel::load_state(std::string_view file_name) {
 }
 
 bool FtrlModel::has_zero_weights() {  // utils.h:63-76 over lin_w, then vec_w (ftrl_offline.cpp:105-119)
-  check(ffm_engine_get_weights(eng_, &bias, lin_w.data(), nullptr), "ffm_engine_get_weights");
+  pull_linear();
   if (std::any_of(lin_w.begin(), lin_w.end(), [](float w) { return w == 0.0f; })) return true;
   const size_t chunk = stream_chunk(), rl = static_cast<size_t>(row_len_), nf = rl ? static_cast<size_t>(n_feats) : 0;
   std::vector<float> buf(chunk * rl);

@@ -41,6 +41,19 @@ class LatentMirror {
   row &at(size_t i);
   std::vector<row>::iterator begin() { pull_all(); return dense_.begin(); }
   std::vector<row>::iterator end() { pull_all(); return dense_.end(); }
+  // `a.vec_w = b.vec_w` copies the VALUES of b's rows (all of them: b is pulled) into a's mirror;
+  // a.push_weights() then writes them to a's device
+  LatentMirror() = default;
+  LatentMirror(const LatentMirror &) = delete;
+  LatentMirror &operator=(const LatentMirror &o) {
+    if (this != &o) {
+      const_cast<LatentMirror &>(o).pull_all();
+      dense_ = o.dense_;
+      dense_ready_ = true;
+      cache_.clear();
+    }
+    return *this;
+  }
   void pull_all();                    // every row, dense (small models, the reference's tests)
   bool is_dense() const { return dense_ready_; }
   size_t rows_mirrored() const { return dense_ready_ ? n_ : cache_.size(); }
@@ -82,6 +95,13 @@ class FtrlModel {
   void unpin_block(CsrBlock &blk);
   long long train_block_pinned(const CsrBlock &blk);
   long long blocks_pulled();
+  // Pipelined evaluation (Evaluator::run_task, evaluate.cpp:23-33, needs the loss only): the block
+  // is uploaded on the side stream while the previous one is predicted; `pinned`: a pin_block()ed
+  // block, pulled in place and untouched until blocks_pulled() has reached the returned ordinal.
+  // eval_flush() waits and returns the sum of loss(y, predict(x)) since the last flush.
+  long long predict_block_async(const CsrBlock &blk, bool pinned);
+  double eval_flush();
+  int n_gpus() const { return n_gpus_; }
 
   // Model files in the reference's formats (ffm.cpp:138-200, lr.cpp:26-39); available for every
   // model type here (the reference has none for FM).  save_state/load_state add the FTRL
@@ -93,6 +113,8 @@ class FtrlModel {
   void save_state(std::string_view file_name, int compress_level = 3);
   void load_state(std::string_view file_name);
 
+  void pull_linear();   // device -> bias, lin_w (from the shards that own them)
+  void push_linear();
   void pull_weights();  // device -> bias, lin_w and the rows of vec_w that are mirrored
   void push_weights();  // bias, lin_w and the mirrored rows of vec_w -> device
   bool has_zero_weights();
@@ -113,7 +135,17 @@ class FtrlModel {
  protected:
   int n_feats, n_fields, n_factors;
   int64_t row_len_ = 0;
-  ffm_engine *eng_ = nullptr;
+  ffm_engine *eng_ = nullptr;   // the engine (shard 0 of the group when there is one)
+  // --n_gpus > 1: one field-pair shard engine per device, RCCL all-reduce of the partial logits per
+  // block (include/ffm_engine.h: ffm_group_*)
+  ffm_group *grp_ = nullptr;
+  int n_gpus_ = 1;
+  std::vector<int32_t> lin_owner_of_field_;  // [n_fields] shard that owns a field's linear terms
+  int bias_owner_ = 0;
+  double eval_loss_pending_ = 0.0;  // group: evaluation blocks are predicted synchronously
+  ffm_engine *shard(int r) const;
+  int field_of(int feat) const { return per_field_ > 0 ? std::min(feat / per_field_, n_fields - 1) : 0; }
+  int per_field_ = 0;  // ids per field under --field_ranges uniform
   CsrBlock one_;  // scratch for the one-row shims
   // engine capacities chosen at construction; blocks beyond max_nnz_ are split into several
   // engine calls (each still a block in row order), a single row beyond max_row_nnz_ is an error

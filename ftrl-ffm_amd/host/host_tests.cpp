@@ -14,6 +14,7 @@
 
 #include "cmd_option.h"
 #include "csr_reader.h"
+#include "csr_stream.h"
 #include "ftrl_model.h"
 #include "persist.h"
 #include "reader.h"
@@ -106,6 +107,62 @@ static void test_csr_reader_matches_line_parsers() {
   bool threw = false;
   { std::ofstream(kPath) << "1 0:5:1\n0 3:7\n"; }
   try { ftrl::load_csr(kPath, "libffm", 1); } catch (const std::out_of_range &) { threw = true; }
+  CHECK(threw);
+  std::remove(kPath);
+}
+
+static void test_csr_stream_is_the_file_in_order() {
+  // 45 000 ragged rows (more than two 20 000-line chunks), blank lines, one giant row
+  std::string text;
+  unsigned s = 777;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+  for (int r = 0; r < 45000; r++) {
+    if (r % 9973 == 0) text += "\n";
+    text += std::to_string(static_cast<int>(rnd() % 2));
+    const int nnz = r == 30000 ? 300 : rnd() % 10;
+    for (int j = 0; j < nnz; j++) {
+      char tok[64];
+      std::snprintf(tok, sizeof tok, " %u:%u:%s", rnd() % 8, rnd() % 10000, rnd() % 4 ? "1" : "0.25");
+      text += tok;
+    }
+    text += "\n";
+  }
+  { std::ofstream(kPath) << text; }
+  const ftrl::CsrData d = ftrl::load_csr(kPath, "libffm", 2);
+  for (int threads : {1, 3}) {
+    ftrl::CsrStream st(kPath, "libffm", threads);
+    for (int pass = 0; pass < 2; pass++) {  // second pass: after rewind()
+      size_t row = 0;
+      bool same = true;
+      CsrBlock b;
+      unsigned step = 0;
+      for (;;) {
+        const size_t want = 1 + (step++ * 7919u) % 5000;  // ragged block sizes across chunk edges
+        const size_t got = st.next(want, b, 20000);
+        if (got == 0) break;
+        same = same && static_cast<size_t>(b.n_rows()) == got && got <= want;
+        same = same && (b.feat.size() <= 20000 || got == 1);
+        for (size_t r = 0; same && r < got; r++, row++) {
+          const int64_t p0 = d.row_ptr[row], len = d.row_ptr[row + 1] - p0;
+          same = b.label[r] == d.label[row] && b.row_ptr[r + 1] - b.row_ptr[r] == len;
+          for (int64_t j = 0; same && j < len; j++)
+            same = b.field[b.row_ptr[r] + j] == d.field[p0 + j] && b.feat[b.row_ptr[r] + j] == d.feat[p0 + j] &&
+                   b.val[b.row_ptr[r] + j] == d.val[p0 + j];
+        }
+        if (!same) break;
+      }
+      CHECK(same);
+      CHECK(row == d.n_rows());
+      st.rewind();
+    }
+  }
+  { std::ofstream(kPath) << "1 0:5:1\n0 3:7\n"; }
+  bool threw = false;
+  try {
+    ftrl::CsrStream bad(kPath, "libffm", 2);
+    CsrBlock b;
+    while (bad.next(10, b)) {}
+  } catch (const std::out_of_range &) { threw = true; }
   CHECK(threw);
   std::remove(kPath);
 }
@@ -306,12 +363,32 @@ static int ingest(int argc, char **argv) {
   return d.n_rows() == reader.get_size() ? 0 : 1;
 }
 
+// host_tests stream <file> <libffm|libsvm> <threads>: rows/s of the chunked stream reader alone
+// (parse only: what the online trainer's worker threads sustain), blocks of 8192 rows
+static int stream_rate(int argc, char **argv) {
+  if (argc < 5) return 2;
+  const int threads = std::stoi(argv[4]);
+  ftrl::CsrStream st(argv[2], argv[3], threads);
+  CsrBlock b;
+  for (int pass = 0; pass < 2; pass++) {  // (the second pass reads the page cache)
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t rows = 0, got;
+    while ((got = st.next(8192, b)) != 0) rows += got;
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("pass %d: rows %zu  csr_stream %.0f rows/s  (threads %d)\n", pass, rows, rows / s, threads);
+    st.rewind();
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && std::strcmp(argv[1], "convert") == 0) return convert(argc, argv);
+  if (argc > 1 && std::strcmp(argv[1], "stream") == 0) return stream_rate(argc, argv);
   if (argc > 1 && std::strcmp(argv[1], "ingest") == 0) return ingest(argc, argv);
   const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
   test_reader_and_parsers();
   test_csr_reader_matches_line_parsers();
+  test_csr_stream_is_the_file_in_order();
   test_flags();
   test_loss_known_answers();
   if (gpu) {

@@ -35,23 +35,30 @@ FtrlOffline::FtrlOffline(const config_options &opt)
   }
 }
 
-FtrlOffline::~FtrlOffline() {
-  for (auto &b : ring_) model_ptr->unpin_block(b);
-}
+FtrlOffline::~FtrlOffline() = default;
 
-bool FtrlOffline::ensure_ring() {
-  if (ring_tried_) return !ring_.empty();
-  ring_tried_ = true;
+// ---------------- the ring of page-locked blocks ----------------
+
+BlockRing::~BlockRing() {
+  for (auto &b : ring_) model_->unpin_block(b);
+}
+bool BlockRing::ready() {
+  if (tried_) return !ring_.empty();
+  tried_ = true;
   if (std::getenv("FTRL_NO_PINNED_RING")) return false;  // (A/B aid: the copying path)
   ring_.resize(kRing);
-  ring_seq_.assign(kRing, 0);
+  seq_.assign(kRing, 0);
   for (int i = 0; i < kRing; i++)
-    if (!model_ptr->pin_block(ring_[i])) {  // no page-locked memory to be had: the copying path
-      for (int j = 0; j < i; j++) model_ptr->unpin_block(ring_[j]);
+    if (!model_->pin_block(ring_[i])) {  // no page-locked memory to be had: the copying path
+      for (int j = 0; j < i; j++) model_->unpin_block(ring_[j]);
       ring_.clear();
       return false;
     }
   return true;
+}
+CsrBlock &BlockRing::acquire() {
+  while (model_->blocks_pulled() < seq_[slot_]) std::this_thread::yield();
+  return ring_[slot_];
 }
 
 // One pass over a CSR file image: training visits the rows in a seeded shuffle, block by block;
@@ -67,31 +74,31 @@ double FtrlOffline::csr_epoch(const CsrData &d, bool train) {
   }
   double total_loss = 0.0;
   CsrBlock blk;
-  const bool ring = train && ensure_ring();
-  int slot = 0;
+  if (!ring_) ring_ = std::make_unique<BlockRing>(model_ptr.get());
+  const bool ring = ring_->ready();
   size_t pos = 0;
   while (pos < total) {
     const size_t rows = std::min<size_t>(train ? sched_.next_block_rows() : sched_.max_block_rows(), total - pos);
-    // training is pipelined: this block is uploaded and grouped while the previous ones train
-    // and the next one is gathered here -- straight into page-locked memory when there is a ring
-    // entry it fits (the device then pulls it from there; the entry is reused once it has)
-    if (train && ring && rows < ring_[slot].row_ptr.capacity() &&
-        d.gather_nnz(indices.data() + pos, rows) <= ring_[slot].feat.capacity()) {
-      while (model_ptr->blocks_pulled() < ring_seq_[slot]) std::this_thread::yield();
-      d.gather(indices.data() + pos, rows, ring_[slot], n_threads);
-      ring_seq_[slot] = model_ptr->train_block_pinned(ring_[slot]);
-      slot = (slot + 1) % kRing;
+    // both passes are pipelined: this block is uploaded (and, training, grouped) while the previous
+    // ones run and the next one is gathered here -- straight into page-locked memory when there is a
+    // ring entry it fits (the device then pulls it from there; the entry is reused once it has)
+    const size_t nnz = train ? d.gather_nnz(indices.data() + pos, rows)
+                             : static_cast<size_t>(d.row_ptr[pos + rows] - d.row_ptr[pos]);
+    if (ring && rows <= ring_->row_capacity() && nnz <= ring_->nnz_capacity()) {
+      CsrBlock &rb = ring_->acquire();
+      if (train) d.gather(indices.data() + pos, rows, rb, n_threads); else d.slice(pos, pos + rows, rb);
+      ring_->handed_over(train ? model_ptr->train_block_pinned(rb) : model_ptr->predict_block_async(rb, true));
     } else if (train) {
       d.gather(indices.data() + pos, rows, blk, n_threads);
       model_ptr->train_block_async(blk);
     } else {
       d.slice(pos, pos + rows, blk);
-      total_loss += model_ptr->predict_block(blk, false);
+      model_ptr->predict_block_async(blk, false);
     }
     if (train) sched_.consumed(static_cast<int>(rows));
     pos += rows;
   }
-  if (train) total_loss = model_ptr->train_flush();
+  total_loss = train ? model_ptr->train_flush() : model_ptr->eval_flush();
   return total_loss / static_cast<double>(total);
 }
 
@@ -138,53 +145,49 @@ double FtrlOffline::one_epoch(std::vector<Sample> &samples, bool train, bool /*u
 
 FtrlOnline::FtrlOnline(const config_options &opt)
     : model_ptr(make_model(opt)), n_epochs(opt.epoch), cmd_(opt.cmd),
-      sched_(opt.batch_size, opt.batch_ramp), parser_(make_parser(opt.file_type)) {
+      sched_(opt.batch_size, opt.batch_ramp) {
   if (!cmd_) {
-    train_ifs_.open(opt.train_path, std::ios::in | std::ios::binary);
-    if (!train_ifs_.good()) {
-      std::fprintf(stderr, "open file <%s> error. \n", opt.train_path.c_str());
-      std::exit(EXIT_FAILURE);
-    }
+    train_stream_ = std::make_unique<CsrStream>(opt.train_path, opt.file_type, opt.thread_num);
     if (!opt.eval_path.empty()) {
-      eval_ifs_.open(opt.eval_path, std::ios::in | std::ios::binary);
-      if (!eval_ifs_.good()) {
-        std::fprintf(stderr, "open file <%s> error. \n", opt.eval_path.c_str());
-        std::exit(EXIT_FAILURE);
-      }
-      has_eval_ = true;
+      evaluator = std::make_unique<Evaluator>(opt);
+      evaluator->load_trained_model(model_ptr);
     }
   }
 }
 
-// Reads the stream to its end, parsing rows into blocks (parse time is inside the timed region,
-// as in the reference's online mode) and feeding them to the engine in file order.
-double FtrlOnline::run_file(std::ifstream &ifs, bool train) {
+// One pass over the training file in FILE ORDER (the reference's deterministic order at one
+// thread): worker threads parse chunks of <= 20 000 lines ahead (parse time is inside
+// the timed region, as in the reference's online mode), the rows are cut into blocks by the
+// block-size ramp, gathered in page-locked ring entries and handed to the engine, which uploads
+// and groups block t+2 while block t trains.
+void FtrlOnline::run_train_file() {
+  if (!ring_) ring_ = std::make_unique<BlockRing>(model_ptr.get());
+  const bool ring = ring_->ready();
   CsrBlock blk;
-  std::string line;
-  Sample sample;
-  double sum = 0.0;
-  unsigned long long rows = 0, line_num = 0;
-  bool more = true;
-  while (more) {
-    const int want = train ? sched_.next_block_rows() : sched_.max_block_rows();
-    blk.clear();
-    while (blk.n_rows() < want) {
-      if (!std::getline(ifs, line)) { more = false; break; }
-      parser_->parse(line, sample);
-      blk.push(sample);
-      if (++line_num % 1000000 == 0) std::printf("%llu lines finished...\n", line_num);
+  unsigned long long rows = 0, next_report = 1000000;
+  for (;;) {
+    const size_t want = static_cast<size_t>(sched_.next_block_rows());
+    size_t got;
+    if (ring) {
+      CsrBlock &rb = ring_->acquire();
+      got = train_stream_->next(std::min(want, ring_->row_capacity()), rb, ring_->nnz_capacity());
+      if (got == 0) break;
+      ring_->handed_over(model_ptr->train_block_pinned(rb));
+    } else {
+      got = train_stream_->next(want, blk);
+      if (got == 0) break;
+      model_ptr->train_block_async(blk);
     }
-    if (blk.n_rows() == 0) break;
-    if (train) model_ptr->train_block_async(blk); else sum += model_ptr->predict_block(blk, false);
-    if (train) sched_.consumed(blk.n_rows());
-    rows += blk.n_rows();
+    sched_.consumed(static_cast<int>(got));
+    rows += got;
+    if (rows >= next_report) {  // pc_task.cpp:47-49
+      std::printf("%llu lines finished...\n", next_report);
+      next_report += 1000000;
+    }
   }
-  if (train) sum = model_ptr->train_flush();  // parsing of block t+1 overlapped the training of t
-  ifs.clear();
-  ifs.seekg(0, std::ios::beg);
-  loss_sum_ = sum;
+  loss_sum_ = model_ptr->train_flush();
   loss_rows_ = rows;
-  return rows ? sum / static_cast<double>(rows) : 0.0;
+  train_stream_->rewind();
 }
 
 double FtrlOnline::get_loss() {
@@ -198,18 +201,62 @@ void FtrlOnline::train() {
   if (cmd_) return;  // stdin mode is a TODO stub in the reference too (ftrl_online.cpp:55-57)
   for (int i = 1; i <= n_epochs; i++) {
     const auto t0 = timer::now();
-    run_file(train_ifs_, true);
+    run_train_file();
     const double train_loss = get_loss();
     std::printf("epoch %d train time: %.4lfs, train loss: %.4lf\n", i, seconds_since(t0), train_loss);
-    if (has_eval_) evaluate(i);
+    if (evaluator) evaluate(i);
   }
 }
 
 void FtrlOnline::evaluate(int epoch) {
+  if (!evaluator) return;
   const auto t0 = timer::now();
-  run_file(eval_ifs_, false);
-  const double eval_loss = get_loss();
+  evaluator->run();
+  const double eval_loss = evaluator->get_loss();
   std::printf("epoch %d eval time: %.4lfs, eval loss: %.4lf\n", epoch, seconds_since(t0), eval_loss);
+}
+
+// ---------------- Evaluator ----------------
+
+Evaluator::Evaluator(const config_options &opt)
+    : stream_(std::make_unique<CsrStream>(opt.eval_path, opt.file_type, opt.thread_num)),
+      batch_(std::max(1, opt.batch_size)) {}
+Evaluator::~Evaluator() = default;
+
+void Evaluator::load_trained_model(std::shared_ptr<FtrlModel> &train_model) {  // evaluate.cpp:35-37
+  eval_model = train_model;
+  ring_ = std::make_unique<BlockRing>(eval_model.get());
+}
+
+void Evaluator::run() {
+  if (!eval_model) throw std::logic_error("Evaluator::run before load_trained_model");
+  const bool ring = ring_->ready();
+  CsrBlock blk;
+  unsigned long long rows = 0;
+  for (;;) {
+    size_t got;
+    if (ring) {
+      CsrBlock &rb = ring_->acquire();
+      got = stream_->next(std::min<size_t>(batch_, ring_->row_capacity()), rb, ring_->nnz_capacity());
+      if (got == 0) break;
+      ring_->handed_over(eval_model->predict_block_async(rb, true));
+    } else {
+      got = stream_->next(static_cast<size_t>(batch_), blk);
+      if (got == 0) break;
+      eval_model->predict_block_async(blk, false);
+    }
+    rows += got;
+  }
+  loss_sum_ = eval_model->eval_flush();
+  rows_ = rows;
+  stream_->rewind();
+}
+
+double Evaluator::get_loss() {
+  const double r = rows_ ? loss_sum_ / static_cast<double>(rows_) : 0.0;
+  loss_sum_ = 0.0;
+  rows_ = 0;
+  return r;
 }
 
 }  // namespace ftrl

@@ -18,6 +18,7 @@
 
 #include "ftrl_model.h"
 #include "csr_reader.h"
+#include "csr_stream.h"
 #include "reader.h"
 
 namespace ftrl {
@@ -37,6 +38,48 @@ class BlockScheduler {
  private:
   int batch_, ramp_;
   long long seen_ = 0;
+};
+
+// A ring of page-locked blocks the device pulls from in place (FtrlModel::train_block_pinned /
+// predict_block_async): an entry is refilled once the engine has uploaded the block it carried.
+class BlockRing {
+ public:
+  static constexpr int kRing = 6;
+  explicit BlockRing(FtrlModel *m) : model_(m) {}
+  ~BlockRing();
+  bool ready();                       // pins the entries on first use; false: no page-locked memory
+  CsrBlock &acquire();                // the next entry, free to be refilled
+  void handed_over(long long ordinal) { seq_[slot_] = ordinal; slot_ = (slot_ + 1) % kRing; }
+  size_t row_capacity() { return ring_[0].row_ptr.capacity() - 1; }
+  size_t nnz_capacity() { return ring_[0].feat.capacity(); }
+
+ private:
+  FtrlModel *model_;
+  std::vector<CsrBlock> ring_;
+  std::vector<long long> seq_;
+  int slot_ = 0;
+  bool tried_ = false;
+};
+
+// Evaluator (reference src/include/eval/evaluate.h:18-33, src/eval/evaluate.cpp:7-54): streams the
+// eval file through predict() and reports the mean logloss.  Here: chunks parsed by n_threads
+// workers (CsrStream), blocks gathered in page-locked memory, uploaded and predicted pipelined
+// (FtrlModel::predict_block_async).
+class Evaluator {
+ public:
+  explicit Evaluator(const config_options &opt);
+  ~Evaluator();
+  void load_trained_model(std::shared_ptr<FtrlModel> &train_model);
+  void run();          // one pass over the eval file (PcTask::run in the reference)
+  double get_loss();   // mean loss of the last pass (resets it)
+
+ private:
+  std::shared_ptr<FtrlModel> eval_model;
+  std::unique_ptr<CsrStream> stream_;
+  std::unique_ptr<BlockRing> ring_;
+  int batch_;
+  double loss_sum_ = 0.0;
+  unsigned long long rows_ = 0;
 };
 
 class FtrlOffline {
@@ -60,13 +103,9 @@ class FtrlOffline {
   CsrData train_csr_, eval_csr_;                                // what train()/evaluate() walk
   bool has_eval_ = false;
   double csr_epoch(const CsrData &d, bool train);
-  // Training blocks are gathered straight into a ring of page-locked blocks which the device
-  // pulls from (FtrlModel::train_block_pinned): no host copy, three blocks in flight.
-  static constexpr int kRing = 6;
-  std::vector<CsrBlock> ring_;
-  std::vector<long long> ring_seq_;  // ordinal of the block each ring entry carried last
-  bool ring_tried_ = false;
-  bool ensure_ring();
+  // Training and evaluation blocks are gathered straight into a ring of page-locked blocks which
+  // the device pulls from: no host copy, three blocks in flight.
+  std::unique_ptr<BlockRing> ring_;
 };
 
 class FtrlOnline {
@@ -78,15 +117,15 @@ class FtrlOnline {
   bool has_zero_weights() { return model_ptr->has_zero_weights(); }
 
   std::shared_ptr<FtrlModel> model_ptr;
+  std::unique_ptr<Evaluator> evaluator;  // (ftrl_online.h:31; null without --eval_data)
 
  private:
-  double run_file(std::ifstream &ifs, bool train);
+  void run_train_file();
   int n_epochs;
   bool cmd_;
   BlockScheduler sched_;
-  std::unique_ptr<Parser> parser_;
-  std::ifstream train_ifs_, eval_ifs_;
-  bool has_eval_ = false;
+  std::unique_ptr<CsrStream> train_stream_;  // chunks of <= 20 000 lines parsed by n_threads workers
+  std::unique_ptr<BlockRing> ring_;
   double loss_sum_ = 0.0;
   unsigned long long loss_rows_ = 0;
 };

@@ -83,6 +83,38 @@ def test_cli_config1_lr_on_libsvm(tmp_path):
     assert abs(tr - 0.6907) < 2e-4 and abs(ev - 0.6893) < 2e-4
 
 
+@pytest.mark.gpu
+def test_cli_n_gpus_shards_match_one_engine(tmp_path):
+    """--n_gpus N (one field-pair shard engine per device, one all-reduce of the partial logits per
+    block: ffm_group_*).  On a one-GPU box the shards share the device (FTRL_SAME_DEVICE=1: the
+    collective is then a device-local sum, the orchestration is the N-GPU one): the printed epoch
+    losses must be the one-engine run's to the printed precision; and with FFM_GROUP_RCCL=1 a group
+    of ONE runs the librccl ncclAllReduce on the engine's stream -- same losses again."""
+    from ftrl_ffm_amd import synth
+    main_bin, _ = fa.build_host()
+    F, per = 12, 500
+    g = synth.Generator(F, F * per, "zipf", seed=5)
+    data = tmp_path / "s.ffm"
+    data.write_text(synth.to_libffm_text(g.block(20000)))
+    base = [main_bin, "--train_data", str(data), "--eval_data", str(data), "--model_type", "FFM", "--n_fields", str(F),
+            "--n_feats", str(F * per), "--n_factors", "8", "--online", "true", "--n_epochs", "2", "--batch_size", "1024",
+            "--w_alpha", "0.05", "--w_l1", "0.01", "--w_l2", "0.1", "--field_ranges", "uniform"]
+    def losses(extra, env):
+        out = subprocess.run(base + extra, cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stdout + out.stderr
+        return ([float(x) for x in re.findall(r"train loss: ([0-9.]+)", out.stdout)],
+                [float(x) for x in re.findall(r"eval loss: ([0-9.]+)", out.stdout)], out.stdout)
+    tr1, ev1, _ = losses([], {})
+    assert len(tr1) == 2 and len(ev1) == 2 and tr1[1] < tr1[0] < 0.6931
+    for n in (2, 4):
+        tr, ev, text = losses(["--n_gpus", str(n)], {"FTRL_SAME_DEVICE": "1"})
+        assert "%d field-pair shards" % n in text
+        assert np.allclose(tr, tr1, atol=2e-4) and np.allclose(ev, ev1, atol=2e-4), (n, tr, tr1, ev, ev1)
+    tr, ev, text = losses(["--n_gpus", "1"], {"FFM_GROUP_RCCL": "1"})
+    assert tr == tr1 and ev == ev1
+
+
 from oracle import pyoracle  # noqa: E402
 
 needs_ref = pytest.mark.skipif(not pyoracle.have_ref(), reason="oracle/_ref not built here")

@@ -472,6 +472,21 @@ def main():
                     "note": "same loop over %d blocks already resident in HBM (no H2D); not the metric"
                             % len(dev_blocks)}
 
+    host_copy = None
+    if host_leg and zero_copy and not sharded and not args.no_resident:
+        # the same loop for a caller whose rows are NOT page-locked: every block is first copied
+        # into the engine's own pinned staging slot (ffm_engine_train_batch_async), two in flight
+        def run_copy(first, count):
+            for i in range(count):
+                eng.train_batch_async(host_blocks[(first + i) % n_blocks])
+            return eng.train_flush()
+        run_copy(0, min(args.warmup, 3))
+        el3, _ = timed(run_copy, args.warmup, args.steps)
+        host_copy = {"value": round(total_rows / el3, 1), "unit": "samples/s",
+                     "ms_per_step": round(1000.0 * el3 / args.steps, 4),
+                     "note": "rows handed over through the copying entry point (pageable memory: one host memcpy "
+                             "per block into the engine's pinned slot); not the metric"}
+
     if model == "FFM":
         bytes_row = algorithmic_bytes_per_row(N_FIELDS, N_FACTORS)
     else:  # FM, SURVEY.md 8(d): nnz*k*20 + nnz*20 + 20 + nnz*8 + 8 + 12
@@ -508,6 +523,8 @@ def main():
         }
         if resident:
             out["resident"] = resident
+        if host_copy:
+            out["config"]["pageable_host_copy"] = host_copy
         if kname:
             share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, n_shards)
             per_step = max(1, round(klaunches / max(args.steps, 1)))  # (FFM_PHASES > 1: several launches per block)

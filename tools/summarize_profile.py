@@ -73,7 +73,9 @@ def main():
         json.dump(summary, f, indent=1, sort_keys=True)
     # the other artefacts of tools/profile_round.sh, as they are
     for name in ("timeline.txt", "step_gaps.txt", "sq_summary.txt", "sq_summary_emu8.txt", "c2.json", "c3.json",
-                 "c4.json", "emu8_strong_rank3.json") + tuple("emu8_rank%d.json" % r for r in range(8)):
+                 "c4.json", "c2_kernel_stats.csv", "c3_kernel_stats.csv", "c4_kernel_stats.csv", "uniform.json",
+                 "fresh.json", "bench_driver_shape.json",
+                 "emu8_strong_rank3.json") + tuple("emu8_rank%d.json" % r for r in range(8)):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join("profiles", rnd + "_" + name))
     for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["avg_us"]):

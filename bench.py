@@ -46,7 +46,7 @@ CONFIGS = {
     "c4": dict(model="FM", fields=39, factors=64, rows=8192, feats=10_000_000),
 }
 PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-SMALL_MAX, HUGE_MIN = 8, 192  # occurrence classes of the update kernels (csrc/engine_types.h)
+SMALL_MAX, HUGE_MIN = 8, 384  # occurrence classes of the update kernels (csrc/engine_types.h)
 
 
 def algorithmic_bytes_per_row(nnz, k):
@@ -533,7 +533,7 @@ def main():
             achieved = share / avg_s / 1e9
             traffic = None
             pmc = latest_pmc_summary()
-            if pmc and world == 1 and not emu and not args.n_feats and not args.rows:
+            if pmc and world == 1 and not emu and not args.n_feats and not args.rows and args.config == "c5":
                 with open(pmc) as f:  # rocprofv3 --pmc passes of this same command (tools/)
                     for name, v in json.load(f).items():
                         if name.split("<")[0] == kname.split("<")[0]:

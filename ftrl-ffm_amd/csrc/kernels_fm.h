@@ -34,15 +34,17 @@ constexpr int kFmChunk = 8;         // entries whose records are in flight toget
 // keep the first kFmPark entries' records from the refresh to the (n, z) step instead of reading them
 // again.  Measured on config 4 (8192 x 39 rows, k = 64; tools/ab_c4.sh): parking 40 / 32 / 24 / 8
 // entries (169 / 145 / 121 / 73 VGPRs, 3 / 3 / 4 / 6 waves per SIMD) gives 194 / 187 / 182 / 163 us per
-// block -- the bytes saved (655 -> 418 MB) are worth less than the waves lost, so only one chunk is
-// parked; longer rows' other entries are read again out of the L2 / Infinity Cache.
+// block -- the bytes saved (655 -> 418 MB) are worth less than the waves lost, so little is parked;
+// the other entries are read again out of the L2 / Infinity Cache.  Four entries parked fit 61 VGPRs
+// = 8 waves per SIMD, one wave per row of an 8192-row block resident at once: 176 -> 153 us (eight
+// parked at 7 / 8 waves: 170 us / 178 us with 70 spilled registers).
 #ifndef FFM_FM_PARK
-#define FFM_FM_PARK 8
+#define FFM_FM_PARK 4
 #endif
 constexpr int kFmPark = FFM_FM_PARK;
 
 #ifndef FFM_FM_WAVES
-#define FFM_FM_WAVES 6
+#define FFM_FM_WAVES 8
 #endif
 template <bool TRAIN>
 __global__ __launch_bounds__(64 * kFmRowsPerBlock) __attribute__((amdgpu_waves_per_eu(TRAIN ? FFM_FM_WAVES : 8, 8)))

@@ -374,6 +374,7 @@ struct ffm_engine {
   // grouping.  (A fifth stream for them shares a hardware queue with one of the four and
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
   hipStream_t copy = nullptr;  // = prep
+  bool huge_min_fixed = false;  // FFM_HUGE_MIN given: no per-block choice
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
   // Scheduling of a look-ahead grouping (FFM_PREP_WINDOW=0 turns it off): the block being
   // prepared will start training when its predecessor's update ends; its grouping is made to
@@ -789,6 +790,11 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.n_shards = cfg->n_shards;
   m.shard_rank = cfg->shard_rank;
   m.bias_own = 1;
+  m.huge_min = kHugeMin;  // (FFM: chosen per block, huge_min_for)
+  if (const char *sv = std::getenv("FFM_HUGE_MIN")) {
+    m.huge_min = std::max(kSmallMax + 1, std::atoi(sv));
+    e->huge_min_fixed = true;
+  }
   m.rec_slots = m.n_fields;
   e->n_records = cfg->n_feats;
   // field-pair partition: this shard's ranges, and (with per-field id ranges) compact storage
@@ -1316,6 +1322,20 @@ __global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_c
 
 // Groups `rows` by feature into scratch set `set` on stream `st`.
 // timed = false: from the staging thread (no HIP-event bookkeeping of the profiler there).
+// Hot / very hot boundary of one block.  A hot feature's touches are ONE sequential chain per element
+// (~0.55 us per touch beside the other kernels); the very hot ones' chains are cut into 16-touch
+// steps at 40 % more instructions.  So the hot kernel's longest chain should last about as long as
+// what bounds the update phase anyway: half its throughput-bound time (measured 0.88 touch-elements
+// per ns at FFM 39 x 16) or the bias chain's one wave (12 ns per row).  kHugeMin -- the optimum of
+// 8192 x 39-entry rows at k = 16 -- caps it.  (C2, 4096 x 8 entries: 384 -> 89, 17.5 -> 22.8 M rows/s.)
+static int huge_min_for(const ffm_engine *e, const Rows &rows) {
+  if (e->huge_min_fixed || e->m.type != FFM_MODEL_FFM || rows.n_rows <= 0) return e->m.huge_min;
+  const double per_row = static_cast<double>(rows.nnz) / rows.n_rows;
+  const double touch_elems = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / std::max(1, e->m.n_shards);
+  const double span_us = std::max(touch_elems / 0.88e6, rows.n_rows * 0.012);
+  return static_cast<int>(std::min<double>(kHugeMin, std::max(64.0, span_us / 0.55)));
+}
+
 static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st, bool timed = true) {
   Scratch &sc = e->sc[set];
   ScopedTimer tm_all("grouping:all");
@@ -1338,9 +1358,11 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
                                         static_cast<size_t>(nnz), 0u, e->sort_bits, st));
     }
     if (timed) e->prof_end(st);
-    if (timed) LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, e->m, rows, sc,
+    ModelDev mf = e->m;  // (the only kernel that deals features into the hot / very hot lists)
+    mf.huge_min = huge_min_for(e, rows);
+    if (timed) LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, mf, rows, sc,
                          phases_for(e, rows.n_rows));
-    else hipLaunchKernelGGL(group_finish_kernel, dim3(cdiv(nnz, kFinishThreads)), dim3(kFinishThreads), 0, st, e->m, rows, sc,
+    else hipLaunchKernelGGL(group_finish_kernel, dim3(cdiv(nnz, kFinishThreads)), dim3(kFinishThreads), 0, st, mf, rows, sc,
                             phases_for(e, rows.n_rows));
   }
   HIP_TRY(hipGetLastError());

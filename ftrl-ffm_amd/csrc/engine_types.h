@@ -55,6 +55,7 @@ struct ModelDev {
   const long long *rec_base;  // [n_fields] first stored record of a field (compact); -1: none
   const int *lin_own;         // [n_fields] 1 when this shard owns the field's linear terms; null: all
   int bias_own;               // 1 when this shard owns the bias
+  int huge_min;               // occurrences per block above which a feature is "very hot" (kHugeMin)
 };
 
 enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };

@@ -195,9 +195,9 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
   __shared__ int wave_base[kFinishThreads / 64][kLists];
   const int wv = threadIdx.x >> 6;
   const bool pred[kLists] = {head, head && c <= kSmallMax, head && c > 1 && c <= kSmallMax,
-                             head && c > kSmallMax && c <= kHugeMin,
-                             head && c > kHugeMin && c < kGiantMin, head && c == 1,
-                             head && c > kHugeMin && c >= kGiantMin};
+                             head && c > kSmallMax && c <= m.huge_min,
+                             head && c > m.huge_min && c < kGiantMin, head && c == 1,
+                             head && c > m.huge_min && c >= kGiantMin};
   const int which[kLists] = {CNT_NUNIQ, CNT_NSMALL, CNT_NFEW, CNT_NBIG, CNT_NHUGE, CNT_NSINGLE, CNT_NGIANT};
   unsigned long long pm[kLists];
 #pragma unroll
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
     if (c == 1) s.sdesc[slot[5]] = make_int4(static_cast<int>(K), p, s.row_of[p], fld);
     if (c > 1 && c <= kSmallMax) s.few[iw] = u;
     if (c <= kSmallMax) s.small[is] = u;
-    else if (c <= kHugeMin) s.big[ib] = u;
+    else if (c <= m.huge_min) s.big[ib] = u;
     else if (c < kGiantMin) s.huge[ih] = u;
     else s.giant[slot[6]] = u;
   }

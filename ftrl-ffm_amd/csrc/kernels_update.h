@@ -844,7 +844,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     const int4 ud = s.udesc[u];
     const int i = wave_uniform(ud.x);
     const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
-    if (skip_huge && c > kHugeMin) continue;
+    if (skip_huge && c > m.huge_min) continue;
     if (skip_once && c == 1) continue;
     float *rec = lat_row(m, i, 0);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];

@@ -1007,6 +1007,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipStreamSynchronize(e->stream));
     TRY_HIP(hipMemsetAsync(s.counters, 0, kNumCounters * sizeof(int), e->stream));
     m.h.fast_div = bad ? 0 : 1;
+    m.h.fast_w = m.h.fast_div && cfg->w_beta >= 0x1p-40f && cfg->w_beta <= 0x1p40f ? 1 : 0;
   }
   {
     // the row kernels stage one row in dynamic LDS: opt in to what the longest admissible row needs

@@ -12,6 +12,7 @@ struct Hyper {
   float inv_alpha;  // RN(1/alpha)
   int fast_div;     // 1 when div_alpha's short sequence was proven exact for this alpha
   int learn;        // FFM_FLAG_LEARN: opt-in variant (keep w until n > 0; g2*g2 at ffm.cpp:118)
+  int fast_w;       // 1 when fast_div and beta in [2^-40, 2^40]: W(n, z) needs ONE range test, on n
 };
 
 // utils::sgn, reference src/include/utils/utils.h:15-18: x > 0 ? 1 : -1 (sgn(0) = -1)
@@ -25,8 +26,11 @@ __device__ __forceinline__ float sgn_ref(float x) { return x > 0.0f ? 1.0f : -1.
 // sign of two fused residuals) without its denormal pre-scaling, used when every lane of the wave
 // holds 0 or a value in [2^-96, 2^96]; anything else (tiny, huge, negative, NaN) takes sqrtf.
 __device__ __forceinline__ bool sqrt_fast_ok(float x) {
-  return (x == 0.0f) || (x >= 0x1p-96f && x <= 0x1p96f);
+  return (x == 0.0f) || __builtin_amdgcn_fmed3f(x, 0x1p-96f, 0x1p96f) == x;
 }
+// (x == +-0 needs no case of its own: v_sqrt gives s = x, its neighbour below is a NaN pattern --
+// `ed <= 0` false -- and the residual against the neighbour above is a zero -- `eu > 0` false:
+// the result is s = x.)
 __device__ __forceinline__ float sqrt_fast(float x) {  // requires sqrt_fast_ok(x)
   const float s = __builtin_amdgcn_sqrtf(x);
   const float sd = __int_as_float(__float_as_int(s) - 1);
@@ -35,7 +39,7 @@ __device__ __forceinline__ float sqrt_fast(float x) {  // requires sqrt_fast_ok(
   const float eu = fmaf(-su, s, x);
   float r = ed <= 0.0f ? sd : s;
   r = eu > 0.0f ? su : r;
-  return x == 0.0f ? x : r;
+  return r;
 }
 __device__ __forceinline__ float sqrt_cr(float x) {
   if (__all(sqrt_fast_ok(x))) return sqrt_fast(x);
@@ -112,14 +116,26 @@ __device__ __forceinline__ float ftrl_weight(const Hyper &h, float n, float z) {
 template <int N>
 __device__ __forceinline__ void ftrl_weight_n(const Hyper &h, const float (&nn)[N],
                                               const float (&zz)[N], float (&w)[N]) {
-  float sq[N], t[N], dv[N];
-  sqrt_cr_n<N>(nn, sq);
+  float dv[N];
+  // fast_w: beta is comfortably normal, so beta + sqrt(n) lies inside div_alpha_fast's proven range
+  // whenever n lies inside sqrt_fast's -- one range test per value, one vote for all
+  bool ok = h.fast_w != 0;
 #pragma unroll
-  for (int i = 0; i < N; i++) t[i] = h.beta + sq[i];
-  div_alpha_n<N>(h, t, dv);
+  for (int i = 0; i < N; i++) ok = ok && sqrt_fast_ok(nn[i]);
+  if (__all(ok)) {
+#pragma unroll
+    for (int i = 0; i < N; i++) dv[i] = div_alpha_fast(h, h.beta + sqrt_fast(nn[i]));
+  } else {
+    float sq[N], t[N];
+    sqrt_cr_n<N>(nn, sq);
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = h.beta + sq[i];
+    div_alpha_n<N>(h, t, dv);
+  }
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    const float num = zz[i] - sgn_ref(zz[i]) * h.l1;
+    // z - sgn(z)*l1: sgn*l1 is +-l1 exactly, and a - b == a + (-b)
+    const float num = zz[i] + (zz[i] > 0.0f ? -h.l1 : h.l1);
     const float den = h.l2 + dv[i];
     w[i] = fabsf(zz[i]) <= h.l1 ? 0.0f : (-num) / den;
   }

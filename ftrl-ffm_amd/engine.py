@@ -159,6 +159,17 @@ def load_library(path=None):
     return lib
 
 
+def page_aligned(n, dtype):
+    """A numpy array of n elements in an anonymous mapping of its own: page-aligned, whole pages,
+    shared with nothing else -- what Engine.pin_block should be given.  (hipHostRegister locks whole
+    pages; an array in the middle of the Python heap shares its pages with whatever lives next to
+    it, and the runtime then meets half-registered ranges in later copies.)"""
+    import mmap
+    nbytes = max(1, int(n)) * np.dtype(dtype).itemsize
+    size = (nbytes + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE
+    return np.frombuffer(mmap.mmap(-1, size), dtype=dtype, count=int(n))
+
+
 def _f(a):
     return None if a is None else a.ctypes.data_as(_f32p)
 
@@ -314,7 +325,8 @@ class Engine:
         self._check(self.lib.ffm_engine_train_staged(self.h, logit_out, loss_sum_out))
 
     def pin_block(self, c):
-        """Page-locks the block's five arrays in place (for stage_batch(zero_copy=True))."""
+        """Page-locks the block's five arrays in place (for stage_batch(zero_copy=True)).  Give it
+        arrays that own their pages (page_aligned)."""
         for a in (c.row_ptr, c.field, c.feat, c.val, c.label):
             if a is not None and a.size:
                 self._check(self.lib.ffm_engine_pin_host(a.ctypes.data, a.nbytes))

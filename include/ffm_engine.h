@@ -260,7 +260,10 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
 int64_t ffm_engine_blocks_pulled(ffm_engine *e);
 int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit);
 int ffm_engine_train_staged(ffm_engine *e, float *logit_out, double *loss_sum_out);
-/* hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime themselves. */
+/* hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime themselves.
+ * Give it ranges that own their pages (page-aligned, whole pages: mmap, posix_memalign): the
+ * runtime locks whole pages, and a range in the middle of a heap shares its first and last page
+ * with whatever the allocator placed next to it. */
 int ffm_engine_pin_host(void *p, size_t bytes);
 int ffm_engine_unpin_host(void *p);
 

@@ -18,6 +18,17 @@ import torch  # noqa: F401  (first: one HIP runtime per process)
 import ftrl_ffm_amd as fa
 from ftrl_ffm_amd import sharding, synth
 from oracle.pyoracle import CpuModel, Csr
+
+
+def _own_pages(c):
+    """A copy of the block in arrays that own their pages (fa.page_aligned): what pin_block locks."""
+    def cp(a):
+        if a is None:
+            return None
+        out = fa.page_aligned(a.size, a.dtype)
+        out[:] = a
+        return out
+    return Csr(cp(c.row_ptr), cp(c.field), cp(c.feat), cp(c.val), cp(c.label))
 from util import (DEFAULT_HP, STRESS_HP, assert_bitwise, assert_state_bitwise, rand_state)
 
 pytestmark = pytest.mark.gpu
@@ -617,6 +628,7 @@ def test_staged_host_blocks_equal_block_by_block(zero_copy):
     a.close()
     b_ = make()
     if zero_copy:
+        blocks = [_own_pages(blk) for blk in blocks]
         for blk in blocks:
             b_.pin_block(blk)
     logit = torch.zeros(256, device="cuda")
@@ -668,6 +680,7 @@ def test_pinned_async_training_equals_block_by_block():
     sa = a.get_state()
     a.close()
     e = make()
+    blocks = [_own_pages(blk) for blk in blocks]
     for blk in blocks:
         e.pin_block(blk)
     for i, blk in enumerate(blocks):
@@ -706,8 +719,8 @@ def test_ring_of_pinned_buffers_refilled_as_soon_as_blocks_pulled_allows():
     a.close()
     e = make()
     cap = rows * F
-    ring = [Csr(np.zeros(rows + 1, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32),
-                np.zeros(cap, np.float32), np.zeros(rows, np.int32)) for _ in range(R)]
+    ring = [Csr(fa.page_aligned(rows + 1, np.int32), fa.page_aligned(cap, np.int32), fa.page_aligned(cap, np.int32),
+                fa.page_aligned(cap, np.float32), fa.page_aligned(rows, np.int32)) for _ in range(R)]
     for r in ring:
         e.pin_block(r)
     carried = [0] * R

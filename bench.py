@@ -46,7 +46,20 @@ CONFIGS = {
     "c4": dict(model="FM", fields=39, factors=64, rows=8192, feats=10_000_000),
 }
 PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-SMALL_MAX, HUGE_MIN = 8, 384  # occurrence classes of the update kernels (csrc/engine_types.h)
+SMALL_MAX, HUGE_MIN = 8, 192  # occurrence classes of the update kernels (csrc/engine_types.h)
+
+
+def huge_min_for(n_rows, nnz_block, k, n_shards, ffm=True):
+    """The hot / very hot boundary the engine picks for a block (csrc/engine.hip: huge_min_for;
+    FFM_HUGE_MIN overrides): for the byte shares of the hot and the chain kernel."""
+    env = os.environ.get("FFM_HUGE_MIN")
+    if env:
+        return max(SMALL_MAX + 1, int(env))
+    if not ffm or n_rows <= 0:
+        return HUGE_MIN
+    touch_elems = nnz_block * max(0.0, nnz_block / n_rows - 1.0) * k / max(1, n_shards)
+    span_us = max(touch_elems / 0.88e6, n_rows * 0.012)
+    return int(min(float(HUGE_MIN), max(64.0, span_us / 0.55)))
 
 
 def algorithmic_bytes_per_row(nnz, k):
@@ -99,8 +112,9 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
     shares = []
     for f in blocks_feat:
         _, c = np.unique(f, return_counts=True)
+        hm = huge_min_for(len(f) // nnz, len(f), k, n_shards)
         occ = {"single": c[c == 1].sum(), "small": c[(c > 1) & (c <= SMALL_MAX)].sum(),
-               "hot": c[(c > SMALL_MAX) & (c <= HUGE_MIN)].sum(), "huge": c[c > HUGE_MIN].sum()}
+               "hot": c[(c > SMALL_MAX) & (c <= hm)].sum(), "huge": c[c > hm].sum()}
         key = ("huge" if "chain" in kernel or "huge" in kernel else
                next((kk for kk in ("single", "small") if kk in kernel), "hot"))
         shares.append(occ[key] * per_occ * 8 / n_shards)
@@ -113,7 +127,7 @@ def fm_kernel_share_bytes(kernel, blocks_feat, nnz, k):
     every OCCURRENCE's record (read n,z + write w = 12 B per factor), reads the CSR entries, the
     linear terms, writes logit / tmp_grad / loss / the row's k factor sums, and applies the (n, z)
     step (8 B per factor) of the features that occur once in the block; fm_update_kernel owns the
-    features with 2..192 occurrences, fm_update_chain_kernel the rest (8 B per factor-occurrence)."""
+    features with 2..HUGE_MIN occurrences, fm_update_chain_kernel the rest (8 B per factor-occurrence)."""
     rows = [len(f) // nnz for f in blocks_feat]
     counts = [np.unique(f, return_counts=True)[1] for f in blocks_feat]
     if "row_kernel" in kernel:

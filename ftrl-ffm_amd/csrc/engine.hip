@@ -17,6 +17,7 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -184,6 +185,21 @@ __global__ void verify_div_alpha_kernel(Hyper h, int *bad) {
   const float x = __uint_as_float(sign | expo | mant);
   const float a = div_alpha_fast(h, x), b = x / h.alpha;
   if (__float_as_uint(a) != __float_as_uint(b)) atomicOr(bad, 1);
+}
+
+// Compares sqrt_fast / sqrt_fast0 (ftrl_math.h) with sqrtf on EVERY float of their range,
+// [2^-96, 2^96] and +0, on the device the engine runs on; any mismatch raises *bad.
+__global__ void verify_sqrt_fast_kernel(int *bad) {
+  const unsigned lo = __float_as_uint(0x1p-96f), hi = __float_as_uint(0x1p96f);
+  const unsigned stride = gridDim.x * blockDim.x;
+  bool differs = false;
+  for (unsigned b = lo + blockIdx.x * blockDim.x + threadIdx.x; b <= hi && b >= lo; b += stride) {
+    const float x = __uint_as_float(b);
+    const unsigned want = __float_as_uint(sqrtf(x));
+    differs = differs || __float_as_uint(sqrt_fast(x)) != want || __float_as_uint(sqrt_fast0(x)) != want;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) differs = differs || __float_as_uint(sqrt_fast0(0.0f)) != 0u;
+  if (differs) atomicOr(bad, 1);
 }
 
 // Copies one component (n, z or w) of features [feat0, feat0+nf) between the stored records and a
@@ -997,6 +1013,26 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_HIP(hipMemsetAsync(m.lin_w, 0, nf * sizeof(float), e->stream));
   if (n_lat) TRY_HIP(hipMemsetAsync(m.lat, 0, n_lat * sizeof(float), e->stream));
   TRY_HIP(hipMemsetAsync(s.counters, 0, kNumCounters * sizeof(int), e->stream));
+  {
+    // the five-instruction square root rests on this device's v_sqrt_f32 / v_rsq_f32: compare it
+    // with sqrtf over its whole range (1.6e9 inputs, a few milliseconds) before any kernel uses it
+    // (once per device and process: the answer is a property of the hardware)
+    static std::atomic<int> verdict[64];  // 0 unknown, 1 exact, -1 differs
+    const int dev = cfg->device_id & 63;
+    int bad = verdict[dev].load() < 0 ? 1 : 0;
+    if (verdict[dev].load() == 0) {
+      hipLaunchKernelGGL(verify_sqrt_fast_kernel, dim3(16384), dim3(256), 0, e->stream, s.counters);
+      TRY_HIP(hipMemcpyAsync(&bad, s.counters, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+      TRY_HIP(hipStreamSynchronize(e->stream));
+      TRY_HIP(hipMemsetAsync(s.counters, 0, kNumCounters * sizeof(int), e->stream));
+      verdict[dev].store(bad ? -1 : 1);
+    }
+    if (bad) {
+      ffm_engine_destroy(e);
+      return fail(FFM_E_UNSUPPORTED, "this device's v_sqrt_f32 / v_rsq_f32 do not give the correctly rounded "
+                                     "square root in the short sequence the kernels use (built and proven for gfx950)");
+    }
+  }
   if (cfg->w_alpha >= 0x1p-30f && cfg->w_alpha <= 0x1p30f) {
     // prove the short x/alpha sequence exact for this alpha before any kernel may use it
     int bad = 0;

@@ -185,9 +185,12 @@ enum { OCC_FEW = -1, OCC_ONCE = -2 };
 // batches its gathers and ends the update phase's first 200 us instead of its first 380, the hot
 // kernel has room for the features up to 384 occurrences -- 78 VALU lane-instructions per
 // touch-element there against 105 in the chain kernel: resident step 1.066 -> 1.050 ms;
-// 512 and more: the hot kernel's sequential chains become the phase's span, 1.14 ms)
+// 512 and more: the hot kernel's sequential chains become the phase's span, 1.14 ms.  With the
+// five-instruction square root the chain kernel's steps got 17 % shorter and the balance moved
+// back: 192 -> 1.025 ms, 256 -> 1.035, 384 -> 1.060.)  The cap of the per-block choice
+// (engine.hip: huge_min_for).
 #ifndef FFM_HUGE_MIN
-#define FFM_HUGE_MIN 384
+#define FFM_HUGE_MIN 192
 #endif
 constexpr int kHugeMin = FFM_HUGE_MIN;  // occurrences per block above which a feature takes the lane-parallel path
 #ifndef FFM_GIANT_MIN

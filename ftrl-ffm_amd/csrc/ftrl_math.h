@@ -22,27 +22,32 @@ __device__ __forceinline__ float sgn_ref(float x) { return x > 0.0f ? 1.0f : -1.
 // These kernels are VALU-bound (DESIGN.md "Rooflines"): hipcc's IEEE sqrtf/divide expand to ~15
 // instructions each.  Both replacements below return the SAME bits as sqrtf(x) and x / alpha.
 
-// sqrtf(x): the compiler's own algorithm (v_sqrt_f32, then pick among s-1ulp, s, s+1ulp by the
-// sign of two fused residuals) without its denormal pre-scaling, used when every lane of the wave
-// holds 0 or a value in [2^-96, 2^96]; anything else (tiny, huge, negative, NaN) takes sqrtf.
+// sqrtf(x) in five instructions: s = v_sqrt_f32(x) (1 ulp), the exact residual e = x - s*s by FMA,
+// one correction step s + e * (0.5 / sqrt(x)) with v_rsq_f32 -- Markstein's final iteration, which
+// rounds correctly once s and the reciprocal root are this accurate.  Not taken on trust: every
+// float in [2^-96, 2^96] was compared with sqrtf on gfx950 (tools/sqrt_probe.hip: 1 610 612 737
+// inputs, 0 mismatches; with 0.5 * v_rcp_f32(s) instead of v_rsq_f32(x) 96 inputs differ), and
+// ffm_engine_create repeats that comparison on the device it runs on and refuses to start if any
+// input differs.  Used when every lane of the wave holds +0 or a value in that range; anything else
+// (tiny, huge, negative, -0, NaN) takes sqrtf.
 __device__ __forceinline__ bool sqrt_fast_ok(float x) {
-  return (x == 0.0f) || __builtin_amdgcn_fmed3f(x, 0x1p-96f, 0x1p96f) == x;
+  return __float_as_uint(x) == 0u || __builtin_amdgcn_fmed3f(x, 0x1p-96f, 0x1p96f) == x;
 }
-// (x == +-0 needs no case of its own: v_sqrt gives s = x, its neighbour below is a NaN pattern --
-// `ed <= 0` false -- and the residual against the neighbour above is a zero -- `eu > 0` false:
-// the result is s = x.)
-__device__ __forceinline__ float sqrt_fast(float x) {  // requires sqrt_fast_ok(x)
+__device__ __forceinline__ float sqrt_fast(float x) {  // requires x in [2^-96, 2^96]
   const float s = __builtin_amdgcn_sqrtf(x);
-  const float sd = __int_as_float(__float_as_int(s) - 1);
-  const float su = __int_as_float(__float_as_int(s) + 1);
-  const float ed = fmaf(-sd, s, x);
-  const float eu = fmaf(-su, s, x);
-  float r = ed <= 0.0f ? sd : s;
-  r = eu > 0.0f ? su : r;
-  return r;
+  const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+  const float e = fmaf(-s, s, x);
+  return fmaf(e, h, s);
+}
+// ... and +0: v_rsq_f32(0) is +inf; clamped, the correction is 0 * 2^100 = 0 and the result s = 0.
+__device__ __forceinline__ float sqrt_fast0(float x) {  // requires sqrt_fast_ok(x)
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float h = fminf(0.5f * __builtin_amdgcn_rsqf(x), 0x1p100f);
+  const float e = fmaf(-s, s, x);
+  return fmaf(e, h, s);
 }
 __device__ __forceinline__ float sqrt_cr(float x) {
-  if (__all(sqrt_fast_ok(x))) return sqrt_fast(x);
+  if (__all(sqrt_fast_ok(x))) return sqrt_fast0(x);
   return sqrtf(x);
 }
 
@@ -81,7 +86,7 @@ __device__ __forceinline__ void sqrt_cr_n(const float (&x)[N], float (&r)[N]) {
   for (int i = 0; i < N; i++) ok = ok && sqrt_fast_ok(x[i]);
   if (__all(ok)) {
 #pragma unroll
-    for (int i = 0; i < N; i++) r[i] = sqrt_fast(x[i]);
+    for (int i = 0; i < N; i++) r[i] = sqrt_fast0(x[i]);
   } else {
 #pragma unroll
     for (int i = 0; i < N; i++) r[i] = sqrtf(x[i]);
@@ -124,7 +129,7 @@ __device__ __forceinline__ void ftrl_weight_n(const Hyper &h, const float (&nn)[
   for (int i = 0; i < N; i++) ok = ok && sqrt_fast_ok(nn[i]);
   if (__all(ok)) {
 #pragma unroll
-    for (int i = 0; i < N; i++) dv[i] = div_alpha_fast(h, h.beta + sqrt_fast(nn[i]));
+    for (int i = 0; i < N; i++) dv[i] = div_alpha_fast(h, h.beta + sqrt_fast0(nn[i]));
   } else {
     float sq[N], t[N];
     sqrt_cr_n<N>(nn, sq);

@@ -50,7 +50,7 @@ SMALL_MAX, HUGE_MIN = 8, 192  # occurrence classes of the update kernels (csrc/e
 
 
 def huge_min_for(n_rows, nnz_block, k, n_shards, ffm=True):
-    """The hot / very hot boundary the engine picks for a block (csrc/engine.hip: huge_min_for;
+    """The hot / very hot boundary the engine picks for a block (csrc/engine_step.h: huge_min_for;
     FFM_HUGE_MIN overrides): for the byte shares of the hot and the chain kernel."""
     env = os.environ.get("FFM_HUGE_MIN")
     if env:

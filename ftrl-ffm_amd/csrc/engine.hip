@@ -241,132 +241,7 @@ __global__ void lin_rows_copy_kernel(float *lin, int n_feats, float *dense, cons
   if (to_dense) dense[j] = lin[i]; else lin[i] = dense[j];
 }
 
-// ---- field-pair partition (include/ffm_engine.h: ffm_engine_shard_plan) -----------------------
-// The fields are cut into g contiguous groups; the unit of ownership is a BLOCK (a, b), a <= b: all
-// field pairs with one field in group a and the other in group b.  Every shard gets a set of blocks
-// such that, for each group, the partner groups it owns form one interval -- so every field's owned
-// partner fields are ONE contiguous range and the owned slots of a record are contiguous.
-//   1 shard : everything.
-//   2 shards: g = 2; {(0,1)} | {(0,0),(1,1)}.
-//   4 shards: g = 4; {(0,1),(2,3)} | {(0,2),(1,3)} | {(0,3),(1,2)} | the four diagonal blocks.
-//   8 shards: g = 4; the six off-diagonal blocks one each | {(0,0),(1,1)} | {(2,2),(3,3)}: every
-//             shard needs the columns of only two groups (about half of the fields); 100 vs 92.6
-//             cross-field pairs on the busiest shard at 39 fields.
-//   other   : g = n "strips": shard r owns the blocks (r, s), s >= r, with the group sizes chosen
-//             so that the shards' pair counts are as even as the field count allows.
-struct ShardPlan {
-  int n_fields = 0, n_shards = 1;
-  std::vector<int> own_lo, own_n;  // [shard][field]
-  std::vector<int> lin_owner;      // [field] shard that owns the field's linear terms
-  int bias_owner = 0;
-  std::vector<long long> pairs;    // [shard] cross-field pairs owned (load measure)
-  int lo(int r, int f) const { return own_lo[static_cast<size_t>(r) * n_fields + f]; }
-  int n(int r, int f) const { return own_n[static_cast<size_t>(r) * n_fields + f]; }
-  bool owns(int r, int fa, int fb) const { return static_cast<unsigned>(fb - lo(r, fa)) < static_cast<unsigned>(n(r, fa)); }
-};
-
-static ShardPlan make_shard_plan(int F, int N, bool field_map) {
-  ShardPlan p;
-  p.n_fields = F;
-  p.n_shards = N;
-  p.own_lo.assign(static_cast<size_t>(N) * F, 0);
-  p.own_n.assign(static_cast<size_t>(N) * F, 0);
-  p.lin_owner.assign(F, 0);
-  p.pairs.assign(N, 0);
-  std::vector<int> gb;                                  // group boundaries, g + 1 entries
-  std::vector<std::vector<std::pair<int, int>>> blocks(N);
-  auto even_groups = [&](int g) { gb.clear(); for (int j = 0; j <= g; j++) gb.push_back(static_cast<int>(static_cast<long long>(j) * F / g)); };
-  if (N == 1) {
-    even_groups(1);
-    blocks[0] = {{0, 0}};
-  } else if (N == 2 && F >= 2) {
-    even_groups(2);
-    blocks[0] = {{0, 1}};
-    blocks[1] = {{0, 0}, {1, 1}};
-  } else if (N == 4 && F >= 4) {
-    even_groups(4);
-    blocks[0] = {{0, 1}, {2, 3}};
-    blocks[1] = {{0, 2}, {1, 3}};
-    blocks[2] = {{0, 3}, {1, 2}};
-    blocks[3] = {{0, 0}, {1, 1}, {2, 2}, {3, 3}};
-  } else if (N == 8 && F >= 4) {
-    even_groups(4);
-    blocks[0] = {{0, 1}}; blocks[1] = {{0, 2}}; blocks[2] = {{0, 3}};
-    blocks[3] = {{1, 2}}; blocks[4] = {{1, 3}}; blocks[5] = {{2, 3}};
-    blocks[6] = {{0, 0}, {1, 1}};
-    blocks[7] = {{2, 2}, {3, 3}};
-  } else {
-    // strips: choose the boundaries greedily so that shard r's cross-field pair count
-    // |G_r| * (F - end_r) + C(|G_r|, 2) tracks what is left divided by the shards left
-    gb.assign(1, 0);
-    long long left = static_cast<long long>(F) * (F - 1) / 2;
-    for (int r = 0; r < N; r++) {
-      const int b0 = gb.back();
-      int b1 = b0;
-      if (r == N - 1) {
-        b1 = F;
-      } else {
-        const double target = static_cast<double>(left) / (N - r);
-        long long best_cnt = 0;
-        for (int c = b0; c <= F; c++) {
-          const long long sz = c - b0, cnt = sz * (F - c) + sz * (sz - 1) / 2;
-          if (c == b0 || std::abs(static_cast<double>(cnt) - target) <= std::abs(static_cast<double>(best_cnt) - target)) { b1 = c; best_cnt = cnt; }
-          if (static_cast<double>(cnt) > target) break;
-        }
-        left -= best_cnt;
-      }
-      gb.push_back(b1);
-      for (int s2 = r; s2 < N; s2++) blocks[r].push_back({r, s2});
-    }
-  }
-  const int g = static_cast<int>(gb.size()) - 1;
-  for (int r = 0; r < N; r++) {
-    std::vector<int> pmin(g, g), pmax(g, -1);  // partner-group interval of every group on shard r
-    for (auto [a, b] : blocks[r]) {
-      if (b >= g || a >= g) continue;
-      pmin[a] = std::min(pmin[a], b); pmax[a] = std::max(pmax[a], b);
-      pmin[b] = std::min(pmin[b], a); pmax[b] = std::max(pmax[b], a);
-      const long long sa = gb[a + 1] - gb[a], sb = gb[b + 1] - gb[b];
-      p.pairs[r] += a == b ? sa * (sa - 1) / 2 : sa * sb;
-    }
-    for (int a = 0; a < g; a++) {
-      if (pmax[a] < 0) continue;
-      for (int f = gb[a]; f < gb[a + 1]; f++) {
-        p.own_lo[static_cast<size_t>(r) * F + f] = gb[pmin[a]];
-        p.own_n[static_cast<size_t>(r) * F + f] = gb[pmax[a] + 1] - gb[pmin[a]];
-      }
-    }
-  }
-  // Without a field map the bias and all linear terms go to the least loaded shard (a shard then
-  // cannot tell a feature's field from its id).  With one, every field's linear terms go to the
-  // least loaded shard that keeps that column, and the bias (one sequential chain as long as the
-  // block) to the least loaded shard after that; loads in units of one field pair (measured at
-  // 39 fields / 8 shards: a field's linear terms ~ 2 pairs, the bias chain ~ 15).
-  std::vector<double> load(p.pairs.begin(), p.pairs.end());
-  // (a shard made of DIAGONAL blocks -- pairs inside a group -- keeps one useless self slot per
-  // record and measured ~6 % slower per pair than an off-diagonal one at 39 fields / 8 shards)
-  for (int r = 0; r < N; r++) {
-    bool diagonal = false;
-    for (auto [a, b] : blocks[r]) diagonal = diagonal || (a == b && a < g);
-    if (diagonal && field_map) load[r] += 0.12 * static_cast<double>(p.pairs[r]);
-  }
-  p.bias_owner = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
-  if (field_map) {
-    for (int f = 0; f < F; f++) {
-      int best = -1;
-      for (int r = 0; r < N; r++)
-        if (p.n(r, f) > 0 && (best < 0 || load[r] < load[best])) best = r;
-      if (best < 0) best = p.bias_owner;
-      p.lin_owner[f] = best;
-      load[best] += 2.0;
-    }
-    p.bias_owner = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
-  } else {
-    for (int f = 0; f < F; f++) p.lin_owner[f] = p.bias_owner;
-  }
-  return p;
-}
-
+#include "engine_plan.h"
 }  // namespace
 
 struct ffm_engine {
@@ -1158,1021 +1033,10 @@ int ffm_engine_shard_plan(int32_t n_fields, int32_t n_shards, int32_t field_map,
   return FFM_OK;
 }
 
-// ---- dense <-> record layout transfers ----------------------------------------------------
-
-static int vec_transfer(ffm_engine *e, int comp, float *host, bool to_host) {
-  if (!host || e->logical_len == 0) return FFM_OK;
-  const int64_t RL = e->logical_len;
-  const int64_t chunk = e->stage_floats / RL;
-  for (int64_t f0 = 0; f0 < e->m.n_feats; f0 += chunk) {
-    const int64_t nf = std::min<int64_t>(chunk, e->m.n_feats - f0);
-    const size_t bytes = static_cast<size_t>(nf * RL) * sizeof(float);
-    if (!to_host) HIP_TRY(hipMemcpyAsync(e->d_stage, host + f0 * RL, bytes, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(lat_component_copy_kernel, dim3(1024), dim3(256), 0, e->stream, e->m,
-                       static_cast<int>(RL), comp, e->d_stage, f0, nf, to_host ? 1 : 0);
-    if (to_host) HIP_TRY(hipMemcpyAsync(host + f0 * RL, e->d_stage, bytes, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-  }
-  return FFM_OK;
-}
-
-static int flat_transfer(ffm_engine *e, float *dev, float *host, size_t n, bool to_host) {
-  if (!host) return FFM_OK;
-  HIP_TRY(hipMemcpyAsync(to_host ? host : dev, to_host ? dev : host, n * sizeof(float),
-                         to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  return FFM_OK;
-}
-
-int ffm_engine_set_weights(ffm_engine *e, const float *bias, const float *lin_w, const float *vec_w) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  int rc;
-  if ((rc = flat_transfer(e, e->m.bias3 + 0, const_cast<float *>(bias), 1, false))) return rc;
-  if ((rc = flat_transfer(e, e->m.lin_w, const_cast<float *>(lin_w), e->m.n_feats, false))) return rc;
-  return vec_transfer(e, LAT_W, const_cast<float *>(vec_w), false);
-}
-
-int ffm_engine_get_weights(ffm_engine *e, float *bias, float *lin_w, float *vec_w) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  int rc;
-  if ((rc = flat_transfer(e, e->m.bias3 + 0, bias, 1, true))) return rc;
-  if ((rc = flat_transfer(e, e->m.lin_w, lin_w, e->m.n_feats, true))) return rc;
-  return vec_transfer(e, LAT_W, vec_w, true);
-}
-
-int ffm_engine_set_state(ffm_engine *e, const float *bias_n, const float *bias_z,
-                         const float *lin_n, const float *lin_z, const float *vec_n,
-                         const float *vec_z) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  int rc;
-  if ((rc = flat_transfer(e, e->m.bias3 + 1, const_cast<float *>(bias_n), 1, false))) return rc;
-  if ((rc = flat_transfer(e, e->m.bias3 + 2, const_cast<float *>(bias_z), 1, false))) return rc;
-  if ((rc = flat_transfer(e, e->m.lin_n, const_cast<float *>(lin_n), e->m.n_feats, false))) return rc;
-  if ((rc = flat_transfer(e, e->m.lin_z, const_cast<float *>(lin_z), e->m.n_feats, false))) return rc;
-  if ((rc = vec_transfer(e, LAT_N, const_cast<float *>(vec_n), false))) return rc;
-  return vec_transfer(e, LAT_Z, const_cast<float *>(vec_z), false);
-}
-
-int ffm_engine_get_state(ffm_engine *e, float *bias_n, float *bias_z, float *lin_n, float *lin_z,
-                         float *vec_n, float *vec_z) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  int rc;
-  if ((rc = flat_transfer(e, e->m.bias3 + 1, bias_n, 1, true))) return rc;
-  if ((rc = flat_transfer(e, e->m.bias3 + 2, bias_z, 1, true))) return rc;
-  if ((rc = flat_transfer(e, e->m.lin_n, lin_n, e->m.n_feats, true))) return rc;
-  if ((rc = flat_transfer(e, e->m.lin_z, lin_z, e->m.n_feats, true))) return rc;
-  if ((rc = vec_transfer(e, LAT_N, vec_n, true))) return rc;
-  return vec_transfer(e, LAT_Z, vec_z, true);
-}
-
-// Gather / scatter of the records of a list of features (host arrays).
-static int rows_transfer(ffm_engine *e, int32_t n, const int32_t *ids, float *const lin[3],
-                         float *const vec[3], bool to_host) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  if (n < 0 || (n > 0 && !ids)) return fail(FFM_E_INVALID, "bad feature id list");
-  for (int32_t j = 0; j < n; j++)
-    if (ids[j] < 0 || ids[j] >= e->m.n_feats) return fail(FFM_E_INVALID, "feature id out of range");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  const int64_t RL = e->logical_len;
-  const int64_t per = std::min<int64_t>(ffm_engine::kIdsCap, RL > 0 ? e->stage_floats / RL : ffm_engine::kIdsCap);
-  float *const lin_dev[3] = {e->m.lin_n, e->m.lin_z, e->m.lin_w};
-  for (int64_t j0 = 0; j0 < n; j0 += per) {
-    const int nf = static_cast<int>(std::min<int64_t>(per, n - j0));
-    HIP_TRY(hipMemcpyAsync(e->d_ids, ids + j0, sizeof(int) * nf, hipMemcpyHostToDevice, e->stream));
-    for (int comp = 0; comp < 3; comp++) {
-      if (lin[comp]) {
-        if (!to_host) HIP_TRY(hipMemcpyAsync(e->d_stage, lin[comp] + j0, sizeof(float) * nf, hipMemcpyHostToDevice, e->stream));
-        hipLaunchKernelGGL(lin_rows_copy_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, e->stream,
-                           lin_dev[comp], e->m.n_feats, e->d_stage, e->d_ids, nf, to_host ? 1 : 0);
-        if (to_host) HIP_TRY(hipMemcpyAsync(lin[comp] + j0, e->d_stage, sizeof(float) * nf, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-      }
-      if (vec[comp] && RL > 0) {
-        const size_t bytes = static_cast<size_t>(nf) * RL * sizeof(float);
-        if (!to_host) HIP_TRY(hipMemcpyAsync(e->d_stage, vec[comp] + j0 * RL, bytes, hipMemcpyHostToDevice, e->stream));
-        hipLaunchKernelGGL(lat_rows_copy_kernel, dim3(1024), dim3(256), 0, e->stream, e->m,
-                           static_cast<int>(RL), comp, e->d_stage, e->d_ids,
-                           static_cast<int64_t>(nf), to_host ? 1 : 0);
-        if (to_host) HIP_TRY(hipMemcpyAsync(vec[comp] + j0 * RL, e->d_stage, bytes, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-      }
-    }
-  }
-  HIP_TRY(hipGetLastError());
-  return FFM_OK;
-}
-
-int ffm_engine_get_rows(ffm_engine *e, int32_t n, const int32_t *feat_ids, float *lin_w,
-                        float *lin_n, float *lin_z, float *vec_w, float *vec_n, float *vec_z) {
-  float *const lin[3] = {lin_n, lin_z, lin_w}, *const vec[3] = {vec_n, vec_z, vec_w};  // LAT_* order
-  return rows_transfer(e, n, feat_ids, lin, vec, true);
-}
-
-int ffm_engine_set_rows(ffm_engine *e, int32_t n, const int32_t *feat_ids, const float *lin_w,
-                        const float *lin_n, const float *lin_z, const float *vec_w,
-                        const float *vec_n, const float *vec_z) {
-  float *const lin[3] = {const_cast<float *>(lin_n), const_cast<float *>(lin_z), const_cast<float *>(lin_w)};
-  float *const vec[3] = {const_cast<float *>(vec_n), const_cast<float *>(vec_z), const_cast<float *>(vec_w)};
-  return rows_transfer(e, n, feat_ids, lin, vec, false);
-}
-
-// ---- one block of rows ---------------------------------------------------------------------
-
-static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *row_ptr,
-                       const void *field, const void *feat, const void *val) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  if (n_rows < 0 || nnz < 0) return fail(FFM_E_INVALID, "negative n_rows / nnz");
-  if (n_rows > e->max_rows || nnz > e->max_nnz)
-    return fail(FFM_E_CAPACITY, "block exceeds max_batch_rows / max_batch_nnz");
-  if (!row_ptr || (nnz > 0 && (!feat || !val))) return fail(FFM_E_INVALID, "null CSR array");
-  if (e->m.type == FFM_MODEL_FFM && nnz > 0 && !field)
-    return fail(FFM_E_INVALID, "FFM requires the field array (libffm rows)");
-  return FFM_OK;
-}
-
-
-static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float *out, int output_prob, int own_tg = 0) {
-  const int row_cap = e->staged_row_cap > 0 ? e->staged_row_cap : e->max_row_nnz;
-  e->staged_row_cap = 0;
-  if (rows.n_rows == 0) return;
-  // (the kernels recompute the same terms capacity from the same arguments)
-  const int terms_cap = e->m.type == FFM_MODEL_FM ? row_terms_cap(2, 0, e->m.n_factors)
-                        : row_terms_cap(row_cap, e->m.n_shards > 1 ? e->m.rec_slots : 0, 0);
-  const size_t shmem = row_lds_bytes(row_cap, e->m.n_fields, terms_cap);
-  const int kid = train ? K_ROW : K_PREDICT_ROW;
-  if (e->m.type == FFM_MODEL_FM && e->m.n_factors <= 64) {
-    // one wave per row, lane = factor (kernels_fm.h)
-    if (train) e->singles_in_row = own_tg != 0;
-    const int grid = cdiv(rows.n_rows, kFmRowsPerBlock);
-    if (train) LAUNCH(e, kid, fm_row_wave_kernel<true>, grid, 64 * kFmRowsPerBlock, 0, e->m, rows, e->sc[e->cur], row_cap, out, output_prob, own_tg);
-    else LAUNCH(e, kid, fm_row_wave_kernel<false>, grid, 64 * kFmRowsPerBlock, 0, e->m, rows, e->sc[e->cur], row_cap, out, output_prob, 0);
-  } else if (e->m.type == FFM_MODEL_FM) {
-    if (train) e->singles_in_row = false;
-    if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], row_cap, out, output_prob);
-    else LAUNCH(e, kid, fm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], row_cap, out, output_prob);
-  } else {
-    const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
-    const int mr = row_cap;
-    int refreshed = train && e->pre_refresh ? e->refresh_mode : 0;
-    if (refreshed == 3 && !(own_tg && vec4 && e->single_kernel)) refreshed = 2;
-    if (train) e->singles_in_row = refreshed == 3;
-    if (refreshed && rows.nnz > 0) {
-      const int per = vec4 ? e->m.row_len / 4 : e->m.row_len;
-      const int64_t items = static_cast<int64_t>(std::min(rows.nnz, e->max_nnz)) * per;
-      const int grid = static_cast<int>(std::min<int64_t>((items + 255) / 256, 8192));
-      if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
-      else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
-    }
-    if (train) e->cur_phases = own_tg && vec4 ? phases_for(e, rows.n_rows) : 1;
-    if (train && vec4) {
-      // one launch per row phase; the update streams pick each phase up at its event
-      for (int ph = 0; ph < e->cur_phases; ph++) {
-        const int r0 = phase_row(rows.n_rows, e->cur_phases, ph), r1 = phase_row(rows.n_rows, e->cur_phases, ph + 1);
-        if (r1 > r0)
-          LAUNCH(e, kid, (ffm_row_kernel<true, true>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, r0);
-        if (e->cur_phases > 1) (void)hipEventRecord(e->ev_row[ph], e->stream);
-      }
-    }
-    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, 0);
-    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
-    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
-  }
-}
-
-static bool same_block(const Rows &a, const Rows &b) {
-  return a.n_rows == b.n_rows && a.nnz == b.nnz && a.row_ptr == b.row_ptr && a.field == b.field &&
-         a.feat == b.feat && a.val == b.val;
-}
-
-// Zeroes the grouping's counters and per-row field masks (a kernel: hipMemsetAsync costs the
-// submitting thread ~100 us per call here, a launch ~5).
-__global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_counters,
-                                                          unsigned long long *rowmask, int n_mask) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  for (int i = tid; i < n_counters; i += stride) counters[i] = 0;
-  for (int i = tid; i < n_mask; i += stride) rowmask[i] = 0ull;
-}
-
-// Groups `rows` by feature into scratch set `set` on stream `st`.
-// timed = false: from the staging thread (no HIP-event bookkeeping of the profiler there).
-// Hot / very hot boundary of one block.  A hot feature's touches are ONE sequential chain per element
-// (~0.55 us per touch beside the other kernels); the very hot ones' chains are cut into 16-touch
-// steps at 40 % more instructions.  So the hot kernel's longest chain should last about as long as
-// what bounds the update phase anyway: half its throughput-bound time (measured 0.88 touch-elements
-// per ns at FFM 39 x 16) or the bias chain's one wave (12 ns per row).  kHugeMin -- the optimum of
-// 8192 x 39-entry rows at k = 16 -- caps it.  (C2, 4096 x 8 entries: 384 -> 89, 17.5 -> 22.8 M rows/s.)
-static int huge_min_for(const ffm_engine *e, const Rows &rows) {
-  if (e->huge_min_fixed || e->m.type != FFM_MODEL_FFM || rows.n_rows <= 0) return e->m.huge_min;
-  const double per_row = static_cast<double>(rows.nnz) / rows.n_rows;
-  const double touch_elems = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / std::max(1, e->m.n_shards);
-  const double span_us = std::max(touch_elems / 0.88e6, rows.n_rows * 0.012);
-  return static_cast<int>(std::min<double>(kHugeMin, std::max(64.0, span_us / 0.55)));
-}
-
-static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st, bool timed = true) {
-  Scratch &sc = e->sc[set];
-  ScopedTimer tm_all("grouping:all");
-  {
-    ScopedTimer tm_clear("grouping:clear");
-    const int n_mask = rows.nnz > 0 && sc.rowmask ? 2 * rows.n_rows : 0;
-    hipLaunchKernelGGL(group_clear_kernel, dim3(std::max(1, std::min(64, cdiv(n_mask, 1024)))), dim3(256), 0, st,
-                       sc.counters, kNumCounters, sc.rowmask, n_mask);
-  }
-  if (rows.nnz > 0) {
-    const int nnz = rows.nnz;
-    if (timed) LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->max_row_nnz);
-    else hipLaunchKernelGGL(group_keys_kernel, dim3(cdiv(nnz, kGroupThreads)), dim3(kGroupThreads), 0, st, e->m, rows, sc, e->max_row_nnz);
-    if (timed) e->prof_begin(K_GROUP_SORT, st);
-    {
-      ScopedTimer tm_sort("grouping:sort");
-      size_t bytes = e->sort_tmp_bytes;
-      HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
-                                        rocprim::counting_iterator<int>(0), sc.occ,
-                                        static_cast<size_t>(nnz), 0u, e->sort_bits, st));
-    }
-    if (timed) e->prof_end(st);
-    ModelDev mf = e->m;  // (the only kernel that deals features into the hot / very hot lists)
-    mf.huge_min = huge_min_for(e, rows);
-    if (timed) LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, mf, rows, sc,
-                         phases_for(e, rows.n_rows));
-    else hipLaunchKernelGGL(group_finish_kernel, dim3(cdiv(nnz, kFinishThreads)), dim3(kFinishThreads), 0, st, mf, rows, sc,
-                            phases_for(e, rows.n_rows));
-  }
-  HIP_TRY(hipGetLastError());
-  return FFM_OK;
-}
-
-// A look-ahead grouping in two halves: the bookkeeping (caller's thread, in call order) and the
-// stream operations (whoever submits: the caller's thread or the staging thread, in the same order).
-struct PrepPlan {
-  int set = 0;
-  bool wait_free = false;  // the set carried an earlier block: wait for its ev_set_free
-  int ws = -1;             // prep_window: start when this set's block has trained (-1: at once)
-  Rows rows{};
-};
-static int prepare_plan(ffm_engine *e, const Rows &rows, PrepPlan *pl) {
-  if (e->has_pending) return fail(FFM_E_INVALID, "prepare between train_forward and train_update");
-  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "three prepared blocks are already waiting");
-  const int set = (e->last_set + 1) % ffm_engine::kSets;
-  pl->set = set;
-  pl->rows = rows;
-  pl->wait_free = e->set_used[set];
-  pl->ws = -1;
-  if (e->prep_window) {
-    // n_prepared == 1: the predecessor is prepared but not enqueued yet -> wait for the block
-    // enqueued last; n_prepared == 0: the predecessor IS the block enqueued last -> the one before
-    const int ws = e->trained_set[e->n_prepared >= 1 ? 0 : 1];
-    if (ws >= 0 && ws != set) pl->ws = ws;
-  }
-  // the set is in use from now on, also when this look-ahead ends up discarded: whoever takes the
-  // set next must wait for ev_set_free (recorded when the block trains or the look-ahead is dropped)
-  e->set_used[set] = true;
-  e->last_set = set;
-  e->prepared_set[e->n_prepared] = set;
-  e->prepared_rows[e->n_prepared] = rows;
-  e->n_prepared++;
-  return FFM_OK;
-}
-static int prepare_submit(ffm_engine *e, const PrepPlan &pl, bool timed) {
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  if (pl.wait_free) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.set], 0));
-  if (pl.ws >= 0) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.ws], 0));
-  int rc = launch_grouping(e, pl.set, pl.rows, e->prep, timed);
-  if (rc) return rc;
-  HIP_TRY(hipEventRecord(e->ev_grouped[pl.set], e->prep));
-  return FFM_OK;
-}
-
-int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
-                              const int32_t *field, const int32_t *feat, const float *val) {
-  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
-  if (rc) return rc;
-  if ((rc = e->drain())) return rc;  // (staged blocks' submissions come first on the prep stream)
-  PrepPlan pl;
-  if ((rc = prepare_plan(e, Rows{n_rows, nnz, row_ptr, field, feat, val, nullptr}, &pl))) return rc;
-  return prepare_submit(e, pl, true);
-}
-
-int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
-                                    const int32_t *row_ptr, const int32_t *field,
-                                    const int32_t *feat, const float *val, const int32_t *label,
-                                    float *partial_logit) {
-  ScopedTimer tm_fwd("train:forward");
-  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
-  if (rc) return rc;
-  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
-  e->pending = rows;
-  e->has_pending = true;
-  // only train_batch_device has the whole logit in its row kernel (one shard, FFM / LR)
-  e->own_tg_cur = e->whole_step && e->m.n_shards == 1 &&
-                  (e->m.type != FFM_MODEL_FM || e->m.n_factors <= 64);  // (FM: fm_row_wave_kernel)
-  e->whole_step = false;
-  const bool use_prepared = e->n_prepared > 0 && same_block(e->prepared_rows[0], rows);
-  if (e->n_prepared > 0 && !use_prepared) {
-    // groupings made ahead for some other block: forget them all
-    if ((rc = e->drain())) return rc;
-    for (int i = 0; i < e->n_prepared; i++) HIP_TRY(hipEventRecord(e->ev_set_free[e->prepared_set[i]], e->prep));
-    e->n_prepared = 0;
-  }
-  if (use_prepared) {
-    e->cur = e->prepared_set[0];
-    for (int i = 1; i < e->n_prepared; i++) {
-      e->prepared_set[i - 1] = e->prepared_set[i];
-      e->prepared_rows[i - 1] = e->prepared_rows[i];
-    }
-    e->n_prepared--;
-    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_grouped[e->cur], 0));
-  } else {
-    e->cur = (e->last_set + 1) % ffm_engine::kSets;
-    e->last_set = e->cur;
-    if (e->set_used[e->cur]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_set_free[e->cur], 0));
-    rc = launch_grouping(e, e->cur, rows, e->stream);
-    if (rc) return rc;
-  }
-  e->set_used[e->cur] = true;
-  launch_row_kernel(e, rows, true, e->own_tg_cur ? e->own_logit_out : nullptr, 0, e->own_tg_cur ? 1 : 0);
-  if (partial_logit && n_rows > 0)
-    HIP_TRY(hipMemcpyAsync(partial_logit, e->sc[e->cur].logit, sizeof(float) * n_rows, hipMemcpyDeviceToDevice, e->stream));
-  HIP_TRY(hipGetLastError());
-  return FFM_OK;
-}
-
-int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *logit_out,
-                                   double *loss_sum_out) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  if (!e->has_pending) return fail(FFM_E_INVALID, "train_update without a preceding train_forward");
-  ScopedTimer tm_upd("train:update");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  const Rows rows = e->pending;
-  e->has_pending = false;
-  const float *lg = logit ? logit : e->sc[e->cur].logit;
-  const bool own_tg = e->own_tg_cur && !logit;
-  if (rows.n_rows > 0 && !own_tg)
-    LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->sc[e->cur].tg, e->sc[e->cur].loss, logit_out);
-  if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0 && !own_tg)
-    LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
-  // this shard runs the bias chain / a linear update when it owns the bias / any field's linear terms
-  // FM, whole step: fm_row_wave_kernel has applied the touches of the once-only features itself
-  const int fm_in_row = e->m.type == FFM_MODEL_FM && own_tg && e->singles_in_row ? 1 : 0;
-  const bool lin_owner = e->m.bias_own != 0 || e->lin_any;
-  const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
-  const bool vec4 = e->m.n_factors % 4 == 0;
-  const int lin_blocks = rows.nnz > 0 ? std::min(cdiv(rows.nnz, kUpdThreads), 1024) : 0;
-  // The bias and linear chains are short and serial: they run beside the latent update -- inside
-  // the hot-feature launch when there is one (side_blocks), else on the side stream.
-  const bool side_in_hot = ffm && vec4 && lin_owner && rows.n_rows > 0;
-  const int side_blocks = side_in_hot ? 1 + lin_blocks : 0;
-  // FM: the same inside the launch of the few-occurrence features' latent update
-  const bool side_in_fm = e->m.type == FFM_MODEL_FM && lin_owner && rows.n_rows > 0 && rows.nnz > 0 && !e->serial;
-  const int fm_side_blocks = side_in_fm ? 1 + lin_blocks : 0;
-  const bool forked = rows.n_rows > 0 && lin_owner && !e->serial && !side_in_hot && !side_in_fm;
-  if (rows.n_rows > 0 && lin_owner && e->serial && !side_in_hot) {
-    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
-    if (rows.nnz > 0)
-      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
-  }
-  if (forked || side_in_fm || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
-  if (forked) {
-    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
-    // the bias chain (one wave, as long as the block has rows) alone on the side stream; the linear
-    // update shares the main stream with the latent update of the few-occurrence features
-    LAUNCH_ON(e, e->aux2, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
-    HIP_TRY(hipEventRecord(e->ev_join, e->aux2));
-    if (rows.nnz > 0)
-      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
-  }
-  // small features on the main stream: the once-only ones through their descriptor kernel
-  auto launch_small = [&]() {
-    const bool single = e->single_kernel;
-    if (single && !e->singles_in_row) {  // (else: already applied by the row kernel)
-      const int span4 = e->m.rec_slots * (e->m.n_factors / 4);  // 16-byte vectors of a stored record
-      if (flat_pays(e, span4)) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_flat_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-      else if (span4 <= 64) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<1>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-      else if (span4 <= 128) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-      else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-    }
-    if (flat_pays(e, e->m.rec_slots * (e->m.n_factors / 4)))
-      LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
-    else
-      LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
-  };
-  if (ffm && vec4 && e->serial) {
-    launch_ffm_chain(e, e->stream, rows);
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, 0, 1);
-    launch_small();
-  } else if (ffm && vec4) {
-    // the three owner shapes touch disjoint features: run them side by side (long sequential
-    // chains of the hot ones beside the bandwidth-shaped small-feature pass).  With row phases the
-    // two side streams take each phase's touches as soon as its rows are done -- beside the forward
-    // pass of the next phase (which reads w; the update writes n and z).
-    const int P = own_tg ? e->cur_phases : 1;
-    for (int ph = 0; ph < P; ph++) {
-      HIP_TRY(hipStreamWaitEvent(e->aux3, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
-      launch_ffm_chain(e, e->aux3, rows, ph, P);
-    }
-    HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
-    for (int ph = 0; ph < P; ph++) {
-      HIP_TRY(hipStreamWaitEvent(e->aux2, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
-      LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, P);
-    }
-    HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
-    launch_small();
-    if (loss_sum_out)
-      LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
-    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
-    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
-  } else if (ffm) {
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-  } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
-    // the very hot features' long chains on their own stream, lane = (factor, touch)
-    const bool fm_fork = forked || side_in_fm;
-    if (fm_fork) {
-      HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-      LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-      HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
-    } else {
-      LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-    }
-    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048 + fm_side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1, fm_in_row, fm_side_blocks);
-    if (fm_fork) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
-  }
-  if (loss_sum_out && !(ffm && vec4 && !e->serial))
-    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
-  if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
-  HIP_TRY(hipEventRecord(e->ev_set_free[e->cur], e->stream));
-  e->trained_set[1] = e->trained_set[0];
-  e->trained_set[0] = e->cur;
-  if (e->cur_slot >= 0) {  // a staged block: its staging slot may be refilled from here on
-    HIP_TRY(hipEventRecord(e->slots[e->cur_slot].ev_trained, e->stream));
-    e->cur_slot = -1;
-  }
-  HIP_TRY(hipGetLastError());
-  return FFM_OK;
-}
-
-int ffm_engine_train_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
-                                  const int32_t *row_ptr, const int32_t *field,
-                                  const int32_t *feat, const float *val, const int32_t *label,
-                                  float *logit_out, double *loss_sum_out) {
-  if (e && e->m.n_shards > 1)
-    return fail(FFM_E_INVALID, "sharded engines train with train_forward + all-reduce + train_update");
-  if (e) { e->whole_step = true; e->own_logit_out = logit_out; }
-  int rc = ffm_engine_train_forward_device(e, n_rows, nnz, row_ptr, field, feat, val, label, nullptr);
-  if (e) e->whole_step = false;
-  if (rc) return rc;
-  return ffm_engine_train_update_device(e, nullptr, logit_out, loss_sum_out);
-}
-
-int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
-                                    const int32_t *row_ptr, const int32_t *field,
-                                    const int32_t *feat, const float *val, const int32_t *label,
-                                    int32_t output_prob, float *out, double *loss_sum_out) {
-  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
-  if (rc) return rc;
-  if (e->m.n_shards > 1 && (label || output_prob || loss_sum_out))
-    return fail(FFM_E_INVALID, "a sharded engine predicts partial logits only (label = NULL, output_prob = 0, "
-                               "no loss): sum them across shards, then ffm_engine_predict_finish_device");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
-  launch_row_kernel(e, rows, false, out ? out : e->d_out, output_prob);
-  if (loss_sum_out && label)
-    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(n_rows), 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
-  HIP_TRY(hipGetLastError());
-  return FFM_OK;
-}
-
-int ffm_engine_predict_finish_device(ffm_engine *e, int32_t n_rows, const float *logit,
-                                     const int32_t *label, int32_t output_prob, float *out,
-                                     double *loss_sum_out) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  if (n_rows < 0 || n_rows > e->max_rows) return fail(FFM_E_CAPACITY, "n_rows out of range");
-  if (n_rows > 0 && !logit) return fail(FFM_E_INVALID, "null logit array");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  if (n_rows > 0)
-    LAUNCH(e, K_TMP_GRAD, predict_finish_kernel, cdiv(n_rows, 256), 256, 0, n_rows, logit, label, output_prob, out, e->sc[e->cur].loss);
-  if (loss_sum_out) {
-    if (label) LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(n_rows), 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
-    else HIP_TRY(hipMemsetAsync(loss_sum_out, 0, sizeof(double), e->stream));
-  }
-  HIP_TRY(hipGetLastError());
-  return FFM_OK;
-}
-
-// Checks one block of host arrays; returns its nnz and its longest row.
-static int validate_host_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
-                               const int32_t *field, const int32_t *feat, const float *val,
-                               int32_t *nnz_out, int *longest_out) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  if (n_rows < 0) return fail(FFM_E_INVALID, "negative n_rows");
-  if (!row_ptr) return fail(FFM_E_INVALID, "null row_ptr");
-  if (n_rows > e->max_rows) return fail(FFM_E_CAPACITY, "block exceeds max_batch_rows");
-  if (row_ptr[0] != 0) return fail(FFM_E_INVALID, "row_ptr[0] must be 0");
-  for (int r = 0; r < n_rows; r++)
-    if (row_ptr[r + 1] < row_ptr[r]) return fail(FFM_E_INVALID, "row_ptr must be non-decreasing");
-  const int32_t nnz = row_ptr[n_rows];
-  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
-  if (rc) return rc;
-  int longest = 1;
-  for (int r = 0; r < n_rows; r++) {
-    if (row_ptr[r + 1] - row_ptr[r] > e->max_row_nnz)
-      return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz");
-    longest = std::max(longest, row_ptr[r + 1] - row_ptr[r]);
-  }
-  *nnz_out = nnz;
-  *longest_out = longest;
-  return FFM_OK;
-}
-
-static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, const int32_t *field,
-                       const int32_t *feat, const float *val, const int32_t *label, int32_t *nnz_out) {
-  int32_t nnz = 0;
-  int longest = 1;
-  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
-  if (rc) return rc;
-  e->staged_row_cap = longest;
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  HIP_TRY(hipMemcpyAsync(e->d_row_ptr, row_ptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice, e->stream));
-  if (nnz > 0) {
-    if (field) HIP_TRY(hipMemcpyAsync(e->d_field, field, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_feat, feat, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, e->stream));
-  }
-  if (label && n_rows > 0)
-    HIP_TRY(hipMemcpyAsync(e->d_label, label, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, e->stream));
-  *nnz_out = nnz;
-  return FFM_OK;
-}
-
-int ffm_engine_train_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
-                           const int32_t *field, const int32_t *feat, const float *val,
-                           const int32_t *label, float *logit_out, double *loss_sum_out) {
-  int32_t nnz = 0;
-  int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
-  if (rc) return rc;
-  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
-  rc = ffm_engine_train_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
-                                     e->d_feat, e->d_val, e->d_label, e->d_out, e->d_loss_sum);
-  if (rc) return rc;
-  if (logit_out && n_rows > 0)
-    HIP_TRY(hipMemcpyAsync(logit_out, e->d_out, sizeof(float) * n_rows, hipMemcpyDeviceToHost, e->stream));
-  if (loss_sum_out)
-    HIP_TRY(hipMemcpyAsync(loss_sum_out, e->d_loss_sum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  return check_device_errors(e);
-}
-
-int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
-                             const int32_t *field, const int32_t *feat, const float *val,
-                             const int32_t *label, int32_t output_prob, float *out,
-                             double *loss_sum_out) {
-  int32_t nnz = 0;
-  int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
-  if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(e->sc[e->cur].counters, 0, kNumCounters * sizeof(int), e->stream));
-  rc = ffm_engine_predict_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
-                                       e->d_feat, e->d_val, label ? e->d_label : nullptr,
-                                       output_prob, e->d_out, e->d_loss_sum);
-  if (rc) return rc;
-  if (out && n_rows > 0)
-    HIP_TRY(hipMemcpyAsync(out, e->d_out, sizeof(float) * n_rows, hipMemcpyDeviceToHost, e->stream));
-  if (loss_sum_out) {
-    if (label) HIP_TRY(hipMemcpyAsync(loss_sum_out, e->d_loss_sum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    else *loss_sum_out = 0.0;
-  }
-  return check_device_errors(e);
-}
-
-// ---- pipelined host-buffer training ---------------------------------------------------------
-
-__global__ void loss_accumulate_kernel(double *acc, const double *one) { *acc += *one; }
-
-// Upload of one staged block by a kernel: the five CSR arrays are read straight out of page-locked
-// (device-mapped) host memory, 16 bytes per lane, and written to the staging slot's device arrays.
-// A hipMemcpyAsync here makes the SUBMITTING THREAD wait until the stream's earlier kernels have
-// finished (measured: mean 0.38 ms, up to 16 ms per call) -- the host then cannot run ahead of the
-// GPU and every other step starts ~230 us late; a kernel launch never blocks.
-// Every wave starts with a system-scope acquire (it drops the non-coherent lines of its L2): a
-// caller that refills a block buffer it has used before (the trainers' ring) must not be served
-// lines of the previous block that are still on-die, should the runtime map its page-locked memory
-// cacheable.  (System-scope LOADS instead -- 8 bytes per lane -- halved the upload rate.)
-struct PullJob {
-  const char *src[5]; char *dst[5]; unsigned bytes[5];
-  long long ordinal; long long *pulled; unsigned *ticket;  // completion word (host memory), see h_pulled
-};
-__global__ __launch_bounds__(256) void pull_block_kernel(PullJob job) {
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-#pragma unroll
-  for (int a = 0; a < 5; a++) {
-    const unsigned n16 = job.bytes[a] >> 4;
-    const int4 *s = reinterpret_cast<const int4 *>(job.src[a]);
-    int4 *d = reinterpret_cast<int4 *>(job.dst[a]);
-    for (unsigned i = tid; i < n16; i += stride) d[i] = s[i];
-    const unsigned tail = job.bytes[a] & 15u;  // sizes are multiples of 4
-    if (tid < (tail >> 2))
-      reinterpret_cast<int *>(job.dst[a])[(n16 << 2) + tid] = reinterpret_cast<const int *>(job.src[a])[(n16 << 2) + tid];
-  }
-  // the workgroup that finishes last publishes the block's number to the host
-  __syncthreads();  // (every load of this workgroup has returned: its stores were issued after them)
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(job.ticket, 1u) == gridDim.x - 1) {
-      *job.ticket = 0u;
-      __hip_atomic_store(job.pulled, job.ordinal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-
-static int slots_init(ffm_engine *e) {
-  if (e->slots_ready) return FFM_OK;
-  const size_t R = static_cast<size_t>(e->max_rows), E = static_cast<size_t>(e->max_nnz);
-  const size_t bytes = 4 * (R + 1) + 4 * E * 3 + 4 * R + 5 * 16;  // each of the 5 arrays is padded to 16 B
-  for (auto &sl : e->slots) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.pinned), bytes, hipHostMallocDefault));
-    int rc;
-    if ((rc = e->alloc(&sl.row_ptr, R + 1)) || (rc = e->alloc(&sl.field, E)) || (rc = e->alloc(&sl.feat, E)) ||
-        (rc = e->alloc(&sl.val, E)) || (rc = e->alloc(&sl.label, R)))
-      return rc;
-    HIP_TRY(hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sl.ev_trained, hipEventDisableTiming));
-  }
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_pulled), 64, hipHostMallocDefault));
-  *e->h_pulled = 0;
-  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_pulled), e->h_pulled, 0));
-  if (int rc_t = e->alloc(&e->d_pull_ticket, 1)) return rc_t;
-  HIP_TRY(hipMemsetAsync(e->d_pull_ticket, 0, sizeof(unsigned), e->copy));
-  int rc = e->alloc(&e->d_loss_acc, 1);
-  if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(e->d_loss_acc, 0, sizeof(double), e->stream));
-  e->slots_ready = true;
-  return FFM_OK;
-}
-
-int ffm_engine_pin_host(void *p, size_t bytes) {
-  if (!p || !bytes) return fail(FFM_E_INVALID, "null range");
-  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterMapped));
-  return FFM_OK;
-}
-int ffm_engine_unpin_host(void *p) {
-  if (!p) return fail(FFM_E_INVALID, "null pointer");
-  HIP_TRY(hipHostUnregister(p));
-  return FFM_OK;
-}
-
-// The next staging slot for a host block: waits until the slot's own pinned image is free, copies
-// the caller's arrays into it (unless zero_copy) and describes the upload (pull_block_kernel's
-// argument; the block's ordinal is n_staged_total + 1).  Bookkeeping of the slot is the caller's.
-static int claim_slot(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
-                      const int32_t *field, const int32_t *feat, const float *val, const int32_t *label,
-                      int32_t zero_copy, int *slot_out, bool *was_used, PullJob *job_out) {
-  int rc;
-  if ((rc = slots_init(e))) return rc;
-  ffm_engine::Slot &sl = e->slots[e->slot_next];
-  *slot_out = e->slot_next;
-  *was_used = sl.used;
-  if (sl.used && !sl.zero_copy) {
-    ScopedTimer tm("stage:slot_wait");
-    // the slot's own pinned image must have been pulled before it is overwritten.  (Not so for a
-    // zero_copy block, whose image is the caller's: blocking the submitting thread here costs
-    // ~0.2 ms per step; such callers ask ffm_engine_blocks_pulled before reusing their memory.)
-    if ((rc = e->wait_issued(sl.seq))) return rc;
-    HIP_TRY(hipEventSynchronize(sl.ev_copied));
-  }
-  // host arrays -> pinned image (the caller may reuse its buffers on return) -> device, prep stream
-  const size_t R1 = static_cast<size_t>(n_rows) + 1, E = static_cast<size_t>(nnz);
-  char *p = sl.pinned;
-  PullJob &job = *job_out;
-  int n_job = 0;
-  // page-locked source of each array: the caller's own (zero_copy: untouched until the block has
-  // trained) or its image in the slot's pinned buffer; the device then pulls it (pull_block_kernel)
-  auto put = [&](const void *src, size_t bytes, void *dst) -> hipError_t {
-    if (!bytes || !src) return hipSuccess;
-    const void *host = src;
-    if (!zero_copy) {
-      std::memcpy(p, src, bytes);
-      host = p;
-      p += (bytes + 15) & ~static_cast<size_t>(15);
-    }
-    void *mapped = nullptr;
-    hipError_t err = hipHostGetDevicePointer(&mapped, const_cast<void *>(host), 0);
-    if (err != hipSuccess) return err;
-    if ((reinterpret_cast<uintptr_t>(mapped) & 15u) != 0) return hipErrorInvalidValue;  // 16-byte aligned arrays only
-    job.src[n_job] = static_cast<const char *>(mapped);
-    job.dst[n_job] = static_cast<char *>(dst);
-    job.bytes[n_job] = static_cast<unsigned>(bytes);
-    n_job++;
-    return hipSuccess;
-  };
-  ScopedTimer tm("stage:copies");
-  HIP_TRY(put(row_ptr, 4 * R1, sl.row_ptr));
-  if (field) HIP_TRY(put(field, 4 * E, sl.field));
-  HIP_TRY(put(feat, 4 * E, sl.feat));
-  HIP_TRY(put(val, 4 * E, sl.val));
-  HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
-  job.ordinal = e->n_staged_total + 1;
-  job.pulled = e->d_pulled;
-  job.ticket = e->d_pull_ticket;
-  return FFM_OK;
-}
-
-// Stage one block of host rows: (pinned image ->) HBM -> grouping, all on the prep stream.
-int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
-                           const int32_t *field, const int32_t *feat, const float *val,
-                           const int32_t *label, int32_t zero_copy) {
-  int32_t nnz = 0;
-  int longest = 1;
-  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
-  if (rc) return rc;
-  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
-  if (e->n_staged >= ffm_engine::kSlots - 1) return fail(FFM_E_CAPACITY, "three staged blocks are already waiting");
-  if (e->has_pending) return fail(FFM_E_INVALID, "stage between train_forward and train_update");
-  // everything ffm_engine_prepare_device can refuse is refused HERE, before the upload kernel is
-  // launched: that kernel publishes the block's ordinal to ffm_engine_blocks_pulled, and a block
-  // that then failed to stage would leave the count one ahead for good
-  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "three prepared blocks are already waiting");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  int this_slot = 0;
-  bool slot_was_used = false;
-  PullJob job{};
-  if ((rc = claim_slot(e, n_rows, nnz, row_ptr, field, feat, val, label, zero_copy, &this_slot, &slot_was_used, &job)))
-    return rc;
-  ffm_engine::Slot &sl = e->slots[this_slot];
-  // its grouping, behind its own upload on the prep stream: planned here, submitted with the upload
-  PrepPlan plan;
-  if ((rc = prepare_plan(e, Rows{n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val, nullptr}, &plan)))
-    return rc;
-  const int64_t seq = e->n_staged_total + 1;
-  const int grid_pull = e->grid_pull;
-  const bool timed = !e->stage_thread_on || e->prof_on;
-  rc = e->submit([e, this_slot, slot_was_used, job, plan, seq, grid_pull, timed]() -> int {
-    ScopedTimer tm("stage:submit");
-    ffm_engine::Slot &s2 = e->slots[this_slot];
-    int rc2 = FFM_OK;
-    auto body = [&]() -> int {
-      HIP_TRY(hipSetDevice(e->cfg.device_id));
-      if (slot_was_used) HIP_TRY(hipStreamWaitEvent(e->copy, s2.ev_trained, 0));  // nothing reads its device arrays
-      hipLaunchKernelGGL(pull_block_kernel, dim3(grid_pull), dim3(256), 0, e->copy, job);
-      HIP_TRY(hipEventRecord(s2.ev_copied, e->copy));
-      return prepare_submit(e, plan, timed);
-    };
-    rc2 = body();
-    {
-      std::lock_guard<std::mutex> lock(e->wmu);
-      e->staged_issued = seq;  // (also after a failure: nobody may wait for it forever)
-    }
-    return rc2;
-  });
-  if (rc) return rc;
-  sl.used = true;
-  sl.zero_copy = zero_copy != 0;
-  sl.n_rows = n_rows;
-  sl.nnz = nnz;
-  sl.row_cap = longest;
-  sl.has_field = field != nullptr;
-  sl.seq = ++e->n_staged_total;
-  e->slot_next = (e->slot_next + 1) % ffm_engine::kSlots;
-  e->staged[e->n_staged++] = this_slot;
-  return FFM_OK;
-}
-
-// How many of the blocks staged so far have been uploaded (their host arrays are free again).
-int64_t ffm_engine_blocks_pulled(ffm_engine *e) {
-  if (!e || !e->slots_ready) return 0;
-  e->n_pulled = std::max<int64_t>(e->n_pulled, __atomic_load_n(e->h_pulled, __ATOMIC_ACQUIRE));
-  return e->n_pulled;
-}
-
-// Phase 1 (grouping is done: refresh + forward) on the oldest staged block.
-int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  if (e->n_staged == 0) return fail(FFM_E_INVALID, "no staged block");
-  if (e->has_pending) return fail(FFM_E_INVALID, "the previous block still awaits train_update");
-  const int slot = e->staged[0];
-  ffm_engine::Slot &sl = e->slots[slot];
-  e->staged_row_cap = sl.row_cap;
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  if (int rc_w = e->wait_issued(sl.seq)) return rc_w;  // its upload + grouping launches are out
-  HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));  // (also when its grouping was discarded)
-  int rc = ffm_engine_train_forward_device(e, sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr,
-                                           sl.feat, sl.val, sl.label, partial_logit);
-  if (rc) return rc;
-  for (int i = 1; i < e->n_staged; i++) e->staged[i - 1] = e->staged[i];
-  e->n_staged--;
-  e->cur_slot = slot;  // released (ev_trained) by the train_update that follows
-  return FFM_OK;
-}
-
-// Whole step (ffm_engine_train_batch_device) on the oldest staged block.
-int ffm_engine_train_staged(ffm_engine *e, float *logit_out, double *loss_sum_out) {
-  if (e && e->m.n_shards > 1)
-    return fail(FFM_E_INVALID, "sharded engines train with train_forward_staged + all-reduce + train_update");
-  if (e) { e->whole_step = true; e->own_logit_out = logit_out; }
-  int rc = ffm_engine_train_forward_staged(e, nullptr);
-  if (e) e->whole_step = false;
-  if (rc) return rc;
-  return ffm_engine_train_update_device(e, nullptr, logit_out, loss_sum_out);
-}
-
-// ... with its loss going into the running sum of the flush.
-static int train_one_staged(ffm_engine *e) {
-  int rc = ffm_engine_train_staged(e, nullptr, e->d_loss_sum);
-  if (rc) return rc;
-  hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
-  return FFM_OK;
-}
-
-int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
-                                 const int32_t *field, const int32_t *feat, const float *val,
-                                 const int32_t *label) {
-  if (e && e->m.n_shards > 1)
-    return fail(FFM_E_INVALID, "sharded engines train with stage_batch + train_forward_staged + all-reduce + train_update");
-  int rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label, 0);
-  if (rc) return rc;
-  // train what the previous call staged; the block staged just now keeps uploading and grouping
-  // beside it (and beside the caller's preparation of the next one)
-  while (e->n_staged > 1)
-    if ((rc = train_one_staged(e))) return rc;
-  return FFM_OK;
-}
-
-int ffm_engine_train_batch_async_pinned(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
-                                        const int32_t *field, const int32_t *feat, const float *val,
-                                        const int32_t *label) {
-  if (e && e->m.n_shards > 1)
-    return fail(FFM_E_INVALID, "sharded engines train with stage_batch + train_forward_staged + all-reduce + train_update");
-  int rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label, 1);
-  if (rc) return rc;
-  // block t+2 is staged: train block t (bench.py's schedule; the grouping of t+2 then has its
-  // window beside block t and until block t+1 ends)
-  while (e->n_staged > 2)
-    if ((rc = train_one_staged(e))) return rc;
-  return FFM_OK;
-}
-
-// Pipelined evaluation: upload through a staging slot on the side stream, predict on the main one.
-int ffm_engine_predict_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
-                                   const int32_t *field, const int32_t *feat, const float *val,
-                                   const int32_t *label, int32_t zero_copy) {
-  int32_t nnz = 0;
-  int longest = 1;
-  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
-  if (rc) return rc;
-  if (e->m.n_shards > 1) return fail(FFM_E_INVALID, "a sharded engine predicts through predict_batch_device + predict_finish_device");
-  if (e->n_staged > 0 || e->has_pending) return fail(FFM_E_INVALID, "staged training blocks are still waiting");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  if ((rc = e->drain())) return rc;
-  int this_slot = 0;
-  bool slot_was_used = false;
-  PullJob job{};
-  if ((rc = claim_slot(e, n_rows, nnz, row_ptr, field, feat, val, label, zero_copy, &this_slot, &slot_was_used, &job)))
-    return rc;
-  ffm_engine::Slot &sl = e->slots[this_slot];
-  if (slot_was_used) HIP_TRY(hipStreamWaitEvent(e->copy, sl.ev_trained, 0));  // nothing reads its device arrays
-  hipLaunchKernelGGL(pull_block_kernel, dim3(e->grid_pull), dim3(256), 0, e->copy, job);
-  HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
-  sl.used = true;
-  sl.zero_copy = zero_copy != 0;
-  sl.n_rows = n_rows;
-  sl.nnz = nnz;
-  sl.row_cap = longest;
-  sl.has_field = field != nullptr;
-  sl.seq = ++e->n_staged_total;
-  {
-    std::lock_guard<std::mutex> lock(e->wmu);
-    e->staged_issued = sl.seq;
-  }
-  e->slot_next = (e->slot_next + 1) % ffm_engine::kSlots;
-  HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));
-  e->staged_row_cap = longest;
-  rc = ffm_engine_predict_batch_device(e, n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val,
-                                       label ? sl.label : nullptr, 0, e->d_out, label ? e->d_loss_sum : nullptr);
-  if (rc) return rc;
-  if (label) hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
-  HIP_TRY(hipEventRecord(sl.ev_trained, e->stream));  // the slot's device arrays are free again
-  HIP_TRY(hipGetLastError());
-  return FFM_OK;
-}
-
-int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  int rc;
-  if (e->m.n_shards == 1)
-    while (e->n_staged > 0)
-      if ((rc = train_one_staged(e))) return rc;
-  double total = 0.0;
-  if (e->slots_ready) {
-    HIP_TRY(hipMemcpyAsync(&total, e->d_loss_acc, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemsetAsync(e->d_loss_acc, 0, sizeof(double), e->stream));
-  }
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (loss_sum_out) *loss_sum_out = total;
-  return check_device_errors(e);
-}
-
-// ---- profiling -----------------------------------------------------------------------------
-
-int ffm_engine_profile_enable(ffm_engine *e, int32_t on) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  if (int rc_w = e->drain()) return rc_w;
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  HIP_TRY(hipDeviceSynchronize());
-  for (auto &r : e->prof) { e->event_pool.push_back(r.e0); e->event_pool.push_back(r.e1); }
-  e->prof.clear();
-  e->prof_on = on != 0;
-  e->prof_only = -1;
-  return FFM_OK;
-}
-
-static int profile_totals(ffm_engine *e, double *ms, int *n);
-
-// The kernel with the largest total time among those on the step's critical path.  The look-ahead
-// grouping is left out: it runs beside the step on its own queue, and its "time" is mostly waiting.
-static int dominant_kernel(const double *ms) {
-  int best = K_ROW;
-  for (int k = 0; k < K_COUNT; k++) {
-    if (k == K_GROUP_KEYS || k == K_GROUP_SORT || k == K_GROUP_FINISH) continue;
-    if (ms[k] > ms[best]) best = k;
-  }
-  return best;
-}
-
-int ffm_engine_profile_focus(ffm_engine *e) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  double ms[K_COUNT];
-  int n[K_COUNT];
-  int rc = profile_totals(e, ms, n);
-  if (rc) return rc;
-  const int best = dominant_kernel(ms);
-  for (auto &r : e->prof) { e->event_pool.push_back(r.e0); e->event_pool.push_back(r.e1); }
-  e->prof.clear();
-  e->prof_only = best;
-  return FFM_OK;
-}
-
-static int profile_totals(ffm_engine *e, double *ms, int *n) {
-  HIP_TRY(hipSetDevice(e->cfg.device_id));
-  HIP_TRY(hipDeviceSynchronize());
-  for (int k = 0; k < K_COUNT; k++) { ms[k] = 0.0; n[k] = 0; }
-  for (auto &r : e->prof) {
-    float t = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
-    ms[r.kid] += t;
-    n[r.kid]++;
-  }
-  return FFM_OK;
-}
-
-int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms,
-                            char *kernel_name, size_t kernel_name_cap) {
-  if (!e) return fail(FFM_E_INVALID, "null engine");
-  double ms[K_COUNT];
-  int n[K_COUNT];
-  int rc = profile_totals(e, ms, n);
-  if (rc) return rc;
-  const int best = dominant_kernel(ms);
-  if (n_launches) *n_launches = n[best];
-  if (total_ms) *total_ms = ms[best];
-  if (kernel_name && kernel_name_cap) {
-    std::string name = kKernelNames[best];
-    if (best == K_REFRESH) name = "ffm_refresh_kernel";
-    else if (best == K_LATENT_UPDATE_SINGLE) name = "ffm_update_single_kernel";
-    else if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT ||
-        best == K_LATENT_UPDATE_HUGE)
-      name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +
-             (best == K_LATENT_UPDATE ? (e->m.type == FFM_MODEL_FM ? "update_kernel" : "update_small_kernel")
-              : best == K_LATENT_UPDATE_HOT ? "update_hot_kernel"
-              : best == K_LATENT_UPDATE_HUGE ? "update_chain_kernel"
-              : (best == K_ROW ? "row_kernel<train>" : "row_kernel<predict>"));
-    std::snprintf(kernel_name, kernel_name_cap, "%s", name.c_str());
-  }
-  return FFM_OK;
-}
-
-// Text table of every kernel's launches and total time since profiling was enabled.
-int ffm_engine_profile_dump(ffm_engine *e, char *buf, size_t cap) {
-  if (!e || !buf || !cap) return fail(FFM_E_INVALID, "null argument");
-  double ms[K_COUNT];
-  int n[K_COUNT];
-  int rc = profile_totals(e, ms, n);
-  if (rc) return rc;
-  std::string out;
-  char line[160];
-  for (int k = 0; k < K_COUNT; k++) {
-    if (!n[k]) continue;
-    std::snprintf(line, sizeof line, "%-24s launches=%6d total_ms=%10.3f avg_us=%10.2f\n",
-                  kKernelNames[k], n[k], ms[k], 1000.0 * ms[k] / n[k]);
-    out += line;
-  }
-  std::snprintf(buf, cap, "%s", out.c_str());
-  return FFM_OK;
-}
-
+#include "engine_state.h"
+#include "engine_step.h"
+#include "engine_stage.h"
+#include "engine_profile.h"
 }  // extern "C"
 
 #include "engine_group.h"

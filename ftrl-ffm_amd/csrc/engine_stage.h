@@ -1,0 +1,331 @@
+// engine_stage.h -- rows streaming from host memory inside the training loop: staging slots, the
+// upload kernel, stage_batch / train_staged / train_batch_async[_pinned] / predict_batch_async.
+// Part of engine.hip's translation unit (included inside its extern "C" block).
+
+// ---- pipelined host-buffer training ---------------------------------------------------------
+
+__global__ void loss_accumulate_kernel(double *acc, const double *one) { *acc += *one; }
+
+// Upload of one staged block by a kernel: the five CSR arrays are read straight out of page-locked
+// (device-mapped) host memory, 16 bytes per lane, and written to the staging slot's device arrays.
+// A hipMemcpyAsync here makes the SUBMITTING THREAD wait until the stream's earlier kernels have
+// finished (measured: mean 0.38 ms, up to 16 ms per call) -- the host then cannot run ahead of the
+// GPU and every other step starts ~230 us late; a kernel launch never blocks.
+// Every wave starts with a system-scope acquire (it drops the non-coherent lines of its L2): a
+// caller that refills a block buffer it has used before (the trainers' ring) must not be served
+// lines of the previous block that are still on-die, should the runtime map its page-locked memory
+// cacheable.  (System-scope LOADS instead -- 8 bytes per lane -- halved the upload rate.)
+struct PullJob {
+  const char *src[5]; char *dst[5]; unsigned bytes[5];
+  long long ordinal; long long *pulled; unsigned *ticket;  // completion word (host memory), see h_pulled
+};
+__global__ __launch_bounds__(256) void pull_block_kernel(PullJob job) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+#pragma unroll
+  for (int a = 0; a < 5; a++) {
+    const unsigned n16 = job.bytes[a] >> 4;
+    const int4 *s = reinterpret_cast<const int4 *>(job.src[a]);
+    int4 *d = reinterpret_cast<int4 *>(job.dst[a]);
+    for (unsigned i = tid; i < n16; i += stride) d[i] = s[i];
+    const unsigned tail = job.bytes[a] & 15u;  // sizes are multiples of 4
+    if (tid < (tail >> 2))
+      reinterpret_cast<int *>(job.dst[a])[(n16 << 2) + tid] = reinterpret_cast<const int *>(job.src[a])[(n16 << 2) + tid];
+  }
+  // the workgroup that finishes last publishes the block's number to the host
+  __syncthreads();  // (every load of this workgroup has returned: its stores were issued after them)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(job.ticket, 1u) == gridDim.x - 1) {
+      *job.ticket = 0u;
+      __hip_atomic_store(job.pulled, job.ordinal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+static int slots_init(ffm_engine *e) {
+  if (e->slots_ready) return FFM_OK;
+  const size_t R = static_cast<size_t>(e->max_rows), E = static_cast<size_t>(e->max_nnz);
+  const size_t bytes = 4 * (R + 1) + 4 * E * 3 + 4 * R + 5 * 16;  // each of the 5 arrays is padded to 16 B
+  for (auto &sl : e->slots) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.pinned), bytes, hipHostMallocDefault));
+    int rc;
+    if ((rc = e->alloc(&sl.row_ptr, R + 1)) || (rc = e->alloc(&sl.field, E)) || (rc = e->alloc(&sl.feat, E)) ||
+        (rc = e->alloc(&sl.val, E)) || (rc = e->alloc(&sl.label, R)))
+      return rc;
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev_trained, hipEventDisableTiming));
+  }
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_pulled), 64, hipHostMallocDefault));
+  *e->h_pulled = 0;
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_pulled), e->h_pulled, 0));
+  if (int rc_t = e->alloc(&e->d_pull_ticket, 1)) return rc_t;
+  HIP_TRY(hipMemsetAsync(e->d_pull_ticket, 0, sizeof(unsigned), e->copy));
+  int rc = e->alloc(&e->d_loss_acc, 1);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(e->d_loss_acc, 0, sizeof(double), e->stream));
+  e->slots_ready = true;
+  return FFM_OK;
+}
+
+int ffm_engine_pin_host(void *p, size_t bytes) {
+  if (!p || !bytes) return fail(FFM_E_INVALID, "null range");
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterMapped));
+  return FFM_OK;
+}
+int ffm_engine_unpin_host(void *p) {
+  if (!p) return fail(FFM_E_INVALID, "null pointer");
+  HIP_TRY(hipHostUnregister(p));
+  return FFM_OK;
+}
+
+// The next staging slot for a host block: waits until the slot's own pinned image is free, copies
+// the caller's arrays into it (unless zero_copy) and describes the upload (pull_block_kernel's
+// argument; the block's ordinal is n_staged_total + 1).  Bookkeeping of the slot is the caller's.
+static int claim_slot(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
+                      const int32_t *field, const int32_t *feat, const float *val, const int32_t *label,
+                      int32_t zero_copy, int *slot_out, bool *was_used, PullJob *job_out) {
+  int rc;
+  if ((rc = slots_init(e))) return rc;
+  ffm_engine::Slot &sl = e->slots[e->slot_next];
+  *slot_out = e->slot_next;
+  *was_used = sl.used;
+  if (sl.used && !sl.zero_copy) {
+    ScopedTimer tm("stage:slot_wait");
+    // the slot's own pinned image must have been pulled before it is overwritten.  (Not so for a
+    // zero_copy block, whose image is the caller's: blocking the submitting thread here costs
+    // ~0.2 ms per step; such callers ask ffm_engine_blocks_pulled before reusing their memory.)
+    if ((rc = e->wait_issued(sl.seq))) return rc;
+    HIP_TRY(hipEventSynchronize(sl.ev_copied));
+  }
+  // host arrays -> pinned image (the caller may reuse its buffers on return) -> device, prep stream
+  const size_t R1 = static_cast<size_t>(n_rows) + 1, E = static_cast<size_t>(nnz);
+  char *p = sl.pinned;
+  PullJob &job = *job_out;
+  int n_job = 0;
+  // page-locked source of each array: the caller's own (zero_copy: untouched until the block has
+  // trained) or its image in the slot's pinned buffer; the device then pulls it (pull_block_kernel)
+  auto put = [&](const void *src, size_t bytes, void *dst) -> hipError_t {
+    if (!bytes || !src) return hipSuccess;
+    const void *host = src;
+    if (!zero_copy) {
+      std::memcpy(p, src, bytes);
+      host = p;
+      p += (bytes + 15) & ~static_cast<size_t>(15);
+    }
+    void *mapped = nullptr;
+    hipError_t err = hipHostGetDevicePointer(&mapped, const_cast<void *>(host), 0);
+    if (err != hipSuccess) return err;
+    if ((reinterpret_cast<uintptr_t>(mapped) & 15u) != 0) return hipErrorInvalidValue;  // 16-byte aligned arrays only
+    job.src[n_job] = static_cast<const char *>(mapped);
+    job.dst[n_job] = static_cast<char *>(dst);
+    job.bytes[n_job] = static_cast<unsigned>(bytes);
+    n_job++;
+    return hipSuccess;
+  };
+  ScopedTimer tm("stage:copies");
+  HIP_TRY(put(row_ptr, 4 * R1, sl.row_ptr));
+  if (field) HIP_TRY(put(field, 4 * E, sl.field));
+  HIP_TRY(put(feat, 4 * E, sl.feat));
+  HIP_TRY(put(val, 4 * E, sl.val));
+  HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
+  job.ordinal = e->n_staged_total + 1;
+  job.pulled = e->d_pulled;
+  job.ticket = e->d_pull_ticket;
+  return FFM_OK;
+}
+
+// Stage one block of host rows: (pinned image ->) HBM -> grouping, all on the prep stream.
+int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                           const int32_t *field, const int32_t *feat, const float *val,
+                           const int32_t *label, int32_t zero_copy) {
+  int32_t nnz = 0;
+  int longest = 1;
+  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
+  if (rc) return rc;
+  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
+  if (e->n_staged >= ffm_engine::kSlots - 1) return fail(FFM_E_CAPACITY, "three staged blocks are already waiting");
+  if (e->has_pending) return fail(FFM_E_INVALID, "stage between train_forward and train_update");
+  // everything ffm_engine_prepare_device can refuse is refused HERE, before the upload kernel is
+  // launched: that kernel publishes the block's ordinal to ffm_engine_blocks_pulled, and a block
+  // that then failed to stage would leave the count one ahead for good
+  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "three prepared blocks are already waiting");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  int this_slot = 0;
+  bool slot_was_used = false;
+  PullJob job{};
+  if ((rc = claim_slot(e, n_rows, nnz, row_ptr, field, feat, val, label, zero_copy, &this_slot, &slot_was_used, &job)))
+    return rc;
+  ffm_engine::Slot &sl = e->slots[this_slot];
+  // its grouping, behind its own upload on the prep stream: planned here, submitted with the upload
+  PrepPlan plan;
+  if ((rc = prepare_plan(e, Rows{n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val, nullptr}, &plan)))
+    return rc;
+  const int64_t seq = e->n_staged_total + 1;
+  const int grid_pull = e->grid_pull;
+  const bool timed = !e->stage_thread_on || e->prof_on;
+  rc = e->submit([e, this_slot, slot_was_used, job, plan, seq, grid_pull, timed]() -> int {
+    ScopedTimer tm("stage:submit");
+    ffm_engine::Slot &s2 = e->slots[this_slot];
+    int rc2 = FFM_OK;
+    auto body = [&]() -> int {
+      HIP_TRY(hipSetDevice(e->cfg.device_id));
+      if (slot_was_used) HIP_TRY(hipStreamWaitEvent(e->copy, s2.ev_trained, 0));  // nothing reads its device arrays
+      hipLaunchKernelGGL(pull_block_kernel, dim3(grid_pull), dim3(256), 0, e->copy, job);
+      HIP_TRY(hipEventRecord(s2.ev_copied, e->copy));
+      return prepare_submit(e, plan, timed);
+    };
+    rc2 = body();
+    {
+      std::lock_guard<std::mutex> lock(e->wmu);
+      e->staged_issued = seq;  // (also after a failure: nobody may wait for it forever)
+    }
+    return rc2;
+  });
+  if (rc) return rc;
+  sl.used = true;
+  sl.zero_copy = zero_copy != 0;
+  sl.n_rows = n_rows;
+  sl.nnz = nnz;
+  sl.row_cap = longest;
+  sl.has_field = field != nullptr;
+  sl.seq = ++e->n_staged_total;
+  e->slot_next = (e->slot_next + 1) % ffm_engine::kSlots;
+  e->staged[e->n_staged++] = this_slot;
+  return FFM_OK;
+}
+
+// How many of the blocks staged so far have been uploaded (their host arrays are free again).
+int64_t ffm_engine_blocks_pulled(ffm_engine *e) {
+  if (!e || !e->slots_ready) return 0;
+  e->n_pulled = std::max<int64_t>(e->n_pulled, __atomic_load_n(e->h_pulled, __ATOMIC_ACQUIRE));
+  return e->n_pulled;
+}
+
+// Phase 1 (grouping is done: refresh + forward) on the oldest staged block.
+int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (e->n_staged == 0) return fail(FFM_E_INVALID, "no staged block");
+  if (e->has_pending) return fail(FFM_E_INVALID, "the previous block still awaits train_update");
+  const int slot = e->staged[0];
+  ffm_engine::Slot &sl = e->slots[slot];
+  e->staged_row_cap = sl.row_cap;
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if (int rc_w = e->wait_issued(sl.seq)) return rc_w;  // its upload + grouping launches are out
+  HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));  // (also when its grouping was discarded)
+  int rc = ffm_engine_train_forward_device(e, sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr,
+                                           sl.feat, sl.val, sl.label, partial_logit);
+  if (rc) return rc;
+  for (int i = 1; i < e->n_staged; i++) e->staged[i - 1] = e->staged[i];
+  e->n_staged--;
+  e->cur_slot = slot;  // released (ev_trained) by the train_update that follows
+  return FFM_OK;
+}
+
+// Whole step (ffm_engine_train_batch_device) on the oldest staged block.
+int ffm_engine_train_staged(ffm_engine *e, float *logit_out, double *loss_sum_out) {
+  if (e && e->m.n_shards > 1)
+    return fail(FFM_E_INVALID, "sharded engines train with train_forward_staged + all-reduce + train_update");
+  if (e) { e->whole_step = true; e->own_logit_out = logit_out; }
+  int rc = ffm_engine_train_forward_staged(e, nullptr);
+  if (e) e->whole_step = false;
+  if (rc) return rc;
+  return ffm_engine_train_update_device(e, nullptr, logit_out, loss_sum_out);
+}
+
+// ... with its loss going into the running sum of the flush.
+static int train_one_staged(ffm_engine *e) {
+  int rc = ffm_engine_train_staged(e, nullptr, e->d_loss_sum);
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
+  return FFM_OK;
+}
+
+int ffm_engine_train_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                 const int32_t *field, const int32_t *feat, const float *val,
+                                 const int32_t *label) {
+  if (e && e->m.n_shards > 1)
+    return fail(FFM_E_INVALID, "sharded engines train with stage_batch + train_forward_staged + all-reduce + train_update");
+  int rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label, 0);
+  if (rc) return rc;
+  // train what the previous call staged; the block staged just now keeps uploading and grouping
+  // beside it (and beside the caller's preparation of the next one)
+  while (e->n_staged > 1)
+    if ((rc = train_one_staged(e))) return rc;
+  return FFM_OK;
+}
+
+int ffm_engine_train_batch_async_pinned(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                        const int32_t *field, const int32_t *feat, const float *val,
+                                        const int32_t *label) {
+  if (e && e->m.n_shards > 1)
+    return fail(FFM_E_INVALID, "sharded engines train with stage_batch + train_forward_staged + all-reduce + train_update");
+  int rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label, 1);
+  if (rc) return rc;
+  // block t+2 is staged: train block t (bench.py's schedule; the grouping of t+2 then has its
+  // window beside block t and until block t+1 ends)
+  while (e->n_staged > 2)
+    if ((rc = train_one_staged(e))) return rc;
+  return FFM_OK;
+}
+
+// Pipelined evaluation: upload through a staging slot on the side stream, predict on the main one.
+int ffm_engine_predict_batch_async(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                                   const int32_t *field, const int32_t *feat, const float *val,
+                                   const int32_t *label, int32_t zero_copy) {
+  int32_t nnz = 0;
+  int longest = 1;
+  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
+  if (rc) return rc;
+  if (e->m.n_shards > 1) return fail(FFM_E_INVALID, "a sharded engine predicts through predict_batch_device + predict_finish_device");
+  if (e->n_staged > 0 || e->has_pending) return fail(FFM_E_INVALID, "staged training blocks are still waiting");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if ((rc = e->drain())) return rc;
+  int this_slot = 0;
+  bool slot_was_used = false;
+  PullJob job{};
+  if ((rc = claim_slot(e, n_rows, nnz, row_ptr, field, feat, val, label, zero_copy, &this_slot, &slot_was_used, &job)))
+    return rc;
+  ffm_engine::Slot &sl = e->slots[this_slot];
+  if (slot_was_used) HIP_TRY(hipStreamWaitEvent(e->copy, sl.ev_trained, 0));  // nothing reads its device arrays
+  hipLaunchKernelGGL(pull_block_kernel, dim3(e->grid_pull), dim3(256), 0, e->copy, job);
+  HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
+  sl.used = true;
+  sl.zero_copy = zero_copy != 0;
+  sl.n_rows = n_rows;
+  sl.nnz = nnz;
+  sl.row_cap = longest;
+  sl.has_field = field != nullptr;
+  sl.seq = ++e->n_staged_total;
+  {
+    std::lock_guard<std::mutex> lock(e->wmu);
+    e->staged_issued = sl.seq;
+  }
+  e->slot_next = (e->slot_next + 1) % ffm_engine::kSlots;
+  HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));
+  e->staged_row_cap = longest;
+  rc = ffm_engine_predict_batch_device(e, n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val,
+                                       label ? sl.label : nullptr, 0, e->d_out, label ? e->d_loss_sum : nullptr);
+  if (rc) return rc;
+  if (label) hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
+  HIP_TRY(hipEventRecord(sl.ev_trained, e->stream));  // the slot's device arrays are free again
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+int ffm_engine_train_flush(ffm_engine *e, double *loss_sum_out) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  int rc;
+  if (e->m.n_shards == 1)
+    while (e->n_staged > 0)
+      if ((rc = train_one_staged(e))) return rc;
+  double total = 0.0;
+  if (e->slots_ready) {
+    HIP_TRY(hipMemcpyAsync(&total, e->d_loss_acc, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_loss_acc, 0, sizeof(double), e->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (loss_sum_out) *loss_sum_out = total;
+  return check_device_errors(e);
+}

@@ -1,0 +1,470 @@
+// engine_step.h -- one block of rows on the device: grouping, look-ahead, forward, update, predict
+// (the *_device entry points and the copying train_batch / predict_batch).
+// Part of engine.hip's translation unit (included inside its extern "C" block).
+
+// ---- one block of rows ---------------------------------------------------------------------
+
+static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *row_ptr,
+                       const void *field, const void *feat, const void *val) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (n_rows < 0 || nnz < 0) return fail(FFM_E_INVALID, "negative n_rows / nnz");
+  if (n_rows > e->max_rows || nnz > e->max_nnz)
+    return fail(FFM_E_CAPACITY, "block exceeds max_batch_rows / max_batch_nnz");
+  if (!row_ptr || (nnz > 0 && (!feat || !val))) return fail(FFM_E_INVALID, "null CSR array");
+  if (e->m.type == FFM_MODEL_FFM && nnz > 0 && !field)
+    return fail(FFM_E_INVALID, "FFM requires the field array (libffm rows)");
+  return FFM_OK;
+}
+
+
+static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float *out, int output_prob, int own_tg = 0) {
+  const int row_cap = e->staged_row_cap > 0 ? e->staged_row_cap : e->max_row_nnz;
+  e->staged_row_cap = 0;
+  if (rows.n_rows == 0) return;
+  // (the kernels recompute the same terms capacity from the same arguments)
+  const int terms_cap = e->m.type == FFM_MODEL_FM ? row_terms_cap(2, 0, e->m.n_factors)
+                        : row_terms_cap(row_cap, e->m.n_shards > 1 ? e->m.rec_slots : 0, 0);
+  const size_t shmem = row_lds_bytes(row_cap, e->m.n_fields, terms_cap);
+  const int kid = train ? K_ROW : K_PREDICT_ROW;
+  if (e->m.type == FFM_MODEL_FM && e->m.n_factors <= 64) {
+    // one wave per row, lane = factor (kernels_fm.h)
+    if (train) e->singles_in_row = own_tg != 0;
+    const int grid = cdiv(rows.n_rows, kFmRowsPerBlock);
+    if (train) LAUNCH(e, kid, fm_row_wave_kernel<true>, grid, 64 * kFmRowsPerBlock, 0, e->m, rows, e->sc[e->cur], row_cap, out, output_prob, own_tg);
+    else LAUNCH(e, kid, fm_row_wave_kernel<false>, grid, 64 * kFmRowsPerBlock, 0, e->m, rows, e->sc[e->cur], row_cap, out, output_prob, 0);
+  } else if (e->m.type == FFM_MODEL_FM) {
+    if (train) e->singles_in_row = false;
+    if (train) LAUNCH(e, kid, fm_row_kernel<true>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], row_cap, out, output_prob);
+    else LAUNCH(e, kid, fm_row_kernel<false>, rows.n_rows, kRowThreads, shmem, e->m, rows, e->sc[e->cur], row_cap, out, output_prob);
+  } else {
+    const bool vec4 = e->m.n_factors > 0 && e->m.n_factors % 4 == 0;
+    const int mr = row_cap;
+    int refreshed = train && e->pre_refresh ? e->refresh_mode : 0;
+    if (refreshed == 3 && !(own_tg && vec4 && e->single_kernel)) refreshed = 2;
+    if (train) e->singles_in_row = refreshed == 3;
+    if (refreshed && rows.nnz > 0) {
+      const int per = vec4 ? e->m.row_len / 4 : e->m.row_len;
+      const int64_t items = static_cast<int64_t>(std::min(rows.nnz, e->max_nnz)) * per;
+      const int grid = static_cast<int>(std::min<int64_t>((items + 255) / 256, 8192));
+      if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
+      else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
+    }
+    if (train) e->cur_phases = own_tg && vec4 ? phases_for(e, rows.n_rows) : 1;
+    if (train && vec4) {
+      // one launch per row phase; the update streams pick each phase up at its event
+      for (int ph = 0; ph < e->cur_phases; ph++) {
+        const int r0 = phase_row(rows.n_rows, e->cur_phases, ph), r1 = phase_row(rows.n_rows, e->cur_phases, ph + 1);
+        if (r1 > r0)
+          LAUNCH(e, kid, (ffm_row_kernel<true, true>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, r0);
+        if (e->cur_phases > 1) (void)hipEventRecord(e->ev_row[ph], e->stream);
+      }
+    }
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, 0);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
+  }
+}
+
+static bool same_block(const Rows &a, const Rows &b) {
+  return a.n_rows == b.n_rows && a.nnz == b.nnz && a.row_ptr == b.row_ptr && a.field == b.field &&
+         a.feat == b.feat && a.val == b.val;
+}
+
+// Zeroes the grouping's counters and per-row field masks (a kernel: hipMemsetAsync costs the
+// submitting thread ~100 us per call here, a launch ~5).
+__global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_counters,
+                                                          unsigned long long *rowmask, int n_mask) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int i = tid; i < n_counters; i += stride) counters[i] = 0;
+  for (int i = tid; i < n_mask; i += stride) rowmask[i] = 0ull;
+}
+
+// Groups `rows` by feature into scratch set `set` on stream `st`.
+// timed = false: from the staging thread (no HIP-event bookkeeping of the profiler there).
+// Hot / very hot boundary of one block.  A hot feature's touches are ONE sequential chain per element
+// (~0.55 us per touch beside the other kernels); the very hot ones' chains are cut into 16-touch
+// steps at 40 % more instructions.  So the hot kernel's longest chain should last about as long as
+// what bounds the update phase anyway: half its throughput-bound time (measured 0.88 touch-elements
+// per ns at FFM 39 x 16) or the bias chain's one wave (12 ns per row).  kHugeMin -- the optimum of
+// 8192 x 39-entry rows at k = 16 -- caps it.  (C2, 4096 x 8 entries: 384 -> 89, 17.5 -> 22.8 M rows/s.)
+static int huge_min_for(const ffm_engine *e, const Rows &rows) {
+  if (e->huge_min_fixed || e->m.type != FFM_MODEL_FFM || rows.n_rows <= 0) return e->m.huge_min;
+  const double per_row = static_cast<double>(rows.nnz) / rows.n_rows;
+  const double touch_elems = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / std::max(1, e->m.n_shards);
+  const double span_us = std::max(touch_elems / 0.88e6, rows.n_rows * 0.012);
+  return static_cast<int>(std::min<double>(kHugeMin, std::max(64.0, span_us / 0.55)));
+}
+
+static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st, bool timed = true) {
+  Scratch &sc = e->sc[set];
+  ScopedTimer tm_all("grouping:all");
+  {
+    ScopedTimer tm_clear("grouping:clear");
+    const int n_mask = rows.nnz > 0 && sc.rowmask ? 2 * rows.n_rows : 0;
+    hipLaunchKernelGGL(group_clear_kernel, dim3(std::max(1, std::min(64, cdiv(n_mask, 1024)))), dim3(256), 0, st,
+                       sc.counters, kNumCounters, sc.rowmask, n_mask);
+  }
+  if (rows.nnz > 0) {
+    const int nnz = rows.nnz;
+    if (timed) LAUNCH_ON(e, st, K_GROUP_KEYS, group_keys_kernel, cdiv(nnz, kGroupThreads), kGroupThreads, 0, e->m, rows, sc, e->max_row_nnz);
+    else hipLaunchKernelGGL(group_keys_kernel, dim3(cdiv(nnz, kGroupThreads)), dim3(kGroupThreads), 0, st, e->m, rows, sc, e->max_row_nnz);
+    if (timed) e->prof_begin(K_GROUP_SORT, st);
+    {
+      ScopedTimer tm_sort("grouping:sort");
+      size_t bytes = e->sort_tmp_bytes;
+      HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
+                                        rocprim::counting_iterator<int>(0), sc.occ,
+                                        static_cast<size_t>(nnz), 0u, e->sort_bits, st));
+    }
+    if (timed) e->prof_end(st);
+    ModelDev mf = e->m;  // (the only kernel that deals features into the hot / very hot lists)
+    mf.huge_min = huge_min_for(e, rows);
+    if (timed) LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, mf, rows, sc,
+                         phases_for(e, rows.n_rows));
+    else hipLaunchKernelGGL(group_finish_kernel, dim3(cdiv(nnz, kFinishThreads)), dim3(kFinishThreads), 0, st, mf, rows, sc,
+                            phases_for(e, rows.n_rows));
+  }
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+// A look-ahead grouping in two halves: the bookkeeping (caller's thread, in call order) and the
+// stream operations (whoever submits: the caller's thread or the staging thread, in the same order).
+struct PrepPlan {
+  int set = 0;
+  bool wait_free = false;  // the set carried an earlier block: wait for its ev_set_free
+  int ws = -1;             // prep_window: start when this set's block has trained (-1: at once)
+  Rows rows{};
+};
+static int prepare_plan(ffm_engine *e, const Rows &rows, PrepPlan *pl) {
+  if (e->has_pending) return fail(FFM_E_INVALID, "prepare between train_forward and train_update");
+  if (e->n_prepared >= ffm_engine::kSets - 1) return fail(FFM_E_CAPACITY, "three prepared blocks are already waiting");
+  const int set = (e->last_set + 1) % ffm_engine::kSets;
+  pl->set = set;
+  pl->rows = rows;
+  pl->wait_free = e->set_used[set];
+  pl->ws = -1;
+  if (e->prep_window) {
+    // n_prepared == 1: the predecessor is prepared but not enqueued yet -> wait for the block
+    // enqueued last; n_prepared == 0: the predecessor IS the block enqueued last -> the one before
+    const int ws = e->trained_set[e->n_prepared >= 1 ? 0 : 1];
+    if (ws >= 0 && ws != set) pl->ws = ws;
+  }
+  // the set is in use from now on, also when this look-ahead ends up discarded: whoever takes the
+  // set next must wait for ev_set_free (recorded when the block trains or the look-ahead is dropped)
+  e->set_used[set] = true;
+  e->last_set = set;
+  e->prepared_set[e->n_prepared] = set;
+  e->prepared_rows[e->n_prepared] = rows;
+  e->n_prepared++;
+  return FFM_OK;
+}
+static int prepare_submit(ffm_engine *e, const PrepPlan &pl, bool timed) {
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if (pl.wait_free) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.set], 0));
+  if (pl.ws >= 0) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.ws], 0));
+  int rc = launch_grouping(e, pl.set, pl.rows, e->prep, timed);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(e->ev_grouped[pl.set], e->prep));
+  return FFM_OK;
+}
+
+int ffm_engine_prepare_device(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t *row_ptr,
+                              const int32_t *field, const int32_t *feat, const float *val) {
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  if (rc) return rc;
+  if ((rc = e->drain())) return rc;  // (staged blocks' submissions come first on the prep stream)
+  PrepPlan pl;
+  if ((rc = prepare_plan(e, Rows{n_rows, nnz, row_ptr, field, feat, val, nullptr}, &pl))) return rc;
+  return prepare_submit(e, pl, true);
+}
+
+int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
+                                    const int32_t *row_ptr, const int32_t *field,
+                                    const int32_t *feat, const float *val, const int32_t *label,
+                                    float *partial_logit) {
+  ScopedTimer tm_fwd("train:forward");
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  if (rc) return rc;
+  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
+  e->pending = rows;
+  e->has_pending = true;
+  // only train_batch_device has the whole logit in its row kernel (one shard, FFM / LR)
+  e->own_tg_cur = e->whole_step && e->m.n_shards == 1 &&
+                  (e->m.type != FFM_MODEL_FM || e->m.n_factors <= 64);  // (FM: fm_row_wave_kernel)
+  e->whole_step = false;
+  const bool use_prepared = e->n_prepared > 0 && same_block(e->prepared_rows[0], rows);
+  if (e->n_prepared > 0 && !use_prepared) {
+    // groupings made ahead for some other block: forget them all
+    if ((rc = e->drain())) return rc;
+    for (int i = 0; i < e->n_prepared; i++) HIP_TRY(hipEventRecord(e->ev_set_free[e->prepared_set[i]], e->prep));
+    e->n_prepared = 0;
+  }
+  if (use_prepared) {
+    e->cur = e->prepared_set[0];
+    for (int i = 1; i < e->n_prepared; i++) {
+      e->prepared_set[i - 1] = e->prepared_set[i];
+      e->prepared_rows[i - 1] = e->prepared_rows[i];
+    }
+    e->n_prepared--;
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_grouped[e->cur], 0));
+  } else {
+    e->cur = (e->last_set + 1) % ffm_engine::kSets;
+    e->last_set = e->cur;
+    if (e->set_used[e->cur]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_set_free[e->cur], 0));
+    rc = launch_grouping(e, e->cur, rows, e->stream);
+    if (rc) return rc;
+  }
+  e->set_used[e->cur] = true;
+  launch_row_kernel(e, rows, true, e->own_tg_cur ? e->own_logit_out : nullptr, 0, e->own_tg_cur ? 1 : 0);
+  if (partial_logit && n_rows > 0)
+    HIP_TRY(hipMemcpyAsync(partial_logit, e->sc[e->cur].logit, sizeof(float) * n_rows, hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *logit_out,
+                                   double *loss_sum_out) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (!e->has_pending) return fail(FFM_E_INVALID, "train_update without a preceding train_forward");
+  ScopedTimer tm_upd("train:update");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  const Rows rows = e->pending;
+  e->has_pending = false;
+  const float *lg = logit ? logit : e->sc[e->cur].logit;
+  const bool own_tg = e->own_tg_cur && !logit;
+  if (rows.n_rows > 0 && !own_tg)
+    LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->sc[e->cur].tg, e->sc[e->cur].loss, logit_out);
+  if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0 && !own_tg)
+    LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
+  // this shard runs the bias chain / a linear update when it owns the bias / any field's linear terms
+  // FM, whole step: fm_row_wave_kernel has applied the touches of the once-only features itself
+  const int fm_in_row = e->m.type == FFM_MODEL_FM && own_tg && e->singles_in_row ? 1 : 0;
+  const bool lin_owner = e->m.bias_own != 0 || e->lin_any;
+  const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
+  const bool vec4 = e->m.n_factors % 4 == 0;
+  const int lin_blocks = rows.nnz > 0 ? std::min(cdiv(rows.nnz, kUpdThreads), 1024) : 0;
+  // The bias and linear chains are short and serial: they run beside the latent update -- inside
+  // the hot-feature launch when there is one (side_blocks), else on the side stream.
+  const bool side_in_hot = ffm && vec4 && lin_owner && rows.n_rows > 0;
+  const int side_blocks = side_in_hot ? 1 + lin_blocks : 0;
+  // FM: the same inside the launch of the few-occurrence features' latent update
+  const bool side_in_fm = e->m.type == FFM_MODEL_FM && lin_owner && rows.n_rows > 0 && rows.nnz > 0 && !e->serial;
+  const int fm_side_blocks = side_in_fm ? 1 + lin_blocks : 0;
+  const bool forked = rows.n_rows > 0 && lin_owner && !e->serial && !side_in_hot && !side_in_fm;
+  if (rows.n_rows > 0 && lin_owner && e->serial && !side_in_hot) {
+    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
+    if (rows.nnz > 0)
+      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
+  }
+  if (forked || side_in_fm || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
+  if (forked) {
+    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
+    // the bias chain (one wave, as long as the block has rows) alone on the side stream; the linear
+    // update shares the main stream with the latent update of the few-occurrence features
+    LAUNCH_ON(e, e->aux2, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
+    HIP_TRY(hipEventRecord(e->ev_join, e->aux2));
+    if (rows.nnz > 0)
+      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
+  }
+  // small features on the main stream: the once-only ones through their descriptor kernel
+  auto launch_small = [&]() {
+    const bool single = e->single_kernel;
+    if (single && !e->singles_in_row) {  // (else: already applied by the row kernel)
+      const int span4 = e->m.rec_slots * (e->m.n_factors / 4);  // 16-byte vectors of a stored record
+      if (flat_pays(e, span4)) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_flat_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      else if (span4 <= 64) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<1>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      else if (span4 <= 128) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    }
+    if (flat_pays(e, e->m.rec_slots * (e->m.n_factors / 4)))
+      LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
+    else
+      LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
+  };
+  if (ffm && vec4 && e->serial) {
+    launch_ffm_chain(e, e->stream, rows);
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, 0, 1);
+    launch_small();
+  } else if (ffm && vec4) {
+    // the three owner shapes touch disjoint features: run them side by side (long sequential
+    // chains of the hot ones beside the bandwidth-shaped small-feature pass).  With row phases the
+    // two side streams take each phase's touches as soon as its rows are done -- beside the forward
+    // pass of the next phase (which reads w; the update writes n and z).
+    const int P = own_tg ? e->cur_phases : 1;
+    for (int ph = 0; ph < P; ph++) {
+      HIP_TRY(hipStreamWaitEvent(e->aux3, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
+      launch_ffm_chain(e, e->aux3, rows, ph, P);
+    }
+    HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
+    for (int ph = 0; ph < P; ph++) {
+      HIP_TRY(hipStreamWaitEvent(e->aux2, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
+      LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, P);
+    }
+    HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
+    launch_small();
+    if (loss_sum_out)
+      LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
+  } else if (ffm) {
+    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+  } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
+    // the very hot features' long chains on their own stream, lane = (factor, touch)
+    const bool fm_fork = forked || side_in_fm;
+    if (fm_fork) {
+      HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
+      LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
+    } else {
+      LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    }
+    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048 + fm_side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1, fm_in_row, fm_side_blocks);
+    if (fm_fork) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
+  }
+  if (loss_sum_out && !(ffm && vec4 && !e->serial))
+    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
+  if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+  HIP_TRY(hipEventRecord(e->ev_set_free[e->cur], e->stream));
+  e->trained_set[1] = e->trained_set[0];
+  e->trained_set[0] = e->cur;
+  if (e->cur_slot >= 0) {  // a staged block: its staging slot may be refilled from here on
+    HIP_TRY(hipEventRecord(e->slots[e->cur_slot].ev_trained, e->stream));
+    e->cur_slot = -1;
+  }
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+int ffm_engine_train_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
+                                  const int32_t *row_ptr, const int32_t *field,
+                                  const int32_t *feat, const float *val, const int32_t *label,
+                                  float *logit_out, double *loss_sum_out) {
+  if (e && e->m.n_shards > 1)
+    return fail(FFM_E_INVALID, "sharded engines train with train_forward + all-reduce + train_update");
+  if (e) { e->whole_step = true; e->own_logit_out = logit_out; }
+  int rc = ffm_engine_train_forward_device(e, n_rows, nnz, row_ptr, field, feat, val, label, nullptr);
+  if (e) e->whole_step = false;
+  if (rc) return rc;
+  return ffm_engine_train_update_device(e, nullptr, logit_out, loss_sum_out);
+}
+
+int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
+                                    const int32_t *row_ptr, const int32_t *field,
+                                    const int32_t *feat, const float *val, const int32_t *label,
+                                    int32_t output_prob, float *out, double *loss_sum_out) {
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  if (rc) return rc;
+  if (e->m.n_shards > 1 && (label || output_prob || loss_sum_out))
+    return fail(FFM_E_INVALID, "a sharded engine predicts partial logits only (label = NULL, output_prob = 0, "
+                               "no loss): sum them across shards, then ffm_engine_predict_finish_device");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  Rows rows{n_rows, nnz, row_ptr, field, feat, val, label};
+  launch_row_kernel(e, rows, false, out ? out : e->d_out, output_prob);
+  if (loss_sum_out && label)
+    LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(n_rows), 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+int ffm_engine_predict_finish_device(ffm_engine *e, int32_t n_rows, const float *logit,
+                                     const int32_t *label, int32_t output_prob, float *out,
+                                     double *loss_sum_out) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (n_rows < 0 || n_rows > e->max_rows) return fail(FFM_E_CAPACITY, "n_rows out of range");
+  if (n_rows > 0 && !logit) return fail(FFM_E_INVALID, "null logit array");
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if (n_rows > 0)
+    LAUNCH(e, K_TMP_GRAD, predict_finish_kernel, cdiv(n_rows, 256), 256, 0, n_rows, logit, label, output_prob, out, e->sc[e->cur].loss);
+  if (loss_sum_out) {
+    if (label) LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(n_rows), 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
+    else HIP_TRY(hipMemsetAsync(loss_sum_out, 0, sizeof(double), e->stream));
+  }
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+// Checks one block of host arrays; returns its nnz and its longest row.
+static int validate_host_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                               const int32_t *field, const int32_t *feat, const float *val,
+                               int32_t *nnz_out, int *longest_out) {
+  if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (n_rows < 0) return fail(FFM_E_INVALID, "negative n_rows");
+  if (!row_ptr) return fail(FFM_E_INVALID, "null row_ptr");
+  if (n_rows > e->max_rows) return fail(FFM_E_CAPACITY, "block exceeds max_batch_rows");
+  if (row_ptr[0] != 0) return fail(FFM_E_INVALID, "row_ptr[0] must be 0");
+  for (int r = 0; r < n_rows; r++)
+    if (row_ptr[r + 1] < row_ptr[r]) return fail(FFM_E_INVALID, "row_ptr must be non-decreasing");
+  const int32_t nnz = row_ptr[n_rows];
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  if (rc) return rc;
+  int longest = 1;
+  for (int r = 0; r < n_rows; r++) {
+    if (row_ptr[r + 1] - row_ptr[r] > e->max_row_nnz)
+      return fail(FFM_E_CAPACITY, "a row has more entries than max_row_nnz");
+    longest = std::max(longest, row_ptr[r + 1] - row_ptr[r]);
+  }
+  *nnz_out = nnz;
+  *longest_out = longest;
+  return FFM_OK;
+}
+
+static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, const int32_t *field,
+                       const int32_t *feat, const float *val, const int32_t *label, int32_t *nnz_out) {
+  int32_t nnz = 0;
+  int longest = 1;
+  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
+  if (rc) return rc;
+  e->staged_row_cap = longest;
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  HIP_TRY(hipMemcpyAsync(e->d_row_ptr, row_ptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice, e->stream));
+  if (nnz > 0) {
+    if (field) HIP_TRY(hipMemcpyAsync(e->d_field, field, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_feat, feat, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_val, val, sizeof(float) * nnz, hipMemcpyHostToDevice, e->stream));
+  }
+  if (label && n_rows > 0)
+    HIP_TRY(hipMemcpyAsync(e->d_label, label, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, e->stream));
+  *nnz_out = nnz;
+  return FFM_OK;
+}
+
+int ffm_engine_train_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                           const int32_t *field, const int32_t *feat, const float *val,
+                           const int32_t *label, float *logit_out, double *loss_sum_out) {
+  int32_t nnz = 0;
+  int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
+  if (rc) return rc;
+  if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
+  rc = ffm_engine_train_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
+                                     e->d_feat, e->d_val, e->d_label, e->d_out, e->d_loss_sum);
+  if (rc) return rc;
+  if (logit_out && n_rows > 0)
+    HIP_TRY(hipMemcpyAsync(logit_out, e->d_out, sizeof(float) * n_rows, hipMemcpyDeviceToHost, e->stream));
+  if (loss_sum_out)
+    HIP_TRY(hipMemcpyAsync(loss_sum_out, e->d_loss_sum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  return check_device_errors(e);
+}
+
+int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
+                             const int32_t *field, const int32_t *feat, const float *val,
+                             const int32_t *label, int32_t output_prob, float *out,
+                             double *loss_sum_out) {
+  int32_t nnz = 0;
+  int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(e->sc[e->cur].counters, 0, kNumCounters * sizeof(int), e->stream));
+  rc = ffm_engine_predict_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
+                                       e->d_feat, e->d_val, label ? e->d_label : nullptr,
+                                       output_prob, e->d_out, e->d_loss_sum);
+  if (rc) return rc;
+  if (out && n_rows > 0)
+    HIP_TRY(hipMemcpyAsync(out, e->d_out, sizeof(float) * n_rows, hipMemcpyDeviceToHost, e->stream));
+  if (loss_sum_out) {
+    if (label) HIP_TRY(hipMemcpyAsync(loss_sum_out, e->d_loss_sum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    else *loss_sum_out = 0.0;
+  }
+  return check_device_errors(e);
+}

@@ -188,7 +188,7 @@ enum { OCC_FEW = -1, OCC_ONCE = -2 };
 // 512 and more: the hot kernel's sequential chains become the phase's span, 1.14 ms.  With the
 // five-instruction square root the chain kernel's steps got 17 % shorter and the balance moved
 // back: 192 -> 1.025 ms, 256 -> 1.035, 384 -> 1.060.)  The cap of the per-block choice
-// (engine.hip: huge_min_for).
+// (engine_step.h: huge_min_for).
 #ifndef FFM_HUGE_MIN
 #define FFM_HUGE_MIN 192
 #endif

@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident leg")
+    ap.add_argument("--no-eval", action="store_true", help="skip the evaluation (predict + logloss) leg")
     ap.add_argument("--resident-blocks", type=int, default=8, help="blocks uploaded for the resident leg")
     ap.add_argument("--host-copy", action="store_true",
                     help="host leg through ffm_engine_train_batch_async (pageable caller arrays, "
@@ -501,6 +502,41 @@ def main():
                      "note": "rows handed over through the copying entry point (pageable memory: one host memcpy "
                              "per block into the engine's pinned slot); not the metric"}
 
+    # ---- evaluation: predict + logloss of the same blocks, pipelined ----
+    eval_leg = None
+    if host_leg and zero_copy and not sharded and not args.no_resident and not args.no_eval:
+        def run_eval(first, count):
+            for i in range(count):
+                eng.predict_batch_async(host_blocks[(first + i) % n_blocks], zero_copy=True)
+            return eng.train_flush()
+
+        def run_eval_resident(first, count):
+            ptr = lambda t: t.data_ptr()  # noqa: E731
+            for i in range(count):
+                blk = dev_blocks[(first + i) % len(dev_blocks)]
+                eng.predict_batch_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
+                                         ptr(blk["feat"]), ptr(blk["val"]), ptr(blk["label"]), 0, ptr(logit),
+                                         loss_sum.data_ptr())
+        run_eval(0, 3)
+        el4, eval_loss = timed(run_eval, args.warmup, args.steps)
+        run_eval_resident(0, 3)
+        el5, _ = timed(run_eval_resident, args.warmup, args.steps)
+        # read-only path: every touched weight once (4 B per slot-factor), CSR in, loss out
+        if model == "FFM":
+            eval_bytes = N_FIELDS * (N_FIELDS - 1) * N_FACTORS * 4 + N_FIELDS * 4 + 4 + (N_FIELDS * 12 + 8) + 8
+        else:
+            eval_bytes = N_FIELDS * N_FACTORS * 4 + N_FIELDS * 4 + 4 + (N_FIELDS * 8 + 8) + 8
+        eval_leg = {"value": round(total_rows / el4, 1), "unit": "samples/s",
+                    "ms_per_step": round(1000.0 * el4 / args.steps, 4),
+                    "resident": round(total_rows / el5, 1),
+                    "logloss": round(eval_loss / total_rows, 6),
+                    "algorithmic_bytes_per_row": eval_bytes,
+                    "roofline_frac": round(total_rows / el4 * eval_bytes / 1e9 / PEAK_HBM_GBPS, 4),
+                    "roofline_frac_resident": round(total_rows / el5 * eval_bytes / 1e9 / PEAK_HBM_GBPS, 4),
+                    "note": "predict + logloss of the same host blocks through ffm_engine_predict_batch_async "
+                            "(upload on the side stream, H2D included) and of the resident blocks through "
+                            "ffm_engine_predict_batch_device; not the metric"}
+
     if model == "FFM":
         bytes_row = algorithmic_bytes_per_row(N_FIELDS, N_FACTORS)
     else:  # FM, SURVEY.md 8(d): nnz*k*20 + nnz*20 + 20 + nnz*8 + 8 + 12
@@ -539,6 +575,8 @@ def main():
             out["resident"] = resident
         if host_copy:
             out["config"]["pageable_host_copy"] = host_copy
+        if eval_leg:
+            out["eval"] = eval_leg
         if kname:
             share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, n_shards)
             per_step = max(1, round(klaunches / max(args.steps, 1)))  # (FFM_PHASES > 1: several launches per block)

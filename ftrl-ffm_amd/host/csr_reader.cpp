@@ -40,10 +40,64 @@ inline float to_float(const char *b, const char *e, const char *lb, const char *
   return v;
 }
 
+// Fast path of one "field:feat:value" / "feat:value" token starting at q (a non-blank): plain
+// unsigned decimal ids of at most 9 digits and a plain decimal value ([-]digits[.digits], no
+// exponent) of at most 7 significant digits and 10 fraction digits, ended by a blank or the line's
+// end.  For those the value is EXACTLY what from_chars returns: the digit string D < 10^7 < 2^24
+// and 10^k (k <= 10) are both exact floats, so one IEEE division rounds the decimal correctly
+// (Clinger's fast path).  Anything else returns false with nothing consumed and the caller takes
+// the general path (from_chars, the reference's error behaviour).
+inline bool fast_uint(const char *&c, const char *stop, int &v) {
+  const char *b = c;
+  unsigned x = 0;
+  while (c < stop && static_cast<unsigned>(*c - '0') <= 9u) x = x * 10u + static_cast<unsigned>(*c++ - '0');
+  if (c == b || c - b > 9) return false;
+  v = static_cast<int>(x);
+  return true;
+}
+inline bool fast_token(const char *&q, const char *stop, bool has_field, int &fld, int &ft, float &v) {
+  static const float kPow10[11] = {1e0f, 1e1f, 1e2f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f};
+  const char *c = q;
+  fld = 0;
+  if (has_field) {
+    if (!fast_uint(c, stop, fld) || c >= stop || *c != ':') return false;
+    c++;
+  }
+  if (!fast_uint(c, stop, ft) || c >= stop || *c != ':') return false;
+  c++;
+  bool neg = false;
+  if (c < stop && *c == '-') { neg = true; c++; }
+  unsigned digits = 0;  // the significand as an integer
+  int n_sig = 0, n_frac = 0, n_any = 0;
+  while (c < stop && static_cast<unsigned>(*c - '0') <= 9u) {
+    digits = digits * 10u + static_cast<unsigned>(*c - '0');
+    n_sig += (n_sig > 0 || *c != '0') ? 1 : 0;
+    n_any++;
+    c++;
+    if (n_sig > 7) return false;
+  }
+  if (c < stop && *c == '.') {
+    c++;
+    while (c < stop && static_cast<unsigned>(*c - '0') <= 9u) {
+      digits = digits * 10u + static_cast<unsigned>(*c - '0');
+      n_sig += (n_sig > 0 || *c != '0') ? 1 : 0;
+      n_any++;
+      n_frac++;
+      c++;
+      if (n_sig > 7 || n_frac > 10) return false;
+    }
+  }
+  if (n_any == 0 || (c < stop && *c != ' ')) return false;
+  const float mag = n_frac ? static_cast<float>(digits) / kPow10[n_frac] : static_cast<float>(digits);
+  v = neg ? -mag : mag;
+  q = c;
+  return true;
+}
+
 void parse_range(const char *p, const char *end, bool has_field, Part &out) {
   while (p < end) {
-    const char *le = p;
-    while (le < end && *le != '\n') le++;
+    const char *le = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+    if (!le) le = end;
     const char *lb = p;
     const char *q = lb, *stop = le;
     if (stop > lb && stop[-1] == '\r') stop--;
@@ -57,6 +111,19 @@ void parse_range(const char *p, const char *end, bool has_field, Part &out) {
       while (true) {
         while (q < stop && *q == ' ') q++;
         if (q >= stop) break;
+        {
+          int ffld, fft;
+          float fv;
+          if (fast_token(q, stop, has_field, ffld, fft, fv)) {
+            if (fv != 0.0f) {
+              out.field.push_back(ffld);
+              out.feat.push_back(fft);
+              out.val.push_back(fv);
+              n++;
+            }
+            continue;
+          }
+        }
         t = q;
         while (t < stop && *t != ' ') t++;
         const char *c1 = q;

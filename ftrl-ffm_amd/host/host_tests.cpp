@@ -111,6 +111,45 @@ static void test_csr_reader_matches_line_parsers() {
   std::remove(kPath);
 }
 
+static void test_csr_fast_tokens_are_strtof() {
+  // the reader's fast path (ids by digit loop, short decimals by one float division) against
+  // strtof on every spelling it accepts and on those it must hand to the general path
+  std::vector<std::string> vals = {"1", "0", "-1", "17", "0.6182", "0.551", "-0.25", "1.", "007.5000", "0.1", "0.3",
+                                   "9999999", "0.9999999", "16777215", "16777217", "0.0000001", "0.00000000015",
+                                   "123.4567", "1234567.8", "0.1234567", "0.12345678", "1e-3", "2.5e-3", "+3.5",
+                                   "3.4028235e38", "1e-45", "0.0000000001", "4.7", "33.333334", "8.25", ".5", "-.5"};
+  unsigned s = 777;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+  for (int i = 0; i < 20000; i++) {
+    char buf[64];
+    const int decimals = rnd() % 9;
+    const double mag = static_cast<double>(rnd() % 10000000) / std::pow(10.0, rnd() % 8);
+    std::snprintf(buf, sizeof buf, "%s%.*f", rnd() % 5 == 0 ? "-" : "", decimals, mag);
+    vals.push_back(buf);
+  }
+  std::string text;
+  for (size_t i = 0; i < vals.size(); i++)
+    text += "1 " + std::to_string(i % 39) + ":" + std::to_string(i) + ":" + vals[i] + " 3:000123:1\n";
+  ftrl::CsrPart part;
+  ftrl::parse_csr_range(text.data(), text.data() + text.size(), true, part);
+  CHECK(part.label.size() == vals.size());
+  bool same = part.label.size() == vals.size();
+  size_t p = 0;
+  for (size_t i = 0; same && i < vals.size(); i++) {
+    const float want = std::strtof(vals[i].c_str(), nullptr);
+    if (want != 0.0f) {
+      same = p < part.val.size() && part.feat[p] == static_cast<int>(i) && part.field[p] == static_cast<int>(i % 39) &&
+             std::memcmp(&part.val[p], &want, 4) == 0;
+      if (!same) std::printf("value %s: got %.9g want %.9g\n", vals[i].c_str(), p < part.val.size() ? part.val[p] : -1.0f, want);
+      p++;
+    }
+    same = same && p < part.val.size() && part.feat[p] == 123 && part.field[p] == 3 && part.val[p] == 1.0f;
+    p++;
+  }
+  CHECK(same);
+  CHECK(p == part.val.size());
+}
+
 static void test_csr_stream_is_the_file_in_order() {
   // 45 000 ragged rows (more than two 20 000-line chunks), blank lines, one giant row
   std::string text;
@@ -388,6 +427,7 @@ int main(int argc, char **argv) {
   const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
   test_reader_and_parsers();
   test_csr_reader_matches_line_parsers();
+  test_csr_fast_tokens_are_strtof();
   test_csr_stream_is_the_file_in_order();
   test_flags();
   test_loss_known_answers();

@@ -930,6 +930,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     if (lds > 32 * 1024) {
       const int bytes = static_cast<int>(lds);
       TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));

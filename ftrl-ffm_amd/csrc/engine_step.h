@@ -54,8 +54,10 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
       // one launch per row phase; the update streams pick each phase up at its event
       for (int ph = 0; ph < e->cur_phases; ph++) {
         const int r0 = phase_row(rows.n_rows, e->cur_phases, ph), r1 = phase_row(rows.n_rows, e->cur_phases, ph + 1);
-        if (r1 > r0)
-          LAUNCH(e, kid, (ffm_row_kernel<true, true>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, r0);
+        if (r1 > r0 && own_tg)
+          LAUNCH(e, kid, (ffm_row_kernel<true, true, true>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, r0);
+        else if (r1 > r0)  // a shard: the logit is whole only after the all-reduce
+          LAUNCH(e, kid, (ffm_row_kernel<true, true, false>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, 0, r0);
         if (e->cur_phases > 1) (void)hipEventRecord(e->ev_row[ph], e->stream);
       }
     }

@@ -246,16 +246,20 @@ __device__ __forceinline__ float wave_add_terms_in_order(const float *terms, int
 #else
 #define FFM_ROW_OCC
 #endif
-template <bool TRAIN, bool VEC4>
+// WHOLE: the kernel has the whole logit (one shard): it also produces tmp_grad / loss / hmeta and may
+// apply the once-only features' update (own_tg, refreshed == 3).  A shard's instantiation leaves all
+// of that out -- and the registers it costs: more rows in flight per SIMD.
+template <bool TRAIN, bool VEC4, bool WHOLE = TRAIN>
 __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
                                                               int output_prob, int refreshed,
-                                                              int own_tg, int row0) {
+                                                              int own_tg_arg, int row0) {
+  const int own_tg = WHOLE ? own_tg_arg : 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv, s_ns;
   __shared__ float s_tg;
   __shared__ uint64_t s_tab[32];  // expf's table, staged so the row's last step waits on no load
-  if (TRAIN && own_tg && threadIdx.x < 32) s_tab[threadIdx.x] = kExpTab[threadIdx.x];
+  if (TRAIN && WHOLE && own_tg && threadIdx.x < 32) s_tab[threadIdx.x] = kExpTab[threadIdx.x];
   const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
   const int terms_cap = row_terms_cap(max_row_nnz, m.n_shards > 1 ? record_span(m, 1) : 0, 0);
   RowLds lds = carve_row_lds(smem, max_row_nnz, F, terms_cap);
@@ -342,7 +346,8 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
 #ifndef FFM_REFRESH_FLY
 #define FFM_REFRESH_FLY 4
 #endif
-      constexpr int kRefreshFly = FFM_REFRESH_FLY;
+      // (a shard's instantiation: two, its records are short -- 49 VGPRs instead of 77, a wave more per SIMD)
+      constexpr int kRefreshFly = WHOLE ? FFM_REFRESH_FLY : 2;
       const int RL4 = RL >> 2, k4 = k >> 2;
       const int per = record_span(m, k4);  // vectors walked per record
       const float inv_per = 1.0f / static_cast<float>(per), inv_k4 = 1.0f / static_cast<float>(k4);
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
   if (threadIdx.x == 0) {
     if (TRAIN) {
       s.logit[r] = result;
-      if (own_tg) {
+      if (WHOLE && own_tg) {
         // the whole logit is here (one shard): tmp_grad = sigmoid(logit) - y (ffm.cpp:44) and the
         // row's logloss (ftrl_offline.cpp:80) without a pass of their own
         const int y = rows.label[r];
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
       if (rows.label) s.loss[r] = logloss_ref(rows.label[r], result);
     }
   }
-  if (TRAIN && own_tg && is_ffm) {
+  if (TRAIN && WHOLE && own_tg && is_ffm) {
     // {tmp_grad, own value} of this row's hot entries, by occurrence position, for their owners
     __syncthreads();
     const float tg = s_tg;

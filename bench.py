@@ -126,16 +126,19 @@ def fm_kernel_share_bytes(kernel, blocks_feat, nnz, k):
     row; a feature's record is k slot-factors).  fm_row_wave_kernel (csrc/kernels_fm.h) refreshes
     every OCCURRENCE's record (read n,z + write w = 12 B per factor), reads the CSR entries, the
     linear terms, writes logit / tmp_grad / loss / the row's k factor sums, and applies the (n, z)
-    step (8 B per factor) of the features that occur once in the block; fm_update_kernel owns the
-    features with 2..HUGE_MIN occurrences, fm_update_chain_kernel the rest (8 B per factor-occurrence)."""
+    step (8 B per factor) of the features that occur once in the block; fm_update_all_kernel owns every
+    other feature (8 B per factor-occurrence): the lists of 2..HUGE_MIN occurrences and the chains."""
     rows = [len(f) // nnz for f in blocks_feat]
     counts = [np.unique(f, return_counts=True)[1] for f in blocks_feat]
     if "row_kernel" in kernel:
         return float(np.mean([r * (nnz * k * 12 + nnz * 12 + (nnz * 8 + 8) + 4 + 16 + 4 * k) + int((c == 1).sum()) * (k * 8 + 8)
                               for r, c in zip(rows, counts)]))
-    if "chain" in kernel or "huge" in kernel:
+    if "chain" in kernel or "huge" in kernel:  # (a launch of its own only with FFM_ENGINE_SERIAL=1)
         return float(np.mean([c[c > HUGE_MIN].sum() * k * 8 for c in counts]))
-    return float(np.mean([c[(c > 1) & (c <= HUGE_MIN)].sum() * k * 8 for c in counts]))
+    if os.environ.get("FFM_ENGINE_SERIAL", "0") == "1":
+        return float(np.mean([c[(c > 1) & (c <= HUGE_MIN)].sum() * k * 8 for c in counts]))
+    # fm_update_all_kernel: every feature in more than one row of the block, chains included
+    return float(np.mean([c[c > 1].sum() * k * 8 for c in counts]))
 
 
 def cpu_baseline(args, gen_kwargs):

@@ -261,7 +261,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     if (rows.nnz > 0)
       LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
   }
-  if (forked || side_in_fm || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
+  if (forked || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
   if (forked) {
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
     // the bias chain (one wave, as long as the block has rows) alone on the side stream; the linear
@@ -315,16 +315,22 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
     // the very hot features' long chains on their own stream, lane = (factor, touch)
-    const bool fm_fork = forked || side_in_fm;
-    if (fm_fork) {
-      HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-      LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-      HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
+    if (side_in_fm) {
+      // everything in one launch on the main stream: bias + linear, the very hot chains, the lists
+      const int chain_blocks = 1024;
+      LAUNCH(e, K_LATENT_UPDATE, fm_update_all_kernel, fm_side_blocks + chain_blocks + 2048, kUpdThreads, 0, e->m, rows,
+             e->sc[e->cur], fm_in_row, fm_side_blocks, chain_blocks);
     } else {
-      LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      if (forked) {
+        HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
+        LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+        HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
+      } else {
+        LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      }
+      LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1, fm_in_row, 0);
+      if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
     }
-    LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048 + fm_side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1, fm_in_row, fm_side_blocks);
-    if (fm_fork) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
   }
   if (loss_sum_out && !(ffm && vec4 && !e->serial))
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);

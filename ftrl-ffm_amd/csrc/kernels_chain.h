@@ -448,17 +448,18 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
 // ---- FM -------------------------------------------------------------------------------------
 // The same shape for FM::update_vector_nz (fm.cpp:80-101): work item = (very hot feature, pass over
 // 16 of its factors); the per-touch inputs are the row's value, tmp_grad and factor sum (s.svx).
+// (block of n_blocks: the workgroups of a launch that walk the very hot list)
 template <int G>
-__global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m, Rows rows,
-                                                                      Scratch s) {
+__device__ __forceinline__ void fm_chain_body(const ModelDev &m, const Rows &rows, const Scratch &s,
+                                              unsigned block, unsigned n_blocks) {
   const int k = m.n_factors;
   const int lane = threadIdx.x & 63;
   const int tl = lane & (kChainT - 1), el = lane >> 4;
   const bool l0 = tl == 0;
   const int groups = (k + 3) >> 2;
   const unsigned passes = (groups + G - 1) / G;
-  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const unsigned n_waves = gridDim.x * kUpdWaves;
+  const unsigned wave = block * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = n_blocks * kUpdWaves;
   const unsigned n_huge = static_cast<unsigned>(s.counters[CNT_NHUGE]);
   const unsigned n_items = (n_huge + static_cast<unsigned>(s.counters[CNT_NGIANT])) * passes;
   for (unsigned item = wave; item < n_items; item += n_waves) {
@@ -548,6 +549,33 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m
           rec[LAT_Z * k + kk[g]] = zc[g];
         }
     }
+  }
+}
+template <int G>
+__global__ __launch_bounds__(kUpdThreads) void fm_update_chain_kernel(ModelDev m, Rows rows,
+                                                                      Scratch s) {
+  fm_chain_body<G>(m, rows, s, blockIdx.x, gridDim.x);
+}
+
+// The whole FM update of a block in ONE launch (no fork / join between streams: at FM's 0.3 ms per
+// block the two event hops were 8 % of the step): workgroups [0, side_blocks) carry the bias chain
+// and the linear update, the next chain_blocks the very hot features' chains (dispatched first: the
+// longest), the rest the features in 2 .. huge_min rows.
+__global__ __launch_bounds__(kUpdThreads) void fm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
+                                                                    int skip_once, int side_blocks,
+                                                                    int chain_blocks) {
+  const int b = blockIdx.x;
+  if (b < side_blocks) {
+    if (b == 0) {
+      __builtin_amdgcn_s_setprio(3);  // one wave, n_rows dependent touches
+      if (threadIdx.x < 64) bias_update_body(m, 0, rows.n_rows, s);
+    } else {
+      linear_update_body(m, rows, s, b - 1, side_blocks - 1, 0, 1, skip_once);
+    }
+  } else if (b < side_blocks + chain_blocks) {
+    fm_chain_body<4>(m, rows, s, b - side_blocks, chain_blocks);
+  } else {
+    fm_update_body(m, rows, s, 1, skip_once, b - side_blocks - chain_blocks, gridDim.x - side_blocks - chain_blocks);
   }
 }
 

@@ -810,25 +810,14 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_flat_kernel(Mod
 struct FmTouchOps {
   float x[kFmUnroll], tg[kFmUnroll], sv[kFmUnroll];
 };
-// side_blocks: the first workgroups carry the bias chain (block 0) and the linear update -- short
-// serial chains that would otherwise need a stream of their own (as in ffm_update_hot_kernel).
-__global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s,
-                                                                int skip_huge, int skip_once,
-                                                                int side_blocks) {
-  if (static_cast<int>(blockIdx.x) < side_blocks) {
-    if (blockIdx.x == 0) {
-      __builtin_amdgcn_s_setprio(3);  // one wave, n_rows dependent touches
-      if (threadIdx.x < 64) bias_update_body(m, 0, rows.n_rows, s);
-    } else {
-      linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, 0, 1, skip_once);
-    }
-    return;
-  }
+// (block of n_blocks: the workgroups of a launch that walk these lists)
+__device__ __forceinline__ void fm_update_body(const ModelDev &m, const Rows &rows, const Scratch &s,
+                                               int skip_huge, int skip_once, int block, int n_blocks) {
   const int k = m.n_factors;
   const int chunks = (k + 63) / 64;
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x - side_blocks) * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const int n_waves = (gridDim.x - side_blocks) * kUpdWaves;
+  const int wave = block * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = n_blocks * kUpdWaves;
   // skip_once: only the features with 2 .. kHugeMin occurrences are left -- the `few` and `big`
   // lists -- instead of a walk over every distinct feature of the block
   const int n_few = s.counters[CNT_NFEW], n_big = s.counters[CNT_NBIG];
@@ -910,6 +899,22 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     rec[LAT_N * k + e] = n;
     rec[LAT_Z * k + e] = z;
   }
+}
+// side_blocks: the first workgroups carry the bias chain (block 0) and the linear update -- short
+// serial chains that would otherwise need a stream of their own (as in ffm_update_hot_kernel).
+__global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s,
+                                                                int skip_huge, int skip_once,
+                                                                int side_blocks) {
+  if (static_cast<int>(blockIdx.x) < side_blocks) {
+    if (blockIdx.x == 0) {
+      __builtin_amdgcn_s_setprio(3);  // one wave, n_rows dependent touches
+      if (threadIdx.x < 64) bias_update_body(m, 0, rows.n_rows, s);
+    } else {
+      linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, 0, 1, skip_once);
+    }
+    return;
+  }
+  fm_update_body(m, rows, s, skip_huge, skip_once, blockIdx.x - side_blocks, gridDim.x - side_blocks);
 }
 
 }  // namespace ftrl_dev

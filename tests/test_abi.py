@@ -103,3 +103,23 @@ def test_synthetic_generator_shape():
         assert np.array_equal(b.feat, b2.feat) and np.array_equal(b.label, b2.label)
     text = synth.to_libffm_text(b.rows(0, 2))
     assert text.count("\n") == 2 and text.split()[1].count(":") == 2
+
+
+def test_page_aligned_arrays_own_their_pages():
+    """What Engine.pin_block should be given (hipHostRegister locks whole pages): page-aligned,
+    writable, and not sharing its mapping with another array."""
+    import mmap
+
+    import numpy as np
+
+    import ftrl_ffm_amd as fa
+    a = fa.page_aligned(1000, np.int32)
+    b = fa.page_aligned(1, np.float32)
+    for x in (a, b):
+        assert x.ctypes.data % mmap.PAGESIZE == 0
+    assert a.size == 1000 and a.dtype == np.int32 and b.size == 1
+    a[:] = 7
+    b[0] = 1.5
+    assert int(a.sum()) == 7000 and float(b[0]) == 1.5
+    lo, hi = sorted((a.ctypes.data, b.ctypes.data))
+    assert hi - lo >= mmap.PAGESIZE

@@ -19,6 +19,24 @@
 
 namespace ftrl_dev {
 
+// The once-only features' (n, z) stream through the row kernel -- read by the refresh, read again and
+// written back by the in-row update, touched by no other row of the block -- while the w rows of
+// the features many rows share are what the 4 MB L2 of an XCD should keep: the (n, z) traffic
+// carries the non-temporal hint (global_load / store ... nt).  Bits of FFM_ROW_NT: 1 the update's
+// stores, 2 the refresh's loads, 4 the update's loads, 8 the update's w load.  Measured on C5
+// (profiles/r03_fused_row_experiment.txt): 7 -> row kernel 550 -> 540 us; 1, 2, 3, 4 alone: noise.
+#ifndef FFM_ROW_NT
+#define FFM_ROW_NT 7
+#endif
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_nt(const float4 *p) {
+  const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_nt(float4 *p, float4 x) {
+  const v4f_nt v = {x.x, x.y, x.z, x.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt *>(p));
+}
 constexpr int kRowThreads = 256;
 constexpr int kTermsCap = 2048;  // most pair terms staged in LDS per pass
 // Terms buffer a row kernel actually needs (a multiple of 4, at most kTermsCap): all pairs of the
@@ -371,8 +389,13 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
           const bool touched = fp >= 0 && (lds.fcnt[fp] - (fa == fp ? 1 : 0)) > 0 && owns_pair(m, fa, fp);
           if (touched) {
             float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a], fa));
+            if (FFM_ROW_NT & 2) {
+              n4[u] = load_nt(row + LAT_N * RL4 + c4);
+              z4[u] = load_nt(row + LAT_Z * RL4 + c4);
+            } else {
             n4[u] = row[LAT_N * RL4 + c4];
             z4[u] = row[LAT_Z * RL4 + c4];
+            }
             w4[u] = m.h.learn ? row[LAT_W * RL4 + c4] : n4[u];
             wp[u] = row + LAT_W * RL4 + c4;
           }
@@ -580,9 +603,14 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
           const int fp = walk_field(m, fa, sl);
           if (fp < 0 || (lds.fcnt[fp] - (fa == fp ? 1 : 0)) <= 0) continue;
           float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a], fa));
+          if (FFM_ROW_NT & 4) {
+            n4[u] = load_nt(row + LAT_N * RL4 + c4);
+            z4[u] = load_nt(row + LAT_Z * RL4 + c4);
+          } else {
           n4[u] = row[LAT_N * RL4 + c4];
           z4[u] = row[LAT_Z * RL4 + c4];
-          w4[u] = row[LAT_W * RL4 + c4];
+          }
+          w4[u] = (FFM_ROW_NT & 8) ? load_nt(row + LAT_W * RL4 + c4) : row[LAT_W * RL4 + c4];
           rp[u] = row + c4;
           ia[u] = a;
           ifp[u] = fp;
@@ -606,8 +634,13 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
               ffm_touch4(m.h, a < bb, tg, lds.val[a], lds.val[bb], vq, w4[u], n4[u], z4[u]);
             }
           }
+          if (FFM_ROW_NT & 1) {
+            store_nt(rp[u] + LAT_N * RL4, n4[u]);
+            store_nt(rp[u] + LAT_Z * RL4, z4[u]);
+          } else {
           rp[u][LAT_N * RL4] = n4[u];
           rp[u][LAT_Z * RL4] = z4[u];
+          }
         }
       }
     }

@@ -60,6 +60,20 @@ struct ModelDev {
 
 enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };
 
+// 16-byte loads / stores with the non-temporal hint (global_load / store ... nt): for record data
+// that one owner streams through once per block, so that it does not push the shared w rows out
+// of an XCD's 4 MB L2.
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_nt(const float4 *p) {
+  const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_nt(float4 *p, float4 x) {
+  const v4f_nt v = {x.x, x.y, x.z, x.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt *>(p));
+}
+
+
 // Field-pair ownership: both latent slots of a pair (i, field_j) and (j, field_i) belong to the
 // shard that owns {field_i, field_j}.
 __device__ __forceinline__ bool owns_pair(const ModelDev &m, int fa, int fb) {

@@ -28,15 +28,6 @@ namespace ftrl_dev {
 #ifndef FFM_ROW_NT
 #define FFM_ROW_NT 7
 #endif
-typedef float v4f_nt __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 load_nt(const float4 *p) {
-  const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt *>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void store_nt(float4 *p, float4 x) {
-  const v4f_nt v = {x.x, x.y, x.z, x.w};
-  __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt *>(p));
-}
 constexpr int kRowThreads = 256;
 constexpr int kTermsCap = 2048;  // most pair terms staged in LDS per pass
 // Terms buffer a row kernel actually needs (a multiple of 4, at most kTermsCap): all pairs of the

@@ -8,7 +8,7 @@
  * Parity status: PINNED.  oracle/ref_harness.cpp + oracle/Makefile compile the unmodified
  * reference sources where they lie (/root/reference/src/model/{ftrl_model,lr,fm,ffm}.cpp) into
  * oracle/_ref/libftrl_ref.so; tests/test_oracle_golden.py checks this restatement
- * bit-for-bit against it, and tests/golden/*.npz (made by tests/golden/make_golden.py from that
+ * bit-for-bit against it, and the .npz vectors under tests/golden/ (made by tests/golden/make_golden.py from that
  * same build) pin it wherever /root/reference is absent.
  *
  * Every function cites the reference file:line it follows (paths relative to /root/reference).

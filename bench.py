@@ -62,6 +62,18 @@ def huge_min_for(n_rows, nnz_block, k, n_shards, ffm=True):
     return int(min(float(HUGE_MIN), max(64.0, span_us / 0.55)))
 
 
+def update_fused(n_rows, nnz_block, k, n_shards):
+    """Whether the engine runs a block's whole FFM update as ONE launch (csrc/engine_step.h: small
+    blocks on one shard, k >= 12; FFM_UPDATE_FUSED overrides): the launch is timed under the hot
+    kernel's name and owns the bytes of all three occurrence classes."""
+    env = os.environ.get("FFM_UPDATE_FUSED")
+    if n_shards != 1 or k < 12 or n_rows <= 0:
+        return False
+    if env is not None:
+        return int(env) != 0
+    return nnz_block * max(0.0, nnz_block / n_rows - 1.0) * k / 0.44e6 < 150.0
+
+
 def algorithmic_bytes_per_row(nnz, k):
     """every touched state element read once + written once per row, no reuse
     credit: latent nnz(nnz-1)k*20 + linear nnz*20 + bias 20 + CSR (nnz*12+8) + outputs 12."""
@@ -117,7 +129,10 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
                "hot": c[(c > SMALL_MAX) & (c <= hm)].sum(), "huge": c[c > hm].sum()}
         key = ("huge" if "chain" in kernel or "huge" in kernel else
                next((kk for kk in ("single", "small") if kk in kernel), "hot"))
-        shares.append(occ[key] * per_occ * 8 / n_shards)
+        if key == "hot" and update_fused(len(f) // nnz, len(f), k, n_shards):
+            shares.append((occ["small"] + occ["hot"] + occ["huge"]) * per_occ * 8)
+        else:
+            shares.append(occ[key] * per_occ * 8 / n_shards)
     return float(np.mean(shares))
 
 

@@ -296,6 +296,20 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // two side streams take each phase's touches as soon as its rows are done -- beside the forward
     // pass of the next phase (which reads w; the update writes n and z).
     const int P = own_tg ? e->cur_phases : 1;
+    // Small blocks: the whole update in one launch (kernels_chain.h: ffm_update_all_kernel) -- the
+    // fork / join hops between the three streams cost more than the fused kernel's extra registers.
+    // The same estimate of the phase's length as for the hot / very hot boundary (huge_min_for).
+    static const int fused_env = std::getenv("FFM_UPDATE_FUSED") ? std::atoi(std::getenv("FFM_UPDATE_FUSED")) : -1;
+    const double per_row = rows.n_rows > 0 ? static_cast<double>(rows.nnz) / rows.n_rows : 0.0;
+    const double phase_us = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / 0.44e6;
+    const bool fused = fused_env >= 0 ? fused_env != 0 : phase_us < 150.0;
+    if (fused && P == 1 && own_tg && e->singles_in_row && e->m.n_factors >= 12 && e->m.n_shards == 1) {
+      const int fc = e->grid_huge, fh = e->grid_hot, fs = e->grid_small;
+      const int gb = std::min(e->grid_giant, 64);
+      const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
+      LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel, side_blocks + gb + fc + fh + fs + lb, kUpdThreads, 0, e->m, rows,
+             e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
+    } else {
     for (int ph = 0; ph < P; ph++) {
       HIP_TRY(hipStreamWaitEvent(e->aux3, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
       launch_ffm_chain(e, e->aux3, rows, ph, P);
@@ -311,6 +325,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
     HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
+    }
   } else if (ffm) {
     LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
   } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {

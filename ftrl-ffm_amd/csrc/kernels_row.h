@@ -813,12 +813,13 @@ __global__ void predict_finish_kernel(int n_rows, const float *logit, const int 
 // workgroup took 110-150 us for the 65536 rows of an 8-GPU rank's block, at the end of the main
 // stream.)  scratch: [kLossParts] partial sums, then the ticket counter.
 constexpr int kLossParts = 64;
-__global__ __launch_bounds__(256) void loss_sum_kernel(int n_rows, const double *loss,
-                                                       double *out, double *scratch) {
+// (bidx of gdim: the workgroups of a launch that sum the losses)
+__device__ __forceinline__ void loss_sum_body(int n_rows, const double *loss, double *out, double *scratch,
+                                              unsigned bidx, unsigned gdim) {
   __shared__ double part[256];
   __shared__ bool last;
-  const int per = (n_rows + gridDim.x - 1) / gridDim.x;
-  const int r0 = blockIdx.x * per, r1 = min(n_rows, r0 + per);
+  const int per = (n_rows + gdim - 1) / gdim;
+  const int r0 = bidx * per, r1 = min(n_rows, r0 + per);
   double acc = 0.0;
   for (int r = r0 + threadIdx.x; r < r1; r += 256) acc += loss[r];
   part[threadIdx.x] = acc;
@@ -829,19 +830,23 @@ __global__ __launch_bounds__(256) void loss_sum_kernel(int n_rows, const double 
   }
   unsigned *ticket = reinterpret_cast<unsigned *>(scratch + kLossParts);
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&scratch[blockIdx.x], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&scratch[bidx], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    last = atomicAdd(ticket, 1u) == gdim - 1;
   }
   __syncthreads();
   if (last && threadIdx.x == 0) {
     __threadfence();
     double total = 0.0;
-    for (unsigned b = 0; b < gridDim.x; b++)
+    for (unsigned b = 0; b < gdim; b++)
       total += __hip_atomic_load(&scratch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *out = total;
     *ticket = 0u;
   }
+}
+__global__ __launch_bounds__(256) void loss_sum_kernel(int n_rows, const double *loss,
+                                                       double *out, double *scratch) {
+  loss_sum_body(n_rows, loss, out, scratch, blockIdx.x, gridDim.x);
 }
 
 // Evaluates sigmoid_ref on an array (self-test entry point: lets the parity tests compare the

@@ -257,26 +257,27 @@ __device__ __forceinline__ void hot_issue_weights(const float *wcol, const HotFa
 #define FFM_HOT_FWD 0
 #endif
 // ph of `phases`: the touches that come from the rows of one row phase (engine_types.h).
-__global__ __launch_bounds__(kUpdThreads) FFM_HOT_OCC void ffm_update_hot_kernel(ModelDev m, Rows rows,
-                                                                     Scratch s, int side_blocks,
-                                                                     int ph, int phases) {
-  if (static_cast<int>(blockIdx.x) < side_blocks) {
-    if (blockIdx.x == 0) {
+// (bidx of gdim: the workgroups of a launch that carry the side chains and the hot list)
+__device__ __forceinline__ void ffm_hot_body(const ModelDev &m, const Rows &rows, const Scratch &s,
+                                             int side_blocks, int ph, int phases, unsigned bidx,
+                                             unsigned gdim) {
+  if (static_cast<int>(bidx) < side_blocks) {
+    if (bidx == 0) {
       // one wave, 8192 dependent touches: let it win the issue arbitration on its SIMD
       __builtin_amdgcn_s_setprio(3);
       // (the whole chain in the last row phase: the row kernel of a later phase still derives the
       // bias weight from the block-start bias_n / bias_z)
       if (threadIdx.x < 64 && ph == phases - 1) bias_update_body(m, 0, rows.n_rows, s);
     } else {
-      linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, ph, phases);
+      linear_update_body(m, rows, s, bidx - 1, side_blocks - 1, ph, phases);
     }
     return;
   }
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const unsigned chunks = (record_span(m, k) + 63) / 64;
   const int lane = threadIdx.x & 63;
-  const unsigned wave = (blockIdx.x - side_blocks) * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const unsigned n_waves = (gridDim.x - side_blocks) * kUpdWaves;
+  const unsigned wave = (bidx - side_blocks) * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = (gdim - side_blocks) * kUpdWaves;
   const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NBIG]) * chunks;
   const float inv_k = 1.0f / static_cast<float>(k);
   const int span = record_span(m, k);
@@ -440,6 +441,11 @@ __global__ __launch_bounds__(kUpdThreads) FFM_HOT_OCC void ffm_update_hot_kernel
     }
   }
 }
+__global__ __launch_bounds__(kUpdThreads) FFM_HOT_OCC void ffm_update_hot_kernel(ModelDev m, Rows rows,
+                                                                     Scratch s, int side_blocks,
+                                                                     int ph, int phases) {
+  ffm_hot_body(m, rows, s, side_blocks, ph, phases, blockIdx.x, gridDim.x);
+}
 
 // n_factors not a multiple of 4: every distinct feature, hot or not, is owned per 64 elements
 // and gathers its inputs in place (no float4 path, no occurrence-ordered streams).
@@ -499,13 +505,13 @@ constexpr int kSmallBatch = FFM_SMALL_BATCH < kSmallMax ? FFM_SMALL_BATCH : kSma
 #else
 #define FFM_SMALL_OCC
 #endif
-__global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_kernel(ModelDev m, Rows rows,
-                                                                       Scratch s, int few_only) {
+__device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &rows, const Scratch &s,
+                                               int few_only, unsigned bidx, unsigned gdim) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int RL4 = RL >> 2, k4 = k >> 2;
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const int n_waves = gridDim.x * kUpdWaves;
+  const int wave = bidx * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = gdim * kUpdWaves;
   const int *list = few_only ? s.few : s.small;
   const int n_small = s.counters[few_only ? CNT_NFEW : CNT_NSMALL];
   const float inv_k4 = 1.0f / static_cast<float>(k4);
@@ -596,6 +602,10 @@ __global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_ke
       }
     }
   }
+}
+__global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_kernel(ModelDev m, Rows rows,
+                                                                       Scratch s, int few_only) {
+  ffm_small_body(m, rows, s, few_only, blockIdx.x, gridDim.x);
 }
 
 // The same for SHORT stored records (a compact shard's), a lane = one (feature, vector) of a flat

@@ -64,10 +64,10 @@ def huge_min_for(n_rows, nnz_block, k, n_shards, ffm=True):
 
 def update_fused(n_rows, nnz_block, k, n_shards):
     """Whether the engine runs a block's whole FFM update as ONE launch (csrc/engine_step.h: small
-    blocks on one shard, k >= 12; FFM_UPDATE_FUSED overrides): the launch is timed under the hot
+    blocks on one shard; FFM_UPDATE_FUSED overrides): the launch is timed under the hot
     kernel's name and owns the bytes of all three occurrence classes."""
     env = os.environ.get("FFM_UPDATE_FUSED")
-    if n_shards != 1 or k < 12 or n_rows <= 0:
+    if n_shards != 1 or n_rows <= 0:
         return False
     if env is not None:
         return int(env) != 0

@@ -303,12 +303,17 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     const double per_row = rows.n_rows > 0 ? static_cast<double>(rows.nnz) / rows.n_rows : 0.0;
     const double phase_us = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / 0.44e6;
     const bool fused = fused_env >= 0 ? fused_env != 0 : phase_us < 150.0;
-    if (fused && P == 1 && own_tg && e->singles_in_row && e->m.n_factors >= 12 && e->m.n_shards == 1) {
+    if (fused && P == 1 && own_tg && e->singles_in_row && e->m.n_shards == 1) {
       const int fc = e->grid_huge, fh = e->grid_hot, fs = e->grid_small;
       const int gb = std::min(e->grid_giant, 64);
       const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
-      LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel, side_blocks + gb + fc + fh + fs + lb, kUpdThreads, 0, e->m, rows,
-             e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
+      const int grid = side_blocks + gb + fc + fh + fs + lb, groups = e->m.n_factors / 4;
+      if (groups >= 3)
+        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
+      else if (groups == 2)
+        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
+      else
+        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
     } else {
     for (int ph = 0; ph < P; ph++) {
       HIP_TRY(hipStreamWaitEvent(e->aux3, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
 // are 3 % and the fused kernel gives them back (126 VGPRs and ~700 spilled SGPRs for the union of the
 // parts' live ranges; as calls instead of inlined the parts need 248 VGPRs): the engine fuses small
 // blocks only (engine_step.h).
+template <int G>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
                                                                      int side_blocks, int giant_blocks,
                                                                      int nc, int nh, int ns, int few_only,
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_all_kernel(ModelDev m,
   int r = blockIdx.x;
   if (r < side_blocks) { ffm_hot_body(m, rows, s, side_blocks, 0, 1, r, side_blocks + nh); return; }
   r -= side_blocks;
-  if (r < giant_blocks + nc) { ffm_chain_body<4>(m, rows, s, giant_blocks, 0, 1, r, giant_blocks + nc); return; }
+  if (r < giant_blocks + nc) { ffm_chain_body<G>(m, rows, s, giant_blocks, 0, 1, r, giant_blocks + nc); return; }
   r -= giant_blocks + nc;
   if (r < nh) { ffm_hot_body(m, rows, s, side_blocks, 0, 1, side_blocks + r, side_blocks + nh); return; }
   r -= nh;

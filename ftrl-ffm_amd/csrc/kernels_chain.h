@@ -465,11 +465,11 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_all_kernel(ModelDev m,
                                                                      int loss_blocks, double *loss_out,
                                                                      double *loss_scratch) {
   int r = blockIdx.x;
-  if (r < side_blocks) { ffm_hot_body(m, rows, s, side_blocks, 0, 1, r, side_blocks + nh); return; }
+  if (r < side_blocks) { ffm_hot_part(m, rows, s, side_blocks, 0, 1, r, side_blocks + nh); return; }
   r -= side_blocks;
   if (r < giant_blocks + nc) { ffm_chain_body<G>(m, rows, s, giant_blocks, 0, 1, r, giant_blocks + nc); return; }
   r -= giant_blocks + nc;
-  if (r < nh) { ffm_hot_body(m, rows, s, side_blocks, 0, 1, side_blocks + r, side_blocks + nh); return; }
+  if (r < nh) { ffm_hot_part(m, rows, s, side_blocks, 0, 1, side_blocks + r, side_blocks + nh); return; }
   r -= nh;
   if (r < ns) { ffm_small_body(m, rows, s, few_only, r, ns); return; }
   loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - ns, loss_blocks);

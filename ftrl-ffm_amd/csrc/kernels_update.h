@@ -258,193 +258,24 @@ __device__ __forceinline__ void hot_issue_weights(const float *wcol, const HotFa
 #endif
 // ph of `phases`: the touches that come from the rows of one row phase (engine_types.h).
 // (bidx of gdim: the workgroups of a launch that carry the side chains and the hot list)
-__device__ __forceinline__ void ffm_hot_body(const ModelDev &m, const Rows &rows, const Scratch &s,
+// (HOT_BIDX of HOT_GDIM: the workgroups of a launch that carry the side chains and the hot list)
+__device__ __forceinline__ void ffm_hot_part(const ModelDev &m, const Rows &rows, const Scratch &s,
                                              int side_blocks, int ph, int phases, unsigned bidx,
                                              unsigned gdim) {
-  if (static_cast<int>(bidx) < side_blocks) {
-    if (bidx == 0) {
-      // one wave, 8192 dependent touches: let it win the issue arbitration on its SIMD
-      __builtin_amdgcn_s_setprio(3);
-      // (the whole chain in the last row phase: the row kernel of a later phase still derives the
-      // bias weight from the block-start bias_n / bias_z)
-      if (threadIdx.x < 64 && ph == phases - 1) bias_update_body(m, 0, rows.n_rows, s);
-    } else {
-      linear_update_body(m, rows, s, bidx - 1, side_blocks - 1, ph, phases);
-    }
-    return;
-  }
-  const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
-  const unsigned chunks = (record_span(m, k) + 63) / 64;
-  const int lane = threadIdx.x & 63;
-  const unsigned wave = (bidx - side_blocks) * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const unsigned n_waves = (gdim - side_blocks) * kUpdWaves;
-  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NBIG]) * chunks;
-  const float inv_k = 1.0f / static_cast<float>(k);
-  const int span = record_span(m, k);
-  for (unsigned item = wave; item < n_items; item += n_waves) {
-    const unsigned li = item / chunks;
-    const int u = wave_uniform(s.big[li]);
-    const int4 ud = s.udesc[u];  // {feature, start, count, field}
-    const int fa = wave_uniform(ud.w);
-    const int epos = static_cast<int>(item - li * chunks) * 64 + lane;  // element of the stored record
-    const int eb = epos < span ? epos : 0;
-    int sl = static_cast<int>((eb + 0.5f) * inv_k);  // this lane's slot
-    sl += (sl + 1) * k <= eb ? 1 : (sl * k > eb ? -1 : 0);
-    const int fpw = epos < span ? walk_field(m, fa, sl) : -1;  // its partner field
-    const bool active = fpw >= 0;
-    const int ee = active ? eb : 0;
-    const int fp = active ? fpw : 0;  // (idle lanes still form valid fact addresses)
-    const int kk = active ? eb - sl * k : 0;  // and factor
-    const int i = wave_uniform(ud.x);
-    const int start = wave_uniform(ud.y);
-    int t_lo, c;  // this phase's touches [t_lo, c) of the feature's occurrences
-    phase_touches(s, start, wave_uniform(ud.z), ph, phases, t_lo, c);
-    t_lo = wave_uniform(t_lo);
-    c = wave_uniform(c);
-    if (t_lo >= c) continue;
-    float *rec = lat_row(m, i, fa);
-    float n = rec[LAT_N * RL + ee], z = rec[LAT_Z * RL + ee];
-    const float w = rec[LAT_W * RL + ee];
-    const unsigned long long own_bits = owner_bits(m, fp);  // (no loads inside the touch loop)
-    const int4 *acol = s.haux + static_cast<int64_t>(start) * F + fp;     // + t*F
-    const float2 *mcol = s.hmeta + start;                                 // + t
-    bool touched = false;
-    const int nb = (c - t_lo + kUnroll - 1) / kUnroll;
-    float sqn = 0.0f;       // sqrt(n) while sq_valid: the last touch's sqrt(n + g*g), forwarded
-    bool sq_valid = false;  // (wave-uniform)
-
-    HotFacts fA, fB, fC;          // facts of groups b+2, b+1, b
-    int peA[kUnroll], peB[kUnroll], peC[kUnroll];
-    float vpB[kUnroll], vpC[kUnroll];
-    hot_load_facts(acol, F, c, t_lo, fB, peB);
-    if (nb > 1) hot_load_facts(acol, F, c, t_lo + kUnroll, fA, peA);
-    hot_issue_weights(m.lat + kk, fB, peB, vpB);
-    for (int b = 0; b < nb; b++) {
-      const int t0 = t_lo + b * kUnroll;
-      fC = fB;
-#pragma unroll
-      for (int j = 0; j < kUnroll; j++) { vpC[j] = vpB[j]; peC[j] = peB[j]; }
-      if (b + 1 < nb) {
-        fB = fA;
-#pragma unroll
-        for (int j = 0; j < kUnroll; j++) peB[j] = peA[j];
-        hot_issue_weights(m.lat + kk, fB, peB, vpB);  // weights of group b+1
-      }
-      if (b + 2 < nb) hot_load_facts(acol, F, c, t0 + 2 * kUnroll, fA, peA);  // facts of group b+2
-      float tgj[kUnroll], xmj[kUnroll];
-#pragma unroll
-      for (int j = 0; j < kUnroll; j++) {
-        const float2 mt = mcol[min(t0 + j, c - 1)];  // wave-uniform, contiguous
-        tgj[j] = mt.x;
-        xmj[j] = mt.y;
-      }
-      bool simple[kUnroll], any_chain = false, gg_side = true;
-#pragma unroll
-      for (int j = 0; j < kUnroll; j++) {
-        const bool live = t0 + j < c && active && owns_bit(own_bits, fC.fl[j] >> 8);
-        simple[j] = live && (fC.fl[j] & HF_SIMPLE);
-        any_chain = any_chain || (live && (fC.fl[j] & HF_CHAIN));
-        gg_side = gg_side && (!simple[j] || (fC.fl[j] & HF_FIRST) || m.h.learn);
-      }
-      if (!__any(any_chain)) {
-        float gj[kUnroll], aj[kUnroll], nbv[kUnroll], mj[kUnroll];
-#pragma unroll
-        for (int j = 0; j < kUnroll; j++) {
-          const bool first = fC.fl[j] & HF_FIRST;
-          const float x = first ? xmj[j] * fC.xo[j] : fC.xo[j] * xmj[j];
-          const float g = tgj[j] * vpC[j] * x;  // own slot's gradient (g1 if first, else g2)
-          const float g1 = tgj[j] * w * x;      // second-entry case: the first entry's gradient
-          gj[j] = g;
-          aj[j] = (first || m.h.learn) ? g * g : g * g1;  // what the square root sees added to n (:118)
-        }
-        float naf[kUnroll];  // n after touch j
-#pragma unroll
-        for (int j = 0; j < kUnroll; j++) {
-          nbv[j] = n;
-          if (simple[j]) n = n + gj[j] * gj[j];
-          naf[j] = n;
-        }
-        // Every live touch of the group on the g*g side (own entry first): sqrt(n + g*g) of a touch
-        // IS sqrt(n-before) of the next, so one square root per touch, the last one carried into the
-        // next group.  In their short exact forms (ftrl_math.h) behind one wave vote.
-        bool done = false;
-        if (FFM_HOT_FWD && __all(gg_side)) {
-          bool ok = m.h.fast_div != 0 && (sq_valid || chain_operand_ok(nbv[0]));
-#pragma unroll
-          for (int j = 0; j < kUnroll; j++) ok = ok && chain_operand_ok(naf[j]);
-          if (__all(ok)) {
-            float sq = sqn;
-            if (!sq_valid) {
-              asm volatile("" ::: "memory");  // (a real branch, not a select with the root always evaluated)
-              sq = sqrt_fast(nbv[0]);
-            }
-#pragma unroll
-            for (int j = 0; j < kUnroll; j++) {
-              const float sa = sqrt_fast(naf[j]);
-              mj[j] = div_alpha_fast(m.h, sa - sq) * w;
-              sq = sa;
-            }
-            sqn = sq;
-            done = true;
-          }
-        }
-        sq_valid = done;
-        if (!done) {
-          // the group's square roots and alpha divides in their short exact forms when every
-          // operand of the wave is comfortably normal (one vote), else IEEE
-          float arg[kUnroll];
-          bool ok = m.h.fast_div != 0;
-#pragma unroll
-          for (int j = 0; j < kUnroll; j++) {
-            arg[j] = nbv[j] + aj[j];
-            ok = ok && chain_operand_ok(arg[j]) && chain_operand_ok(nbv[j]);
-          }
-          if (__all(ok)) {
-#pragma unroll
-            for (int j = 0; j < kUnroll; j++)
-              mj[j] = div_alpha_fast(m.h, sqrt_fast(arg[j]) - sqrt_fast(nbv[j])) * w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < kUnroll; j++) mj[j] = ((sqrtf(arg[j]) - sqrtf(nbv[j])) / m.h.alpha) * w;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kUnroll; j++)
-          if (simple[j]) { z = (z + gj[j]) - mj[j]; touched = true; }
-      } else {
-        // a multi-valued field somewhere in the group: one touch after another, chains walked
-        sq_valid = false;
-#pragma unroll
-        for (int j = 0; j < kUnroll; j++) {
-          const int fm = fC.fl[j] >> 8;
-          if (t0 + j < c && active && owns_bit(own_bits, fm)) {
-            if (fC.fl[j] & HF_SIMPLE) {
-              ffm_touch(m.h, fC.fl[j] & HF_FIRST, tgj[j], xmj[j], fC.xo[j], vpC[j], w, n, z);
-              touched = true;
-            } else if (fC.fl[j] & HF_CHAIN) {
-              const int p = s.occ2[start + t0 + j].x;  // the touch's own entry
-              const int r = s.row_of[p];
-              for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
-                if (qq == p) continue;
-                const float vp = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk];
-                ffm_touch(m.h, p < qq, tgj[j], xmj[j], rows.val[qq], vp, w, n, z);
-                touched = true;
-              }
-            }
-          }
-        }
-      }
-    }
-    if (touched && active) {  // idle lanes of the last chunk alias element 0: never store
-      rec[LAT_N * RL + ee] = n;
-      rec[LAT_Z * RL + ee] = z;
-    }
-  }
+#define HOT_BIDX bidx
+#define HOT_GDIM gdim
+#include "kernels_hot_body.inc"
+#undef HOT_BIDX
+#undef HOT_GDIM
 }
 __global__ __launch_bounds__(kUpdThreads) FFM_HOT_OCC void ffm_update_hot_kernel(ModelDev m, Rows rows,
                                                                      Scratch s, int side_blocks,
                                                                      int ph, int phases) {
-  ffm_hot_body(m, rows, s, side_blocks, ph, phases, blockIdx.x, gridDim.x);
+#define HOT_BIDX blockIdx.x
+#define HOT_GDIM gridDim.x
+#include "kernels_hot_body.inc"
+#undef HOT_BIDX
+#undef HOT_GDIM
 }
 
 // n_factors not a multiple of 4: every distinct feature, hot or not, is owned per 64 elements

@@ -266,6 +266,7 @@ struct ffm_engine {
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
   hipStream_t copy = nullptr;  // = prep
   bool huge_min_fixed = false;  // FFM_HUGE_MIN given: no per-block choice
+  int update_fused = -1;        // FFM_UPDATE_FUSED: 1 / 0 the whole FFM update in one launch always / never (-1: small blocks)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
   // Scheduling of a look-ahead grouping (FFM_PREP_WINDOW=0 turns it off): the block being
   // prepared will start training when its predecessor's update ends; its grouping is made to
@@ -638,6 +639,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_PREP_WINDOW")) e->prep_window = sv[0] != '0';
+  if (const char *sv = std::getenv("FFM_UPDATE_FUSED")) e->update_fused = std::atoi(sv) != 0 ? 1 : 0;
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
   // a shard's row holds ~1/n_shards of the pairs: one wave per row, so that (with the small LDS

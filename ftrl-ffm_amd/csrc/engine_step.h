@@ -299,10 +299,9 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // Small blocks: the whole update in one launch (kernels_chain.h: ffm_update_all_kernel) -- the
     // fork / join hops between the three streams cost more than the fused kernel's extra registers.
     // The same estimate of the phase's length as for the hot / very hot boundary (huge_min_for).
-    static const int fused_env = std::getenv("FFM_UPDATE_FUSED") ? std::atoi(std::getenv("FFM_UPDATE_FUSED")) : -1;
     const double per_row = rows.n_rows > 0 ? static_cast<double>(rows.nnz) / rows.n_rows : 0.0;
     const double phase_us = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / 0.44e6;
-    const bool fused = fused_env >= 0 ? fused_env != 0 : phase_us < 150.0;
+    const bool fused = e->update_fused >= 0 ? e->update_fused != 0 : phase_us < 150.0;
     if (fused && P == 1 && own_tg && e->singles_in_row && e->m.n_shards == 1) {
       const int fc = e->grid_huge, fh = e->grid_hot, fs = e->grid_small;
       const int gb = std::min(e->grid_giant, 64);

@@ -173,6 +173,37 @@ def test_refresh_modes_are_bit_identical(mode, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("k", [4, 8, 16])
+def test_update_in_one_launch_or_on_three_streams_is_bit_identical(fused, k, monkeypatch):
+    """The whole FFM update of a block as ONE launch (FFM_UPDATE_FUSED=1: what small blocks get by
+    default) or as three kernels on three streams (=0: what large blocks get): both must give the
+    oracle's bits -- on blocks with once-only, few-occurrence, hot and very hot features (a feature
+    in every row included), the bias / linear chains and the loss sum riding in the same launch."""
+    monkeypatch.setenv("FFM_UPDATE_FUSED", fused)
+    rng = np.random.default_rng(31 + k)
+    F, per = 6, 30
+    nf = F * per
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o)
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=1024, **STRESS_HP)
+    e.set_state(st)
+    g = synth.Generator(F, nf, "zipf", seed=9)
+    for n in (1024, 700, 33, 1):
+        blk = g.block(n)
+        blk.feat[::F] = 0  # field 0's entry of every row: one feature with n occurrences
+        lo, so = o.train_batch(blk)
+        lg, sg = e.train_batch(blk)
+        assert_bitwise(lg, lo, "fused=%s k=%d logits of a %d-row block" % (fused, k, n))
+        if np.isnan(so):  # (the ffm.cpp:118 NaNs of n near 0 reach the logits: the loss sums are NaN too)
+            assert np.isnan(sg)
+        else:
+            assert abs(sg - so) <= 1e-9 * max(1.0, abs(so))
+    assert_state_bitwise(e.get_state(), o.get_state(), "fused=%s k=%d" % (fused, k))
+    e.close()
+
+
 def test_empty_block_and_capacity_errors():
     e = fa.Engine("FFM", 100, 4, 4, max_batch_rows=8, max_batch_nnz=64, max_row_nnz=16)
     empty = Csr(np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32),

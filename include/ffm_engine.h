@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define FFM_ENGINE_ABI_VERSION 2
+/* 3: + ffm_engine_predict_batch_async, ffm_group_* (additions only: a caller built against 2 runs
+ * unchanged) */
+#define FFM_ENGINE_ABI_VERSION 3
 
 /* ModelType, reference src/include/utils/types.h:21-25 */
 enum { FFM_MODEL_LR = 0, FFM_MODEL_FM = 1, FFM_MODEL_FFM = 2 };

@@ -451,14 +451,23 @@ def main():
                 prepared += 1
             step_resident(first + i, dev_blocks[(first + i) % len(dev_blocks)])
 
-    def timed(run, first, count):
+    import gc
+
+    def quiet_gc():
         # the interpreter's cyclic garbage collector stays out of the timed region (BENCH_GC=1 lets it
         # run): a full collection over torch's and numpy's module graphs takes tens of milliseconds
-        # -- one of them inside 20 steps of 1.1 ms would be most of the measurement
-        import gc
+        # -- one of them inside 20 steps of 1.1 ms would be most of the measurement.  Collected
+        # BEFORE the warm-up steps, not between them and the timed ones: tens of idle milliseconds
+        # there let the GPU's clocks fall, and the first timed steps paid ~1 ms for it (a 20-step run
+        # read 1.116 ms per step where a 200-step run read 1.059).
         gc.collect()
         if os.environ.get("BENCH_GC", "0") != "1":
             gc.disable()
+
+    def timed(run, first, count, warm=None):
+        if warm is not None:  # (the main leg has had quiet_gc() + its warm-up steps already)
+            quiet_gc()
+            warm()
         fence()
         t0 = time.perf_counter()
         out = run(first, count)
@@ -478,6 +487,7 @@ def main():
         upload_resident()
     if not args.no_profile:
         eng.profile_enable(True)
+    quiet_gc()
     (run_host if host_leg else run_resident)(0, args.warmup)
     fence()
     table = ""
@@ -498,8 +508,7 @@ def main():
                            .sum().item()) / total_rows
     resident = None
     if host_leg and not args.no_resident:
-        run_resident(0, min(args.warmup, 3))
-        el2, _ = timed(run_resident, args.warmup, args.steps)
+        el2, _ = timed(run_resident, args.warmup, args.steps, warm=lambda: run_resident(0, min(args.warmup, 3)))
         resident = {"value": round(total_rows / el2, 1), "unit": "samples/s",
                     "ms_per_step": round(1000.0 * el2 / args.steps, 4),
                     "note": "same loop over %d blocks already resident in HBM (no H2D); not the metric"
@@ -513,8 +522,7 @@ def main():
             for i in range(count):
                 eng.train_batch_async(host_blocks[(first + i) % n_blocks])
             return eng.train_flush()
-        run_copy(0, min(args.warmup, 3))
-        el3, _ = timed(run_copy, args.warmup, args.steps)
+        el3, _ = timed(run_copy, args.warmup, args.steps, warm=lambda: run_copy(0, min(args.warmup, 3)))
         host_copy = {"value": round(total_rows / el3, 1), "unit": "samples/s",
                      "ms_per_step": round(1000.0 * el3 / args.steps, 4),
                      "note": "rows handed over through the copying entry point (pageable memory: one host memcpy "
@@ -535,10 +543,8 @@ def main():
                 eng.predict_batch_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
                                          ptr(blk["feat"]), ptr(blk["val"]), ptr(blk["label"]), 0, ptr(logit),
                                          loss_sum.data_ptr())
-        run_eval(0, 3)
-        el4, eval_loss = timed(run_eval, args.warmup, args.steps)
-        run_eval_resident(0, 3)
-        el5, _ = timed(run_eval_resident, args.warmup, args.steps)
+        el4, eval_loss = timed(run_eval, args.warmup, args.steps, warm=lambda: run_eval(0, 3))
+        el5, _ = timed(run_eval_resident, args.warmup, args.steps, warm=lambda: run_eval_resident(0, 3))
         # read-only path: every touched weight once (4 B per slot-factor), CSR in, loss out
         if model == "FFM":
             eval_bytes = N_FIELDS * (N_FIELDS - 1) * N_FACTORS * 4 + N_FIELDS * 4 + 4 + (N_FIELDS * 12 + 8) + 8

@@ -288,7 +288,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   };
   if (ffm && vec4 && e->serial) {
     launch_ffm_chain(e, e->stream, rows);
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, 0, 1);
+    launch_ffm_hot(e, e->stream, rows, side_blocks);
     launch_small();
   } else if (ffm && vec4) {
     // the three owner shapes touch disjoint features: run them side by side (long sequential
@@ -306,13 +306,25 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       const int fc = e->grid_huge, fh = e->grid_hot, fs = e->grid_small;
       const int gb = std::min(e->grid_giant, 64);
       const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
-      const int grid = side_blocks + gb + fc + fh + fs + lb, groups = e->m.n_factors / 4;
+      const int groups = e->m.n_factors / 4;
+      if (e->tile_mode >= 1) {
+        const int wg = e->tile_mode == 2 ? 1 : 0, gbt = wg ? 0 : gb, nf = tile_nf(e);
+        const int grid = side_blocks + gbt + fh + fs + lb;
+        if (nf == 1)
+          LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gbt, fh, fs, 1, wg, lb, loss_sum_out, e->d_loss_part);
+        else if (nf == 2)
+          LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gbt, fh, fs, 1, wg, lb, loss_sum_out, e->d_loss_part);
+        else
+          LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gbt, fh, fs, 1, wg, lb, loss_sum_out, e->d_loss_part);
+      } else {
+      const int grid = side_blocks + gb + fc + fh + fs + lb;
       if (groups >= 3)
         LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
       else if (groups == 2)
         LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
       else
         LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
+      }
     } else {
     for (int ph = 0; ph < P; ph++) {
       HIP_TRY(hipStreamWaitEvent(e->aux3, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
@@ -321,7 +333,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
     for (int ph = 0; ph < P; ph++) {
       HIP_TRY(hipStreamWaitEvent(e->aux2, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
-      LAUNCH_ON(e, e->aux2, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, e->grid_hot + side_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, P);
+      launch_ffm_hot(e, e->aux2, rows, side_blocks, ph, P);
     }
     HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
     launch_small();

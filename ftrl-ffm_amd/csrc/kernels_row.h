@@ -183,7 +183,13 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
       if (op < 0) continue;
       const int fa = lds.field[a];
       const int f = walk_field(m, fa, j);
-      if (f < 0 || !owns_pair(m, fa, f)) continue;
+      if (f < 0) continue;
+      if (!owns_pair(m, fa, f)) {
+        // a walked slot another shard owns (full-length records of a sharded model): a dead fact, so
+        // that its owner-side readers never see what an earlier block left at this position
+        s.haux[static_cast<int64_t>(op) * F + f] = make_int4(0, fa << 8, 0, 0);
+        continue;
+      }
       emit_facts(a, f, op);
     }
   }

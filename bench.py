@@ -46,20 +46,7 @@ CONFIGS = {
     "c4": dict(model="FM", fields=39, factors=64, rows=8192, feats=10_000_000),
 }
 PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-SMALL_MAX, HUGE_MIN = 8, 192  # occurrence classes of the update kernels (csrc/engine_types.h)
-
-
-def huge_min_for(n_rows, nnz_block, k, n_shards, ffm=True):
-    """The hot / very hot boundary the engine picks for a block (csrc/engine_step.h: huge_min_for;
-    FFM_HUGE_MIN overrides): for the byte shares of the hot and the chain kernel."""
-    env = os.environ.get("FFM_HUGE_MIN")
-    if env:
-        return max(SMALL_MAX + 1, int(env))
-    if not ffm or n_rows <= 0:
-        return HUGE_MIN
-    touch_elems = nnz_block * max(0.0, nnz_block / n_rows - 1.0) * k / max(1, n_shards)
-    span_us = max(touch_elems / 0.88e6, n_rows * 0.012)
-    return int(min(float(HUGE_MIN), max(64.0, span_us / 0.55)))
+SMALL_MAX, HUGE_MIN, GIANT_MIN = 8, 192, 2048  # occurrence classes of the update kernels (csrc/engine_types.h)
 
 
 def update_fused(n_rows, nnz_block, k, n_shards):
@@ -103,7 +90,8 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
       row kernel           : CSR in, linear weights, logit / tmp_grad / loss out (+ the above; + in
                              mode 3 the once-only features' update)
       update               : write (n,z) = 8 B per slot-factor of the occurrences each kernel owns
-                             (features with 1, 2..8, 9..192, > 192 occurrences in the block)
+                             (features with 1, 2..8, 9..2047 -- the tile kernel --, >= 2048 -- the
+                             chain kernel -- occurrences in the block)
     Under field-pair sharding every rank moves 1/n_shards of the slot-factors."""
     if MODEL == "FM":
         return fm_kernel_share_bytes(kernel, blocks_feat, nnz, k)
@@ -124,9 +112,8 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
     shares = []
     for f in blocks_feat:
         _, c = np.unique(f, return_counts=True)
-        hm = huge_min_for(len(f) // nnz, len(f), k, n_shards)
         occ = {"single": c[c == 1].sum(), "small": c[(c > 1) & (c <= SMALL_MAX)].sum(),
-               "hot": c[(c > SMALL_MAX) & (c <= hm)].sum(), "huge": c[c > hm].sum()}
+               "hot": c[(c > SMALL_MAX) & (c < GIANT_MIN)].sum(), "huge": c[c >= GIANT_MIN].sum()}
         key = ("huge" if "chain" in kernel or "huge" in kernel else
                next((kk for kk in ("single", "small") if kk in kernel), "hot"))
         if key == "hot" and update_fused(len(f) // nnz, len(f), k, n_shards):
@@ -655,7 +642,7 @@ def main():
                         "refresh_kernel": "ffm_refresh_kernel",
                         "latent_update_single_kernel": "ffm_update_single_kernel",
                         "latent_update_kernel": "ffm_update_small_kernel",
-                        "latent_update_hot_kernel": "ffm_update_hot_kernel",
+                        "latent_update_hot_kernel": "ffm_update_tile_kernel",
                         "latent_update_huge_kernel": "ffm_update_chain_kernel"}.get(nm)
                 if not full:
                     continue

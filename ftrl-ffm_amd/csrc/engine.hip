@@ -266,8 +266,6 @@ struct ffm_engine {
   // grouping.  (A fifth stream for them shares a hardware queue with one of the four and
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
   hipStream_t copy = nullptr;  // = prep
-  bool huge_min_fixed = false;  // FFM_HUGE_MIN given: no per-block choice
-  int tile_mode = 1;            // FFM_TILE: 0 the r03 hot + chain kernels, 1 tile kernel (giant features: chains), 2 tile kernel for all
   int update_fused = -1;        // FFM_UPDATE_FUSED: 1 / 0 the whole FFM update in one launch always / never (-1: small blocks)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
   // Scheduling of a look-ahead grouping (FFM_PREP_WINDOW=0 turns it off): the block being
@@ -364,7 +362,7 @@ struct ffm_engine {
   std::vector<int> field_start; // copy of cfg->field_start (compact shards)
   // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
   // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
-  int grid_small = 768, grid_hot = 2048, grid_huge = 2048, grid_single = 768;
+  int grid_small = 768, grid_hot = 2048, grid_single = 768;
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
   // slowed the HBM-bound kernels they ran beside up to 4x (refresh of a 65536-row block 70 -> 330 us),
@@ -514,39 +512,27 @@ struct ffm_engine {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int loss_grid(int n_rows) { return std::max(1, std::min(kLossParts, cdiv(n_rows, 1024))); }
 
-// The very-hot-feature chain kernels are instantiated per number of interleaved chains (groups of
-// 4 factors of a slot handled by one wave): 1, 2 or 4.  tile_mode >= 1: only the giant features
-// are left to them (one chain per wave); the big and huge lists are the tile kernel's.
+// The giant features (kGiantMin occurrences or more: only the 65536-row blocks of a multi-GPU job
+// have them) keep the touch-parallel DPP chains, one chain per wave (kernels_chain.h): a lane =
+// element chain of 8000 touches is 500 tiles of one wave, longer than the rest of the update phase.
 static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows, int ph = 0, int phases = 1) {
-  const int groups = e->m.n_factors / 4;
-  const int gb = e->grid_giant, grid = e->grid_huge + gb;
-  if (e->tile_mode >= 1) {
-    if (e->tile_mode == 1 && gb > 0)
-      LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, gb, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
-    return;
-  }
-  if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
-  else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
-  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
+  const int gb = e->grid_giant;
+  if (gb <= 0 || rows.nnz < kGiantMin) return;
+  LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, gb, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
 }
 
-// The hot features' update (big and huge lists; tile_mode 2: the giant list too), with the bias
-// chain and the linear update in its first side_blocks workgroups.  Instantiated per number of facts
-// a stager lane carries (kernels_tile.h): slots per 64-element chunk / 4.
+// The hot features' update (kernels_tile.h: the big and huge lists), with the bias chain and the
+// linear update in its first side_blocks workgroups.  Instantiated per number of facts a stager
+// lane carries: slots per 64-element chunk / 4.
 static int tile_nf(const ffm_engine *e) {
   const int k = e->m.n_factors, spc = k <= 64 ? 64 / k : 1;
   return spc > 8 ? 4 : spc > 4 ? 2 : 1;
 }
 static void launch_ffm_hot(ffm_engine *e, hipStream_t st, const Rows &rows, int side_blocks, int ph = 0, int phases = 1) {
-  const int grid = e->grid_hot + side_blocks;
-  if (e->tile_mode == 0) {
-    LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_hot_kernel, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases);
-    return;
-  }
-  const int wg = e->tile_mode == 2 ? 1 : 0, nf = tile_nf(e);
-  if (nf == 1) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, wg);
-  else if (nf == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, wg);
-  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, wg);
+  const int grid = e->grid_hot + side_blocks, nf = tile_nf(e);
+  if (nf == 1) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 0);
+  else if (nf == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 0);
+  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 0);
 }
 
 // The once-only / few-occurrence kernels over a flat (feature, vector) index space instead of a
@@ -666,7 +652,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_PREP_WINDOW")) e->prep_window = sv[0] != '0';
-  if (const char *sv = std::getenv("FFM_TILE")) e->tile_mode = std::min(2, std::max(0, std::atoi(sv)));
   if (const char *sv = std::getenv("FFM_UPDATE_FUSED")) e->update_fused = std::atoi(sv) != 0 ? 1 : 0;
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
@@ -677,9 +662,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_SINGLE_FLAT")) e->single_flat = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_GRID_SINGLE")) e->grid_single = std::max(1, std::atoi(sv));
-  // a sharded rank's very hot list holds n_shards times the rows' worth of features, each with
-  // 1/n_shards of its slots: more, shorter items (measured under bench.py --emulate-shards 8)
-  if (cfg->n_shards > 1) e->grid_huge = 4096;
   // (the lean once-only kernel of a compact shard holds six waves per SIMD: 1152 workgroups
   // measured 2.5 % per step better than 768 on an 8-GPU rank's blocks)
   if (cfg->n_shards > 1) e->grid_single = 1152;
@@ -688,7 +670,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_PHASES")) e->phases = std::min(kMaxPhases, std::max(1, std::atoi(sv)));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
-  if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_GIANT")) e->grid_giant = std::max(0, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_STAGE_THREAD")) e->stage_thread_on = sv[0] != '0';
   {
@@ -711,10 +692,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.n_shards = cfg->n_shards;
   m.shard_rank = cfg->shard_rank;
   m.bias_own = 1;
-  m.huge_min = kHugeMin;  // (FFM: chosen per block, huge_min_for)
+  m.huge_min = kHugeMin;
   if (const char *sv = std::getenv("FFM_HUGE_MIN")) {
     m.huge_min = std::max(kSmallMax + 1, std::atoi(sv));
-    e->huge_min_fixed = true;
   }
   m.rec_slots = m.n_fields;
   e->n_records = cfg->n_feats;

@@ -72,7 +72,7 @@ int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms
         best == K_LATENT_UPDATE_HUGE)
       name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +
              (best == K_LATENT_UPDATE ? (e->m.type == FFM_MODEL_FM ? "update_kernel" : "update_small_kernel")
-              : best == K_LATENT_UPDATE_HOT ? "update_hot_kernel"
+              : best == K_LATENT_UPDATE_HOT ? (e->m.type == FFM_MODEL_FM ? "update_hot_kernel" : "update_tile_kernel")
               : best == K_LATENT_UPDATE_HUGE ? "update_chain_kernel"
               : (best == K_ROW ? "row_kernel<train>" : "row_kernel<predict>"));
     std::snprintf(kernel_name, kernel_name_cap, "%s", name.c_str());

@@ -83,20 +83,6 @@ __global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_c
 
 // Groups `rows` by feature into scratch set `set` on stream `st`.
 // timed = false: from the staging thread (no HIP-event bookkeeping of the profiler there).
-// Hot / very hot boundary of one block.  A hot feature's touches are ONE sequential chain per element
-// (~0.55 us per touch beside the other kernels); the very hot ones' chains are cut into 16-touch
-// steps at 40 % more instructions.  So the hot kernel's longest chain should last about as long as
-// what bounds the update phase anyway: half its throughput-bound time (measured 0.88 touch-elements
-// per ns at FFM 39 x 16) or the bias chain's one wave (12 ns per row).  kHugeMin -- the optimum of
-// 8192 x 39-entry rows at k = 16 -- caps it.  (C2, 4096 x 8 entries: 384 -> 89, 17.5 -> 22.8 M rows/s.)
-static int huge_min_for(const ffm_engine *e, const Rows &rows) {
-  if (e->huge_min_fixed || e->m.type != FFM_MODEL_FFM || rows.n_rows <= 0) return e->m.huge_min;
-  const double per_row = static_cast<double>(rows.nnz) / rows.n_rows;
-  const double touch_elems = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / std::max(1, e->m.n_shards);
-  const double span_us = std::max(touch_elems / 0.88e6, rows.n_rows * 0.012);
-  return static_cast<int>(std::min<double>(kHugeMin, std::max(64.0, span_us / 0.55)));
-}
-
 static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st, bool timed = true) {
   Scratch &sc = e->sc[set];
   ScopedTimer tm_all("grouping:all");
@@ -119,8 +105,7 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
                                         static_cast<size_t>(nnz), 0u, e->sort_bits, st));
     }
     if (timed) e->prof_end(st);
-    ModelDev mf = e->m;  // (the only kernel that deals features into the hot / very hot lists)
-    mf.huge_min = huge_min_for(e, rows);
+    const ModelDev &mf = e->m;  // (huge_min: where the hot list ends and the very hot one starts)
     if (timed) LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, mf, rows, sc,
                          phases_for(e, rows.n_rows));
     else hipLaunchKernelGGL(group_finish_kernel, dim3(cdiv(nnz, kFinishThreads)), dim3(kFinishThreads), 0, st, mf, rows, sc,
@@ -296,35 +281,23 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // two side streams take each phase's touches as soon as its rows are done -- beside the forward
     // pass of the next phase (which reads w; the update writes n and z).
     const int P = own_tg ? e->cur_phases : 1;
-    // Small blocks: the whole update in one launch (kernels_chain.h: ffm_update_all_kernel) -- the
+    // Small blocks: the whole update in one launch (kernels_tile.h: ffm_update_all_tile_kernel) -- the
     // fork / join hops between the three streams cost more than the fused kernel's extra registers.
-    // The same estimate of the phase's length as for the hot / very hot boundary (huge_min_for).
+    // An estimate of the phase's length from the touch-elements of the block (0.44 per ns measured at FFM 39 x 16).
     const double per_row = rows.n_rows > 0 ? static_cast<double>(rows.nnz) / rows.n_rows : 0.0;
     const double phase_us = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / 0.44e6;
     const bool fused = e->update_fused >= 0 ? e->update_fused != 0 : phase_us < 150.0;
     if (fused && P == 1 && own_tg && e->singles_in_row && e->m.n_shards == 1) {
-      const int fc = e->grid_huge, fh = e->grid_hot, fs = e->grid_small;
-      const int gb = std::min(e->grid_giant, 64);
+      const int fh = e->grid_hot, fs = e->grid_small, nf = tile_nf(e);
+      const int gb = rows.nnz < kGiantMin ? 0 : std::min(e->grid_giant, 64);
       const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
-      const int groups = e->m.n_factors / 4;
-      if (e->tile_mode >= 1) {
-        const int wg = e->tile_mode == 2 ? 1 : 0, gbt = wg ? 0 : gb, nf = tile_nf(e);
-        const int grid = side_blocks + gbt + fh + fs + lb;
-        if (nf == 1)
-          LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gbt, fh, fs, 1, wg, lb, loss_sum_out, e->d_loss_part);
-        else if (nf == 2)
-          LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gbt, fh, fs, 1, wg, lb, loss_sum_out, e->d_loss_part);
-        else
-          LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gbt, fh, fs, 1, wg, lb, loss_sum_out, e->d_loss_part);
-      } else {
-      const int grid = side_blocks + gb + fc + fh + fs + lb;
-      if (groups >= 3)
-        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
-      else if (groups == 2)
-        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
+      const int grid = side_blocks + gb + fh + fs + lb;
+      if (nf == 1)
+        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fh, fs, 1, 0, lb, loss_sum_out, e->d_loss_part);
+      else if (nf == 2)
+        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fh, fs, 1, 0, lb, loss_sum_out, e->d_loss_part);
       else
-        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part);
-      }
+        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fh, fs, 1, 0, lb, loss_sum_out, e->d_loss_part);
     } else {
     for (int ph = 0; ph < P; ph++) {
       HIP_TRY(hipStreamWaitEvent(e->aux3, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));

@@ -195,18 +195,13 @@ enum { CNT_NUNIQ = 0, CNT_CURSOR = 1 * kLineInts, CNT_NMULTI = 2 * kLineInts, CN
        CNT_NFEW = 7 * kLineInts, CNT_NSINGLE = 9 * kLineInts, CNT_NGIANT = 10 * kLineInts };
 constexpr int kNumCounters = 11 * kLineInts;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
-// (96 while the hot kernel ran four waves per SIMD, 192 at five; since the few-occurrence kernel
-// batches its gathers and ends the update phase's first 200 us instead of its first 380, the hot
-// kernel has room for the features up to 384 occurrences -- 78 VALU lane-instructions per
-// touch-element there against 105 in the chain kernel: resident step 1.066 -> 1.050 ms;
-// 512 and more: the hot kernel's sequential chains become the phase's span, 1.14 ms.  With the
-// five-instruction square root the chain kernel's steps got 17 % shorter and the balance moved
-// back: 192 -> 1.025 ms, 256 -> 1.035, 384 -> 1.060.)  The cap of the per-block choice
-// (engine_step.h: huge_min_for).
+// Occurrences per block above which a hot feature is listed as "very hot" (s.huge): the tile kernel
+// starts those first and at raised issue priority -- their chains bound the update phase.  (FM: the
+// features the touch-parallel chain kernel takes.)
 #ifndef FFM_HUGE_MIN
 #define FFM_HUGE_MIN 192
 #endif
-constexpr int kHugeMin = FFM_HUGE_MIN;  // occurrences per block above which a feature takes the lane-parallel path
+constexpr int kHugeMin = FFM_HUGE_MIN;
 #ifndef FFM_GIANT_MIN
 #define FFM_GIANT_MIN 2048
 #endif

@@ -451,30 +451,6 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev 
   ffm_chain_body<G>(m, rows, s, giant_blocks, ph, phases, blockIdx.x, gridDim.x);
 }
 
-// The whole FFM update of a block in ONE launch on the main stream (one shard, one row phase): the
-// workgroup ranges [bias + linear | giant chains | very hot chains | hot | few-occurrence | loss sum]
-// at the grids of the stand-alone kernels.  No fork / join between streams: the two event hops per
-// block are a quarter of C2's 0.17 ms step (17.5 -> 29 M rows/s there).  At C5's 1 ms step the hops
-// are 3 % and the fused kernel gives them back (126 VGPRs and ~700 spilled SGPRs for the union of the
-// parts' live ranges; as calls instead of inlined the parts need 248 VGPRs): the engine fuses small
-// blocks only (engine_step.h).
-template <int G>
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
-                                                                     int side_blocks, int giant_blocks,
-                                                                     int nc, int nh, int ns, int few_only,
-                                                                     int loss_blocks, double *loss_out,
-                                                                     double *loss_scratch) {
-  int r = blockIdx.x;
-  if (r < side_blocks) { ffm_hot_part(m, rows, s, side_blocks, 0, 1, r, side_blocks + nh); return; }
-  r -= side_blocks;
-  if (r < giant_blocks + nc) { ffm_chain_body<G>(m, rows, s, giant_blocks, 0, 1, r, giant_blocks + nc); return; }
-  r -= giant_blocks + nc;
-  if (r < nh) { ffm_hot_part(m, rows, s, side_blocks, 0, 1, side_blocks + r, side_blocks + nh); return; }
-  r -= nh;
-  if (r < ns) { ffm_small_body(m, rows, s, few_only, r, ns); return; }
-  loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - ns, loss_blocks);
-}
-
 // ---- FM -------------------------------------------------------------------------------------
 // The same shape for FM::update_vector_nz (fm.cpp:80-101): work item = (very hot feature, pass over
 // 16 of its factors); the per-touch inputs are the row's value, tmp_grad and factor sum (s.svx).

@@ -23,6 +23,8 @@
 // read microseconds ago), as ffm_row_kernel does for FFM; fm_update_kernel / linear_update_kernel
 // then skip the features with one occurrence.  Same touches, same order: bit-identical.
 #pragma once
+#include <type_traits>
+
 #include "engine_types.h"
 #include "kernels_update.h"
 
@@ -42,6 +44,7 @@ constexpr int kFmChunk = 8;         // entries whose records are in flight toget
 #define FFM_FM_PARK 4
 #endif
 constexpr int kFmPark = FFM_FM_PARK;
+constexpr int kFmParkStep = kFmPark < kFmChunk ? kFmPark : kFmChunk;  // parked entries walked at a time
 
 #ifndef FFM_FM_WAVES
 #define FFM_FM_WAVES 8
@@ -124,15 +127,19 @@ void fm_row_wave_kernel(ModelDev m, Rows rows, Scratch s,
   // ---- factor part, lane = factor: w = W(n, z) of every entry's record (FM::update_vector_w,
   // fm.cpp:69-78), s_f = sum v*x, q_f = sum (v*x)^2 in entry order (fm.cpp:47-55)
   float s_vx = 0.0f, sum_sqr = 0.0f;
-  constexpr int kPark = TRAIN ? kFmPark : kFmChunk;  // (predict parks nothing)
-  float pn[kPark], pz[kPark], pw[kPark];             // records of entries 0 .. kFmPark-1 (TRAIN)
-  // one chunk of entries: ids / values (wave-uniform scalar loads), the records' loads in flight
-  // together, then W(n, z) and the running sums; `park`: keep (n, z, w) at pn/pz/pw[base + j]
-  auto chunk = [&](int a0, float *kn, float *kz, float *kw) {
-    int ids[kFmChunk];
-    float xs[kFmChunk];
+  // The parked entries are walked in steps of kFmParkStep (a chunk, or all of them when fewer are
+  // parked than a chunk holds): every step reads and writes exactly the registers it is handed.
+  static_assert(kFmPark >= 1 && kFmPark % kFmParkStep == 0, "parked entries are whole steps");
+  constexpr int kPark = TRAIN ? kFmPark : 1;  // (predict parks nothing)
+  float pn[kPark], pz[kPark], pw[kPark];      // records of entries 0 .. kFmPark-1 (TRAIN)
+  // one chunk of N entries: ids / values (wave-uniform scalar loads), the records' loads in flight
+  // together, then W(n, z) and the running sums; (n, z, w) stay in kn / kz / kw[0 .. N)
+  auto chunk = [&](int a0, float *kn, float *kz, float *kw, auto n_tag) {
+    constexpr int N = decltype(n_tag)::value;
+    int ids[N];
+    float xs[N];
 #pragma unroll
-    for (int j = 0; j < kFmChunk; j++) {
+    for (int j = 0; j < N; j++) {
       const int a = a0 + j;
       int i = -1;
       float x = 0.0f;
@@ -145,7 +152,7 @@ void fm_row_wave_kernel(ModelDev m, Rows rows, Scratch s,
       xs[j] = __int_as_float(wave_uniform(__float_as_int(x)));
     }
 #pragma unroll
-    for (int j = 0; j < kFmChunk; j++) {
+    for (int j = 0; j < N; j++) {
       if (ids[j] < 0) continue;
       const float *rec = m.lat + ids[j] * rec_stride;
       if (TRAIN) {
@@ -157,7 +164,7 @@ void fm_row_wave_kernel(ModelDev m, Rows rows, Scratch s,
       }
     }
 #pragma unroll
-    for (int j = 0; j < kFmChunk; j++) {
+    for (int j = 0; j < N; j++) {
       if (ids[j] < 0) continue;
       if (TRAIN) {
         kw[j] = latent_weight(m.h, kn[j], kz[j], kw[j]);
@@ -170,12 +177,12 @@ void fm_row_wave_kernel(ModelDev m, Rows rows, Scratch s,
   };
   if (TRAIN) {
 #pragma unroll
-    for (int c0 = 0; c0 < kFmPark; c0 += kFmChunk)
-      if (c0 < nnz) chunk(c0, pn + c0, pz + c0, pw + c0);
+    for (int c0 = 0; c0 < kFmPark; c0 += kFmParkStep)
+      if (c0 < nnz) chunk(c0, pn + c0, pz + c0, pw + c0, std::integral_constant<int, kFmParkStep>{});
   }
   for (int a0 = TRAIN ? kFmPark : 0; a0 < nnz; a0 += kFmChunk) {
     float tn[kFmChunk], tz[kFmChunk], tw[kFmChunk];
-    chunk(a0, tn, tz, tw);
+    chunk(a0, tn, tz, tw, std::integral_constant<int, kFmChunk>{});
   }
   if (TRAIN && fl) s.svx[static_cast<int64_t>(r) * k + f] = s_vx;  // sum_vx (fm.h:24) for the update kernels
   // logit += 0.5 * (s_f^2 - q_f), factor after factor (fm.cpp:56-64)
@@ -229,11 +236,12 @@ void fm_row_wave_kernel(ModelDev m, Rows rows, Scratch s,
     }
   }
   // latent (FM::update_vector_nz, fm.cpp:80-101), lane = factor: g = tmp_grad * (x * s_f - v * x^2)
-  auto update_chunk = [&](int a0, float *kn, float *kz, float *kw, bool parked) {
-    int ids[kFmChunk];
-    float xs[kFmChunk];
+  auto update_chunk = [&](int a0, float *kn, float *kz, float *kw, bool parked, auto n_tag) {
+    constexpr int N = decltype(n_tag)::value;
+    int ids[N];
+    float xs[N];
 #pragma unroll
-    for (int j = 0; j < kFmChunk; j++) {
+    for (int j = 0; j < N; j++) {
       const int a = a0 + j;
       int i = -1;
       float x = 0.0f;
@@ -247,7 +255,7 @@ void fm_row_wave_kernel(ModelDev m, Rows rows, Scratch s,
     }
     if (!parked) {
 #pragma unroll
-      for (int j = 0; j < kFmChunk; j++) {
+      for (int j = 0; j < N; j++) {
         if (ids[j] < 0) continue;
         const float *rec = m.lat + ids[j] * rec_stride;
         kn[j] = rec[LAT_N * k + f];
@@ -256,7 +264,7 @@ void fm_row_wave_kernel(ModelDev m, Rows rows, Scratch s,
       }
     }
 #pragma unroll
-    for (int j = 0; j < kFmChunk; j++) {
+    for (int j = 0; j < N; j++) {
       if (ids[j] < 0) continue;
       const float x = xs[j];
       const float g = tg * (x * s_vx - kw[j] * x * x);  // fm.cpp:84-95
@@ -269,11 +277,11 @@ void fm_row_wave_kernel(ModelDev m, Rows rows, Scratch s,
     }
   };
 #pragma unroll
-  for (int c0 = 0; c0 < kFmPark; c0 += kFmChunk)
-    if (c0 < nnz) update_chunk(c0, pn + c0, pz + c0, pw + c0, true);
+  for (int c0 = 0; c0 < kFmPark; c0 += kFmParkStep)
+    if (c0 < nnz) update_chunk(c0, pn + c0, pz + c0, pw + c0, true, std::integral_constant<int, kFmParkStep>{});
   for (int a0 = kFmPark; a0 < nnz; a0 += kFmChunk) {
     float tn[kFmChunk], tz[kFmChunk], tw[kFmChunk];
-    update_chunk(a0, tn, tz, tw, false);
+    update_chunk(a0, tn, tz, tw, false, std::integral_constant<int, kFmChunk>{});
   }
 }
 

@@ -19,11 +19,21 @@
 // the same order as the one-thread loop: bit-identical.
 //
 // Work item = (hot feature, chunk of its stored record): a chunk is 64 / k whole slots (k <= 64) or
-// 64 factors of one slot (k > 64).  Pipeline per wave, tile st:
-//   facts of tile st+2 (global -> registers)                                        in flight
-//   facts of tile st+1 -> LDS records {tmp_grad, x_own*x_other, flags, offset}; partner weights of
-//                         tile st+1 requested at those offsets (global -> registers)  in flight
-//   partner weights of tile st -> LDS transposer -> chain arithmetic of tile st
+// 64 factors of one slot (k > 64).  Pipeline per wave, tile st (D = kTileDV):
+//   partner weights of tile st -> LDS transposer
+//   facts of tile st+D (registers, loaded a tile ago) -> LDS records {tmp_grad, x_own*x_other,
+//                         flags, offset}
+//   facts of tile st+D+1 requested (global -> registers)
+//   partner weights of tile st+D requested at the offsets just staged (global -> registers): with
+//                         the tiles st+1 .. st+D-1 that is 16 D touches of gathers in flight
+//   chain arithmetic of tile st
+// The ORDER of the two requests matters: the memory counter (vmcnt) retires loads in issue order,
+// so the facts the next tile's staging waits for must be requested BEFORE this tile's gathers --
+// requested after them, every tile waited for the gathers it had just issued (a gather into a
+// 247 GB tensor is a page walk and a trip to HBM).
+// The loop is unrolled by D so that the D sets of weight registers keep their names (no moves).
+// Chunks with a multi-valued partner field somewhere (s.cmask, rare) take a plain tile-after-tile
+// loop that walks the chains.
 #pragma once
 #include "engine_types.h"
 #include "kernels_touch.h"
@@ -35,7 +45,15 @@ namespace ftrl_dev {
 constexpr int kTileT = 16;    // touches per tile
 constexpr int kTileRow = 80;  // floats per transposer row: 64 + 16 of padding (16-byte writes of
                               // consecutive touches land 16 banks apart)
-constexpr int kTileG = 4;     // touches per arithmetic group (one range vote per group)
+#ifndef FFM_TILE_DV
+#define FFM_TILE_DV 1
+#endif
+constexpr int kTileDV = FFM_TILE_DV;  // tiles whose partner weights are in flight (1 .. 3)
+constexpr int kTileNR = 4;            // fact-record buffers: the tiles in flight and the one being applied
+#ifndef FFM_TILE_G
+#define FFM_TILE_G 4
+#endif
+constexpr int kTileG = FFM_TILE_G;  // touches per arithmetic group (one range vote per group)
 
 // flags word of an LDS fact record: bits 0..7 high bits of the weights' offset, 8..10 HF_* flags,
 // 16..23 the touch's own field
@@ -134,7 +152,7 @@ struct TileFacts {  // what a stager lane holds of one tile: NF facts of its tou
 
 // NF: facts a stager lane carries per tile = ceil(slots per chunk / 4): 1 for k >= 16, 2 for
 // k = 8 / 12, 4 for k = 4.  T: the wave's transposer [kTileT][kTileRow]; R: its fact records
-// [2][kTileT * 4 * NF].
+// [kTileNR][kTileT * 4 * NF].
 template <int NF>
 __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &rows, const Scratch &s,
                                                unsigned wave, unsigned n_waves, int ph, int phases,
@@ -181,7 +199,13 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
       const unsigned long long gm = s.gmask[start];
       if (!__any(active && ((gm >> fp) & 1ull))) continue;
     }
-    if (li < n_huge) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+    // issue priority by chain length: the longest chains bound the update phase
+#ifndef FFM_TILE_PRIO_LONG
+#define FFM_TILE_PRIO_LONG 640
+#endif
+    if (c - t_lo > FFM_TILE_PRIO_LONG) __builtin_amdgcn_s_setprio(3);
+    else if (li < n_huge) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
     float *rec = lat_row(m, i, fa) + (fp >= 0 ? sb + es : sb) * K + ekk;
     float n = rec[LAT_N * RL], z = rec[LAT_Z * RL];
     const float w = rec[LAT_W * RL];
@@ -217,7 +241,7 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
     // facts of tile st -> LDS records; true when a live touch of the tile has a multi-valued partner field
     auto stage_facts = [&](int st, const TileFacts &f) {
       const bool in_range = t_lo + st * kTileT + tl < c;
-      float4 *Rb = R + (st & 1) * (kTileT * RS) + tl * RS;
+      float4 *Rb = R + (st & (kTileNR - 1)) * (kTileT * RS) + tl * RS;
       bool chainy = false;
 #pragma unroll
       for (int j = 0; j < NF; j++) {
@@ -242,7 +266,7 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
       return *reinterpret_cast<const float4 *>(m.lat + off + kkQ[r]);
     };
     auto issue_weights = [&](int st) {
-      const float4 *Rb = R + (st & 1) * (kTileT * RS) + tl * RS;
+      const float4 *Rb = R + (st & (kTileNR - 1)) * (kTileT * RS) + tl * RS;
       TileWeights v;
       v.q0 = issue_weight(Rb, 0);
       v.q1 = issue_weight(Rb, 1);
@@ -251,74 +275,121 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
       return v;
     };
 
-    TileFacts fA, fB;
-    TileWeights vpB, vpC;
-    bool chainB, chainC;
-    load_facts(0, fB);
-    if (steps > 1) load_facts(1, fA);
-    chainB = stage_facts(0, fB);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    vpB = issue_weights(0);
-    for (int st = 0; st < steps; st++) {
-      vpC = vpB;
-      chainC = chainB;
-      if (st + 1 < steps) {
-        fB = fA;
-        chainB = stage_facts(st + 1, fB);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        vpB = issue_weights(st + 1);  // partner weights of tile st + 1
-      }
-      if (st + 2 < steps) load_facts(st + 2, fA);  // facts of tile st + 2
-      // ---- transpose the partner weights of tile st ----
+    auto transpose = [&](const TileWeights &v) {
       float4 *Tw = reinterpret_cast<float4 *>(T + tl * kTileRow + 4 * cq);
-      Tw[0] = vpC.q0;
-      Tw[4] = vpC.q1;
-      Tw[8] = vpC.q2;
-      Tw[12] = vpC.q3;
+      Tw[0] = v.q0;
+      Tw[4] = v.q1;
+      Tw[8] = v.q2;
+      Tw[12] = v.q3;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      asm volatile("" ::: "memory");
-      const float4 *Rc = R + (st & 1) * (kTileT * RS) + es;
+    };
+    // the chain arithmetic of tile st, all of its touches plain
+    auto apply_tile = [&](int st) {
+      const float4 *Rc = R + (st & (kTileNR - 1)) * (kTileT * RS) + es;
       const float *Tc = T + lane;
       const int cnt = min(kTileT, c - t_lo - st * kTileT);  // live touches of this tile
-      if (!chainC) {
-        for (int g0 = 0; g0 < cnt; g0 += kTileG) {
-          float tg[kTileG], x[kTileG], vp[kTileG];
-          int hw[kTileG];
+      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+        float tg[kTileG], x[kTileG], vp[kTileG];
+        int hw[kTileG];
 #pragma unroll
-          for (int j = 0; j < kTileG; j++) {
-            const float4 rc = Rc[(g0 + j) * RS];
-            tg[j] = rc.x;
-            x[j] = rc.y;
-            hw[j] = __float_as_int(rc.z);
-            vp[j] = Tc[(g0 + j) * kTileRow];
-          }
-          tile_touch_group(m.h, tg, x, hw, vp, w, n, z, sqn, sq_valid, touched);
+        for (int j = 0; j < kTileG; j++) {
+          const float4 rc = Rc[(g0 + j) * RS];
+          tg[j] = rc.x;
+          x[j] = rc.y;
+          hw[j] = __float_as_int(rc.z);
+          vp[j] = Tc[(g0 + j) * kTileRow];
         }
-      } else {
-        // a multi-valued field somewhere in the tile: one touch after another, chains walked
-        sq_valid = false;
-        for (int tt = 0; tt < cnt; tt++) {
-          const float4 rc = Rc[tt * RS];
-          const int hw = __float_as_int(rc.z);
-          if (!active) continue;
-          if (hw & (HF_SIMPLE << 8)) {
-            ffm_touch_x(m.h, (hw & (HF_FIRST << 8)) != 0, rc.x, rc.y, Tc[tt * kTileRow], w, n, z);
+        tile_touch_group(m.h, tg, x, hw, vp, w, n, z, sqn, sq_valid, touched);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    // the same for a tile that may hold touches with a multi-valued partner field: one touch after
+    // another, chains walked
+    auto apply_tile_walk = [&](int st) {
+      const float4 *Rc = R + (st & (kTileNR - 1)) * (kTileT * RS) + es;
+      const float *Tc = T + lane;
+      const int cnt = min(kTileT, c - t_lo - st * kTileT);
+      sq_valid = false;
+      for (int tt = 0; tt < cnt; tt++) {
+        const float4 rc = Rc[tt * RS];
+        const int hw = __float_as_int(rc.z);
+        if (!active) continue;
+        if (hw & (HF_SIMPLE << 8)) {
+          ffm_touch_x(m.h, (hw & (HF_FIRST << 8)) != 0, rc.x, rc.y, Tc[tt * kTileRow], w, n, z);
+          touched = true;
+        } else if (hw & (HF_CHAIN << 8)) {
+          const int fm = (hw >> 16) & 0xff;
+          const int p = s.occ2[start + t_lo + st * kTileT + tt].x;  // the touch's own entry
+          const int r = s.row_of[p];
+          const float xm = rows.val[p];
+          for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+            if (qq == p) continue;
+            const float vq = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + ekk];
+            ffm_touch(m.h, p < qq, rc.x, xm, rows.val[qq], vq, w, n, z);
             touched = true;
-          } else if (hw & (HF_CHAIN << 8)) {
-            const int fm = (hw >> 16) & 0xff;
-            const int p = s.occ2[start + t_lo + st * kTileT + tt].x;  // the touch's own entry
-            const int r = s.row_of[p];
-            const float xm = rows.val[p];
-            for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
-              if (qq == p) continue;
-              const float vq = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + ekk];
-              ffm_touch(m.h, p < qq, rc.x, xm, rows.val[qq], vq, w, n, z);
-              touched = true;
-            }
           }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    // Does any slot of the chunk have a multi-valued partner field in some row of the feature?
+    bool walk = true;
+    if (s.cmask) {
+      const unsigned long long cm = s.cmask[start];
+      walk = __any(active && ((cm >> fp) & 1ull));
+    }
+    if (walk) {
+      for (int st = 0; st < steps; st++) {
+        TileFacts f;
+        load_facts(st, f);
+        (void)stage_facts(st, f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const TileWeights v = issue_weights(st);
+        transpose(v);
+        apply_tile_walk(st);
+      }
+    } else {
+      static_assert(kTileDV >= 1 && kTileDV <= 3 && kTileDV + 1 <= kTileNR, "weights of 1 .. 3 tiles in flight");
+      TileFacts fN;
+      TileWeights V0, V1, V2;
+      {
+        TileFacts f0, f1, f2;
+        load_facts(0, f0);
+        if (kTileDV > 1 && steps > 1) load_facts(1, f1);
+        if (kTileDV > 2 && steps > 2) load_facts(2, f2);
+        if (steps > kTileDV) load_facts(kTileDV, fN);
+        (void)stage_facts(0, f0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        V0 = issue_weights(0);
+        if (kTileDV > 1 && steps > 1) {
+          (void)stage_facts(1, f1);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          V1 = issue_weights(1);
+        }
+        if (kTileDV > 2 && steps > 2) {
+          (void)stage_facts(2, f2);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          V2 = issue_weights(2);
+        }
+      }
+#define FTRL_TILE_STEP(ST, V)                                                      \
+      if ((ST) < steps) {                                                          \
+        transpose(V);                                                              \
+        const bool more__ = (ST) + kTileDV < steps;                                \
+        if (more__) {                                                              \
+          (void)stage_facts((ST) + kTileDV, fN);                                   \
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   \
+        }                                                                          \
+        if ((ST) + kTileDV + 1 < steps) load_facts((ST) + kTileDV + 1, fN);        \
+        if (more__) V = issue_weights((ST) + kTileDV);                             \
+        apply_tile(ST);                                                            \
+      }
+      for (int st = 0; st < steps; st += kTileDV) {
+        FTRL_TILE_STEP(st, V0)
+        if (kTileDV > 1) { FTRL_TILE_STEP(st + 1, V1) }
+        if (kTileDV > 2) { FTRL_TILE_STEP(st + 2, V2) }
+      }
+#undef FTRL_TILE_STEP
     }
     if (touched && active) {
       rec[LAT_N * RL] = n;
@@ -339,7 +410,7 @@ __device__ __forceinline__ void ffm_tile_part(const ModelDev &m, const Rows &row
                                               int side_blocks, int ph, int phases, int with_giant,
                                               unsigned bidx, unsigned gdim) {
   __shared__ __attribute__((aligned(16))) float lds_T[kUpdWaves][kTileT * kTileRow];
-  __shared__ float4 lds_R[kUpdWaves][2 * kTileT * 4 * NF];
+  __shared__ float4 lds_R[kUpdWaves][kTileNR * kTileT * 4 * NF];
   if (static_cast<int>(bidx) < side_blocks) {
     if (bidx == 0) {
       // one wave, n_rows dependent touches: let it win the issue arbitration on its SIMD

@@ -13,9 +13,9 @@
 //  * "small" features (<= kSmallMax occurrences, the vast majority): ONE wave owns the whole
 //    record, each lane holding 4 consecutive factors of one slot (16-byte loads of n, z, w and of
 //    each partner slot), all of a record's gathers in flight together -- bandwidth-shaped.
-//  * "hot" features: one wave per 64 elements of the record, touches handled kUnroll at a time
-//    (all of a group's gathers issued before the accumulator chain consumes them) -- keeps the
-//    long sequential chains of a hot feature spread over many waves.
+//  * "hot" features: one wave per 64 elements of the record, sixteen touches at a time, their
+//    operands loaded touch-parallel and transposed through LDS (kernels_tile.h); the giant ones --
+//    thousands of occurrences -- as touch-parallel DPP chains (kernels_chain.h).
 #pragma once
 #include "engine_types.h"
 #include "kernels_touch.h"
@@ -24,7 +24,6 @@ namespace ftrl_dev {
 
 constexpr int kUpdThreads = 256;
 constexpr int kUpdWaves = kUpdThreads / 64;
-constexpr int kUnroll = 4;    // touches per group in the hot kernel (8: more registers, measured slower)
 constexpr int kFmUnroll = 8;  // touches per prefetch group in the FM update kernel
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -210,72 +209,6 @@ __device__ __forceinline__ void bias_update_body(const ModelDev &m, int row_lo, 
 }
 __global__ __launch_bounds__(64) void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
   bias_update_body(m, 0, n_rows, s);
-}
-
-// ---- hot features, moderate counts: work item = (feature from the big list, 64 elements) ----
-// One wave owns 64 elements and walks the touches kUnroll at a time, software-pipelined three
-// groups deep over the same occurrence-ordered streams (group b applied while group b+1's partner
-// weights and group b+2's facts are in flight).  Per group: gradients, then the running n (plain
-// adds), then every touch's sigma (independent given the running n), then the running z.
-struct HotFacts {  // per-lane facts of a group of touches
-  float xo[kUnroll];
-  int fl[kUnroll];   // flags | own field << 8
-  int fq[kUnroll];   // offset of the partner's weights inside lat, low word (high word: pe[])
-};
-
-__device__ __forceinline__ void hot_load_facts(const int4 *acol, int F, int c, int t0,
-                                               HotFacts &f, int (&pe)[kUnroll]) {
-#pragma unroll
-  for (int j = 0; j < kUnroll; j++) {
-    const int4 ax = acol[static_cast<int64_t>(min(t0 + j, c - 1)) * F];  // tail: repeats, unused
-    f.xo[j] = __int_as_float(ax.x);
-    f.fl[j] = ax.y;
-    f.fq[j] = ax.z;
-    pe[j] = ax.w;  // with fq: the 64-bit offset of the partner's weights
-  }
-}
-
-__device__ __forceinline__ void hot_issue_weights(const float *wcol, const HotFacts &f,
-                                                  const int (&pe)[kUnroll], float (&vp)[kUnroll]) {
-#pragma unroll
-  for (int j = 0; j < kUnroll; j++) vp[j] = wcol[haux_offset(f.fq[j], pe[j])];
-}
-
-// side_blocks > 0: the first workgroups of the launch carry the block's two short serial jobs --
-// workgroup 0 the bias chain, workgroups 1..side_blocks-1 the linear update -- so that they run
-// beside the latent chains without a stream (and a hardware queue) of their own.
-// Five waves per SIMD (at most 96 VGPRs): the kernel waits on gathers half of the time, and the
-// fifth wave is worth 1.5 % of the step.  It fits without spilling only WITHOUT the square-root
-// forwarding below (94 VGPRs; with it 105, or 96 + 20 bytes of scratch), whose 6 % fewer
-// instructions did not show in the step time -- so the forwarding is compiled out here
-// (FFM_HOT_FWD=1 -DFFM_HOT_WAVES=4 brings it back); the chain kernels keep theirs.
-#ifndef FFM_HOT_WAVES
-#define FFM_HOT_WAVES 5
-#endif
-#define FFM_HOT_OCC __attribute__((amdgpu_waves_per_eu(FFM_HOT_WAVES, FFM_HOT_WAVES)))
-#ifndef FFM_HOT_FWD
-#define FFM_HOT_FWD 0
-#endif
-// ph of `phases`: the touches that come from the rows of one row phase (engine_types.h).
-// (bidx of gdim: the workgroups of a launch that carry the side chains and the hot list)
-// (HOT_BIDX of HOT_GDIM: the workgroups of a launch that carry the side chains and the hot list)
-__device__ __forceinline__ void ffm_hot_part(const ModelDev &m, const Rows &rows, const Scratch &s,
-                                             int side_blocks, int ph, int phases, unsigned bidx,
-                                             unsigned gdim) {
-#define HOT_BIDX bidx
-#define HOT_GDIM gdim
-#include "kernels_hot_body.inc"
-#undef HOT_BIDX
-#undef HOT_GDIM
-}
-__global__ __launch_bounds__(kUpdThreads) FFM_HOT_OCC void ffm_update_hot_kernel(ModelDev m, Rows rows,
-                                                                     Scratch s, int side_blocks,
-                                                                     int ph, int phases) {
-#define HOT_BIDX blockIdx.x
-#define HOT_GDIM gridDim.x
-#include "kernels_hot_body.inc"
-#undef HOT_BIDX
-#undef HOT_GDIM
 }
 
 // n_factors not a multiple of 4: every distinct feature, hot or not, is owned per 64 elements
@@ -742,7 +675,7 @@ __device__ __forceinline__ void fm_update_body(const ModelDev &m, const Rows &ro
   }
 }
 // side_blocks: the first workgroups carry the bias chain (block 0) and the linear update -- short
-// serial chains that would otherwise need a stream of their own (as in ffm_update_hot_kernel).
+// serial chains that would otherwise need a stream of their own (as in ffm_update_tile_kernel).
 __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s,
                                                                 int skip_huge, int skip_once,
                                                                 int side_blocks) {

@@ -49,6 +49,19 @@ PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s p
 SMALL_MAX, HUGE_MIN, GIANT_MIN = 8, 192, 2048  # occurrence classes of the update kernels (csrc/engine_types.h)
 
 
+def chain_min_for(n_rows, nnz_block, k, n_shards, ffm=True):
+    """From how many occurrences a feature takes the DPP chain kernel instead of the tile kernel
+    (csrc/engine_step.h: chain_min_for; FFM_CHAIN_MIN overrides): for the two kernels' byte shares."""
+    env = os.environ.get("FFM_CHAIN_MIN")
+    if env:
+        return min(GIANT_MIN, max(64, int(env)))
+    if not ffm or n_rows <= 0:
+        return GIANT_MIN
+    touch_elems = nnz_block * max(0.0, nnz_block / n_rows - 1.0) * k / max(1, n_shards)
+    span_us = max(touch_elems / 0.88e6, n_rows * 0.012)
+    return int(min(float(GIANT_MIN), max(64.0, span_us / 0.2)))
+
+
 def update_fused(n_rows, nnz_block, k, n_shards):
     """Whether the engine runs a block's whole FFM update as ONE launch (csrc/engine_step.h: small
     blocks on one shard; FFM_UPDATE_FUSED overrides): the launch is timed under the hot
@@ -90,8 +103,8 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
       row kernel           : CSR in, linear weights, logit / tmp_grad / loss out (+ the above; + in
                              mode 3 the once-only features' update)
       update               : write (n,z) = 8 B per slot-factor of the occurrences each kernel owns
-                             (features with 1, 2..8, 9..2047 -- the tile kernel --, >= 2048 -- the
-                             chain kernel -- occurrences in the block)
+                             (features with 1, 2..8, 9 .. -- the tile kernel --, chain_min_for() or more
+                             -- the chain kernel -- occurrences in the block)
     Under field-pair sharding every rank moves 1/n_shards of the slot-factors."""
     if MODEL == "FM":
         return fm_kernel_share_bytes(kernel, blocks_feat, nnz, k)
@@ -112,8 +125,9 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
     shares = []
     for f in blocks_feat:
         _, c = np.unique(f, return_counts=True)
+        cm = chain_min_for(len(f) // nnz, len(f), k, n_shards)
         occ = {"single": c[c == 1].sum(), "small": c[(c > 1) & (c <= SMALL_MAX)].sum(),
-               "hot": c[(c > SMALL_MAX) & (c < GIANT_MIN)].sum(), "huge": c[c >= GIANT_MIN].sum()}
+               "hot": c[(c > SMALL_MAX) & (c < cm)].sum(), "huge": c[c >= cm].sum()}
         key = ("huge" if "chain" in kernel or "huge" in kernel else
                next((kk for kk in ("single", "small") if kk in kernel), "hot"))
         if key == "hot" and update_fused(len(f) // nnz, len(f), k, n_shards):
@@ -193,6 +207,41 @@ def cpu_baseline(args, gen_kwargs):
                           ", ".join("%dT=%.0f/s" % kv for kv in sorted(tried.items())), ncpu)}
 
 
+def spawn_ranks(n):
+    """One rank per GPU through torch.distributed.run, as the driver would launch them
+    (rendezvous on 127.0.0.1, a free port); returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def block_logloss_cost(rows):
+    """What training in blocks of `rows` rows costs in logloss against the reference's per-sample
+    loop (FFM 39 x 16, default hyper-parameters, block ramp 32; measured with the oracle, which the
+    GPU path equals bit for bit): the committed table's entry for the largest block <= rows, from
+    its longest run."""
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_logloss_vs_block*.json"))):
+        try:
+            d = json.load(open(fn))
+        except (OSError, ValueError):
+            continue
+        for b, e in d.get("blocks", {}).items():
+            key = (int(b), e.get("full_blocks", 0))
+            if int(b) <= rows and (best is None or key > best[0]):
+                best = (key, {"block_rows": int(b), "d_train_logloss": e["d_train"], "d_eval_logloss": e["d_eval"],
+                              "full_blocks": e.get("full_blocks"), "shape": d.get("shape"),
+                              "source": os.path.relpath(fn, ROOT)})
+    return best[1] if best else None
+
+
 def latest_pmc_summary():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.json")))
     return files[-1] if files else None
@@ -239,18 +288,23 @@ def main():
                          "then keeps full-length records and all columns)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    if n_gpus > 1 and world == 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, one fresh
+        # process per GPU, BEFORE anything in this process has touched the GPU (no torch import,
+        # no HIP call yet), wait for them and hand their exit code on.  Never exec from a process
+        # that has initialised the GPU.
+        sys.exit(spawn_ranks(n_gpus))
+
     import torch
     import ftrl_ffm_amd as fa
     from ftrl_ffm_amd import sharding, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
     if world > 1 and world != n_gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (n_gpus, world))
-    if n_gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs torch.distributed.run (one rank per GPU)" % n_gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     if args.same_device:
@@ -336,20 +390,24 @@ def main():
         plan = fa.shard_plan(N_FIELDS, n_shards, field_map=True)
         me = args.emulate_rank if emu else rank
         keep = (plan["pair_owner"] == me).any(axis=1) | (plan["lin_owner"] == me)
-    host_blocks = []
     blocks_feat = []
-    for _ in range(n_blocks):
-        b = gen.block(rows)
-        if model != "FFM":
-            b.field[:] = 0  # libsvm rows
-        if len(blocks_feat) < 8:
-            blocks_feat.append(b.feat)
-        if keep is not None:
-            sel = keep[b.field]
-            per_row = np.add.reduceat(sel.astype(np.int64), b.row_ptr[:-1].astype(np.int64))
-            b = synth.Block(np.concatenate([[0], np.cumsum(per_row)]).astype(np.int32), b.field[sel].copy(),
-                            b.feat[sel].copy(), b.val[sel].copy(), b.label)
-        host_blocks.append(b)
+
+    def make_blocks(n_rows_block, count, note_feats=False):
+        out_blocks = []
+        for _ in range(count):
+            b = gen.block(n_rows_block)
+            if model != "FFM":
+                b.field[:] = 0  # libsvm rows
+            if note_feats and len(blocks_feat) < 8:
+                blocks_feat.append(b.feat)
+            if keep is not None:
+                sel = keep[b.field]
+                per_row = np.add.reduceat(sel.astype(np.int64), b.row_ptr[:-1].astype(np.int64))
+                b = synth.Block(np.concatenate([[0], np.cumsum(per_row)]).astype(np.int32), b.field[sel].copy(),
+                                b.feat[sel].copy(), b.val[sel].copy(), b.label)
+            out_blocks.append(b)
+        return out_blocks
+    host_blocks = make_blocks(rows, n_blocks, note_feats=True)
     total_steps = args.steps + args.warmup + 1
     logit = torch.zeros(rows, dtype=torch.float32, device="cuda")
     loss_sum = torch.zeros(2 * total_steps, dtype=torch.float64, device="cuda")
@@ -365,19 +423,24 @@ def main():
     # ---- leg 1 (the metric): rows stream from host memory, H2D inside the timed region ----
     zero_copy = not args.host_copy
     pinned_keep = []
-    if zero_copy and not args.resident_only:
+    def pin_blocks(blocks):
         # the parsed rows live in page-locked host memory (allocated pinned, as a loader that
         # targets this engine would): the DMA reads them in place
-        for b in host_blocks:
+        for b in blocks:
             for name in ("row_ptr", "field", "feat", "val", "label"):
                 t = torch.from_numpy(getattr(b, name)).pin_memory()
                 pinned_keep.append(t)
                 setattr(b, name, t.numpy())
+    if zero_copy and not args.resident_only:
+        pin_blocks(host_blocks)
 
+    main_blocks = host_blocks
     STAGE_AHEAD = int(os.environ.get("BENCH_STAGE_AHEAD", "2"))  # blocks staged ahead of the one in training
 
-    def run_host(first, count):
+    def run_host(first, count, blocks=None):
         """`count` steps; returns the sum of the steps' losses (all enqueued work is flushed)."""
+        host_blocks = blocks if blocks is not None else main_blocks
+        n_blocks = len(host_blocks)
         if count == 0:
             return 0.0
         if not sharded and not zero_copy:
@@ -393,7 +456,7 @@ def main():
                 eng.stage_batch(host_blocks[(first + staged) % n_blocks], zero_copy)
                 staged += 1
             if sharded:
-                sstep.train_staged(rows, loss_sum.data_ptr() + 8 * (first + i))
+                sstep.train_staged(host_blocks[(first + i) % n_blocks].n_rows, loss_sum.data_ptr() + 8 * (first + i))
             else:
                 eng.train_staged(None, loss_sum.data_ptr() + 8 * (first + i))
         eng.sync()
@@ -529,6 +592,25 @@ def main():
                      "note": "rows handed over through the copying entry point (pageable memory: one host memcpy "
                              "per block into the engine's pinned slot); not the metric"}
 
+    # ---- sharded runs: the OTHER scaling beside the one `value` is quoted on ----
+    # `--scaling weak` (default) multiplies the block with the GPUs; SURVEY.md 8(d)'s literal C5 is
+    # 8192 rows per step GLOBALLY -- the strong line.  Both legs on the same engines, same process.
+    other_scaling = None
+    if sharded and host_leg and zero_copy and not args.rows:
+        o_rows = cfgw["rows"] * (1 if args.scaling == "weak" else n_shards)
+        if o_rows <= rows:  # (the engines were created for `rows` rows per block)
+            o_blocks = make_blocks(o_rows, max(8, min(64, (1 << 19) // o_rows)))
+            pin_blocks(o_blocks)
+            o_steps = args.steps
+            el_o, _ = timed(lambda f, c: run_host(f, c, o_blocks), 0, o_steps,
+                            warm=lambda: run_host(0, min(args.warmup, 5), o_blocks))
+            o_val = o_rows * o_steps / el_o
+            other_scaling = {"scaling": "strong" if args.scaling == "weak" else "weak",
+                             "value": round(o_val, 1), "unit": "samples/s",
+                             "rows_per_step": o_rows, "ms_per_step": round(1000.0 * el_o / o_steps, 4),
+                             "block_logloss_cost": block_logloss_cost(o_rows),
+                             "note": "same engines, same run: %d rows per step over all GPUs (H2D included)" % o_rows}
+
     # ---- evaluation: predict + logloss of the same blocks, pipelined ----
     eval_leg = None
     if host_leg and zero_copy and not sharded and not args.no_resident and not args.no_eval:
@@ -596,6 +678,11 @@ def main():
             "train_logloss": round(train_loss, 6),
             "step_algorithmic_GBps": round(value * bytes_row / n_gpus / 1e9, 1),
         }
+        if sharded and model == "FFM":
+            # what the block size of this line costs in logloss against the per-sample reference loop
+            out["block_logloss_cost"] = block_logloss_cost(rows)
+        if other_scaling:
+            out["other_scaling"] = other_scaling
         if resident:
             out["resident"] = resident
         if host_copy:

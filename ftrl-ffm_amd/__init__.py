@@ -4,7 +4,7 @@ include/ffm_engine.h (csrc/), plus the host-side mirror of the reference's model
 creating an Engine without libffm_engine.so or without a GPU raises."""
 from . import build as _build
 from .engine import (ABI, FFM, FM, LR, Config, Engine, EngineError, Group, LIB_PATH,  # noqa: F401
-                     init_weights_host, load_library, page_aligned, shard_plan)
+                     default_batch_ramp, init_weights_host, load_library, page_aligned, shard_plan)
 
 
 def build(force=False, verbose=False):

@@ -17,6 +17,7 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -266,6 +267,7 @@ struct ffm_engine {
   // grouping.  (A fifth stream for them shares a hardware queue with one of the four and
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
   hipStream_t copy = nullptr;  // = prep
+  int chain_min_fixed = 0;      // FFM_CHAIN_MIN: the giant list's boundary for every block (0: chosen per block)
   int update_fused = -1;        // FFM_UPDATE_FUSED: 1 / 0 the whole FFM update in one launch always / never (-1: small blocks)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
   // Scheduling of a look-ahead grouping (FFM_PREP_WINDOW=0 turns it off): the block being
@@ -362,7 +364,7 @@ struct ffm_engine {
   std::vector<int> field_start; // copy of cfg->field_start (compact shards)
   // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
   // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
-  int grid_small = 768, grid_hot = 2048, grid_single = 768;
+  int grid_small = 768, grid_hot = 2048, grid_huge = 1024, grid_single = 768;
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
   // slowed the HBM-bound kernels they ran beside up to 4x (refresh of a 65536-row block 70 -> 330 us),
@@ -512,16 +514,20 @@ struct ffm_engine {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int loss_grid(int n_rows) { return std::max(1, std::min(kLossParts, cdiv(n_rows, 1024))); }
 
-// The giant features (kGiantMin occurrences or more: only the 65536-row blocks of a multi-GPU job
-// have them) keep the touch-parallel DPP chains, one chain per wave (kernels_chain.h): a lane =
-// element chain of 8000 touches is 500 tiles of one wave, longer than the rest of the update phase.
+// The giant list (the block's giant_min occurrences or more, engine_step.h: chain_min_for) takes the
+// touch-parallel DPP chains of kernels_chain.h, instantiated per number of interleaved chains
+// (groups of 4 factors of a slot handled by one wave): 1, 2 or 4; the features with kGiantMin
+// occurrences or more (only the 65536-row blocks of a multi-GPU job have them) one chain per wave,
+// in the launch's first workgroups.
 static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows, int ph = 0, int phases = 1) {
-  const int gb = e->grid_giant;
-  if (gb <= 0 || rows.nnz < kGiantMin) return;
-  LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, gb, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
+  const int groups = e->m.n_factors / 4;
+  const int gb = rows.nnz < kGiantMin ? 0 : e->grid_giant, grid = e->grid_huge + gb;
+  if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
+  else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
+  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
 }
 
-// The hot features' update (kernels_tile.h: the big and huge lists), with the bias chain and the
+// The hot features' update (kernels_tile.h: the huge and big lists), with the bias chain and the
 // linear update in its first side_blocks workgroups.  Instantiated per number of facts a stager
 // lane carries: slots per 64-element chunk / 4.
 static int tile_nf(const ffm_engine *e) {
@@ -530,9 +536,9 @@ static int tile_nf(const ffm_engine *e) {
 }
 static void launch_ffm_hot(ffm_engine *e, hipStream_t st, const Rows &rows, int side_blocks, int ph = 0, int phases = 1) {
   const int grid = e->grid_hot + side_blocks, nf = tile_nf(e);
-  if (nf == 1) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 0);
-  else if (nf == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 0);
-  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 0);
+  if (nf == 1) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 3);
+  else if (nf == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 3);
+  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 3);
 }
 
 // The once-only / few-occurrence kernels over a flat (feature, vector) index space instead of a
@@ -670,6 +676,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_PHASES")) e->phases = std::min(kMaxPhases, std::max(1, std::atoi(sv)));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_CHAIN_MIN")) e->chain_min_fixed = std::max(kChainMin, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_GIANT")) e->grid_giant = std::max(0, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_STAGE_THREAD")) e->stage_thread_on = sv[0] != '0';
   {
@@ -693,6 +701,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.shard_rank = cfg->shard_rank;
   m.bias_own = 1;
   m.huge_min = kHugeMin;
+  m.giant_min = kGiantMin;  // (FFM: chosen per block, chain_min_for)
   if (const char *sv = std::getenv("FFM_HUGE_MIN")) {
     m.huge_min = std::max(kSmallMax + 1, std::atoi(sv));
   }
@@ -768,7 +777,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.sdesc, E));
   TRY_ALLOC(e->alloc(&s.big, E));
   TRY_ALLOC(e->alloc(&s.huge, E));
-  TRY_ALLOC(e->alloc(&s.giant, E / kGiantMin + 1));
+  TRY_ALLOC(e->alloc(&s.giant, E / kChainMin + 1));
   TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
   TRY_ALLOC(e->alloc(&e->d_err, 1));
   TRY_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), e->stream));
@@ -858,7 +867,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.sdesc, E));
     TRY_ALLOC(e->alloc(&t.big, E));
     TRY_ALLOC(e->alloc(&t.huge, E));
-    TRY_ALLOC(e->alloc(&t.giant, E / kGiantMin + 1));
+    TRY_ALLOC(e->alloc(&t.giant, E / kChainMin + 1));
     TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
     TRY_ALLOC(e->alloc(&t.occpos, E));
     TRY_ALLOC(e->alloc(&t.usplit, E));
@@ -1026,6 +1035,12 @@ int ffm_engine_check_errors(ffm_engine *e) { return ffm_engine_sync(e); }
 void *ffm_engine_stream(ffm_engine *e) { return e ? static_cast<void *>(e->stream) : nullptr; }
 
 // Who owns what under field-pair sharding (host arithmetic only, no device needed).
+int32_t ffm_engine_default_batch_ramp(float w_alpha) {
+  if (!(w_alpha > 1e-3f)) return 32;
+  const double r = 32.0 * std::pow(8.0, std::log10(static_cast<double>(w_alpha) / 1e-3));  // x 8 per decade
+  return static_cast<int32_t>(std::min(r, 1048576.0) + 0.5);
+}
+
 int ffm_engine_shard_plan(int32_t n_fields, int32_t n_shards, int32_t field_map, int32_t *pair_owner,
                           int32_t *lin_owner, int32_t *bias_owner) {
   if (n_fields <= 0 || n_shards <= 0) return fail(FFM_E_INVALID, "n_fields and n_shards must be positive");

@@ -79,6 +79,7 @@ struct ffm_group {
   int max_rows = 0;
   int64_t handed = 0;  // blocks handed over so far
   int n_staged = 0;    // staged on every engine, not trained yet
+  bool poisoned = false;  // a block was staged on SOME engines only: the shards no longer hold the same queue
 };
 
 static int group_allreduce(ffm_group *g, int n_rows) {
@@ -86,12 +87,18 @@ static int group_allreduce(ffm_group *g, int n_rows) {
   if (n == 1 && !g->use_rccl) return FFM_OK;
   if (g->use_rccl) {
     int rc = rccl().GroupStart();
-    for (int r = 0; r < n && rc == 0; r++) {
-      HIP_TRY(hipSetDevice(g->dev[r]));
+    hipError_t dev_err = hipSuccess;
+    for (int r = 0; r < n && rc == 0 && dev_err == hipSuccess; r++) {
+      // (no early return between GroupStart and GroupEnd: an open RCCL group would swallow every
+      // later collective of the process)
+      dev_err = hipSetDevice(g->dev[r]);
+      if (dev_err != hipSuccess) break;
       rc = rccl().AllReduce(g->logit[r], g->logit[r], static_cast<size_t>(n_rows), kNcclFloat32, kNcclSum,
                             g->comm[r], g->eng[r]->stream);
     }
     const int rc2 = rccl().GroupEnd();
+    if (dev_err != hipSuccess)
+      return fail(FFM_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(dev_err));
     if (rc || rc2)
       return fail(FFM_E_DEVICE, std::string("ncclAllReduce: ") +
                                     (rccl().GetErrorString ? rccl().GetErrorString(rc ? rc : rc2) : "error"));
@@ -197,8 +204,11 @@ void ffm_group_destroy(ffm_group *g) {
     (void)hipSetDevice(g->dev[r]);
     (void)hipStreamSynchronize(g->eng[r]->stream);
   }
-  for (auto c : g->comm)
-    if (c) (void)rccl().CommDestroy(c);
+  for (size_t r = 0; r < g->comm.size(); r++)
+    if (g->comm[r]) {
+      (void)hipSetDevice(g->dev[r]);  // a communicator is torn down on its own device
+      (void)rccl().CommDestroy(g->comm[r]);
+    }
   for (auto &ev : g->ev_part) if (ev) (void)hipEventDestroy(ev);
   if (g->ev_sum) (void)hipEventDestroy(g->ev_sum);
   for (auto *e : g->eng) ffm_engine_destroy(e);
@@ -217,9 +227,15 @@ int ffm_group_train_batch_async(ffm_group *g, int32_t n_rows, const int32_t *row
                                 const int32_t *field, const int32_t *feat, const float *val,
                                 const int32_t *label, int32_t zero_copy) {
   if (!g) return fail(FFM_E_INVALID, "null group");
+  if (g->poisoned) return fail(FFM_E_INVALID, "an earlier block reached only some of the group's engines: destroy the group");
   int rc;
-  for (auto *e : g->eng)
-    if ((rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label, zero_copy))) return rc;
+  for (size_t r = 0; r < g->eng.size(); r++)
+    if ((rc = ffm_engine_stage_batch(g->eng[r], n_rows, row_ptr, field, feat, val, label, zero_copy))) {
+      // (engine 0 refuses what any engine would refuse -- the checks are the block's -- so r > 0 means
+      // a device error; the engines before r hold one block more than the rest)
+      if (r > 0) g->poisoned = true;
+      return rc;
+    }
   g->n_staged++;
   g->handed++;
   // copying path: two blocks in flight (the one staged just now keeps uploading and grouping while
@@ -250,9 +266,13 @@ int ffm_group_train_batch(ffm_group *g, int32_t n_rows, const int32_t *row_ptr, 
                           float *logit_out, double *loss_sum_out) {
   if (!g) return fail(FFM_E_INVALID, "null group");
   if (g->n_staged > 0) return fail(FFM_E_INVALID, "pipelined blocks are still waiting: flush first");
+  if (g->poisoned) return fail(FFM_E_INVALID, "an earlier block reached only some of the group's engines: destroy the group");
   int rc;
-  for (auto *e : g->eng)
-    if ((rc = ffm_engine_stage_batch(e, n_rows, row_ptr, field, feat, val, label, 0))) return rc;
+  for (size_t r = 0; r < g->eng.size(); r++)
+    if ((rc = ffm_engine_stage_batch(g->eng[r], n_rows, row_ptr, field, feat, val, label, 0))) {
+      if (r > 0) g->poisoned = true;
+      return rc;
+    }
   g->n_staged++;
   g->handed++;
   if ((rc = group_train_one_staged(g, logit_out))) return rc;

@@ -48,7 +48,9 @@ static int slots_init(ffm_engine *e) {
   const size_t R = static_cast<size_t>(e->max_rows), E = static_cast<size_t>(e->max_nnz);
   const size_t bytes = 4 * (R + 1) + 4 * E * 3 + 4 * R + 5 * 16;  // each of the 5 arrays is padded to 16 B
   for (auto &sl : e->slots) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.pinned), bytes, hipHostMallocDefault));
+    // (portable: page-locked for EVERY device of the process -- an ffm_group's engines sit on
+    // different GPUs and all read host blocks)
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.pinned), bytes, hipHostMallocPortable | hipHostMallocMapped));
     int rc;
     if ((rc = e->alloc(&sl.row_ptr, R + 1)) || (rc = e->alloc(&sl.field, E)) || (rc = e->alloc(&sl.feat, E)) ||
         (rc = e->alloc(&sl.val, E)) || (rc = e->alloc(&sl.label, R)))
@@ -56,7 +58,7 @@ static int slots_init(ffm_engine *e) {
     HIP_TRY(hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&sl.ev_trained, hipEventDisableTiming));
   }
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_pulled), 64, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_pulled), 64, hipHostMallocPortable | hipHostMallocMapped));
   *e->h_pulled = 0;
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_pulled), e->h_pulled, 0));
   if (int rc_t = e->alloc(&e->d_pull_ticket, 1)) return rc_t;
@@ -70,7 +72,9 @@ static int slots_init(ffm_engine *e) {
 
 int ffm_engine_pin_host(void *p, size_t bytes) {
   if (!p || !bytes) return fail(FFM_E_INVALID, "null range");
-  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterMapped));
+  // portable: one registration serves every GPU of the process (an ffm_group stages the same host
+  // block on all of its engines; without the flag only the current device may read it)
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
   return FFM_OK;
 }
 int ffm_engine_unpin_host(void *p) {

@@ -83,6 +83,24 @@ __global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_c
 
 // Groups `rows` by feature into scratch set `set` on stream `st`.
 // timed = false: from the staging thread (no HIP-event bookkeeping of the profiler there).
+// From how many occurrences in a block a feature's update takes the touch-parallel DPP chains
+// (kernels_chain.h) instead of the tile kernel (kernels_tile.h).  The tile kernel applies a hot
+// feature's touches as one chain per element at ~0.2 us per touch of one wave (a tile of 16 touches
+// in ~3 us: s_memtime stamps at FFM 39 x 16); the DPP chains take ~0.03 us per touch of a chain at
+// two to three times the instructions.  So the tile kernel's longest chain should last about as
+// long as what bounds the update phase anyway -- its throughput-bound time (0.88 touch-elements per
+// ns measured) or the bias chain's one wave (12 ns per row) -- and only longer chains are worth the
+// DPP kernel's instructions: none of a 8192 x 39 block's (1080 touches at most), the few
+// hundred-touch features of a 4096 x 8 block.  Never above kGiantMin.
+static int chain_min_for(const ffm_engine *e, const Rows &rows) {
+  if (e->m.type != FFM_MODEL_FFM || rows.n_rows <= 0) return e->m.giant_min;
+  if (e->chain_min_fixed) return std::min(e->chain_min_fixed, kGiantMin);
+  const double per_row = static_cast<double>(rows.nnz) / rows.n_rows;
+  const double touch_elems = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / std::max(1, e->m.n_shards);
+  const double span_us = std::max(touch_elems / 0.88e6, rows.n_rows * 0.012);
+  return static_cast<int>(std::min<double>(kGiantMin, std::max<double>(kChainMin, span_us / 0.2)));
+}
+
 static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st, bool timed = true) {
   Scratch &sc = e->sc[set];
   ScopedTimer tm_all("grouping:all");
@@ -105,7 +123,9 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
                                         static_cast<size_t>(nnz), 0u, e->sort_bits, st));
     }
     if (timed) e->prof_end(st);
-    const ModelDev &mf = e->m;  // (huge_min: where the hot list ends and the very hot one starts)
+    ModelDev mf = e->m;  // (the only kernel that deals features into the hot / very hot / giant lists)
+    mf.giant_min = chain_min_for(e, rows);
+    mf.huge_min = std::min(mf.huge_min, mf.giant_min - 1);
     if (timed) LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, mf, rows, sc,
                          phases_for(e, rows.n_rows));
     else hipLaunchKernelGGL(group_finish_kernel, dim3(cdiv(nnz, kFinishThreads)), dim3(kFinishThreads), 0, st, mf, rows, sc,
@@ -288,16 +308,17 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     const double phase_us = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / 0.44e6;
     const bool fused = e->update_fused >= 0 ? e->update_fused != 0 : phase_us < 150.0;
     if (fused && P == 1 && own_tg && e->singles_in_row && e->m.n_shards == 1) {
-      const int fh = e->grid_hot, fs = e->grid_small, nf = tile_nf(e);
+      const int fc = e->grid_huge, fh = e->grid_hot, fs = e->grid_small, nf = tile_nf(e);
       const int gb = rows.nnz < kGiantMin ? 0 : std::min(e->grid_giant, 64);
       const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
-      const int grid = side_blocks + gb + fh + fs + lb;
-      if (nf == 1)
-        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fh, fs, 1, 0, lb, loss_sum_out, e->d_loss_part);
-      else if (nf == 2)
-        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fh, fs, 1, 0, lb, loss_sum_out, e->d_loss_part);
-      else
-        LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_all_tile_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, gb, fh, fs, 1, 0, lb, loss_sum_out, e->d_loss_part);
+      const int grid = side_blocks + gb + fc + fh + fs + lb;
+#define FTRL_LAUNCH_ALL(NF, G)                                                                                     \
+      LAUNCH(e, K_LATENT_UPDATE_HOT, (ffm_update_all_tile_kernel<NF, G>), grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
+             side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part)
+      if (nf == 1) FTRL_LAUNCH_ALL(1, 4);       // k >= 16: four groups of four factors per slot and wave
+      else if (nf == 2) FTRL_LAUNCH_ALL(2, 2);  // k = 8 / 12
+      else FTRL_LAUNCH_ALL(4, 1);               // k = 4
+#undef FTRL_LAUNCH_ALL
     } else {
     for (int ph = 0; ph < P; ph++) {
       HIP_TRY(hipStreamWaitEvent(e->aux3, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));

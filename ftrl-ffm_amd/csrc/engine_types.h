@@ -55,7 +55,8 @@ struct ModelDev {
   const long long *rec_base;  // [n_fields] first stored record of a field (compact); -1: none
   const int *lin_own;         // [n_fields] 1 when this shard owns the field's linear terms; null: all
   int bias_own;               // 1 when this shard owns the bias
-  int huge_min;               // occurrences per block above which a feature is "very hot" (kHugeMin)
+  int huge_min;               // occurrences per block above which a hot feature is listed as "very hot" (kHugeMin)
+  int giant_min;              // ... from which it is listed as "giant": the touch-parallel chains' (FFM: per block)
 };
 
 enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };
@@ -139,8 +140,8 @@ struct Scratch {
   int *few;       // [nnz] ... with 2..kSmallMax occurrences (the small list minus the features
                   //      that occur once, which ffm_update_single_kernel owns)
   int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
-  int *huge;      // [nnz] ... with more, below kGiantMin ("very hot": present in many rows)
-  int *giant;     // [nnz] ... with kGiantMin or more
+  int *huge;      // [nnz] ... with more, below ModelDev::giant_min ("very hot": present in many rows)
+  int *giant;     // [nnz / kChainMin + 1] ... with giant_min or more
   int *counters;  // [kNumCounters] CNT_* below
   int *err;       // [1] sticky ERR_* flags, shared by all sets: what ffm_engine_sync reports
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
@@ -195,9 +196,14 @@ enum { CNT_NUNIQ = 0, CNT_CURSOR = 1 * kLineInts, CNT_NMULTI = 2 * kLineInts, CN
        CNT_NFEW = 7 * kLineInts, CNT_NSINGLE = 9 * kLineInts, CNT_NGIANT = 10 * kLineInts };
 constexpr int kNumCounters = 11 * kLineInts;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
-// Occurrences per block above which a hot feature is listed as "very hot" (s.huge): the tile kernel
-// starts those first and at raised issue priority -- their chains bound the update phase.  (FM: the
-// features the touch-parallel chain kernel takes.)
+// Occurrence classes of a block's hot features (more than kSmallMax occurrences):
+//   big   (.. huge_min]             tile kernel (FFM) / list kernel (FM)
+//   huge  (huge_min .. giant_min)   FFM: the tile kernel too, started first and at raised issue
+//                                   priority; FM: the touch-parallel chain kernel
+//   giant [giant_min ..             touch-parallel DPP chains (kernels_chain.h); one chain per wave
+//                                   from kGiantMin occurrences on
+// huge_min = kHugeMin; giant_min = kGiantMin for FM, chosen per block for FFM (engine_step.h:
+// chain_min_for).
 #ifndef FFM_HUGE_MIN
 #define FFM_HUGE_MIN 192
 #endif
@@ -208,6 +214,7 @@ constexpr int kHugeMin = FFM_HUGE_MIN;
 // ... and from which its chains are so long that their LATENCY sets the update phase's span: such
 // "giant" features are listed apart (s.giant) and walked one group of 4 factors per wave
 constexpr int kGiantMin = FFM_GIANT_MIN;
+constexpr int kChainMin = 64;  // the least giant_min an engine may choose (sizes Scratch::giant)
 enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
                                                      // first / several entries share the field
 // (4 until the once-only features left the update phase; re-swept since: 8)

@@ -243,10 +243,12 @@ __device__ __forceinline__ void chain_step(const ModelDev &m, unsigned long long
 
 // The items of one list of features (s.huge or s.giant), G interleaved chains per wave; `wave` of
 // `n_waves` waves share the list.
+// c_lo <= occurrences < c_hi: the share of the list this call walks
 template <int G>
 __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &rows, const Scratch &s,
                                                 const int *list, int n_list, unsigned wave,
-                                                unsigned n_waves, int ph, int phases) {
+                                                unsigned n_waves, int ph, int phases, int c_lo = 0,
+                                                int c_hi = 0x7fffffff) {
   // One chain per wave (the giant features) takes 0.9 us per 16-touch step even alone on the
   // chip, three times its issue cost; deeper prefetch for it (chunks of 2, 4, 8 steps: facts and
   // weights up to 16 / 8 steps ahead, 107 VGPRs) measured 0 to 5 % SLOWER per step on an 8-GPU
@@ -272,8 +274,10 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
     const int fp = wave_uniform(walk_field(m, fa, sc));  // partner field of slot sc
     if (fp < 0) continue;
     const int start = wave_uniform(ud.y);
+    const int c_all = wave_uniform(ud.z);
+    if (c_all < c_lo || c_all >= c_hi) continue;  // the other call's
     int t_lo, c;  // this row phase's touches [t_lo, c) of the feature's occurrences
-    phase_touches(s, start, wave_uniform(ud.z), ph, phases, t_lo, c);
+    phase_touches(s, start, c_all, ph, phases, t_lo, c);
     t_lo = wave_uniform(t_lo);
     c = wave_uniform(c);
     if (t_lo >= c) continue;
@@ -423,26 +427,26 @@ __device__ __forceinline__ void ffm_chain_items(const ModelDev &m, const Rows &r
   }
 }
 
-// One launch for all very hot features.  The first giant_blocks workgroups take the GIANT ones
-// (kGiantMin occurrences or more) ONE chain per wave: a wave issues at most one VALU instruction
-// every four cycles, so a wave carrying four interleaved chains needs ~2.4 us per 16-touch step --
-// for the 8600-touch chains of an 8-GPU job's 65536-row blocks that alone was 1.3 ms, the span of
-// the whole update phase; one chain per wave is four times shorter, and there are few enough giant
-// features for the extra s_nop slots not to matter.  Dispatched first, the long chains also start
-// first.  The other workgroups take the rest, G chains per wave.
+// One launch for the giant list (ModelDev::giant_min occurrences or more).  The first giant_blocks
+// workgroups take the features with kGiantMin occurrences or more ONE chain per wave: a wave issues
+// at most one VALU instruction every four cycles, so a wave carrying four interleaved chains needs
+// ~2.4 us per 16-touch step -- for the 8600-touch chains of an 8-GPU job's 65536-row blocks that
+// alone was 1.3 ms, the span of the whole update phase; one chain per wave is four times shorter,
+// and there are few enough such features for the extra s_nop slots not to matter.  Dispatched first,
+// the long chains also start first.  The other workgroups take the rest, G chains per wave.
 // ph of `phases`: the touches that come from the rows of one row phase (engine_types.h).
 template <int G>
 __device__ __forceinline__ void ffm_chain_body(const ModelDev &m, const Rows &rows, const Scratch &s,
                                                int giant_blocks, int ph, int phases, unsigned bidx,
                                                unsigned gdim) {
   const unsigned w = wave_uniform(threadIdx.x >> 6);
+  const int n_list = s.counters[CNT_NGIANT];
   if (static_cast<int>(bidx) < giant_blocks) {
-    ffm_chain_items<1>(m, rows, s, s.giant, s.counters[CNT_NGIANT], bidx * kUpdWaves + w,
-                       giant_blocks * kUpdWaves, ph, phases);
+    ffm_chain_items<1>(m, rows, s, s.giant, n_list, bidx * kUpdWaves + w, giant_blocks * kUpdWaves, ph, phases,
+                       kGiantMin);
   } else
-    ffm_chain_items<G>(m, rows, s, s.huge, s.counters[CNT_NHUGE],
-                       (bidx - giant_blocks) * kUpdWaves + w, (gdim - giant_blocks) * kUpdWaves,
-                       ph, phases);
+    ffm_chain_items<G>(m, rows, s, s.giant, n_list, (bidx - giant_blocks) * kUpdWaves + w,
+                       (gdim - giant_blocks) * kUpdWaves, ph, phases, 0, giant_blocks > 0 ? kGiantMin : 0x7fffffff);
 }
 template <int G>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_chain_kernel(ModelDev m, Rows rows,

@@ -196,8 +196,8 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
   const int wv = threadIdx.x >> 6;
   const bool pred[kLists] = {head, head && c <= kSmallMax, head && c > 1 && c <= kSmallMax,
                              head && c > kSmallMax && c <= m.huge_min,
-                             head && c > m.huge_min && c < kGiantMin, head && c == 1,
-                             head && c > m.huge_min && c >= kGiantMin};
+                             head && c > m.huge_min && c < m.giant_min, head && c == 1,
+                             head && c > m.huge_min && c >= m.giant_min};
   const int which[kLists] = {CNT_NUNIQ, CNT_NSMALL, CNT_NFEW, CNT_NBIG, CNT_NHUGE, CNT_NSINGLE, CNT_NGIANT};
   unsigned long long pm[kLists];
 #pragma unroll
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
     if (c > 1 && c <= kSmallMax) s.few[iw] = u;
     if (c <= kSmallMax) s.small[is] = u;
     else if (c <= m.huge_min) s.big[ib] = u;
-    else if (c < kGiantMin) s.huge[ih] = u;
+    else if (c < m.giant_min) s.huge[ih] = u;
     else s.giant[slot[6]] = u;
   }
   // slots of the feature that p's row touches: slot fp is touched when the row holds ANOTHER

@@ -156,7 +156,7 @@ struct TileFacts {  // what a stager lane holds of one tile: NF facts of its tou
 template <int NF>
 __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &rows, const Scratch &s,
                                                unsigned wave, unsigned n_waves, int ph, int phases,
-                                               int with_giant, float *T, float4 *R) {
+                                               int lists, float *T, float4 *R) {
   constexpr int RS = 4 * NF;  // records per touch in R (>= slots per chunk)
   const int K = m.n_factors, F = m.n_fields, RL = m.row_len;
   const int lane = threadIdx.x & 63;
@@ -165,10 +165,11 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
   const int cps = K <= 64 ? 1 : (K + 63) >> 6;  // chunks per slot
   const int slots = record_span(m, 1);
   const unsigned per_feat = K <= 64 ? (slots + SPC - 1) / SPC : slots * cps;
-  // the lists, longest chains first: [giant (when this launch takes them) | huge | big]
-  const unsigned n_giant = with_giant ? static_cast<unsigned>(s.counters[CNT_NGIANT]) : 0u;
-  const unsigned n_huge = n_giant + static_cast<unsigned>(s.counters[CNT_NHUGE]);
-  const unsigned n_items = (n_huge + static_cast<unsigned>(s.counters[CNT_NBIG])) * per_feat;
+  // the lists this launch takes (bits of `lists`: 1 big, 2 huge, 4 giant; the engine: big and huge --
+  // the giant list is the DPP kernel's), longest chains first: [giant | huge | big]
+  const unsigned n_giant = (lists & 4) ? static_cast<unsigned>(s.counters[CNT_NGIANT]) : 0u;
+  const unsigned n_huge = n_giant + ((lists & 2) ? static_cast<unsigned>(s.counters[CNT_NHUGE]) : 0u);
+  const unsigned n_items = (n_huge + ((lists & 1) ? static_cast<unsigned>(s.counters[CNT_NBIG]) : 0u)) * per_feat;
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned li = item / per_feat;
     const int ci = static_cast<int>(item - li * per_feat);
@@ -399,15 +400,14 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
   __builtin_amdgcn_s_setprio(0);
 }
 
-// One launch for the hot features of a block (the big and huge lists; the giant ones -- kGiantMin
-// occurrences or more, only the 65536-row blocks of a multi-GPU job have them -- keep the
-// touch-parallel chains of kernels_chain.h, one chain per wave).  side_blocks > 0: the first
+// One launch for the hot features of a block (the huge and big lists: below the block's giant_min
+// occurrences; longer chains take the touch-parallel DPP chains of kernels_chain.h).  side_blocks > 0: the first
 // workgroups carry the block's two short serial jobs -- workgroup 0 the bias chain, workgroups
 // 1..side_blocks-1 the linear update -- so that they run beside the latent chains without a stream
 // (and a hardware queue) of their own.
 template <int NF>
 __device__ __forceinline__ void ffm_tile_part(const ModelDev &m, const Rows &rows, const Scratch &s,
-                                              int side_blocks, int ph, int phases, int with_giant,
+                                              int side_blocks, int ph, int phases, int lists,
                                               unsigned bidx, unsigned gdim) {
   __shared__ __attribute__((aligned(16))) float lds_T[kUpdWaves][kTileT * kTileRow];
   __shared__ float4 lds_R[kUpdWaves][kTileNR * kTileT * 4 * NF];
@@ -425,35 +425,32 @@ __device__ __forceinline__ void ffm_tile_part(const ModelDev &m, const Rows &row
   }
   const unsigned wv = wave_uniform(threadIdx.x >> 6);
   ffm_tile_items<NF>(m, rows, s, (bidx - side_blocks) * kUpdWaves + wv, (gdim - side_blocks) * kUpdWaves,
-                     ph, phases, with_giant, lds_T[wv], lds_R[wv]);
+                     ph, phases, lists, lds_T[wv], lds_R[wv]);
 }
 template <int NF>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_tile_kernel(ModelDev m, Rows rows, Scratch s,
                                                                       int side_blocks, int ph, int phases,
-                                                                      int with_giant) {
-  ffm_tile_part<NF>(m, rows, s, side_blocks, ph, phases, with_giant, blockIdx.x, gridDim.x);
+                                                                      int lists) {
+  ffm_tile_part<NF>(m, rows, s, side_blocks, ph, phases, lists, blockIdx.x, gridDim.x);
 }
 
 // The whole FFM update of a block in ONE launch on the main stream (one shard, one row phase): the
-// workgroup ranges [bias + linear | giant chains | hot tiles | few-occurrence | loss sum].  No fork /
-// join between streams: the two event hops per block are a quarter of a small block's step
-// (engine_step.h fuses blocks whose update phase is estimated under 150 us).
-template <int NF>
+// workgroup ranges [bias + linear | giant and very hot chains | hot tiles | few-occurrence | loss sum].
+// No fork / join between streams: the two event hops per block are a quarter of a small block's step
+// (engine_step.h fuses blocks whose update phase is estimated under 150 us).  G: interleaved DPP
+// chains per wave (kernels_chain.h).
+template <int NF, int G>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_all_tile_kernel(ModelDev m, Rows rows, Scratch s,
                                                                           int side_blocks, int giant_blocks,
-                                                                          int nt, int ns, int few_only,
-                                                                          int with_giant, int loss_blocks,
-                                                                          double *loss_out, double *loss_scratch) {
+                                                                          int nc, int nt, int ns, int few_only,
+                                                                          int loss_blocks, double *loss_out,
+                                                                          double *loss_scratch) {
   int r = blockIdx.x;
-  if (r < side_blocks) { ffm_tile_part<NF>(m, rows, s, side_blocks, 0, 1, with_giant, r, side_blocks + nt); return; }
+  if (r < side_blocks) { ffm_tile_part<NF>(m, rows, s, side_blocks, 0, 1, 3, r, side_blocks + nt); return; }
   r -= side_blocks;
-  if (r < giant_blocks) {
-    ffm_chain_items<1>(m, rows, s, s.giant, s.counters[CNT_NGIANT], r * kUpdWaves + wave_uniform(threadIdx.x >> 6),
-                       giant_blocks * kUpdWaves, 0, 1);
-    return;
-  }
-  r -= giant_blocks;
-  if (r < nt) { ffm_tile_part<NF>(m, rows, s, side_blocks, 0, 1, with_giant, side_blocks + r, side_blocks + nt); return; }
+  if (r < giant_blocks + nc) { ffm_chain_body<G>(m, rows, s, giant_blocks, 0, 1, r, giant_blocks + nc); return; }
+  r -= giant_blocks + nc;
+  if (r < nt) { ffm_tile_part<NF>(m, rows, s, side_blocks, 0, 1, 3, side_blocks + r, side_blocks + nt); return; }
   r -= nt;
   if (r < ns) { ffm_small_body(m, rows, s, few_only, r, ns); return; }
   loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - ns, loss_blocks);

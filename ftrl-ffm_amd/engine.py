@@ -55,6 +55,7 @@ ABI = [
     ("ffm_engine_last_error", ctypes.c_char_p, []),
     ("ffm_engine_abi_version", ctypes.c_int, []),
     ("ffm_engine_row_len", ctypes.c_int64, [_vp]),
+    ("ffm_engine_default_batch_ramp", ctypes.c_int32, [ctypes.c_float]),
     ("ffm_engine_shard_plan", ctypes.c_int,
      [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i32p, _i32p, _i32p]),
     ("ffm_engine_set_weights", ctypes.c_int, [_vp, _f32p, _f32p, _f32p]),
@@ -113,6 +114,11 @@ ABI = [
 ]
 
 _lib = None
+
+
+def default_batch_ramp(w_alpha):
+    """The block scheduler's default ramp for a learning rate (ffm_engine_default_batch_ramp)."""
+    return int(load_library().ffm_engine_default_batch_ramp(float(w_alpha)))
 
 
 def shard_plan(n_fields, n_shards, field_map=False):

@@ -28,7 +28,7 @@ const std::string_view cmd_help =
     "--n_epochs <epochs>: how many epochs to train\tdefault:1\n"
     "--online <online>: whether to online training mode\tdefault:true\n"
     "--batch_size <rows>: rows per block sent to the GPU\tdefault:4096\n"
-    "--batch_ramp <r>: block size grows as rows_seen/r (0 disables)\tdefault:32\n"
+    "--batch_ramp <r>: block size grows as rows_seen/r (0 disables)\tdefault: by w_alpha (32 up to 1e-3)\n"
     "--seed <seed>: seed of the weight init and the offline shuffle\tdefault:42\n"
     "--device <id>: HIP device ordinal\tdefault:0\n"
     "--n_gpus <n>: shard the field pairs over n devices (one engine each, RCCL all-reduce of the\n"

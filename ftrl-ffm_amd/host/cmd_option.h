@@ -18,7 +18,8 @@ struct config_options {
   bool online = true;
   // --- new: the mini-batch scheduler that replaces the per-sample thread pool ---
   int batch_size = 4096;   // --batch_size: rows per block handed to the engine
-  int batch_ramp = 32;     // --batch_ramp: block size <= rows_seen / ramp (0 = off); DESIGN.md
+  int batch_ramp = -1;     // --batch_ramp: block size <= rows_seen / ramp (0 = off; -1 = the engine's default
+                           //   for w_alpha, ffm_engine_default_batch_ramp: 32 at the reference's rates); DESIGN.md
   uint64_t seed = 42;      // --seed: weight init and the offline shuffle (the reference is unseeded)
   int device = 0;          // --device: HIP device ordinal
   bool learn = false;      // --learn: FFM_FLAG_LEARN, the opt-in variant in which the factors train

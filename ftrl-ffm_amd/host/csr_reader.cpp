@@ -218,8 +218,11 @@ CsrData load_csr(const std::string &path, const std::string &file_type, int n_th
   const size_t len = static_cast<size_t>(st.st_size);
   CsrData out;
   if (len == 0) { close(fd); return out; }
-  const char *base = static_cast<const char *>(mmap(nullptr, len, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0));
+  // (no MAP_POPULATE: that maps the whole file from this one thread before any parsing starts; the
+  // reader threads fault their own ranges in, in parallel)
+  const char *base = static_cast<const char *>(mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0));
   if (base == MAP_FAILED) { close(fd); throw std::runtime_error("mmap failed: " + path); }
+  (void)madvise(const_cast<char *>(base), len, MADV_WILLNEED);
   if (n_threads < 1) n_threads = 1;
   std::vector<size_t> cut(static_cast<size_t>(n_threads) + 1, len);
   cut[0] = 0;
@@ -240,17 +243,37 @@ CsrData load_csr(const std::string &path, const std::string &file_type, int n_th
       parse_range(base + cut[i], base + cut[i + 1], has_field, parts[i]);
     }));
   for (auto &f : futs) f.get();
-  size_t rows = 0, nnz = 0;
-  for (auto &p : parts) { rows += p.nnz.size(); nnz += p.feat.size(); }
-  out.row_ptr.reserve(rows + 1);
-  out.field.reserve(nnz); out.feat.reserve(nnz); out.val.reserve(nnz); out.label.reserve(rows);
-  for (auto &p : parts) {
-    for (int n : p.nnz) out.row_ptr.push_back(out.row_ptr.back() + n);
-    out.field.insert(out.field.end(), p.field.begin(), p.field.end());
-    out.feat.insert(out.feat.end(), p.feat.begin(), p.feat.end());
-    out.val.insert(out.val.end(), p.val.begin(), p.val.end());
-    out.label.insert(out.label.end(), p.label.begin(), p.label.end());
+  // the parts into one CSR: sized once (uninitialised, pod_vector), then every thread copies its own
+  // part to its place -- the concatenation used to be one thread's memcpy of the whole file's
+  // arrays (3.1 M rows/s against the chunked stream's 18.9 M)
+  std::vector<size_t> row0(static_cast<size_t>(n_threads) + 1, 0), ent0(static_cast<size_t>(n_threads) + 1, 0);
+  for (int i = 0; i < n_threads; i++) {
+    row0[i + 1] = row0[i] + parts[i].nnz.size();
+    ent0[i + 1] = ent0[i] + parts[i].feat.size();
   }
+  const size_t rows = row0[n_threads], nnz = ent0[n_threads];
+  out.row_ptr.resize(rows + 1);
+  out.field.resize(nnz); out.feat.resize(nnz); out.val.resize(nnz); out.label.resize(rows);
+  out.row_ptr[0] = 0;
+  futs.clear();
+  for (int i = 0; i < n_threads; i++)
+    futs.emplace_back(std::async(std::launch::async, [&, i] {
+      Part &p = parts[i];
+      const size_t e0 = ent0[i], r0 = row0[i];
+      if (!p.feat.empty()) {
+        std::memcpy(out.field.data() + e0, p.field.data(), 4 * p.feat.size());
+        std::memcpy(out.feat.data() + e0, p.feat.data(), 4 * p.feat.size());
+        std::memcpy(out.val.data() + e0, p.val.data(), 4 * p.feat.size());
+      }
+      int64_t run = static_cast<int64_t>(e0);
+      for (size_t r = 0; r < p.nnz.size(); r++) {
+        run += p.nnz[r];
+        out.row_ptr[r0 + r + 1] = run;
+        out.label[r0 + r] = p.label[r];
+      }
+      Part().swap_clear(p);
+    }));
+  for (auto &f : futs) f.get();
   munmap(const_cast<char *>(base), len);
   close(fd);
   return out;

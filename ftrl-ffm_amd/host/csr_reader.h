@@ -6,17 +6,31 @@
 // Sample-based Reader stays for API parity.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "types.h"
 
 namespace ftrl {
 
+// std::vector whose resize() leaves new elements uninitialised: the loader sizes the whole file's
+// arrays once and its threads then fill disjoint ranges -- a value-initialising resize would first
+// zero every page from ONE thread (as slow as the parse itself).
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_allocator<U>; };
+  using std::allocator<T>::allocator;
+  template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using pod_vector = std::vector<T, default_init_allocator<T>>;
+
 struct CsrData {
-  std::vector<int64_t> row_ptr{0};
-  std::vector<int32_t> field, feat, label;
-  std::vector<float> val;
+  pod_vector<int64_t> row_ptr{0};
+  pod_vector<int32_t> field, feat, label;
+  pod_vector<float> val;
   size_t n_rows() const { return row_ptr.size() - 1; }
   // rows [r0, r1) as one block
   void slice(size_t r0, size_t r1, CsrBlock &out) const;
@@ -35,6 +49,7 @@ struct CsrPart {
   std::vector<int32_t> nnz, field, feat, label;  // nnz, label: per row
   std::vector<float> val;
   void clear() { nnz.clear(); field.clear(); feat.clear(); label.clear(); val.clear(); }
+  void swap_clear(CsrPart &other) { CsrPart empty; std::swap(other, empty); }  // releases other's memory
 };
 void parse_csr_range(const char *begin, const char *end, bool has_field, CsrPart &out);
 

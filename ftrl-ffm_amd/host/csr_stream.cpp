@@ -135,7 +135,12 @@ size_t CsrStream::next(size_t want, CsrBlock &out, size_t max_nnz) {
     while (take > 0 && out.feat.size() + entries(take) > max_nnz) { take--; cut = true; }
     if (take == 0) {
       if (got > 0) break;
-      take = 1;  // a single row beyond the budget goes out alone (the model splits or rejects it)
+      // a single row beyond the budget: `out` may be a page-locked ring entry whose vectors are
+      // registered at their current capacity -- growing them would free pages the runtime still
+      // maps -- so the row is refused here instead of being written
+      if (out.feat.capacity() > 0 && entries(1) > out.feat.capacity())
+        throw std::length_error("a row has more entries than a block can hold (max_nnz)");
+      take = 1;  // (a growable block: the row goes out alone and the model splits or rejects it)
     }
     const int64_t e1 = c->row_ptr[consume_row_ + take];
     const size_t base = out.feat.size();

@@ -59,7 +59,10 @@ FtrlModel::FtrlModel(const config_options &opt, int mt)
     if (n_gpus_ > 1 && opt.field_ranges != "uniform")
       throw std::invalid_argument("--n_gpus > 1 needs --field_ranges uniform (per-field id ranges)");
     std::vector<int32_t> fs(static_cast<size_t>(opt.n_fields) + 1);
+    if (n_gpus_ <= 1) std::printf("FFM_GROUP_RCCL=1: one engine behind the group path (synchronous evaluation, RCCL all-reduce of one rank)\n");
     if (opt.field_ranges == "uniform") {
+      if (opt.n_feats < opt.n_fields)
+        throw std::invalid_argument("--field_ranges uniform needs n_feats >= n_fields (every field owns an id range)");
       per_field_ = opt.n_feats / opt.n_fields;
       for (int f = 0; f <= opt.n_fields; f++) fs[f] = f == opt.n_fields ? opt.n_feats : f * per_field_;
       if (n_gpus_ > 1) cfg.field_start = fs.data();

@@ -58,7 +58,8 @@ constexpr size_t kIoBuf = 1 << 20;
 bool zstd_available() { return zstd().ok; }
 
 struct FloatFrameWriter::Impl {
-  std::string path;
+  std::string path;      // the file as the caller named it
+  std::string tmp_path;  // what is written: renamed over `path` by finish(), removed otherwise
   std::FILE *f = nullptr;
   void *cctx = nullptr;
   std::vector<char> out = std::vector<char>(kIoBuf);
@@ -81,16 +82,24 @@ FloatFrameWriter::FloatFrameWriter(const std::string &path, size_t total_floats,
   if (!zstd().ok) throw std::runtime_error("libzstd.so.1 not available");
   d_->path = path;
   d_->total_bytes = total_floats * sizeof(float);
-  d_->f = std::fopen(path.c_str(), "wb");
-  if (!d_->f) throw std::runtime_error("cannot write " + path);
+  // written beside the target and renamed when complete: an exception half way (a device error while
+  // the model is pulled, a full disk) leaves the previous checkpoint where it was
+  d_->tmp_path = path + ".tmp";
+  d_->f = std::fopen(d_->tmp_path.c_str(), "wb");
+  if (!d_->f) throw std::runtime_error("cannot write " + d_->tmp_path);
   d_->cctx = zstd().createCCtx();
-  zstd().cctxSetParameter(d_->cctx, kParamCompressionLevel, level);
-  // the frame header then carries the content size, as a one-shot ZSTD_compress frame does
-  zstd().cctxSetPledgedSrcSize(d_->cctx, d_->total_bytes);
+  if (!d_->cctx) throw std::runtime_error("ZSTD_createCCtx failed");
+  if (zstd().isError(zstd().cctxSetParameter(d_->cctx, kParamCompressionLevel, level)))
+    throw std::runtime_error("ZSTD_CCtx_setParameter(compressionLevel) failed");
+  // the frame header then carries the content size, as a one-shot ZSTD_compress frame does -- this
+  // reader and the reference's loader both need it there
+  if (zstd().isError(zstd().cctxSetPledgedSrcSize(d_->cctx, d_->total_bytes)))
+    throw std::runtime_error("ZSTD_CCtx_setPledgedSrcSize failed");
 }
 FloatFrameWriter::~FloatFrameWriter() {
   if (d_->cctx) zstd().freeCCtx(d_->cctx);
   if (d_->f) std::fclose(d_->f);
+  if (!d_->done && !d_->tmp_path.empty()) std::remove(d_->tmp_path.c_str());  // an unfinished file
 }
 void FloatFrameWriter::write(const float *p, size_t n) {
   d_->fed += n * sizeof(float);
@@ -101,8 +110,10 @@ void FloatFrameWriter::finish() {
   if (d_->done) return;
   if (d_->fed != d_->total_bytes) throw std::logic_error("FloatFrameWriter: fewer floats than pledged");
   d_->pump(nullptr, 0, kEndEnd);
-  std::fclose(d_->f);
+  const bool closed = std::fclose(d_->f) == 0;
   d_->f = nullptr;
+  if (!closed || std::rename(d_->tmp_path.c_str(), d_->path.c_str()) != 0)
+    throw std::runtime_error("cannot write " + d_->path);
   d_->done = true;
   std::printf("saving to %s, before: %zu -> after: %zu\n", d_->path.c_str(), d_->total_bytes, d_->written);
 }

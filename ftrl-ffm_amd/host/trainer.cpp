@@ -19,7 +19,7 @@ static double seconds_since(timer::time_point t0) {
 
 FtrlOffline::FtrlOffline(const config_options &opt)
     : model_ptr(make_model(opt)), n_epochs(opt.epoch), n_threads(opt.thread_num), seed_(opt.seed),
-      sched_(opt.batch_size, opt.batch_ramp) {
+      sched_(opt.batch_size, opt.batch_ramp < 0 ? ffm_engine_default_batch_ramp(opt.w_alpha) : opt.batch_ramp) {
   // the files go straight into CSR (csr_reader.h); the Sample-based readers exist for callers
   // that use one_epoch(std::vector<Sample>&, ...) as the reference's tests do
   train_data_loader = std::make_unique<Reader>(opt.file_type);
@@ -145,7 +145,7 @@ double FtrlOffline::one_epoch(std::vector<Sample> &samples, bool train, bool /*u
 
 FtrlOnline::FtrlOnline(const config_options &opt)
     : model_ptr(make_model(opt)), n_epochs(opt.epoch), cmd_(opt.cmd),
-      sched_(opt.batch_size, opt.batch_ramp) {
+      sched_(opt.batch_size, opt.batch_ramp < 0 ? ffm_engine_default_batch_ramp(opt.w_alpha) : opt.batch_ramp) {
   if (!cmd_) {
     train_stream_ = std::make_unique<CsrStream>(opt.train_path, opt.file_type, opt.thread_num);
     if (!opt.eval_path.empty()) {

@@ -9,7 +9,8 @@
 // Block-size ramp: block t holds min(batch_size, max(1, rows_seen / batch_ramp)) rows, so the
 // staleness of the weights a row sees never exceeds 1/batch_ramp of the rows already learned
 // from -- that keeps the epoch logloss within 1e-4 of the reference's strictly sequential loop
-// (DESIGN.md "Batch semantics"; batch_ramp = 0 turns the ramp off).
+// (DESIGN.md "Batch semantics"; batch_ramp = 0 turns the ramp off; the default follows the learning
+// rate: ffm_engine_default_batch_ramp(w_alpha), 32 at the reference's rates).
 #pragma once
 #include <fstream>
 #include <memory>

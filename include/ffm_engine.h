@@ -129,6 +129,16 @@ int ffm_engine_abi_version(void);
 int ffm_engine_shard_plan(int32_t n_fields, int32_t n_shards, int32_t field_map, int32_t *pair_owner,
                           int32_t *lin_owner, int32_t *bias_owner);
 
+/* The block scheduler's default block-size ramp for a learning rate (the mini-batch scheduler that
+ * replaces the per-sample loop of src/task/ftrl_offline.cpp:74-83 sizes block t as
+ * min(batch_size, max(1, rows_seen / ramp)): the weights a row sees are then never staler than
+ * 1/ramp of the rows already learned from).  32 at the reference's default w_alpha = 1e-4 and up to
+ * 1e-3; above, eight times more per decade of learning rate -- 256 at 0.01, 2048 at w_alpha = 0.1
+ * --, which keeps train and eval logloss within 1e-4 of the sequential loop at the rates where
+ * weights really move (tests/test_gpu_scale.py pins both ends; at alpha = 0.1 a ramp of 32 is off
+ * by 5e-4 and one of 689 still by 1.5e-4 on the held-out rows). */
+int32_t ffm_engine_default_batch_ramp(float w_alpha);
+
 /* Row length of the (logical) latent arrays: n_fields*n_factors (FFM), n_factors (FM), 0 (LR). */
 int64_t ffm_engine_row_len(const ffm_engine *e);
 

@@ -605,6 +605,49 @@ def test_logloss_within_1e4_of_sequential_reference_at_39x16_blocks_of_8192():
     assert abs(d_train) < 1e-4 and abs(d_eval) < 1e-4
 
 
+def test_logloss_within_1e4_at_blocks_of_65536():
+    """The same bound at the block size every weak-scaling number of the 8-GPU job rests on
+    (8192 x 8 rows per step): FFM F=39 k=16, reference default hyper-parameters, the scheduler's
+    default ramp (32: 65 536-row blocks from row 2 097 152 on), 2.4 M training rows.  The strictly
+    sequential loop over 2.4 M rows is minutes of one CPU core, so its two means are a committed
+    fixture (tests/golden/g10_sequential_logloss_39x16.json, written by
+    tests/golden/make_sequential_logloss.py with the oracle the CPU suite pins to the compiled
+    reference); this test regenerates the same seeded rows and trains them in blocks on the GPU."""
+    import json
+    import os
+    import sys
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, golden)
+    import make_sequential_logloss as g10
+    with open(os.path.join(golden, "g10_sequential_logloss_39x16.json")) as f:
+        want = json.load(f)
+    F, k, nf, Bmax = g10.F, g10.K, g10.F * g10.PER, 65536
+    ramp = fa.default_batch_ramp(g10.HP["w_alpha"])
+    assert ramp == 32
+    train, held, lin_w, vec_w = g10.inputs()
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=Bmax, max_batch_nnz=Bmax * F,
+                  max_row_nnz=F, **g10.HP)
+    st = e.zero_state()
+    st["lin_w"][...] = lin_w
+    st["vec_w"][...] = vec_w
+    e.set_state(st)
+    del vec_w, st
+    seen, n_full = 0, 0
+    while seen < g10.N_TRAIN:
+        rows = min(Bmax, max(1, seen // ramp), g10.N_TRAIN - seen)
+        e.train_batch_async(train.rows(seen, seen + rows))
+        n_full += rows == Bmax
+        seen += rows
+    tl = e.train_flush()
+    el = sum(e.predict_batch(held.rows(r0, min(r0 + Bmax, g10.N_EVAL)))[1] for r0 in range(0, g10.N_EVAL, Bmax))
+    e.close()
+    assert n_full >= 3  # the bound is exercised at full 65 536-row blocks
+    d_train = tl / g10.N_TRAIN - want["sequential_train_logloss"]
+    d_eval = el / g10.N_EVAL - want["sequential_eval_logloss"]
+    print("delta logloss at 65536-row blocks: train %+.3e eval %+.3e" % (d_train, d_eval))
+    assert abs(d_train) < 1e-4 and abs(d_eval) < 1e-4
+
+
 @pytest.mark.parametrize("zero_copy", [False, True], ids=["copied", "zero_copy"])
 def test_staged_host_blocks_equal_block_by_block(zero_copy):
     """ffm_engine_stage_batch + train_forward_staged + train_update_device (what a sharded rank
@@ -752,9 +795,12 @@ def test_block_ramp_under_stress_hyperparameters_is_pinned():
     table, pinned: FFM F=8 k=16, 200 000 Zipf rows + 20 000 held out, fresh model.  The engine's
     block semantics are the oracle's bit for bit, so the deltas are reproducible numbers, not
     estimates -- a regression in the ramp, the block algorithm or the loss shows up here:
-        ramp   32 (the CLI default):  +2.07e-4 train, +5.45e-4 eval   (OUTSIDE the north star's 1e-4)
-        ramp 2048:                    +8.8e-6 train,  -5.6e-6 eval    (inside)
-    and the reference's default hyper-parameters stay inside 1e-4 at ramp 32 (the other gpu test)."""
+        ramp   32 (the default at the reference's rates):  +2.07e-4 train, +5.45e-4 eval   (OUTSIDE 1e-4)
+        ramp 2048:                                         +8.8e-6 train,  -5.6e-6 eval    (inside)
+    which is why the scheduler's default follows the learning rate (ffm_engine_default_batch_ramp:
+    eight times more per decade above 1e-3, 2048 at alpha = 0.1 -- a ramp of 689 measured -1.5e-4 on
+    the held-out rows): that ramp must land inside the north star's 1e-4, and the reference's default
+    hyper-parameters stay inside at ramp 32 (the other gpu tests)."""
     F, K, PER = 8, 16, 1250
     nf = F * PER
     N, NE = 200_000, 20_000
@@ -769,8 +815,11 @@ def test_block_ramp_under_stress_hyperparameters_is_pinned():
     _, seq_t = o.train_rows(train)
     _, seq_e = o.predict_batch(held)
     assert abs(seq_t / N - 0.681666943362949) < 1e-9 and abs(seq_e / NE - 0.6791794026370438) < 1e-9
+    auto = fa.default_batch_ramp(STRESS_HP["w_alpha"])
+    assert auto == 2048 and fa.default_batch_ramp(DEFAULT_HP["w_alpha"]) == 32
+    assert fa.default_batch_ramp(0.01) == 256 and fa.default_batch_ramp(1e-3) == 32
     want = {32: (2.0671599e-4, 5.4488624e-4), 2048: (8.772928e-6, -5.551089e-6)}
-    for ramp, (dt_want, de_want) in want.items():
+    for ramp, pinned in want.items():
         e = fa.Engine("FFM", nf, F, K, skip_init=True, max_batch_rows=8192, max_batch_nnz=8192 * F,
                       max_row_nnz=F, **STRESS_HP)
         e.set_state(st)
@@ -783,4 +832,8 @@ def test_block_ramp_under_stress_hyperparameters_is_pinned():
         el = sum(e.predict_batch(held.rows(r0, min(r0 + 8192, NE)))[1] for r0 in range(0, NE, 8192))
         e.close()
         dt, de = tl / N - seq_t / N, el / NE - seq_e / NE
-        assert abs(dt - dt_want) < 2e-8 and abs(de - de_want) < 2e-8, (ramp, dt, de)
+        assert abs(dt - pinned[0]) < 2e-8 and abs(de - pinned[1]) < 2e-8, (ramp, dt, de)
+        if ramp == auto:
+            # the scheduler's default for this learning rate (what the CLI uses without --batch_ramp)
+            # lands inside the north star's bound
+            assert abs(dt) < 1e-4 and abs(de) < 1e-4, (ramp, dt, de)

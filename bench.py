@@ -71,7 +71,7 @@ def update_fused(n_rows, nnz_block, k, n_shards):
         return False
     if env is not None:
         return int(env) != 0
-    return nnz_block * max(0.0, nnz_block / n_rows - 1.0) * k / 0.44e6 < 150.0
+    return nnz_block * max(0.0, nnz_block / n_rows - 1.0) * k / 0.44e6 < 100.0
 
 
 def algorithmic_bytes_per_row(nnz, k):

@@ -262,7 +262,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   const int fm_side_blocks = side_in_fm ? 1 + lin_blocks : 0;
   const bool forked = rows.n_rows > 0 && lin_owner && !e->serial && !side_in_hot && !side_in_fm;
   if (rows.n_rows > 0 && lin_owner && e->serial && !side_in_hot) {
-    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
+    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, kUpdThreads, 0, e->m, rows.n_rows, e->sc[e->cur]);
     if (rows.nnz > 0)
       LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
   }
@@ -271,7 +271,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
     // the bias chain (one wave, as long as the block has rows) alone on the side stream; the linear
     // update shares the main stream with the latent update of the few-occurrence features
-    LAUNCH_ON(e, e->aux2, K_BIAS_UPDATE, bias_update_kernel, 1, 64, 0, e->m, rows.n_rows, e->sc[e->cur]);
+    LAUNCH_ON(e, e->aux2, K_BIAS_UPDATE, bias_update_kernel, 1, kUpdThreads, 0, e->m, rows.n_rows, e->sc[e->cur]);
     HIP_TRY(hipEventRecord(e->ev_join, e->aux2));
     if (rows.nnz > 0)
       LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
@@ -306,7 +306,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // An estimate of the phase's length from the touch-elements of the block (0.44 per ns measured at FFM 39 x 16).
     const double per_row = rows.n_rows > 0 ? static_cast<double>(rows.nnz) / rows.n_rows : 0.0;
     const double phase_us = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / 0.44e6;
-    const bool fused = e->update_fused >= 0 ? e->update_fused != 0 : phase_us < 150.0;
+    const bool fused = e->update_fused >= 0 ? e->update_fused != 0 : phase_us < 100.0;
     if (fused && P == 1 && own_tg && e->singles_in_row && e->m.n_shards == 1) {
       const int fc = e->grid_huge, fh = e->grid_hot, fs = e->grid_small, nf = tile_nf(e);
       const int gb = rows.nnz < kGiantMin ? 0 : std::min(e->grid_giant, 64);

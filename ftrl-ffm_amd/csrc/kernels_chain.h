@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_all_kernel(ModelDev m, 
   if (b < side_blocks) {
     if (b == 0) {
       __builtin_amdgcn_s_setprio(3);  // one wave, n_rows dependent touches
-      if (threadIdx.x < 64) bias_update_body(m, 0, rows.n_rows, s);
+      bias_update_body(m, 0, rows.n_rows, s);
     } else {
       linear_update_body(m, rows, s, b - 1, side_blocks - 1, 0, 1, skip_once);
     }

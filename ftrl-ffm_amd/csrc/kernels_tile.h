@@ -49,7 +49,8 @@ constexpr int kTileRow = 80;  // floats per transposer row: 64 + 16 of padding (
 #define FFM_TILE_DV 1
 #endif
 constexpr int kTileDV = FFM_TILE_DV;  // tiles whose partner weights are in flight (1 .. 3)
-constexpr int kTileNR = 4;            // fact-record buffers: the tiles in flight and the one being applied
+constexpr int kTileNR = kTileDV == 1 ? 2 : 4;  // fact-record buffers (a power of two): the tiles in flight and the one being applied
+                                              // (k = 4: 4 KB each per wave -- two of them leave three workgroups per CU, four leave one)
 #ifndef FFM_TILE_G
 #define FFM_TILE_G 4
 #endif
@@ -413,11 +414,11 @@ __device__ __forceinline__ void ffm_tile_part(const ModelDev &m, const Rows &row
   __shared__ float4 lds_R[kUpdWaves][kTileNR * kTileT * 4 * NF];
   if (static_cast<int>(bidx) < side_blocks) {
     if (bidx == 0) {
-      // one wave, n_rows dependent touches: let it win the issue arbitration on its SIMD
+      // 2 n_rows dependent adds: let its waves win the issue arbitration on their SIMDs
       __builtin_amdgcn_s_setprio(3);
       // (the whole chain in the last row phase: the row kernel of a later phase still derives the
       // bias weight from the block-start bias_n / bias_z)
-      if (threadIdx.x < 64 && ph == phases - 1) bias_update_body(m, 0, rows.n_rows, s);
+      if (ph == phases - 1) bias_update_body(m, 0, rows.n_rows, s);
     } else {
       linear_update_body(m, rows, s, bidx - 1, side_blocks - 1, ph, phases);
     }
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_tile_kernel(ModelDev m
 // The whole FFM update of a block in ONE launch on the main stream (one shard, one row phase): the
 // workgroup ranges [bias + linear | giant and very hot chains | hot tiles | few-occurrence | loss sum].
 // No fork / join between streams: the two event hops per block are a quarter of a small block's step
-// (engine_step.h fuses blocks whose update phase is estimated under 150 us).  G: interleaved DPP
+// (engine_step.h fuses blocks whose update phase is estimated under 100 us).  G: interleaved DPP
 // chains per wave (kernels_chain.h).
 template <int NF, int G>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_all_tile_kernel(ModelDev m, Rows rows, Scratch s,

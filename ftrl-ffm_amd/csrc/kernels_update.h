@@ -165,49 +165,113 @@ __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, 
   linear_update_body(m, rows, s, blockIdx.x, gridDim.x, 0, 1, skip_once);
 }
 
-// Bias update: one wave walks all rows of the block in order (update_bias_nz, :79-85).
-// Rows [row_lo, row_hi) of the block (one row phase, or all of them).
+// Bias update: all rows of the block in order (update_bias_nz, ftrl_model.cpp:79-85) -- n_rows
+// dependent touches of ONE accumulator, the longest serial chain of a block.  Rows [row_lo, row_hi)
+// of the block (one row phase, or all of them).  Called by every thread of a 256-thread workgroup.
+//
+// The two recurrences -- n += g*g and z += g - sigma*w -- are 2 * n_rows dependent fp32 adds
+// whatever the layout (5.75 cycles each on gfx950, tools/issue_probe.hip: 39 us for 8192 rows); what
+// the r03 version added on top was the price of keeping touch t in lane t: 63 dependent
+// v_add_f32_dpp wave_shr:1 per 64 rows and chain at 15.5 cycles each (12 ns per row, 100 us per
+// 8192-row block -- the floor of FM's whole update phase).  Here a chain runs in the registers of
+// one lane instead: 64 increments go through LDS into 64 registers of lane 0 (16 ds_read_b128),
+// then 64 plain dependent adds.  Four waves form a pipeline over passes of 64 rows,
+// one workgroup barrier per pass:
+//   wave 0  pass k   : g*g of its rows (lane = row) -> LDS
+//   wave 1  pass k-1 : the running n, every prefix kept -> LDS
+//   wave 2  pass k-2 : lane = row: sigma from the n before and after the row, g - sigma*w -> LDS
+//   wave 3  pass k-3 : the running z
+// Same operations on the same values in the same order as the one-thread loop: bit-identical.
 __device__ __forceinline__ void bias_update_body(const ModelDev &m, int row_lo, int row_hi, const Scratch &sc) {
   if (!m.bias_own) return;             // another shard's
   if (sc.counters[CNT_ERROR]) return;  // untrainable block (ERR_ROW_TOO_LONG): a no-op
-  struct { const float *tg; } s{sc.tg + row_lo};
+  constexpr int kRing = 4;
+  __shared__ __attribute__((aligned(16))) float s_gg[kRing][64];   // g*g of a pass (-0 for rows past the end)
+  __shared__ __attribute__((aligned(16))) float s_na[kRing][64];   // n after row j of the pass
+  __shared__ float s_n0[kRing];                                    // n before the pass
+  __shared__ __attribute__((aligned(16))) float s_inc[kRing][64];  // g - sigma*w (-0 past the end)
+  const float *tg = sc.tg + row_lo;
   const int n_rows = row_hi - row_lo;
   const int lane = threadIdx.x & 63;
-  float n = m.bias3[1], z = m.bias3[2];
+  const int wv = wave_uniform(threadIdx.x >> 6);
+  const int passes = (n_rows + 63) >> 6;
   const float w = m.bias3[0];
-  // 64 rows per pass; the two serial recurrences are software-pipelined against each other: the
-  // running n of rows r0+64.. is computed together with the running z of rows r0.. (two
-  // interleaved DPP chains cost what one costs).  Same operations on the same values in the same
-  // order as linear_chain64 / the one-thread loop.
-  float g = lane < n_rows ? s.tg[lane] : 0.0f;
-  float g_next = (64 + lane) < n_rows ? s.tg[64 + lane] : 0.0f;
-  float n_after = n_rows > 0 ? wave_sequential_prefix(n, lane < n_rows ? g * g : -0.0f) : n;
-  for (int r0 = 0; r0 < n_rows; r0 += 64) {
-    const bool live = r0 + lane < n_rows;
-    const float g_nn = (r0 + 128 + lane) < n_rows ? s.tg[r0 + 128 + lane] : 0.0f;  // two passes ahead
-    float n_before = __int_as_float(__builtin_amdgcn_update_dpp(
-        __float_as_int(n), __float_as_int(n_after), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-    if (lane == 0) n_before = n;
-    n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n_after), 63));
-    const float sgm = div_alpha(m.h, sqrt_cr(n_after) - sqrt_cr(n_before));
-    const float inc = live ? g - sgm * w : -0.0f;
-    float z_run;
-    if (r0 + 64 < n_rows) {
-      const float q_next = (r0 + 64 + lane) < n_rows ? g_next * g_next : -0.0f;
-      wave_sequential_prefix2(z, inc, z_run, n, q_next, n_after);
-    } else {
-      z_run = wave_sequential_prefix(z, inc);
+  float acc = wv == 1 ? m.bias3[1] : wv == 3 ? m.bias3[2] : 0.0f;  // wave 1: running n; wave 3: running z
+  // the 64 values of a pass added one after another in the registers of LANE 0 (the whole chain
+  // under one branch: a predicated store per group of four cost 39 cycles each, tools/issue_probe.hip)
+  auto chain64 = [&](const float *src, float *after_out) {
+    if (lane != 0) return;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *o4 = reinterpret_cast<float4 *>(after_out);
+    float4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = s4[j];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {  // v[j] becomes the running sum after each of its four rows
+      v[j].x = acc + v[j].x;
+      v[j].y = v[j].x + v[j].y;
+      v[j].z = v[j].y + v[j].z;
+      v[j].w = v[j].z + v[j].w;
+      acc = v[j].w;
     }
-    z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_run), 63));
-    g = g_next;
-    g_next = g_nn;
+    // (the stores after the whole chain: a store placed behind the add that produces its data holds
+    // the next add back -- in-order issue -- and doubled the pass: 1450 against 770 cycles)
+    __builtin_amdgcn_sched_barrier(0);
+    if (after_out) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) o4[j] = v[j];
+    }
+  };
+  // waves 0 and 2 read tmp_grad of their rows four passes ahead (a pass takes ~600 cycles, a load
+  // that misses the L2 longer): ga = the current four passes' values, gb = the next four's.  The loop
+  // is unrolled by four so that no register in flight is ever moved.
+  const int off = wv == 2 ? 2 : 0;  // wave 2 works on pass k - 2
+  float ga[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto load4 = [&](int pass0, float (&g)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = ((pass0 + q) << 6) + lane;
+      g[q] = (pass0 + q >= 0 && r < n_rows) ? tg[r] : 0.0f;
+    }
+  };
+  if (wv == 0 || wv == 2) load4(-off, ga);
+  auto step = [&](int k, float g) {
+    if (wv == 0) {
+      if (k < passes) s_gg[k % kRing][lane] = (k << 6) + lane < n_rows ? g * g : -0.0f;  // x + -0.0f == x bit for bit
+    } else if (wv == 1) {
+      if (k >= 1 && k - 1 < passes) {
+        if (lane == 0) s_n0[(k - 1) % kRing] = acc;
+        chain64(s_gg[(k - 1) % kRing], s_na[(k - 1) % kRing]);
+      }
+    } else if (wv == 2) {
+      if (k >= 2 && k - 2 < passes) {
+        const int r0 = (k - 2) << 6, rb = (k - 2) % kRing;
+        const float na = s_na[rb][lane];
+        const float nb = lane == 0 ? s_n0[rb] : s_na[rb][lane == 0 ? 0 : lane - 1];
+        const float sgm = div_alpha(m.h, sqrt_cr(na) - sqrt_cr(nb));  // na = nb + g*g
+        s_inc[rb][lane] = r0 + lane < n_rows ? g - sgm * w : -0.0f;
+      }
+    } else {
+      if (k >= 3) chain64(s_inc[(k - 3) % kRing], nullptr);
+    }
+    __syncthreads();
+  };
+  for (int k0 = 0; k0 < passes + 3; k0 += 8) {
+    if (wv == 0 || wv == 2) load4(k0 + 4 - off, gb);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (k0 + q < passes + 3) step(k0 + q, ga[q]);
+    if (wv == 0 || wv == 2) load4(k0 + 8 - off, ga);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (k0 + 4 + q < passes + 3) step(k0 + 4 + q, gb[q]);
   }
-  if (lane == 0) {
-    m.bias3[1] = n;
-    m.bias3[2] = z;
+  if (lane == 0 && n_rows > 0) {
+    if (wv == 1) m.bias3[1] = acc;
+    if (wv == 3) m.bias3[2] = acc;
   }
 }
-__global__ __launch_bounds__(64) void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
+__global__ __launch_bounds__(kUpdThreads) void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
   bias_update_body(m, 0, n_rows, s);
 }
 
@@ -682,7 +746,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
   if (static_cast<int>(blockIdx.x) < side_blocks) {
     if (blockIdx.x == 0) {
       __builtin_amdgcn_s_setprio(3);  // one wave, n_rows dependent touches
-      if (threadIdx.x < 64) bias_update_body(m, 0, rows.n_rows, s);
+      bias_update_body(m, 0, rows.n_rows, s);
     } else {
       linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, 0, 1, skip_once);
     }

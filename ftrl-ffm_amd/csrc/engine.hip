@@ -657,29 +657,18 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   e->max_nnz = cfg->max_batch_nnz;
   if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
-  if (const char *sv = std::getenv("FFM_PREP_WINDOW")) e->prep_window = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_UPDATE_FUSED")) e->update_fused = std::atoi(sv) != 0 ? 1 : 0;
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
   // a shard's row holds ~1/n_shards of the pairs: one wave per row, so that (with the small LDS
   // footprint of short rows) many more rows are in flight per CU
   if (cfg->n_shards > 1) e->row_threads = 64;
-  if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::min(kRowThreads, std::max(64, std::atoi(sv) / 64 * 64));
-  if (const char *sv = std::getenv("FFM_SINGLE_KERNEL")) e->single_kernel = sv[0] != '0';
-  if (const char *sv = std::getenv("FFM_SINGLE_FLAT")) e->single_flat = sv[0] != '0';
-  if (const char *sv = std::getenv("FFM_GRID_SINGLE")) e->grid_single = std::max(1, std::atoi(sv));
   // (the lean once-only kernel of a compact shard holds six waves per SIMD: 1152 workgroups
   // measured 2.5 % per step better than 768 on an 8-GPU rank's blocks)
   if (cfg->n_shards > 1) e->grid_single = 1152;
 
-  if (const char *sv = std::getenv("FFM_GRID_PULL")) e->grid_pull = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_PHASES")) e->phases = std::min(kMaxPhases, std::max(1, std::atoi(sv)));
-  if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
-  if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_CHAIN_MIN")) e->chain_min_fixed = std::max(kChainMin, std::atoi(sv));
-  if (const char *sv = std::getenv("FFM_GRID_HUGE")) e->grid_huge = std::max(1, std::atoi(sv));
-  if (const char *sv = std::getenv("FFM_GRID_GIANT")) e->grid_giant = std::max(0, std::atoi(sv));
-  if (const char *sv = std::getenv("FFM_STAGE_THREAD")) e->stage_thread_on = sv[0] != '0';
   {
     const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
     const int64_t per = cfg->n_factors % 4 == 0 ? static_cast<int64_t>(cfg->n_fields) * cfg->n_factors / 4
@@ -702,9 +691,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.bias_own = 1;
   m.huge_min = kHugeMin;
   m.giant_min = kGiantMin;  // (FFM: chosen per block, chain_min_for)
-  if (const char *sv = std::getenv("FFM_HUGE_MIN")) {
-    m.huge_min = std::max(kSmallMax + 1, std::atoi(sv));
-  }
   m.rec_slots = m.n_fields;
   e->n_records = cfg->n_feats;
   // field-pair partition: this shard's ranges, and (with per-field id ranges) compact storage

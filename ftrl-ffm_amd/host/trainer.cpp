@@ -45,7 +45,6 @@ BlockRing::~BlockRing() {
 bool BlockRing::ready() {
   if (tried_) return !ring_.empty();
   tried_ = true;
-  if (std::getenv("FTRL_NO_PINNED_RING")) return false;  // (A/B aid: the copying path)
   ring_.resize(kRing);
   seq_.assign(kRing, 0);
   for (int i = 0; i < kRing; i++)

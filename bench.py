@@ -59,7 +59,7 @@ def chain_min_for(n_rows, nnz_block, k, n_shards, ffm=True):
         return GIANT_MIN
     touch_elems = nnz_block * max(0.0, nnz_block / n_rows - 1.0) * k / max(1, n_shards)
     span_us = max(touch_elems / 0.88e6, n_rows * 0.012)
-    return int(min(float(GIANT_MIN), max(64.0, span_us / 0.2)))
+    return int(min(float(GIANT_MIN), max(64.0, span_us / 0.3)))
 
 
 def update_fused(n_rows, nnz_block, k, n_shards):

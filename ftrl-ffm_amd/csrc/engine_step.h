@@ -89,16 +89,19 @@ __global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_c
 // in ~3 us: s_memtime stamps at FFM 39 x 16); the DPP chains take ~0.03 us per touch of a chain at
 // two to three times the instructions.  So the tile kernel's longest chain should last about as
 // long as what bounds the update phase anyway -- its throughput-bound time (0.88 touch-elements per
-// ns measured) or the bias chain's one wave (12 ns per row) -- and only longer chains are worth the
-// DPP kernel's instructions: none of a 8192 x 39 block's (1080 touches at most), the few
-// hundred-touch features of a 4096 x 8 block.  Never above kGiantMin.
+// ns measured with round 3's kernels; the tile kernel needs half the instructions, hence the 0.3
+// below where its 0.2 us per touch would say 0.2) or the bias chain (12 ns per row) -- and only
+// longer chains are worth the DPP kernel's instructions: the top id of every field of an 8192 x 39
+// block (~1030 touches; boundary 733: 1.011 -> 0.978 ms per step, 512 the same, 384 and 256 slower:
+// the DPP kernel's extra instructions then bound the phase), the few hundred-touch features of a
+// 4096 x 8 block.  Never above kGiantMin.
 static int chain_min_for(const ffm_engine *e, const Rows &rows) {
   if (e->m.type != FFM_MODEL_FFM || rows.n_rows <= 0) return e->m.giant_min;
   if (e->chain_min_fixed) return std::min(e->chain_min_fixed, kGiantMin);
   const double per_row = static_cast<double>(rows.nnz) / rows.n_rows;
   const double touch_elems = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / std::max(1, e->m.n_shards);
   const double span_us = std::max(touch_elems / 0.88e6, rows.n_rows * 0.012);
-  return static_cast<int>(std::min<double>(kGiantMin, std::max<double>(kChainMin, span_us / 0.2)));
+  return static_cast<int>(std::min<double>(kGiantMin, std::max<double>(kChainMin, span_us / 0.3)));
 }
 
 static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st, bool timed = true) {

@@ -13,10 +13,12 @@ from ftrl_ffm_amd import synth
 nf = 33_000_000 - 33_000_000 % 39
 g = synth.Generator(39, nf, "zipf", seed=42)
 t0 = time.time()
+import os
+chunks = int(os.environ.get("CLI_CHUNKS", "64"))  # x 32768 rows: 2 M rows (1.1 GB of text) by default
 with open('/tmp/synth33m.ffm', 'w') as f:
-    for _ in range(16):
+    for _ in range(chunks):
         f.write(synth.to_libffm_text(g.block(32768)))
-print("wrote 524288 rows of 39 fields in %.1fs" % (time.time() - t0))
+print("wrote %d rows of 39 fields in %.1fs" % (chunks * 32768, time.time() - t0))
 g2 = synth.Generator(39, 39 * 25000, "zipf", seed=43)
 with open('/tmp/synth1m.ffm', 'w') as f:
     for _ in range(8):

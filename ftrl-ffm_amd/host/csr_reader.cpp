@@ -228,6 +228,16 @@ CsrData load_csr(const std::string &path, const std::string &file_type, int n_th
   const size_t bytes = static_cast<size_t>(st.st_size), tok = file_type == "libffm" ? 6 : 4;
   out.field.reserve(bytes / tok); out.feat.reserve(bytes / tok); out.val.reserve(bytes / tok);
   out.row_ptr.reserve(bytes / 8 + 2); out.label.reserve(bytes / 8 + 1);
+  // first touch of ~1 GB per million rows is what this loop would otherwise spend its time on: ask for
+  // huge pages (512 times fewer faults where transparent huge pages are on "madvise" or "always")
+  auto huge = [](void *p, size_t n) {
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
+    const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + n) & ~uintptr_t(4095);
+    if (e > a) (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
+  };
+  huge(out.field.data(), 4 * out.field.capacity());
+  huge(out.feat.data(), 4 * out.feat.capacity());
+  huge(out.val.data(), 4 * out.val.capacity());
   CsrBlock blk;
   size_t got;
   while ((got = stream.next(CsrStream::kChunkLines, blk)) != 0) {
@@ -242,7 +252,7 @@ CsrData load_csr(const std::string &path, const std::string &file_type, int n_th
     std::memcpy(out.label.data() + r0, blk.label.data(), 4 * got);
     for (size_t r = 0; r < got; r++) out.row_ptr[r0 + r + 1] = static_cast<int64_t>(e0) + blk.row_ptr[r + 1];
   }
-  out.field.shrink_to_fit(); out.feat.shrink_to_fit(); out.val.shrink_to_fit();
+  // (no shrink_to_fit: it would copy the arrays once more; the untouched tail of a reserve costs no memory)
   return out;
 }
 

@@ -102,6 +102,32 @@ void CsrStream::worker() {
   }
 }
 
+bool CsrStream::acquire_chunk(const CsrPart **part, const std::vector<int64_t> **row_ptr) {
+  if (consume_row_ != 0) throw std::logic_error("acquire_chunk after a partial next()");
+  std::unique_lock<std::mutex> lock(mu_);
+  if (consume_id_ >= next_id_ && scan_pos_ >= len_) return false;
+  cv_ready_.wait(lock, [&] {
+    const Chunk &k = ring_[consume_id_ % ring_.size()];
+    return !error_.empty() || (k.ready && k.id == consume_id_);
+  });
+  if (!error_.empty()) throw std::out_of_range(error_);
+  const Chunk &c = ring_[consume_id_ % ring_.size()];
+  *part = &c.part;
+  *row_ptr = &c.row_ptr;
+  return true;
+}
+
+void CsrStream::release_chunk() {
+  {
+    std::lock_guard<std::mutex> lock(mu_);
+    Chunk &c = ring_[consume_id_ % ring_.size()];
+    delivered_ += c.part.nnz.size();
+    c.ready = false;
+    consume_id_++;
+  }
+  cv_work_.notify_all();
+}
+
 size_t CsrStream::next(size_t want, CsrBlock &out, size_t max_nnz) {
   out.clear();
   size_t got = 0;

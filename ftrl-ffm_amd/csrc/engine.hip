@@ -266,7 +266,7 @@ struct ffm_engine {
   // Uploads of staged host blocks (pull_block_kernel) go on the prep stream, ahead of the block's
   // grouping.  (A fifth stream for them shares a hardware queue with one of the four and
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
-  hipStream_t copy = nullptr;  // = prep
+  hipStream_t copy = nullptr;  // the upload kernel's stream: prep, or aux3 for long steps (ffm_engine_create)
   int chain_min_fixed = 0;      // FFM_CHAIN_MIN: the giant list's boundary for every block (0: chosen per block)
   int update_fused = -1;        // FFM_UPDATE_FUSED: 1 / 0 the whole FFM update in one launch always / never (-1: small blocks)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
@@ -868,7 +868,17 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
   TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
-  e->copy = e->prep;
+  // Where the upload kernel runs.  Beside the grouping on the prep queue it costs a long step ~30 us
+  // (0.990 -> 0.957 ms at FFM 39 x 16 with the launch knocked out): it sits between two groupings and
+  // lands on the step boundary.  On the longest chains' stream (idle once they end) it runs in the tail
+  // of the update phase instead: 0.990 -> 0.960 ms.  Steps under ~0.5 ms (C2, C3, FM) measured 1-3 %
+  // slower that way, and a shard rank's chain kernel fills that stream to the end of the step.
+  {
+    const double per_row = e->max_rows > 0 ? static_cast<double>(e->max_nnz) / e->max_rows : 0.0;
+    const double phase_us = static_cast<double>(e->max_nnz) * std::max(0.0, per_row - 1.0) * m.n_factors / 0.44e6;
+    const bool long_step = m.type == FFM_MODEL_FFM && m.n_shards == 1 && m.n_factors % 4 == 0 && phase_us >= 200.0;
+    e->copy = long_step ? e->aux3 : e->prep;
+  }
   for (auto &ev : e->ev_row) TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   for (int i = 0; i < ffm_engine::kSets; i++) {
     TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));

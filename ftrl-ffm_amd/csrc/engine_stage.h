@@ -177,6 +177,7 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
       if (slot_was_used) HIP_TRY(hipStreamWaitEvent(e->copy, s2.ev_trained, 0));  // nothing reads its device arrays
       hipLaunchKernelGGL(pull_block_kernel, dim3(grid_pull), dim3(256), 0, e->copy, job);
       HIP_TRY(hipEventRecord(s2.ev_copied, e->copy));
+      if (e->copy != e->prep) HIP_TRY(hipStreamWaitEvent(e->prep, s2.ev_copied, 0));  // the grouping reads the slot
       return prepare_submit(e, plan, timed);
     };
     rc2 = body();

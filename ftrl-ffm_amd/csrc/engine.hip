@@ -41,6 +41,7 @@
 #include "kernels_chain.h"
 #include "kernels_tile.h"
 #include "kernels_fm.h"
+#include "kernels_sort.h"
 
 using namespace ftrl_dev;
 
@@ -267,6 +268,7 @@ struct ffm_engine {
   // grouping.  (A fifth stream for them shares a hardware queue with one of the four and
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
   hipStream_t copy = nullptr;  // the upload kernel's stream: prep, or aux3 for long steps (ffm_engine_create)
+  bool own_sort = false;        // the grouping's sort: kernels_sort.h (short steps) or rocPRIM Onesweep (ffm_engine_create)
   int chain_min_fixed = 0;      // FFM_CHAIN_MIN: the giant list's boundary for every block (0: chosen per block)
   int update_fused = -1;        // FFM_UPDATE_FUSED: 1 / 0 the whole FFM update in one launch always / never (-1: small blocks)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
@@ -835,6 +837,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(rocprim::radix_sort_pairs<GroupSortConfig>(nullptr, e->sort_tmp_bytes, s.key, s.skey,
                                       rocprim::counting_iterator<int>(0), s.occ, E, 0u, e->sort_bits,
                                       e->stream));
+    e->sort_tmp_bytes = std::max(e->sort_tmp_bytes, sort_scratch_bytes(E));
     unsigned char *tmp = nullptr;
     TRY_ALLOC(e->alloc(&tmp, e->sort_tmp_bytes));
     e->d_sort_tmp[0] = tmp;
@@ -868,16 +871,27 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
   TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
-  // Where the upload kernel runs.  Beside the grouping on the prep queue it costs a long step ~30 us
-  // (0.990 -> 0.957 ms at FFM 39 x 16 with the launch knocked out): it sits between two groupings and
-  // lands on the step boundary.  On the longest chains' stream (idle once they end) it runs in the tail
-  // of the update phase instead: 0.990 -> 0.960 ms.  Steps under ~0.5 ms (C2, C3, FM) measured 1-3 %
-  // slower that way, and a shard rank's chain kernel fills that stream to the end of the step.
+  // Two choices that depend on how long a step of this engine is (estimated like the update phase in
+  // ffm_engine_train_update_device, from the largest block the engine was sized for):
+  // * where the upload kernel runs.  Beside the grouping on the prep queue it costs a long step ~30 us
+  //   (0.990 -> 0.957 ms at FFM 39 x 16 with the launch knocked out): it sits between two groupings and
+  //   lands on the step boundary.  On the longest chains' stream (idle once they end) it runs in the tail
+  //   of the update phase instead: 0.990 -> 0.960 ms.  Steps under ~0.5 ms (C2, C3, FM) measured 1-3 %
+  //   slower that way, and a shard rank's chain kernel fills that stream to the end of the step.
+  // * which sort the grouping uses.  Short steps wait for the look-ahead queue's chain of ~17 launches
+  //   one to one (FM k = 64: 0.32 ms per step of which 0.23 ms are its two kernels) and take the
+  //   one-launch sort of kernels_sort.h (FM 0.323 -> 0.294 ms, FFM 8 x 16 at 4096 rows 0.139 -> 0.122);
+  //   a long FFM step is saturated by its row kernel, a sort that actually runs beside it slows it
+  //   (0.950 -> 0.993 ms), and the library sort's 1024-thread workgroups -- which only find room in
+  //   the gaps -- are the better neighbour.  FFM 39 x 4 is the crossover (no difference).
   {
     const double per_row = e->max_rows > 0 ? static_cast<double>(e->max_nnz) / e->max_rows : 0.0;
     const double phase_us = static_cast<double>(e->max_nnz) * std::max(0.0, per_row - 1.0) * m.n_factors / 0.44e6;
-    const bool long_step = m.type == FFM_MODEL_FFM && m.n_shards == 1 && m.n_factors % 4 == 0 && phase_us >= 200.0;
+    const bool ffm4 = m.type == FFM_MODEL_FFM && m.n_factors % 4 == 0;
+    const bool long_step = ffm4 && m.n_shards == 1 && phase_us >= 200.0;
     e->copy = long_step ? e->aux3 : e->prep;
+    e->own_sort = !(ffm4 && phase_us / std::max(1, m.n_shards) >= 100.0);  // (a shard does 1/n_shards of the pairs)
+    if (const char *sv = std::getenv("FFM_OWN_SORT")) e->own_sort = std::atoi(sv) != 0;
   }
   for (auto &ev : e->ev_row) TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   for (int i = 0; i < ffm_engine::kSets; i++) {

@@ -121,6 +121,14 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
     {
       ScopedTimer tm_sort("grouping:sort");
       size_t bytes = e->sort_tmp_bytes;
+      if (e->own_sort) {
+        const size_t n_al = (static_cast<size_t>(nnz) + 63) & ~static_cast<size_t>(63);
+        unsigned char *tmp = static_cast<unsigned char *>(e->d_sort_tmp[set]);
+        SortJob job{sc.key, sc.skey, sc.occ, reinterpret_cast<unsigned *>(tmp), reinterpret_cast<int *>(tmp + 4 * n_al),
+                    reinterpret_cast<unsigned *>(tmp + 8 * n_al), sc.counters + CNT_SORT_BAR, nnz,
+                    static_cast<int>((e->sort_bits + 7) / 8)};
+        hipLaunchKernelGGL(group_sort_kernel, dim3(sort_grid(nnz)), dim3(kSortThreads), 0, st, job);
+      } else
       HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
                                         rocprim::counting_iterator<int>(0), sc.occ,
                                         static_cast<size_t>(nnz), 0u, e->sort_bits, st));

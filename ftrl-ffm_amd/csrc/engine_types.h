@@ -193,8 +193,9 @@ __device__ __forceinline__ void phase_touches(const Scratch &s, int start, int c
 constexpr int kLineInts = 16;
 enum { CNT_NUNIQ = 0, CNT_CURSOR = 1 * kLineInts, CNT_NMULTI = 2 * kLineInts, CNT_ERROR = 3 * kLineInts,
        CNT_NSMALL = 4 * kLineInts, CNT_NBIG = 5 * kLineInts, CNT_NHUGE = 6 * kLineInts,
-       CNT_NFEW = 7 * kLineInts, CNT_NSINGLE = 9 * kLineInts, CNT_NGIANT = 10 * kLineInts };
-constexpr int kNumCounters = 11 * kLineInts;
+       CNT_NFEW = 7 * kLineInts, CNT_NSINGLE = 9 * kLineInts, CNT_NGIANT = 10 * kLineInts,
+       CNT_SORT_BAR = 11 * kLineInts };  // (the sort's grid barrier, kernels_sort.h)
+constexpr int kNumCounters = 12 * kLineInts;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 // Occurrence classes of a block's hot features (more than kSmallMax occurrences):
 //   big   (.. huge_min]             tile kernel (FFM) / list kernel (FM)

@@ -1,0 +1,168 @@
+// kernels_sort.h -- the grouping's sort as ONE launch: a stable LSD radix sort of (feature id, entry
+// index) pairs, 8 bits per pass, by a few co-resident 256-thread workgroups that meet at grid
+// barriers between the phases of a pass.
+//
+// Why not the library primitive (rocPRIM Onesweep, rounds 1-4): for a block of 320 k entries it is
+// ~14 launches (histogram, scan, and per pass two fills + twenty 1024-thread workgroups), each of which
+// has to find room on a GPU that the row / update kernels keep full -- a 1024-thread workgroup needs
+// 16 free wave slots on ONE CU, and even a one-workgroup fill waited 50-80 us for a slot
+// (profiles/r04_experiments.md).  The grouping is two blocks ahead of its use, but it is a CHAIN: at
+// steps under ~0.5 ms (FM, FFM k = 4, small blocks) the look-ahead queue's ~17 dependent launches per
+// block took as long as the step itself and the main stream waited for them one to one.  Here the
+// sort's workgroups get on the machine once and stay until the block is sorted.
+//
+// Pass p (digit = bits [8p, 8p+8) of the key), workgroup w owning the contiguous chunk w of the
+// pass's input:
+//   A  digit histogram of the chunk (LDS atomics)              -> cnt[digit][w]
+//      -- grid barrier --
+//   B  base[digit] = sum of cnt over (smaller digits, every workgroup) + (this digit, workgroups < w):
+//      every workgroup derives its own 256 bases from the table (no second barrier)
+//   C  the chunk in tiles of 256 keys in order: lanes with the same digit find each other with eight
+//      ballots (rank inside the wave = position among the peers), the four waves' counts go through
+//      LDS, destination = running base of the digit + earlier waves' count + rank.  Stable.
+//      -- grid barrier (the next pass reads what every workgroup scattered) --
+// Integer work only; the result does not depend on scheduling.
+#pragma once
+#include "engine_types.h"
+
+namespace ftrl_dev {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortMaxWgs = 128;
+constexpr int kSortBatch = 4;  // tiles whose loads are in flight together
+
+struct SortJob {
+  const unsigned *key;  // [n] input keys (values are the indices 0 .. n-1)
+  unsigned *okey;       // [n] sorted keys
+  int *oval;            // [n] the indices in sorted order
+  unsigned *tkey;       // [n] scratch
+  int *tval;            // [n] scratch
+  unsigned *cnt;        // [256][gridDim.x] scratch
+  int *bar;             // grid barrier word, zero at launch (the grouping's counters are cleared per block)
+  int n, passes;
+};
+
+// What the workgroups hand each other (the ping-pong buffers, the count table) moves with
+// agent-coherent accesses (sc1: past the XCD's L2) instead of release / acquire fences: a fence is a
+// write-back or an invalidate of the whole L2 of the XCD it runs on, ~450 of each per block with 64
+// workgroups and seven barriers -- beside a row kernel that lives on that L2 (measured: row kernel
+// 518 -> 577 us, the step 0.95 -> 1.01 ms with fences).
+template <class T> __device__ __forceinline__ T coh_load(const T *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T> __device__ __forceinline__ void coh_store(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every workgroup of the launch is resident (the grid is at most kSortMaxWgs small workgroups): the
+// usual counter barrier.  __syncthreads() waits for the wave's own stores (vmcnt) before it arrives.
+__device__ __forceinline__ void sort_grid_barrier(int *bar, int n_wg, int &target) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    target += n_wg;
+    __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kSortThreads) void group_sort_kernel(SortJob a) {
+  __shared__ unsigned hist[256];     // A: the chunk's digit counts; C: running destination per digit
+  __shared__ unsigned wcnt[4][256];  // C: per wave, how many keys of the tile carry each digit
+  __shared__ unsigned wtot[4];
+  const int W = gridDim.x, w = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int per = (((a.n + W - 1) / W) + kSortThreads - 1) & ~(kSortThreads - 1);
+  const int c0 = min(a.n, w * per), c1 = min(a.n, c0 + per);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int target = 0;
+  for (int p = 0; p < a.passes; p++) {
+    const bool to_out = ((a.passes - 1 - p) & 1) == 0;  // the last pass lands in (okey, oval)
+    const unsigned *kin = p == 0 ? a.key : (to_out ? a.tkey : a.okey);
+    const int *vin = p == 0 ? nullptr : (to_out ? a.tval : a.oval);
+    unsigned *kout = to_out ? a.okey : a.tkey;
+    int *vout = to_out ? a.oval : a.tval;
+    const int shift = 8 * p;
+    // ---- A
+    hist[t] = 0u;
+    wcnt[0][t] = 0u; wcnt[1][t] = 0u; wcnt[2][t] = 0u; wcnt[3][t] = 0u;
+    __syncthreads();
+    for (int i = c0 + t; i < c1; i += kSortBatch * kSortThreads) {
+      unsigned k[kSortBatch];
+#pragma unroll
+      for (int j = 0; j < kSortBatch; j++) k[j] = i + j * kSortThreads < c1 ? (p == 0 ? kin[i + j * kSortThreads] : coh_load(kin + i + j * kSortThreads)) : 0u;
+#pragma unroll
+      for (int j = 0; j < kSortBatch; j++)
+        if (i + j * kSortThreads < c1) atomicAdd(&hist[(k[j] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    coh_store(a.cnt + t * W + w, hist[t]);
+    sort_grid_barrier(a.bar, W, target);
+    // ---- B: thread t owns digit t
+    unsigned total = 0u, before = 0u;
+    for (int v = 0; v < W; v++) {
+      const unsigned c = coh_load(a.cnt + t * W + v);
+      total += c;
+      before += v < w ? c : 0u;
+    }
+    unsigned incl = total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned u = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += u;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned prefix = incl - total;
+    for (int v = 0; v < wave; v++) prefix += wtot[v];
+    hist[t] = prefix + before;
+    __syncthreads();
+    // ---- C
+    for (int base = c0; base < c1; base += kSortBatch * kSortThreads) {
+      unsigned k[kSortBatch];
+      int val[kSortBatch];
+#pragma unroll
+      for (int j = 0; j < kSortBatch; j++) {
+        const int i = base + j * kSortThreads + t;
+        k[j] = i < c1 ? (p == 0 ? kin[i] : coh_load(kin + i)) : 0u;
+        val[j] = i < c1 ? (vin ? coh_load(vin + i) : i) : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < kSortBatch; j++) {
+        const int i = base + j * kSortThreads + t;
+        if (base + j * kSortThreads >= c1) break;  // (uniform)
+        const bool in = i < c1;
+        const unsigned d = (k[j] >> shift) & 255u;
+        unsigned long long peers = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          const bool bit = (d >> b) & 1u;
+          const unsigned long long bal = __ballot(bit);
+          peers &= bit ? bal : ~bal;
+        }
+        const unsigned rank = __popcll(peers & below);
+        if (in && rank == 0u) wcnt[wave][d] = __popcll(peers);
+        __syncthreads();
+        unsigned dst = hist[d] + rank;
+        for (int v = 0; v < wave; v++) dst += wcnt[v][d];
+        if (in) {
+          coh_store(kout + dst, k[j]);
+          coh_store(vout + dst, val[j]);
+        }
+        __syncthreads();
+        hist[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
+        wcnt[0][t] = 0u; wcnt[1][t] = 0u; wcnt[2][t] = 0u; wcnt[3][t] = 0u;
+        __syncthreads();
+      }
+    }
+    if (p + 1 < a.passes) sort_grid_barrier(a.bar, W, target);
+  }
+}
+
+// workgroups for n keys: chunks of ~5000 keys (20 tiles), at most kSortMaxWgs
+static inline int sort_grid(int n) { return std::max(1, std::min(kSortMaxWgs, (n + 4999) / 5000)); }
+static inline size_t sort_scratch_bytes(size_t n) {
+  return 8 * ((n + 63) & ~static_cast<size_t>(63)) + sizeof(unsigned) * 256 * kSortMaxWgs + 256;
+}
+
+}  // namespace ftrl_dev

@@ -204,6 +204,32 @@ def test_update_in_one_launch_or_on_three_streams_is_bit_identical(fused, k, mon
     e.close()
 
 
+@pytest.mark.parametrize("own", ["0", "1"], ids=["library_sort", "one_launch_sort"])
+def test_grouping_sorts_agree_on_a_four_pass_block(own, monkeypatch):
+    """The grouping's two sorts (csrc/kernels_sort.h: one launch, 8 bits per pass; rocPRIM Onesweep)
+    on a block that needs four passes (20 M feature ids = 25 key bits), 8192 x 39 Zipf entries with
+    long runs of equal keys, and on a ragged tail block: both bitwise against the oracle."""
+    monkeypatch.setenv("FFM_OWN_SORT", own)
+    rng = np.random.default_rng(11)
+    nf = 20_000_003
+    o = CpuModel("oracle", "LR", nf, 1, 1, **STRESS_HP)
+    e = fa.Engine("LR", nf, 1, 1, skip_init=True, max_batch_rows=8192, **STRESS_HP)
+    st = rand_state(rng, o)
+    st["lin_n"] += np.float32(0.05)
+    o.set_state(st)
+    e.set_state(st)
+    gen = synth.Generator(39, nf, "zipf", seed=5)
+    for n in (8192, 8192, 1237):
+        blk = gen.block(n)
+        blk.field[:] = 0
+        lo, so = o.train_batch(blk)
+        lg, sg = e.train_batch(blk)
+        assert_bitwise(lg, lo, "logits, block of %d" % n)
+        assert loss_close(sg, so)
+    assert_state_bitwise(e.get_state(), o.get_state(), "LR 20 M features, sort %s" % own)
+    e.close()
+
+
 def test_empty_block_and_capacity_errors():
     e = fa.Engine("FFM", 100, 4, 4, max_batch_rows=8, max_batch_nnz=64, max_row_nnz=16)
     empty = Csr(np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32),

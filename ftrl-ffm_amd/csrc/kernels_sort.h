@@ -19,7 +19,8 @@
 //      every workgroup derives its own 256 bases from the table (no second barrier)
 //   C  the chunk in tiles of 256 keys in order: lanes with the same digit find each other with eight
 //      ballots (rank inside the wave = position among the peers), the four waves' counts go through
-//      LDS, destination = running base of the digit + earlier waves' count + rank.  Stable.
+//      LDS (one workgroup barrier per tile), destination = running base of the digit + earlier waves'
+//      count + rank.  Stable.
 //      -- grid barrier (the next pass reads what every workgroup scattered) --
 // Integer work only; the result does not depend on scheduling.
 #pragma once
@@ -28,7 +29,7 @@
 namespace ftrl_dev {
 
 constexpr int kSortThreads = 256;
-constexpr int kSortMaxWgs = 128;
+constexpr int kSortMaxWgs = 64;
 constexpr int kSortBatch = 4;  // tiles whose loads are in flight together
 
 struct SortJob {
@@ -67,14 +68,44 @@ __device__ __forceinline__ void sort_grid_barrier(int *bar, int n_wg, int &targe
   __syncthreads();
 }
 
+// One tile of 256 keys of phase C.  `it` counts the tiles of the pass: the wave counts rotate over
+// three buffers and the running destinations over two, so that a tile needs ONE workgroup barrier
+// (the buffer written here was zeroed a tile ago, behind that tile's barrier).
+struct SortLds {
+  unsigned hist[2][256];     // A: hist[0] = the chunk's digit counts; C: running destination per digit
+  unsigned wcnt[3][4][256];  // C: per wave, how many keys of the tile carry each digit
+  unsigned wtot[4];
+};
+__device__ __forceinline__ void sort_tile(SortLds &l, int it, bool in, unsigned key, int val, int shift,
+                                          unsigned *kout, int *vout) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cb = it % 3, zb = (it + 2) % 3, hb = it & 1;
+  const unsigned d = (key >> shift) & 255u;
+  unsigned long long peers = __ballot(in);
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long bal = __ballot(bit);
+    peers &= bit ? bal : ~bal;
+  }
+  const unsigned rank = __popcll(peers & ((1ull << lane) - 1ull));
+  if (in && rank == 0u) l.wcnt[cb][wave][d] = __popcll(peers);
+  __syncthreads();
+  unsigned dst = l.hist[hb][d] + rank;
+  for (int v = 0; v < wave; v++) dst += l.wcnt[cb][v][d];
+  if (in) {
+    coh_store(kout + dst, key);
+    coh_store(vout + dst, val);
+  }
+  l.hist[hb ^ 1][t] = l.hist[hb][t] + l.wcnt[cb][0][t] + l.wcnt[cb][1][t] + l.wcnt[cb][2][t] + l.wcnt[cb][3][t];
+  l.wcnt[zb][0][t] = 0u; l.wcnt[zb][1][t] = 0u; l.wcnt[zb][2][t] = 0u; l.wcnt[zb][3][t] = 0u;
+}
+
 __global__ __launch_bounds__(kSortThreads) void group_sort_kernel(SortJob a) {
-  __shared__ unsigned hist[256];     // A: the chunk's digit counts; C: running destination per digit
-  __shared__ unsigned wcnt[4][256];  // C: per wave, how many keys of the tile carry each digit
-  __shared__ unsigned wtot[4];
+  __shared__ SortLds l;
   const int W = gridDim.x, w = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int per = (((a.n + W - 1) / W) + kSortThreads - 1) & ~(kSortThreads - 1);
   const int c0 = min(a.n, w * per), c1 = min(a.n, c0 + per);
-  const unsigned long long below = (1ull << lane) - 1ull;
   int target = 0;
   for (int p = 0; p < a.passes; p++) {
     const bool to_out = ((a.passes - 1 - p) & 1) == 0;  // the last pass lands in (okey, oval)
@@ -84,19 +115,21 @@ __global__ __launch_bounds__(kSortThreads) void group_sort_kernel(SortJob a) {
     int *vout = to_out ? a.oval : a.tval;
     const int shift = 8 * p;
     // ---- A
-    hist[t] = 0u;
-    wcnt[0][t] = 0u; wcnt[1][t] = 0u; wcnt[2][t] = 0u; wcnt[3][t] = 0u;
+    l.hist[0][t] = 0u;
+#pragma unroll
+    for (int b = 0; b < 3; b++) { l.wcnt[b][0][t] = 0u; l.wcnt[b][1][t] = 0u; l.wcnt[b][2][t] = 0u; l.wcnt[b][3][t] = 0u; }
     __syncthreads();
     for (int i = c0 + t; i < c1; i += kSortBatch * kSortThreads) {
       unsigned k[kSortBatch];
 #pragma unroll
-      for (int j = 0; j < kSortBatch; j++) k[j] = i + j * kSortThreads < c1 ? (p == 0 ? kin[i + j * kSortThreads] : coh_load(kin + i + j * kSortThreads)) : 0u;
+      for (int j = 0; j < kSortBatch; j++)
+        k[j] = i + j * kSortThreads < c1 ? (p == 0 ? kin[i + j * kSortThreads] : coh_load(kin + i + j * kSortThreads)) : 0u;
 #pragma unroll
       for (int j = 0; j < kSortBatch; j++)
-        if (i + j * kSortThreads < c1) atomicAdd(&hist[(k[j] >> shift) & 255u], 1u);
+        if (i + j * kSortThreads < c1) atomicAdd(&l.hist[0][(k[j] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    coh_store(a.cnt + t * W + w, hist[t]);
+    coh_store(a.cnt + t * W + w, l.hist[0][t]);
     sort_grid_barrier(a.bar, W, target);
     // ---- B: thread t owns digit t
     unsigned total = 0u, before = 0u;
@@ -111,13 +144,14 @@ __global__ __launch_bounds__(kSortThreads) void group_sort_kernel(SortJob a) {
       const unsigned u = __shfl_up(incl, d, 64);
       if (lane >= d) incl += u;
     }
-    if (lane == 63) wtot[wave] = incl;
+    if (lane == 63) l.wtot[wave] = incl;
     __syncthreads();
     unsigned prefix = incl - total;
-    for (int v = 0; v < wave; v++) prefix += wtot[v];
-    hist[t] = prefix + before;
+    for (int v = 0; v < wave; v++) prefix += l.wtot[v];
+    l.hist[0][t] = prefix + before;
     __syncthreads();
     // ---- C
+    int it = 0;
     for (int base = c0; base < c1; base += kSortBatch * kSortThreads) {
       unsigned k[kSortBatch];
       int val[kSortBatch];
@@ -129,37 +163,16 @@ __global__ __launch_bounds__(kSortThreads) void group_sort_kernel(SortJob a) {
       }
 #pragma unroll
       for (int j = 0; j < kSortBatch; j++) {
-        const int i = base + j * kSortThreads + t;
         if (base + j * kSortThreads >= c1) break;  // (uniform)
-        const bool in = i < c1;
-        const unsigned d = (k[j] >> shift) & 255u;
-        unsigned long long peers = __ballot(in);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-          const bool bit = (d >> b) & 1u;
-          const unsigned long long bal = __ballot(bit);
-          peers &= bit ? bal : ~bal;
-        }
-        const unsigned rank = __popcll(peers & below);
-        if (in && rank == 0u) wcnt[wave][d] = __popcll(peers);
-        __syncthreads();
-        unsigned dst = hist[d] + rank;
-        for (int v = 0; v < wave; v++) dst += wcnt[v][d];
-        if (in) {
-          coh_store(kout + dst, k[j]);
-          coh_store(vout + dst, val[j]);
-        }
-        __syncthreads();
-        hist[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
-        wcnt[0][t] = 0u; wcnt[1][t] = 0u; wcnt[2][t] = 0u; wcnt[3][t] = 0u;
-        __syncthreads();
+        sort_tile(l, it++, base + j * kSortThreads + t < c1, k[j], val[j], shift, kout, vout);
       }
     }
     if (p + 1 < a.passes) sort_grid_barrier(a.bar, W, target);
   }
 }
 
-// workgroups for n keys: chunks of ~5000 keys (20 tiles), at most kSortMaxWgs
+// workgroups for n keys: chunks of ~5000 keys (20 tiles), at most 64 (32 / 128 / 16 workgroups for a
+// 320 k-entry block measured 8 / 13 / 35 % slower per FM step: every barrier needs them all resident)
 static inline int sort_grid(int n) { return std::max(1, std::min(kSortMaxWgs, (n + 4999) / 5000)); }
 static inline size_t sort_scratch_bytes(size_t n) {
   return 8 * ((n + 63) & ~static_cast<size_t>(63)) + sizeof(unsigned) * 256 * kSortMaxWgs + 256;

@@ -4,6 +4,7 @@
 // Kernels stamp wall_clock64() (100 MHz) at their first and last instruction into a table; the host
 // enqueues everything ahead and reads the table afterwards, so nothing but the queues is measured.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -177,6 +178,19 @@ int main() {
       for (double x : g) sum += x;
       std::printf("9.%d engine-like FM step%-58s gap mean %6.1f us  p10 %6.1f  p90 %6.1f\n", variant,
                   variant == 0 ? "" : variant == 1 ? " (no 1024-thread passes)" : " (one wait, one record)", sum / g.size(), g[g.size() / 10], g[g.size() * 9 / 10]);
+    }
+    // 10: hipExtAnyOrderLaunch: does a kernel launched "in any order" start before its predecessor on the
+    // same stream ends?  (two small grids: room for both)
+    for (int i = 0; i < N / 2; i++) {
+      hipLaunchKernelGGL(work, dim3(64), dim3(256), 0, a, stamps, 2 * i, TICKS);
+      hipExtLaunchKernelGGL(work, dim3(64), dim3(256), 0, a, nullptr, nullptr, hipExtAnyOrderLaunch, stamps, 2 * i + 1, TICKS);
+    }
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h.data(), stamps, sizeof(long long) * 2 * N, hipMemcpyDeviceToHost));
+    {
+      double ov = 0;
+      for (int i = 1; i < N / 2; i++) ov += (h[2 * (2 * i + 1)] - h[2 * (2 * i)]) / 100.0;  // start of the second - start of the first
+      std::printf("10 any-order launch: second kernel starts %.1f us after the first STARTS (kernels last 100 us)\n", ov / (N / 2 - 1));
     }
   }
   return 0;

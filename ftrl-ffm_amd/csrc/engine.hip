@@ -305,6 +305,9 @@ struct ffm_engine {
     int *row_ptr = nullptr, *field = nullptr, *feat = nullptr, *label = nullptr;
     float *val = nullptr;
     hipEvent_t ev_copied = nullptr, ev_trained = nullptr;
+    // what frees the slot's device arrays: the scratch set's ev_set_free of the block that trained from
+    // it (no record of its own: one packet less on the main stream per step), ev_trained after a prediction
+    hipEvent_t free_ev = nullptr;
     bool used = false, zero_copy = false;
     int64_t seq = 0;  // 1-based number of the block staged in it
     int n_rows = 0, nnz = 0, row_cap = 0;

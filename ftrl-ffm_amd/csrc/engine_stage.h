@@ -168,13 +168,14 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   const int64_t seq = e->n_staged_total + 1;
   const int grid_pull = e->grid_pull;
   const bool timed = !e->stage_thread_on || e->prof_on;
-  rc = e->submit([e, this_slot, slot_was_used, job, plan, seq, grid_pull, timed]() -> int {
+  hipEvent_t free_ev = slot_was_used ? sl.free_ev : nullptr;
+  rc = e->submit([e, this_slot, free_ev, job, plan, seq, grid_pull, timed]() -> int {
     ScopedTimer tm("stage:submit");
     ffm_engine::Slot &s2 = e->slots[this_slot];
     int rc2 = FFM_OK;
     auto body = [&]() -> int {
       HIP_TRY(hipSetDevice(e->cfg.device_id));
-      if (slot_was_used) HIP_TRY(hipStreamWaitEvent(e->copy, s2.ev_trained, 0));  // nothing reads its device arrays
+      if (free_ev) HIP_TRY(hipStreamWaitEvent(e->copy, free_ev, 0));  // nothing reads its device arrays
       hipLaunchKernelGGL(pull_block_kernel, dim3(grid_pull), dim3(256), 0, e->copy, job);
       HIP_TRY(hipEventRecord(s2.ev_copied, e->copy));
       if (e->copy != e->prep) HIP_TRY(hipStreamWaitEvent(e->prep, s2.ev_copied, 0));  // the grouping reads the slot
@@ -217,7 +218,11 @@ int ffm_engine_train_forward_staged(ffm_engine *e, float *partial_logit) {
   e->staged_row_cap = sl.row_cap;
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   if (int rc_w = e->wait_issued(sl.seq)) return rc_w;  // its upload + grouping launches are out
-  HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));  // (also when its grouping was discarded)
+  // its grouping (behind the upload on the prep stream, or waiting for it there) implies the upload:
+  // the main stream waits for ev_copied itself only when that grouping was discarded
+  const Rows staged_rows{sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr, sl.feat, sl.val, nullptr};
+  if (!(e->n_prepared > 0 && same_block(e->prepared_rows[0], staged_rows)))
+    HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));
   int rc = ffm_engine_train_forward_device(e, sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr,
                                            sl.feat, sl.val, sl.label, partial_logit);
   if (rc) return rc;
@@ -292,7 +297,7 @@ int ffm_engine_predict_batch_async(ffm_engine *e, int32_t n_rows, const int32_t 
   if ((rc = claim_slot(e, n_rows, nnz, row_ptr, field, feat, val, label, zero_copy, &this_slot, &slot_was_used, &job)))
     return rc;
   ffm_engine::Slot &sl = e->slots[this_slot];
-  if (slot_was_used) HIP_TRY(hipStreamWaitEvent(e->copy, sl.ev_trained, 0));  // nothing reads its device arrays
+  if (slot_was_used && sl.free_ev) HIP_TRY(hipStreamWaitEvent(e->copy, sl.free_ev, 0));  // nothing reads its device arrays
   hipLaunchKernelGGL(pull_block_kernel, dim3(e->grid_pull), dim3(256), 0, e->copy, job);
   HIP_TRY(hipEventRecord(sl.ev_copied, e->copy));
   sl.used = true;
@@ -314,6 +319,7 @@ int ffm_engine_predict_batch_async(ffm_engine *e, int32_t n_rows, const int32_t 
   if (rc) return rc;
   if (label) hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
   HIP_TRY(hipEventRecord(sl.ev_trained, e->stream));  // the slot's device arrays are free again
+  sl.free_ev = sl.ev_trained;
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }

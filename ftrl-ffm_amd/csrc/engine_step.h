@@ -375,7 +375,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   e->trained_set[1] = e->trained_set[0];
   e->trained_set[0] = e->cur;
   if (e->cur_slot >= 0) {  // a staged block: its staging slot may be refilled from here on
-    HIP_TRY(hipEventRecord(e->slots[e->cur_slot].ev_trained, e->stream));
+    e->slots[e->cur_slot].free_ev = e->ev_set_free[e->cur];  // (not recorded again before the slot's next turn: kSets blocks later)
     e->cur_slot = -1;
   }
   HIP_TRY(hipGetLastError());

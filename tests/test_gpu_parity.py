@@ -205,21 +205,23 @@ def test_update_in_one_launch_or_on_three_streams_is_bit_identical(fused, k, mon
 
 
 @pytest.mark.parametrize("own", ["0", "1"], ids=["library_sort", "one_launch_sort"])
-def test_grouping_sorts_agree_on_a_four_pass_block(own, monkeypatch):
+@pytest.mark.parametrize("rows", [8192, 65536], ids=["8192_rows", "65536_rows"])
+def test_grouping_sorts_agree_on_a_four_pass_block(own, rows, monkeypatch):
     """The grouping's two sorts (csrc/kernels_sort.h: one launch, 8 bits per pass; rocPRIM Onesweep)
-    on a block that needs four passes (20 M feature ids = 25 key bits), 8192 x 39 Zipf entries with
-    long runs of equal keys, and on a ragged tail block: both bitwise against the oracle."""
+    on blocks that need four passes (20 M feature ids = 25 key bits): rows x 39 Zipf entries with
+    long runs of equal keys (2.5 M entries at 65 536 rows: 157 tiles per workgroup of the one-launch
+    sort), and a ragged tail block: both bitwise against the oracle."""
     monkeypatch.setenv("FFM_OWN_SORT", own)
     rng = np.random.default_rng(11)
     nf = 20_000_003
     o = CpuModel("oracle", "LR", nf, 1, 1, **STRESS_HP)
-    e = fa.Engine("LR", nf, 1, 1, skip_init=True, max_batch_rows=8192, **STRESS_HP)
+    e = fa.Engine("LR", nf, 1, 1, skip_init=True, max_batch_rows=rows, **STRESS_HP)
     st = rand_state(rng, o)
     st["lin_n"] += np.float32(0.05)
     o.set_state(st)
     e.set_state(st)
     gen = synth.Generator(39, nf, "zipf", seed=5)
-    for n in (8192, 8192, 1237):
+    for n in (rows, rows, 1237):
         blk = gen.block(n)
         blk.field[:] = 0
         lo, so = o.train_batch(blk)

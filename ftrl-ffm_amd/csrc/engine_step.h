@@ -50,20 +50,37 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
       else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
     }
     if (train) e->cur_phases = own_tg && vec4 ? phases_for(e, rows.n_rows) : 1;
+    // LDS parking (round 4): the first vectors of (n, z) that a row's refresh reads for its once-only
+    // features stay in LDS for the row's own in-row update instead of coming back over the fabric.  As
+    // many as fit beside the staging arrays in 30 KB of dynamic LDS (five rows per CU: 527 us per C5 block
+    // against 543 without; 26 KB = six rows 531; 1 KB more than 30.9 KB and only four rows fit: 585; 44 KB
+    // = three rows: 690), at most what the longest row of the block can use.  FFM_ROW_PARK=bytes
+    // overrides (0: off; test_row_kernel_lds_parking_is_bit_identical pins none / partial / default).
+    int park = 0;
+    size_t shmem_park = shmem;
+    if (refreshed == 3) {
+      static const int park_env = std::getenv("FFM_ROW_PARK") ? std::atoi(std::getenv("FFM_ROW_PARK")) : -1;
+      const size_t base = (shmem + 15) & ~static_cast<size_t>(15), budget = 30 * 1024;
+      long long bytes = park_env >= 0 ? park_env : (base < budget ? static_cast<long long>(budget - base) : 0);
+      bytes = std::min<long long>(bytes, 32ll * row_cap * (e->m.row_len / 4));
+      bytes = std::min<long long>(bytes, static_cast<long long>(budget) - static_cast<long long>(std::min(base, budget)));
+      park = static_cast<int>(std::max<long long>(0, bytes) / 32);
+      if (park > 0) shmem_park = base + 32 * static_cast<size_t>(park);
+    }
     if (train && vec4) {
       // one launch per row phase; the update streams pick each phase up at its event
       for (int ph = 0; ph < e->cur_phases; ph++) {
         const int r0 = phase_row(rows.n_rows, e->cur_phases, ph), r1 = phase_row(rows.n_rows, e->cur_phases, ph + 1);
         if (r1 > r0 && own_tg)
-          LAUNCH(e, kid, (ffm_row_kernel<true, true, true>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, r0);
+          LAUNCH(e, kid, (ffm_row_kernel<true, true, true>), r1 - r0, e->row_threads, shmem_park, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, r0, park);
         else if (r1 > r0)  // a shard: the logit is whole only after the all-reduce
-          LAUNCH(e, kid, (ffm_row_kernel<true, true, false>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, 0, r0);
+          LAUNCH(e, kid, (ffm_row_kernel<true, true, false>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, 0, r0, 0);
         if (e->cur_phases > 1) (void)hipEventRecord(e->ev_row[ph], e->stream);
       }
     }
-    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, 0);
-    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
-    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0);
+    else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, 0, 0);
+    else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0, 0);
+    else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0, 0);
   }
 }
 

@@ -268,7 +268,7 @@ template <bool TRAIN, bool VEC4, bool WHOLE = TRAIN>
 __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
                                                               int output_prob, int refreshed,
-                                                              int own_tg_arg, int row0) {
+                                                              int own_tg_arg, int row0, int park_vecs) {
   const int own_tg = WHOLE ? own_tg_arg : 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_nv, s_ns;
@@ -278,6 +278,10 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
   const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
   const int terms_cap = row_terms_cap(max_row_nnz, m.n_shards > 1 ? record_span(m, 1) : 0, 0);
   RowLds lds = carve_row_lds(smem, max_row_nnz, F, terms_cap);
+  // the first park_vecs 16-byte vectors of (n, z) that this row's refresh reads for its once-only
+  // features stay in LDS for its own in-row update (behind the row's staging arrays)
+  float4 *park_n = reinterpret_cast<float4 *>(smem + ((row_lds_bytes(max_row_nnz, F, terms_cap) + 15) & ~static_cast<size_t>(15)));
+  float4 *park_z = park_n + park_vecs;
   const int r = blockIdx.x + row0;  // (row0: first row of this launch's row phase)
   const int b = rows.row_ptr[r];
   const int nnz = rows.row_ptr[r + 1] - b;
@@ -395,6 +399,7 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
             }
             w4[u] = m.h.learn ? row[LAT_W * RL4 + c4] : n4[u];
             wp[u] = row + LAT_W * RL4 + c4;
+            if (WHOLE && t < park_vecs) { park_n[t] = n4[u]; park_z[t] = z4[u]; }
           }
         }
 #pragma unroll
@@ -606,7 +611,10 @@ __global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelD
           const int fp = walk_field(m, fa, sl);
           if (fp < 0 || (lds.fcnt[fp] - (fa == fp ? 1 : 0)) <= 0) continue;
           float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a], fa));
-          if (FFM_ROW_NT & 4) {
+          if (t < park_vecs) {
+            n4[u] = park_n[t];
+            z4[u] = park_z[t];
+          } else if (FFM_ROW_NT & 4) {
             n4[u] = load_nt(row + LAT_N * RL4 + c4);
             z4[u] = load_nt(row + LAT_Z * RL4 + c4);
           } else {

@@ -135,6 +135,33 @@ def test_ragged_empty_and_multivalued_rows():
         e.close()
 
 
+@pytest.mark.parametrize("park", ["0", "96", "1024", "default"])
+def test_row_kernel_lds_parking_is_bit_identical(park, monkeypatch):
+    """The first vectors of (n, z) of a row's once-only features stay in LDS between the row's refresh
+    and its in-row update (FFM_ROW_PARK = bytes; default: what fits 31 KB): none, three vectors (the
+    boundary falls inside the first record), 32, and the default must all give the oracle's bits --
+    warm and near-zero n (the ffm.cpp:118 NaNs), rows with once-only and hot features mixed."""
+    if park != "default":
+        monkeypatch.setenv("FFM_ROW_PARK", park)
+    rng = np.random.default_rng(29)
+    F, k, per = 10, 8, 400
+    nf = F * per
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o)
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=256, **STRESS_HP)
+    e.set_state(st)
+    blk = synth.Generator(F, nf, "zipf", seed=9).block(512)
+    for r0 in range(0, 512, 256):
+        sub = blk.rows(r0, r0 + 256)
+        lo, so = o.train_batch(sub)
+        lg, sg = e.train_batch(sub)
+        assert_bitwise(lg, lo, "park %s logits at %d" % (park, r0))
+        assert loss_close(sg, so)
+    assert_state_bitwise(e.get_state(), o.get_state(), "park %s" % park)
+    e.close()
+
+
 @pytest.mark.parametrize("mode", ["0", "2", "3", "1"])
 def test_refresh_modes_are_bit_identical(mode, monkeypatch):
     """Where the lazy weight refresh and the once-only features' update run is a scheduling choice

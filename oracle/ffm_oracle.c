@@ -404,9 +404,11 @@ double fo_predict_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const i
   return tmp_loss;
 }
 
-/* Mini-batch semantics (see header).  Three sweeps over the batch; each sweep visits rows in
- * order and, inside a row, follows the reference's statement order. */
-double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int32_t *field,
+/* The ROW-WALK block update (rounds 1-4 of this repo, kept as a yardstick): three sweeps over the
+ * batch; each sweep visits rows in order and, inside a row, follows the reference's statement
+ * order, so every touch of an accumulator lands on the running (n, z).  In exact arithmetic it is
+ * what fo_train_batch below computes with reductions; tests bound the rounding distance. */
+double fo_train_batch_rowwalk(fo_model *m, int n_rows, const int32_t *row_ptr, const int32_t *field,
                       const int32_t *feat, const float *val, const int32_t *label,
                       float *logit_out) {
   const int k = m->n_factors;
@@ -450,6 +452,340 @@ double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int
     if (m->model_type == FO_FFM) ffm_update_vector_nz(m, &rv, tg[r]);
     else if (m->model_type == FO_FM) fm_update_vector_nz(m, &rv, tg[r], svx + (size_t)r * k);
   }
+  free(idx); free(tg); free(svx);
+  return tmp_loss;
+}
+
+
+/* ---------------- block update by reductions (the engine's batch semantics) ----------------
+ *
+ * With w and tmp_grad frozen over the block, the touches t = 0..T-1 of ONE accumulator (n, z),
+ * taken in row order, are folded like this (FO_SEG consecutive touches form a segment s):
+ *   P_s = sum of g_t*g_t, G_s = sum of g_t      (inside a segment left to right; the sums start
+ *                                               from -0.0f, the identity of fp addition)
+ *   B_0 = n_0, B_{s+1} = B_s + P_s,  n_T = B_S   (segment totals joined left to right)
+ *   n_t = B_s + (the segment's partial sum of g*g before touch t)
+ * and, with sigma the reference's step size (ftrl_model.cpp:71, ffm.cpp:113/:118, fm.cpp:92):
+ *   - every touch "plain" (the square root sees n + g*g: linear, bias, FM, the FFM pair's first
+ *     slot): the sigmas telescope, sum sigma_t = (sqrtf(n_T) - sqrtf(n_0)) / alpha  
+ *   - from the first touch t0 of the ffm.cpp:118 kind (the square root sees n + g2*g1) on, every
+ *     touch contributes its own m_t = ((sqrtf(n_t + q_t) - sqrtf(n_t)) / alpha) * w, summed per
+ *     segment then over the segments; the plain touches before t0 telescope to
+ *     H = ((sqrtf(n_t0) - sqrtf(n_0)) / alpha) * w
+ *   latent:        z_T = (z_0 + G) - M          (ffm.cpp:114/:119, fm.cpp:93: z + g - sigma*w)
+ *   linear / bias: z_T = z_0 + (G - sigma*w)    (ftrl_model.cpp:72/:83: z += g - sigma*w)
+ * One touch evaluates the reference's expression literally, so n_rows == 1 is fo_train bit for bit
+ * -- as long as no accumulator is touched twice by one row.  Where a row does that (a field with
+ * several entries: the partner slots see one touch per entry; the same id twice in a row) the
+ * reference's running update inside the row is not a sum, and those accumulators ("serial") keep
+ * the row walk above for the whole block.  Which ones: see mark_serial(). */
+#define FO_SEG 64
+
+typedef struct {
+  float P, G, M;          /* the running segment: sum g*g, sum g, sum m */
+  float B, Gacc, Macc;    /* the segments before it */
+  float ncap;             /* n_t at the first :118 touch */
+  int cnt, any, seen, head_plain;
+} fo_acc;
+
+static inline void acc_init(fo_acc *a, float n0) {
+  a->P = a->G = a->M = a->Gacc = a->Macc = -0.0f;
+  a->B = n0;
+  a->ncap = 0.0f;
+  a->cnt = a->any = a->seen = a->head_plain = 0;
+}
+static inline void acc_flush(fo_acc *a) {
+  a->B = a->B + a->P;
+  a->Gacc = a->Gacc + a->G;
+  a->Macc = a->Macc + a->M;
+  a->P = a->G = a->M = -0.0f;
+  a->cnt = 0;
+}
+/* one touch: gradient g, what the square root adds to n (q), plain = (q is g*g by construction) */
+static inline void acc_touch(const fo_model *m, fo_acc *a, float w, float g, float q, int plain) {
+  if (a->cnt == FO_SEG) acc_flush(a);
+  const float nt = a->B + a->P;
+  if (!a->any) { a->any = 1; a->head_plain = plain; }
+  if (!plain && !a->seen) { a->seen = 1; a->ncap = nt; }
+  if (a->seen) {
+    const float mt = ((sqrtf(nt + q) - sqrtf(nt)) / m->w_alpha) * w;
+    a->M = a->M + mt;
+  }
+  a->G = a->G + g;
+  a->P = a->P + g * g;
+  a->cnt++;
+}
+static inline void acc_finish_latent(const fo_model *m, fo_acc *a, float w, float *n, float *z) {
+  if (!a->any) return;
+  const float n0 = *n;
+  acc_flush(a);
+  float M = -0.0f;
+  if (a->head_plain) {
+    const float ncap = a->seen ? a->ncap : a->B;
+    M = M + ((sqrtf(ncap) - sqrtf(n0)) / m->w_alpha) * w;
+  }
+  M = M + a->Macc;
+  *z = (*z + a->Gacc) - M;
+  *n = a->B;
+}
+static inline void acc_finish_linear(const fo_model *m, fo_acc *a, float w, float *n, float *z) {
+  if (!a->any) return;
+  const float n0 = *n;
+  acc_flush(a);
+  const float si = (sqrtf(a->B) - sqrtf(n0)) / m->w_alpha;
+  *z = *z + (a->Gacc - si * w);
+  *n = a->B;
+}
+
+typedef struct { int feat, p; } fo_ent;
+static int ent_cmp(const void *x, const void *y) {
+  const fo_ent *a = (const fo_ent *)x, *b = (const fo_ent *)y;
+  if (a->feat != b->feat) return a->feat < b->feat ? -1 : 1;
+  return a->p < b->p ? -1 : (a->p > b->p);
+}
+
+/* The block grouped by feature, as the engine's grouping produces it (kernels_group.h): the
+ * surviving entries sorted by (feature, entry index), per row and field the count and the first
+ * surviving entry. */
+typedef struct {
+  int n_ent;       /* surviving entries */
+  fo_ent *ent;     /* sorted */
+  int *row_of;     /* [nnz] */
+  int *gid;        /* [nnz] start of the entry's group in ent[] (-1: erased) */
+  int *rcnt, *rfirst; /* [n_rows * F] (FFM) */
+  int F;
+} fo_groups;
+
+static void groups_build(const fo_model *m, fo_groups *g, int n_rows, const int32_t *row_ptr,
+                         const int32_t *field, const int32_t *feat) {
+  const int nnz = row_ptr[n_rows];
+  g->F = m->model_type == FO_FFM ? m->n_fields : 1;
+  g->ent = (fo_ent *)malloc(sizeof(fo_ent) * (size_t)(nnz > 0 ? nnz : 1));
+  g->row_of = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+  g->gid = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+  const size_t rf = (size_t)(n_rows > 0 ? n_rows : 1) * (size_t)g->F;
+  g->rcnt = (int *)calloc(rf, sizeof(int));
+  g->rfirst = (int *)malloc(sizeof(int) * rf);
+  for (size_t i = 0; i < rf; i++) g->rfirst[i] = -1;
+  g->n_ent = 0;
+  for (int r = 0; r < n_rows; r++)
+    for (int p = row_ptr[r]; p < row_ptr[r + 1]; p++) {
+      g->row_of[p] = r;
+      g->gid[p] = -1;
+      const int f = m->model_type == FO_FFM ? field[p] : 0;
+      if (!in_range(m, f, feat[p])) continue;
+      g->ent[g->n_ent].feat = feat[p];
+      g->ent[g->n_ent].p = p;
+      g->n_ent++;
+      const size_t c = (size_t)r * g->F + (size_t)f;
+      if (g->rcnt[c]++ == 0) g->rfirst[c] = p;
+    }
+  qsort(g->ent, (size_t)g->n_ent, sizeof(fo_ent), ent_cmp);
+  for (int t = 0, lo = 0; t < g->n_ent; t++) {
+    if (t > 0 && g->ent[t].feat != g->ent[t - 1].feat) lo = t;
+    g->gid[g->ent[t].p] = lo;
+  }
+}
+static void groups_free(fo_groups *g) {
+  free(g->ent); free(g->row_of); free(g->gid); free(g->rcnt); free(g->rfirst);
+}
+
+/* Which accumulators of the group ent[lo, hi) keep the row walk.  Mirrors what the engine's
+ * grouping can see (kernels_group.h: cmask):
+ *   FFM: slot fp of the feature, when some row of the feature holds two or more surviving entries
+ *        of field fp, or -- for every slot that row touches -- when the feature itself occurs twice
+ *        in the row.  More than 64 fields (no field masks on the device): every slot.
+ *   FM / LR: the whole feature, when it occurs twice in some row.
+ * ser[fp] (FFM) / ser[0] (FM, LR) receive 0 / 1. */
+static void mark_serial(const fo_model *m, const fo_groups *g, const int32_t *field, int lo, int hi,
+                        unsigned char *ser) {
+  const int F = g->F;
+  memset(ser, 0, (size_t)F);
+  for (int t = lo; t < hi; t++) {
+    const int p = g->ent[t].p, r = g->row_of[p];
+    const int dup = (t > lo && g->row_of[g->ent[t - 1].p] == r) ||
+                    (t + 1 < hi && g->row_of[g->ent[t + 1].p] == r);
+    if (m->model_type != FO_FFM) {
+      if (dup) ser[0] = 1;
+      continue;
+    }
+    if (F > 64) { memset(ser, 1, (size_t)F); return; }
+    const int fa = field[p];
+    for (int fp = 0; fp < F; fp++) {
+      const int c = g->rcnt[(size_t)r * F + fp];
+      if (c >= 2) ser[fp] = 1;
+      if (dup && c - (fp == fa ? 1 : 0) >= 1) ser[fp] = 1;
+    }
+  }
+}
+
+double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int32_t *field,
+                      const int32_t *feat, const float *val, const int32_t *label,
+                      float *logit_out) {
+  const int k = m->n_factors;
+  const int64_t L = m->row_len;
+  int max_nnz = 1;
+  for (int r = 0; r < n_rows; r++)
+    if (row_ptr[r + 1] - row_ptr[r] > max_nnz) max_nnz = row_ptr[r + 1] - row_ptr[r];
+  int *idx = (int *)malloc(sizeof(int) * (size_t)max_nnz);
+  float *tg = (float *)malloc(sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1));
+  float *svx = NULL;
+  if (m->model_type == FO_FM)
+    svx = (float *)malloc(sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1) * (size_t)(k > 0 ? k : 1));
+  rowview rv;
+  double tmp_loss = 0.0;
+  /* sweep 1: lazy refresh of everything the batch touches, from the batch-start (n,z) */
+  for (int r = 0; r < n_rows; r++) {
+    const int b = row_ptr[r];
+    rv_build(m, &rv, row_ptr[r + 1] - b, field + b, feat + b, val + b, idx);
+    update_linear_w(m, &rv);
+    if (m->model_type == FO_FFM) ffm_update_vector_w(m, &rv);
+    else if (m->model_type == FO_FM) fm_update_vector_w(m, &rv);
+  }
+  if (n_rows > 0) update_bias(m);
+  /* sweep 2: forward with frozen weights */
+  for (int r = 0; r < n_rows; r++) {
+    const int b = row_ptr[r];
+    rv_build(m, &rv, row_ptr[r + 1] - b, field + b, feat + b, val + b, idx);
+    float logit;
+    if (m->model_type == FO_FFM) logit = compute_ffm_logit(m, &rv);
+    else if (m->model_type == FO_FM) logit = compute_fm_logit(m, &rv, svx + (size_t)r * k);
+    else logit = compute_linear_logit(m, &rv);
+    tg[r] = fo_sigmoid(logit) - (float)label[r];
+    if (logit_out) logit_out[r] = logit;
+    tmp_loss += fo_loss(label[r], logit);
+  }
+  /* sweep 3: the accumulators.  Bias: one plain touch per row, g = tmp_grad (ftrl_model.cpp:79-85) */
+  if (n_rows > 0) {
+    fo_acc a;
+    acc_init(&a, m->bias3[1]);
+    for (int r = 0; r < n_rows; r++) acc_touch(m, &a, m->bias3[0], tg[r], tg[r] * tg[r], 1);
+    acc_finish_linear(m, &a, m->bias3[0], &m->bias3[1], &m->bias3[2]);
+  }
+  fo_groups g;
+  groups_build(m, &g, n_rows, row_ptr, field, feat);
+  const int F = g.F;
+  /* per group: serial flags, kept per entry group for the row walk below */
+  unsigned char *ser_all = (unsigned char *)calloc((size_t)(g.n_ent > 0 ? g.n_ent : 1) * (size_t)F, 1);
+  int any_serial = 0;
+  for (int lo = 0; lo < g.n_ent;) {
+    int hi = lo + 1;
+    while (hi < g.n_ent && g.ent[hi].feat == g.ent[lo].feat) hi++;
+    unsigned char *ser = ser_all + (size_t)lo * F;
+    mark_serial(m, &g, field, lo, hi, ser);
+    for (int f = 0; f < F; f++) any_serial |= ser[f];
+    const int i = g.ent[lo].feat;
+    /* linear: g = tmp_grad * x (ftrl_model.cpp:66-77); serial when the id repeats inside a row */
+    int lin_serial = 0;
+    for (int t = lo + 1; t < hi; t++)
+      if (g.row_of[g.ent[t].p] == g.row_of[g.ent[t - 1].p]) lin_serial = 1;
+    if (lin_serial) {
+      for (int t = lo; t < hi; t++) {
+        const int p = g.ent[t].p;
+        nz_step(m, m->lin_w[i], tg[g.row_of[p]] * val[p], &m->lin_n[i], &m->lin_z[i]);
+      }
+    } else {
+      fo_acc a;
+      acc_init(&a, m->lin_n[i]);
+      for (int t = lo; t < hi; t++) {
+        const int p = g.ent[t].p;
+        const float gg = tg[g.row_of[p]] * val[p];
+        acc_touch(m, &a, m->lin_w[i], gg, gg * gg, 1);
+      }
+      acc_finish_linear(m, &a, m->lin_w[i], &m->lin_n[i], &m->lin_z[i]);
+    }
+    if (m->model_type == FO_FM) {
+      /* fm.cpp:84-95: g = tmp_grad * (x * s_vx - v * x * x), every touch plain */
+      if (ser[0]) {
+        for (int t = lo; t < hi; t++) {
+          const int p = g.ent[t].p, r = g.row_of[p];
+          fm_feat_step(m, i, val[p], tg[r], svx + (size_t)r * k);
+        }
+      } else {
+        for (int f = 0; f < k; f++) {
+          const int64_t o = (int64_t)i * k + f;
+          const float w = m->vec_w[o];
+          fo_acc a;
+          acc_init(&a, m->vec_n[o]);
+          for (int t = lo; t < hi; t++) {
+            const int p = g.ent[t].p, r = g.row_of[p];
+            const float x = val[p];
+            const float gg = tg[r] * (x * svx[(size_t)r * k + f] - w * x * x);
+            acc_touch(m, &a, w, gg, gg * gg, 1);
+          }
+          acc_finish_latent(m, &a, w, &m->vec_n[o], &m->vec_z[o]);
+        }
+      }
+    } else if (m->model_type == FO_FFM) {
+      /* ffm.cpp:102-121 slot by slot: slot (i, fp) is touched by every occurrence of i whose row
+       * holds an entry q of field fp other than itself (exactly one here: the slot is not serial) */
+      for (int fp = 0; fp < F; fp++) {
+        if (ser[fp]) continue;
+        for (int f = 0; f < k; f++) {
+          const int64_t o = i * L + (int64_t)fp * k + f;
+          const float w = m->vec_w[o];
+          fo_acc a;
+          acc_init(&a, m->vec_n[o]);
+          for (int t = lo; t < hi; t++) {
+            const int p = g.ent[t].p, r = g.row_of[p];
+            const int q = g.rfirst[(size_t)r * F + fp];
+            if (q < 0 || q == p) continue;
+            const float x = p < q ? val[p] * val[q] : val[q] * val[p];
+            const float vp = m->vec_w[feat[q] * L + (int64_t)field[p] * k + f];
+            const float gg = tg[r] * vp * x;
+            if (p < q || m->learn) {
+              acc_touch(m, &a, w, gg, gg * gg, 1); /* ffm.cpp:112-115 */
+            } else {
+              const float g1 = tg[r] * w * x;      /* the pair's first entry's gradient */
+              acc_touch(m, &a, w, gg, gg * g1, 0); /* ffm.cpp:117-120 incl. :118 */
+            }
+          }
+          acc_finish_latent(m, &a, w, &m->vec_n[o], &m->vec_z[o]);
+        }
+      }
+    }
+    lo = hi;
+  }
+  /* the serial FFM slots: the row walk of ffm.cpp:90-136, restricted to them */
+  if (m->model_type == FO_FFM && any_serial) {
+    for (int r = 0; r < n_rows; r++) {
+      const int b = row_ptr[r];
+      rv_build(m, &rv, row_ptr[r + 1] - b, field + b, feat + b, val + b, idx);
+      for (int a = 0; a < rv.n; a++)
+        for (int c = a + 1; c < rv.n; c++) {
+          const int pa = b + rv.idx[a], pc = b + rv.idx[c];
+          const int field1 = field[pa], i = feat[pa], field2 = field[pc], j = feat[pc];
+          const int s1 = ser_all[(size_t)g.gid[pa] * F + field2], s2 = ser_all[(size_t)g.gid[pc] * F + field1];
+          if (!s1 && !s2) continue;
+          const float x = val[pa] * val[pc];
+          const int64_t o1 = i * L + (int64_t)field2 * k, o2 = j * L + (int64_t)field1 * k;
+          for (int f = 0; f < k; f++) {
+            const float v1 = m->vec_w[o1 + f], v2 = m->vec_w[o2 + f];
+            float n1 = m->vec_n[o1 + f], z1 = m->vec_z[o1 + f];
+            if (o1 == o2) {
+              /* the same (field, id) twice in the row: ONE slot on both sides of the pair (the
+               * reference deadlocks here, see fo_train_batch_rowwalk): its i-side step, then its
+               * j-side step on the result; g1 == g2, both partner weights are this slot's */
+              const float gg = tg[r] * v1 * x;
+              const float sa = (sqrtf(n1 + gg * gg) - sqrtf(n1)) / m->w_alpha;
+              z1 = z1 + gg - sa * v1;
+              n1 = n1 + gg * gg;
+              const float sb = (sqrtf(n1 + gg * gg) - sqrtf(n1)) / m->w_alpha;
+              z1 = z1 + gg - sb * v1;
+              n1 = n1 + gg * gg;
+              if (s1) { m->vec_n[o1 + f] = n1; m->vec_z[o1 + f] = z1; }
+              continue;
+            }
+            float n2 = m->vec_n[o2 + f], z2 = m->vec_z[o2 + f];
+            ffm_pair_step(m, tg[r], x, v1, v2, &n1, &z1, &n2, &z2);
+            if (s1) { m->vec_n[o1 + f] = n1; m->vec_z[o1 + f] = z1; }
+            if (s2) { m->vec_n[o2 + f] = n2; m->vec_z[o2 + f] = z2; }
+          }
+        }
+    }
+  }
+  groups_free(&g);
+  free(ser_all);
   free(idx); free(tg); free(svx);
   return tmp_loss;
 }

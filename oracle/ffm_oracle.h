@@ -70,12 +70,23 @@ double fo_train_rows(fo_model *m, int n_rows, const int32_t *row_ptr, const int3
 /* Mini-batch semantics of the MI355X engine (DESIGN.md "Batch semantics"):
  *  1. every slot a row of the batch touches is refreshed from the batch-start (n,z);
  *  2. every row's logit and tmp_grad use those frozen weights;
- *  3. every touched (n,z) then receives the reference's per-sample update once per touching
- *     (row, pair), applied in row order then the reference's pair order, with w and tmp_grad
- *     frozen.  With n_rows == 1 this IS fo_train. */
+ *  3. every touched (n,z) then receives the block's touches -- the reference's per-sample update
+ *     of every touching (row, pair), w and tmp_grad frozen -- folded by REDUCTIONS in row order:
+ *     n += sum g*g, z += sum g - w * sum sigma, where the sigmas of plain touches telescope to
+ *     (sqrtf(n_T) - sqrtf(n_0)) / alpha and the touches of the ffm.cpp:118 kind are evaluated one
+ *     by one against a prefix sum of n (ffm_oracle.c: "block update by reductions" has the exact
+ *     tree: segments of 64 touches, left to right).  An accumulator that ONE row touches twice
+ *     (multi-valued field, repeated id) keeps the row-order walk for the whole block.
+ *     With n_rows == 1 this IS fo_train, bit for bit. */
 double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int32_t *field,
                       const int32_t *feat, const float *val, const int32_t *label,
                       float *logit_out);
+/* The block update of rounds 1-4: step 3 as a strict walk -- every touch applied, in row order then
+ * the reference's pair order, to the running (n, z).  Equal to fo_train_batch in exact arithmetic;
+ * kept so that tests can bound the rounding distance between the two. */
+double fo_train_batch_rowwalk(fo_model *m, int n_rows, const int32_t *row_ptr, const int32_t *field,
+                              const int32_t *feat, const float *val, const int32_t *label,
+                              float *logit_out);
 double fo_predict_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int32_t *field,
                         const int32_t *feat, const float *val, const int32_t *label,
                         int output_prob, float *out);

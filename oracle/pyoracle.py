@@ -117,9 +117,10 @@ def _lib(kind):
     getattr(lib, p + "maybe_zero_weight").restype = ctypes.c_float
     getattr(lib, p + "maybe_zero_weight").argtypes = [vp, ctypes.c_float, ctypes.c_float]
     if kind == "oracle":
-        f = lib.fo_train_batch
-        f.restype = ctypes.c_double
-        f.argtypes = [vp, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p, _c_f32p]
+        for name in ("fo_train_batch", "fo_train_batch_rowwalk"):
+            f = getattr(lib, name)
+            f.restype = ctypes.c_double
+            f.argtypes = [vp, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p, _c_f32p]
         f = lib.fo_train_rows_threaded
         f.restype = ctypes.c_double
         f.argtypes = [vp, ctypes.c_int, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p,
@@ -240,11 +241,13 @@ class CpuModel:
         loss = getattr(self.lib, self.p + "train_rows")(self.h, *self._csr_args(c), _f32(out))
         return out, float(loss)
 
-    def train_batch(self, c):
-        """One mini-batch with the engine's batch semantics (oracle only)."""
+    def train_batch(self, c, rowwalk=False):
+        """One mini-batch with the engine's batch semantics (oracle only).  rowwalk=True: the block
+        update as a strict row-order walk (fo_train_batch_rowwalk) instead of reductions."""
         assert self.kind == "oracle"
         out = np.zeros(c.n_rows, np.float32)
-        loss = self.lib.fo_train_batch(self.h, *self._csr_args(c), _f32(out))
+        fn = self.lib.fo_train_batch_rowwalk if rowwalk else self.lib.fo_train_batch
+        loss = fn(self.h, *self._csr_args(c), _f32(out))
         return out, float(loss)
 
     def predict_batch(self, c, output_prob=False):

@@ -1,0 +1,273 @@
+"""The block update by reductions (oracle/ffm_oracle.c: fo_train_batch) -- properties of the
+definition itself, checked on the CPU:
+
+* a block of ONE row is the reference's train() bit for bit, whatever the row looks like
+  (multi-valued fields, repeated ids, fields out of order) -- against the oracle's sequential loop
+  and, where it can run them, against the compiled reference;
+* on blocks of many rows the reductions and the strict row-order walk of rounds 1-4
+  (fo_train_batch_rowwalk) are the same update in exact arithmetic: same logits (the forward is
+  shared), state within rounding distance, NaNs at the same places;
+* a second, independent restatement of the fold in numpy float32 scalars (segments of 64 touches,
+  left to right; telescoped step sizes; per-touch terms from the first ffm.cpp:118 touch on)
+  agrees with the C bit for bit.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from oracle.pyoracle import CpuModel, Csr
+from util import DEFAULT_HP, STRESS_HP, assert_bitwise, assert_close, assert_state_bitwise, rand_state
+
+SEG = 64  # FO_SEG
+
+
+def rand_rows(rng, n, F, nf, multi=False, dup=False, ordered=True, zipf=1.5, drop=0.15):
+    per = nf // F
+    rows, labels = [], []
+    for _ in range(n):
+        row = []
+        for f in range(F):
+            if rng.random() < drop:
+                continue
+            ids = set()
+            for _ in range(1 + (multi and rng.random() < 0.2)):
+                i = f * per + int(rng.zipf(zipf)) % per
+                if i in ids:  # (the same id twice in a row only where `dup` asks for it)
+                    continue
+                ids.add(i)
+                row.append((f, i, float(np.float32(rng.uniform(0.2, 1.5)))))
+        if dup and row and rng.random() < 0.3:
+            row.append(row[int(rng.integers(len(row)))])
+        if not ordered:
+            rng.shuffle(row)
+        rows.append([tuple(e) for e in row])
+        labels.append(int(rng.integers(2)))
+    return Csr.from_rows(rows, labels)
+
+
+SHAPES = [("FFM", 6, 4), ("FM", 1, 8), ("LR", 1, 1)]
+KINDS = [(False, False, True), (True, False, True), (True, True, False), (False, True, True)]
+
+
+@pytest.mark.parametrize("mt,F,k", SHAPES)
+@pytest.mark.parametrize("multi,dup,ordered", KINDS)
+@pytest.mark.parametrize("hp", [DEFAULT_HP, STRESS_HP], ids=["default_hp", "stress_hp"])
+def test_block_of_one_row_is_the_sequential_step(mt, F, k, multi, dup, ordered, hp):
+    rng = np.random.default_rng(11)
+    nf = 60
+    a = CpuModel("oracle", mt, nf, F, k, **hp)
+    b = CpuModel("oracle", mt, nf, F, k, **hp)
+    st = rand_state(rng, a)
+    a.set_state(st)
+    b.set_state(st)
+    c = rand_rows(rng, 60, F if mt == "FFM" else 6, nf, multi, dup, ordered)
+    if mt != "FFM":
+        c.field[:] = 0
+    la, _ = a.train_rows(c)
+    lb = np.array([b.train_batch(c.rows(r, r + 1))[0][0] for r in range(c.n_rows)], np.float32)
+    assert_bitwise(la, lb, "logits")
+    assert_state_bitwise(a.get_state(), b.get_state(), "state")
+    # FFM rows with a repeated id deadlock the reference
+    if pyoracle.have_ref() and not (mt == "FFM" and dup):
+        r = CpuModel("ref", mt, nf, F, k, **hp)
+        r.set_state(st)
+        lr, _ = r.train_rows(c)
+        assert_bitwise(lr, lb, "logits vs reference")
+        assert_state_bitwise(r.get_state(), b.get_state(), "state vs reference")
+
+
+@pytest.mark.parametrize("mt,F,k", SHAPES)
+@pytest.mark.parametrize("multi,dup,ordered", KINDS)
+def test_reductions_equal_the_row_walk_up_to_rounding(mt, F, k, multi, dup, ordered):
+    rng = np.random.default_rng(5)
+    nf = 60
+    a = CpuModel("oracle", mt, nf, F, k, **STRESS_HP)
+    b = CpuModel("oracle", mt, nf, F, k, **STRESS_HP)
+    st = rand_state(rng, a)
+    a.set_state(st)
+    b.set_state(st)
+    c = rand_rows(rng, 700, F if mt == "FFM" else 6, nf, multi, dup, ordered)
+    if mt != "FFM":
+        c.field[:] = 0
+    la, sa = a.train_batch(c)
+    lb, sb = b.train_batch(c, rowwalk=True)
+    assert_bitwise(la, lb, "logits")  # same refresh, same forward
+    assert sa == sb
+    A, B = a.get_state(), b.get_state()
+    for key in A:
+        # z is a sum with cancellation: bound the distance by the size of what was added
+        assert_close(A[key], B[key], rtol=2e-5, atol=2e-5, what=key)
+    changed = sum(int(np.count_nonzero(A[k_] != st[k_])) for k_ in A)
+    assert changed > 50
+
+
+def test_one_row_touching_a_slot_twice_keeps_the_walk_for_the_block():
+    """A field with two entries in ONE row of a 200-row block: the slots that see both entries are
+    walked in row order for the whole block (bit-identical to the row walk there), all other
+    accumulators are reduced."""
+    rng = np.random.default_rng(8)
+    F, k, nf = 4, 4, 40
+    c = rand_rows(rng, 200, F, nf, drop=0.0, zipf=3.0)
+    rows = [[(int(c.field[p]), int(c.feat[p]), float(c.val[p])) for p in range(c.row_ptr[r], c.row_ptr[r + 1])]
+            for r in range(c.n_rows)]
+    rows[17].insert(2, (1, 10 + 7, 0.5))  # a second entry of field 1 in row 17
+    c = Csr.from_rows(rows, c.label)
+    a = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    b = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, a)
+    a.set_state(st)
+    b.set_state(st)
+    a.train_batch(c)
+    b.train_batch(c, rowwalk=True)
+    A, B = a.get_state(), b.get_state()
+    L = F * k
+    # the features of row 17 in fields 0, 2, 3: their slot for partner field 1 is serial
+    for (f, i, _) in rows[17]:
+        if f == 1:
+            continue
+        sl = slice(1 * k, 2 * k)
+        assert_bitwise(A["vec_n"].reshape(nf, L)[i, sl], B["vec_n"].reshape(nf, L)[i, sl], "serial n")
+        assert_bitwise(A["vec_z"].reshape(nf, L)[i, sl], B["vec_z"].reshape(nf, L)[i, sl], "serial z")
+    assert (A["vec_z"] != B["vec_z"]).any()  # ... and the reductions do round differently elsewhere
+
+
+# ---- an independent restatement of the fold ---------------------------------------------------
+
+f32 = np.float32
+NEG0 = f32(-0.0)
+
+
+class Acc:
+    def __init__(self, n0, alpha):
+        self.P = self.G = self.M = self.Gacc = self.Macc = NEG0
+        self.B = f32(n0)
+        self.n0 = f32(n0)
+        self.alpha = f32(alpha)
+        self.cnt = 0
+        self.any = self.seen = self.head_plain = False
+        self.ncap = f32(0)
+
+    def flush(self):
+        self.B = f32(self.B + self.P)
+        self.Gacc = f32(self.Gacc + self.G)
+        self.Macc = f32(self.Macc + self.M)
+        self.P = self.G = self.M = NEG0
+        self.cnt = 0
+
+    def touch(self, w, g, q, plain):
+        if self.cnt == SEG:
+            self.flush()
+        nt = f32(self.B + self.P)
+        if not self.any:
+            self.any, self.head_plain = True, plain
+        if not plain and not self.seen:
+            self.seen, self.ncap = True, nt
+        if self.seen:
+            with np.errstate(invalid="ignore"):
+                d = f32(np.sqrt(f32(nt + q)) - np.sqrt(nt))
+            self.M = f32(self.M + f32(f32(d / self.alpha) * w))
+        self.G = f32(self.G + g)
+        self.P = f32(self.P + f32(g * g))
+        self.cnt += 1
+
+    def sigma_w_total(self, w):
+        M = NEG0
+        if self.head_plain:
+            ncap = self.ncap if self.seen else self.B
+            M = f32(M + f32(f32(f32(np.sqrt(ncap) - np.sqrt(self.n0)) / self.alpha) * w))
+        return f32(M + self.Macc)
+
+    def finish_latent(self, w, z0):
+        self.flush()
+        return self.B, f32(f32(f32(z0) + self.Gacc) - self.sigma_w_total(w))
+
+    def finish_linear(self, w, z0):
+        self.flush()
+        si = f32(f32(np.sqrt(self.B) - np.sqrt(self.n0)) / self.alpha)
+        return self.B, f32(f32(z0) + f32(self.Gacc - f32(si * w)))
+
+
+def numpy_block(model, st, c, tg, hp, F, k):
+    """(n, z) of every accumulator after one block, from the frozen w of `model` (already refreshed)
+    and the rows' tmp_grad; rows hold one entry per field at most and no repeated ids."""
+    alpha = hp["w_alpha"]
+    w = model.get_state()
+    out = {key: st[key].copy() for key in st}
+    out["lin_w"], out["vec_w"], out["bias3"][0] = w["lin_w"], w["vec_w"], w["bias3"][0]
+    a = Acc(st["bias3"][1], alpha)
+    for r in range(c.n_rows):
+        a.touch(w["bias3"][0], tg[r], f32(tg[r] * tg[r]), True)
+    out["bias3"][1], out["bias3"][2] = a.finish_linear(w["bias3"][0], st["bias3"][2])
+    row_of = np.repeat(np.arange(c.n_rows), np.diff(c.row_ptr))
+    order = np.lexsort((np.arange(len(c.feat)), c.feat))
+    L = F * k
+    vw = w["vec_w"].reshape(-1, L) if L else None
+    byrow = {}
+    for p in range(len(c.feat)):
+        byrow[(int(row_of[p]), int(c.field[p]))] = p
+    lo = 0
+    while lo < len(order):
+        hi = lo
+        while hi < len(order) and c.feat[order[hi]] == c.feat[order[lo]]:
+            hi += 1
+        i = int(c.feat[order[lo]])
+        a = Acc(st["lin_n"][i], alpha)
+        for p in order[lo:hi]:
+            g = f32(tg[row_of[p]] * c.val[p])
+            a.touch(w["lin_w"][i], g, f32(g * g), True)
+        out["lin_n"][i], out["lin_z"][i] = a.finish_linear(w["lin_w"][i], st["lin_z"][i])
+        for fp in range(F if L else 0):
+            for f in range(k):
+                e = fp * k + f
+                wv = vw[i, e]
+                a = Acc(st["vec_n"].reshape(-1, L)[i, e], alpha)
+                for p in order[lo:hi]:
+                    r = int(row_of[p])
+                    q = byrow.get((r, fp))
+                    if q is None or q == p:
+                        continue
+                    x = f32(c.val[p] * c.val[q])
+                    vp = vw[int(c.feat[q]), int(c.field[p]) * k + f]
+                    g = f32(f32(tg[r] * vp) * x)
+                    if p < q:
+                        a.touch(wv, g, f32(g * g), True)
+                    else:
+                        g1 = f32(f32(tg[r] * wv) * x)
+                        a.touch(wv, g, f32(g * g1), False)
+                if a.any:
+                    n_, z_ = a.finish_latent(wv, st["vec_z"].reshape(-1, L)[i, e])
+                    out["vec_n"].reshape(-1, L)[i, e] = n_
+                    out["vec_z"].reshape(-1, L)[i, e] = z_
+        lo = hi
+    return out
+
+
+@pytest.mark.parametrize("mt,F,k,ordered", [("FFM", 4, 2, True), ("FFM", 4, 2, False), ("LR", 1, 1, True)])
+def test_numpy_restatement_of_the_fold_agrees_bit_for_bit(mt, F, k, ordered):
+    rng = np.random.default_rng(21)
+    nf = 24
+    m = CpuModel("oracle", mt, nf, F, k, **STRESS_HP)
+    st = rand_state(rng, m, n_hi=1e-4, w_sd=0.5)  # n small, w large: some ffm.cpp:118 roots go negative (NaN)
+    m.set_state(st)
+    c = rand_rows(rng, 300, 4, nf, ordered=ordered, zipf=2.0, drop=0.1)
+    if mt != "FFM":
+        c.field[:] = 0
+        # distinct ids per row for LR here (a repeated id makes the feature serial)
+        rows = []
+        for r in range(c.n_rows):
+            seen, row = set(), []
+            for p in range(c.row_ptr[r], c.row_ptr[r + 1]):
+                if int(c.feat[p]) not in seen:
+                    seen.add(int(c.feat[p]))
+                    row.append((0, int(c.feat[p]), float(c.val[p])))
+            rows.append(row)
+        c = Csr.from_rows(rows, c.label)
+    logits, _ = m.train_batch(c)
+    tg = np.array([f32(m.sigmoid(float(l))) - f32(y) for l, y in zip(logits, c.label)], f32)
+    want = numpy_block(m, st, c, tg, STRESS_HP, F, k if mt == "FFM" else 0)
+    got = m.get_state()
+    if mt == "FFM":
+        assert np.isnan(got["vec_z"]).any(), "the case should reach ffm.cpp:118's NaN"
+        assert got["vec_z"].size - np.isnan(got["vec_z"]).sum() > 100
+    for key in ("bias3", "lin_n", "lin_z", "vec_n", "vec_z"):
+        assert_bitwise(got[key].ravel(), want[key].ravel(), key)

@@ -460,7 +460,10 @@ double fo_train_batch_rowwalk(fo_model *m, int n_rows, const int32_t *row_ptr, c
 /* ---------------- block update by reductions (the engine's batch semantics) ----------------
  *
  * With w and tmp_grad frozen over the block, the touches t = 0..T-1 of ONE accumulator (n, z),
- * taken in row order, are folded like this (FO_SEG consecutive touches form a segment s):
+ * taken in row order, are folded like this.  The occurrences of a feature in the block (the rows of
+ * the block for the bias), in row order, are cut into segments of FO_SEG; the touches an accumulator
+ * receives from the occurrences of segment s form its segment s (possibly empty: a row may lack the
+ * partner field) -- so all accumulators of a feature share the cut:
  *   P_s = sum of g_t*g_t, G_s = sum of g_t      (inside a segment left to right; the sums start
  *                                               from -0.0f, the identity of fp addition)
  *   B_0 = n_0, B_{s+1} = B_s + P_s,  n_T = B_S   (segment totals joined left to right)
@@ -485,25 +488,28 @@ typedef struct {
   float P, G, M;          /* the running segment: sum g*g, sum g, sum m */
   float B, Gacc, Macc;    /* the segments before it */
   float ncap;             /* n_t at the first :118 touch */
-  int cnt, any, seen, head_plain;
+  int any, seen, head_plain;
 } fo_acc;
 
 static inline void acc_init(fo_acc *a, float n0) {
   a->P = a->G = a->M = a->Gacc = a->Macc = -0.0f;
   a->B = n0;
   a->ncap = 0.0f;
-  a->cnt = a->any = a->seen = a->head_plain = 0;
+  a->any = a->seen = a->head_plain = 0;
 }
 static inline void acc_flush(fo_acc *a) {
   a->B = a->B + a->P;
   a->Gacc = a->Gacc + a->G;
   a->Macc = a->Macc + a->M;
   a->P = a->G = a->M = -0.0f;
-  a->cnt = 0;
+}
+/* before the touches of the feature's occurrence number `occ` (0-based): a new segment starts at
+ * every multiple of FO_SEG (joining an empty segment adds -0.0f: nothing) */
+static inline void acc_at(fo_acc *a, int occ) {
+  if (occ > 0 && occ % FO_SEG == 0) acc_flush(a);
 }
 /* one touch: gradient g, what the square root adds to n (q), plain = (q is g*g by construction) */
 static inline void acc_touch(const fo_model *m, fo_acc *a, float w, float g, float q, int plain) {
-  if (a->cnt == FO_SEG) acc_flush(a);
   const float nt = a->B + a->P;
   if (!a->any) { a->any = 1; a->head_plain = plain; }
   if (!plain && !a->seen) { a->seen = 1; a->ncap = nt; }
@@ -513,7 +519,6 @@ static inline void acc_touch(const fo_model *m, fo_acc *a, float w, float g, flo
   }
   a->G = a->G + g;
   a->P = a->P + g * g;
-  a->cnt++;
 }
 static inline void acc_finish_latent(const fo_model *m, fo_acc *a, float w, float *n, float *z) {
   if (!a->any) return;
@@ -659,7 +664,10 @@ double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int
   if (n_rows > 0) {
     fo_acc a;
     acc_init(&a, m->bias3[1]);
-    for (int r = 0; r < n_rows; r++) acc_touch(m, &a, m->bias3[0], tg[r], tg[r] * tg[r], 1);
+    for (int r = 0; r < n_rows; r++) {
+      acc_at(&a, r);
+      acc_touch(m, &a, m->bias3[0], tg[r], tg[r] * tg[r], 1);
+    }
     acc_finish_linear(m, &a, m->bias3[0], &m->bias3[1], &m->bias3[2]);
   }
   fo_groups g;
@@ -690,6 +698,7 @@ double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int
       for (int t = lo; t < hi; t++) {
         const int p = g.ent[t].p;
         const float gg = tg[g.row_of[p]] * val[p];
+        acc_at(&a, t - lo);
         acc_touch(m, &a, m->lin_w[i], gg, gg * gg, 1);
       }
       acc_finish_linear(m, &a, m->lin_w[i], &m->lin_n[i], &m->lin_z[i]);
@@ -711,6 +720,7 @@ double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int
             const int p = g.ent[t].p, r = g.row_of[p];
             const float x = val[p];
             const float gg = tg[r] * (x * svx[(size_t)r * k + f] - w * x * x);
+            acc_at(&a, t - lo);
             acc_touch(m, &a, w, gg, gg * gg, 1);
           }
           acc_finish_latent(m, &a, w, &m->vec_n[o], &m->vec_z[o]);
@@ -729,6 +739,7 @@ double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int
           for (int t = lo; t < hi; t++) {
             const int p = g.ent[t].p, r = g.row_of[p];
             const int q = g.rfirst[(size_t)r * F + fp];
+            acc_at(&a, t - lo);
             if (q < 0 || q == p) continue;
             const float x = p < q ? val[p] * val[q] : val[q] * val[p];
             const float vp = m->vec_w[feat[q] * L + (int64_t)field[p] * k + f];

@@ -7,8 +7,8 @@ definition itself, checked on the CPU:
 * on blocks of many rows the reductions and the strict row-order walk of rounds 1-4
   (fo_train_batch_rowwalk) are the same update in exact arithmetic: same logits (the forward is
   shared), state within rounding distance, NaNs at the same places;
-* a second, independent restatement of the fold in numpy float32 scalars (segments of 64 touches,
-  left to right; telescoped step sizes; per-touch terms from the first ffm.cpp:118 touch on)
+* a second, independent restatement of the fold in numpy float32 scalars (segments of 64 occurrences
+  of the feature, left to right; telescoped step sizes; per-touch terms from the first ffm.cpp:118 touch on)
   agrees with the C bit for bit.
 """
 import numpy as np
@@ -143,7 +143,6 @@ class Acc:
         self.B = f32(n0)
         self.n0 = f32(n0)
         self.alpha = f32(alpha)
-        self.cnt = 0
         self.any = self.seen = self.head_plain = False
         self.ncap = f32(0)
 
@@ -152,11 +151,13 @@ class Acc:
         self.Gacc = f32(self.Gacc + self.G)
         self.Macc = f32(self.Macc + self.M)
         self.P = self.G = self.M = NEG0
-        self.cnt = 0
+
+    def at(self, occ):
+        """Before the touches of the feature's occurrence number occ: segments are cut by occurrence."""
+        if occ > 0 and occ % SEG == 0:
+            self.flush()
 
     def touch(self, w, g, q, plain):
-        if self.cnt == SEG:
-            self.flush()
         nt = f32(self.B + self.P)
         if not self.any:
             self.any, self.head_plain = True, plain
@@ -168,7 +169,6 @@ class Acc:
             self.M = f32(self.M + f32(f32(d / self.alpha) * w))
         self.G = f32(self.G + g)
         self.P = f32(self.P + f32(g * g))
-        self.cnt += 1
 
     def sigma_w_total(self, w):
         M = NEG0
@@ -196,6 +196,7 @@ def numpy_block(model, st, c, tg, hp, F, k):
     out["lin_w"], out["vec_w"], out["bias3"][0] = w["lin_w"], w["vec_w"], w["bias3"][0]
     a = Acc(st["bias3"][1], alpha)
     for r in range(c.n_rows):
+        a.at(r)
         a.touch(w["bias3"][0], tg[r], f32(tg[r] * tg[r]), True)
     out["bias3"][1], out["bias3"][2] = a.finish_linear(w["bias3"][0], st["bias3"][2])
     row_of = np.repeat(np.arange(c.n_rows), np.diff(c.row_ptr))
@@ -212,8 +213,9 @@ def numpy_block(model, st, c, tg, hp, F, k):
             hi += 1
         i = int(c.feat[order[lo]])
         a = Acc(st["lin_n"][i], alpha)
-        for p in order[lo:hi]:
+        for occ, p in enumerate(order[lo:hi]):
             g = f32(tg[row_of[p]] * c.val[p])
+            a.at(occ)
             a.touch(w["lin_w"][i], g, f32(g * g), True)
         out["lin_n"][i], out["lin_z"][i] = a.finish_linear(w["lin_w"][i], st["lin_z"][i])
         for fp in range(F if L else 0):
@@ -221,9 +223,10 @@ def numpy_block(model, st, c, tg, hp, F, k):
                 e = fp * k + f
                 wv = vw[i, e]
                 a = Acc(st["vec_n"].reshape(-1, L)[i, e], alpha)
-                for p in order[lo:hi]:
+                for occ, p in enumerate(order[lo:hi]):
                     r = int(row_of[p])
                     q = byrow.get((r, fp))
+                    a.at(occ)
                     if q is None or q == p:
                         continue
                     x = f32(c.val[p] * c.val[q])

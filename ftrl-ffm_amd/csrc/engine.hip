@@ -7,7 +7,8 @@
 //   {ffm,fm}_row<TRAIN>   lazy refresh + forward -> logit           (kernels_row.h)
 //   [cross-shard sum of the logits when n_shards > 1 -- done by the caller, RCCL]
 //   tmp_grad -> loss_sum
-//   linear_update, bias_update, {ffm,fm}_update                     (kernels_update.h)
+//   the (n, z) update of every touched accumulator, folded by        (kernels_fold.h, kernels_update.h,
+//   reductions: bias, linear, {ffm,fm} latent                         kernels_tile.h)
 // There is no CPU fallback anywhere in this library.
 #include <hip/hip_runtime.h>
 
@@ -37,8 +38,8 @@
 #include "init_rng.h"
 #include "kernels_group.h"
 #include "kernels_row.h"
+#include "kernels_fold.h"
 #include "kernels_update.h"
-#include "kernels_chain.h"
 #include "kernels_tile.h"
 #include "kernels_fm.h"
 #include "kernels_sort.h"
@@ -104,15 +105,14 @@ int fail(int code, const std::string &msg) {
 enum KernelId {
   K_GROUP_KEYS, K_GROUP_SORT, K_GROUP_FINISH, K_ROW, K_TMP_GRAD,
   K_HOT_META,
-  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_HOT, K_LATENT_UPDATE_HUGE,
+  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_FEW,
   K_PREDICT_ROW, K_REFRESH, K_LATENT_UPDATE_SINGLE,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "group_keys_kernel", "group_radix_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
-    "linear_update_kernel", "bias_update_kernel", "latent_update_kernel", "latent_update_hot_kernel",
-    "latent_update_huge_kernel",
-    "row_kernel<predict>", "refresh_kernel", "latent_update_single_kernel"};
+    "linear_update_kernel", "bias_update_kernel", "update_kernel", "update_few_flat_kernel",
+    "row_kernel<predict>", "refresh_kernel", "update_single_kernel"};
 
 struct ProfRec {
   int kid;
@@ -269,8 +269,6 @@ struct ffm_engine {
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
   hipStream_t copy = nullptr;  // the upload kernel's stream: prep, or aux3 for long steps (ffm_engine_create)
   bool own_sort = false;        // the grouping's sort: kernels_sort.h (short steps) or rocPRIM Onesweep (ffm_engine_create)
-  int chain_min_fixed = 0;      // FFM_CHAIN_MIN: the giant list's boundary for every block (0: chosen per block)
-  int update_fused = -1;        // FFM_UPDATE_FUSED: 1 / 0 the whole FFM update in one launch always / never (-1: small blocks)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
   // Scheduling of a look-ahead grouping (FFM_PREP_WINDOW=0 turns it off): the block being
   // prepared will start training when its predecessor's update ends; its grouping is made to
@@ -285,9 +283,7 @@ struct ffm_engine {
   bool own_stream = false;
   // Streams: the runtime multiplexes streams onto few hardware queues (4 by default), and two
   // streams on one queue run one after the other -- so no more than stream + 2 side + prep here.
-  hipStream_t aux2 = nullptr;  // side stream: hot-feature latent update (or the bias + linear chains)
-  hipStream_t aux3 = nullptr;  // side stream: very-hot-feature latent update
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_join3 = nullptr;
+  hipStream_t aux3 = nullptr;  // side stream: uploads of long-step engines (see `copy`)
   int max_rows = 0, max_nnz = 0, max_row_nnz = 1024;
   // longest row of the block being staged from host memory (known there; 0 = unknown: device
   // callers).  The row kernels size their LDS by it, which decides how many rows a CU holds.
@@ -353,29 +349,19 @@ struct ffm_engine {
   // updated there too when the row kernel has the whole logit (FFM_ENGINE_ROW_REFRESH=0/2/3)
   int refresh_mode = 3;
   bool singles_in_row = false;  // the block in flight had its once-only features updated by the row kernel
-  // Row phases (engine_types.h): the rows of a block cut into `phases` ranges, the hot / very hot
-  // update of one range beside the forward pass of the next (FFM_PHASES=2..4).  Off by default:
-  // bit-identical, but measured 5 % (2 phases) to 16 % (4) SLOWER per step -- the row kernel of
-  // the next phase reaches the chip first and keeps every wave slot refilled, the update kernels
-  // of the previous phase (112 VGPRs per wave against the row kernel's 80) find room only when it
-  // drains, so nothing overlaps and the per-launch fixed costs double.  cur_phases: of the block
-  // in flight.
-  int phases = 1, cur_phases = 1;
-  hipEvent_t ev_row[kMaxPhases] = {};
   unsigned long long *d_ownmask = nullptr;
   bool lin_any = true;          // this shard owns the linear terms of at least one field
   int logical_len = 0;          // n_fields * n_factors (FFM), n_factors (FM), 0 (LR): the reference's row
   int64_t n_records = 0;        // stored latent records (n_feats, or fewer on a compact shard)
   std::vector<int> field_start; // copy of cfg->field_start (compact shards)
-  // workgroups of the three latent-update kernels when they run side by side (tuning knobs:
-  // FFM_GRID_SMALL / FFM_GRID_HOT / FFM_GRID_HUGE)
-  int grid_small = 768, grid_hot = 2048, grid_huge = 1024, grid_single = 768;
+  // workgroups of the update launch's ranges: few-occurrence features, hot tiles, the row-order walk
+  // of serial slots; and of the once-only kernel of a shard
+  int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768;
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
   // slowed the HBM-bound kernels they ran beside up to 4x (refresh of a 65536-row block 70 -> 330 us),
   // 24 (96 KB, about the link's bandwidth-delay product) still move the block at link rate.
   int grid_pull = 24;
-  int grid_giant = 512;  // workgroups that walk the giant features (FFM_GRID_GIANT)
   bool single_kernel = true;  // FFM_SINGLE_KERNEL=0: once-only features through the small kernel
   bool single_flat = true;    // FFM_SINGLE_FLAT=0: one wave per feature also for short stored records
   int row_threads = kRowThreads;  // workgroup size of the FFM row kernel (FFM_ROW_THREADS)
@@ -519,33 +505,12 @@ struct ffm_engine {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int loss_grid(int n_rows) { return std::max(1, std::min(kLossParts, cdiv(n_rows, 1024))); }
 
-// The giant list (the block's giant_min occurrences or more, engine_step.h: chain_min_for) takes the
-// touch-parallel DPP chains of kernels_chain.h, instantiated per number of interleaved chains
-// (groups of 4 factors of a slot handled by one wave): 1, 2 or 4; the features with kGiantMin
-// occurrences or more (only the 65536-row blocks of a multi-GPU job have them) one chain per wave,
-// in the launch's first workgroups.
-static void launch_ffm_chain(ffm_engine *e, hipStream_t st, const Rows &rows, int ph = 0, int phases = 1) {
-  const int groups = e->m.n_factors / 4;
-  const int gb = rows.nnz < kGiantMin ? 0 : e->grid_giant, grid = e->grid_huge + gb;
-  if (groups >= 3) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
-  else if (groups == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
-  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HUGE, ffm_update_chain_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], gb, ph, phases);
-}
-
-// The hot features' update (kernels_tile.h: the huge and big lists), with the bias chain and the
-// linear update in its first side_blocks workgroups.  Instantiated per number of facts a stager
-// lane carries: slots per 64-element chunk / 4.
+// The update launch (kernels_tile.h) is instantiated per number of facts a stager lane of the hot
+// features' tiles carries: slots per 64-element chunk / 4.
 static int tile_nf(const ffm_engine *e) {
   const int k = e->m.n_factors, spc = k <= 64 ? 64 / k : 1;
   return spc > 8 ? 4 : spc > 4 ? 2 : 1;
 }
-static void launch_ffm_hot(ffm_engine *e, hipStream_t st, const Rows &rows, int side_blocks, int ph = 0, int phases = 1) {
-  const int grid = e->grid_hot + side_blocks, nf = tile_nf(e);
-  if (nf == 1) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<1>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 3);
-  else if (nf == 2) LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<2>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 3);
-  else LAUNCH_ON(e, st, K_LATENT_UPDATE_HOT, ffm_update_tile_kernel<4>, grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], side_blocks, ph, phases, 3);
-}
-
 // The once-only / few-occurrence kernels over a flat (feature, vector) index space instead of a
 // wave per feature: when a wave per feature would leave more than a sixth of its lanes idle on a
 // compact shard's records (40 vectors at 8 shards, 80 at 2 or 4).  For full-length records (156
@@ -554,14 +519,6 @@ static bool flat_pays(const ffm_engine *e, int span4) {
   if (!e->single_flat || e->m.n_shards <= 1 || span4 <= 0) return false;
   const int lanes = (span4 + 63) / 64 * 64;
   return span4 * 6 < lanes * 5;
-}
-
-// Row phases a block of n_rows rows is grouped for (and trained in, when the row kernel has the
-// whole logit): only where the forward pass and the hot features' update are both long enough.
-static int phases_for(const ffm_engine *e, int n_rows) {
-  const bool ok = e->m.type == FFM_MODEL_FFM && e->m.n_shards == 1 && e->m.n_factors % 4 == 0 &&
-                  e->pre_refresh && !e->serial && n_rows >= 1024 * e->phases;
-  return ok ? e->phases : 1;
 }
 
 extern "C" {
@@ -599,7 +556,6 @@ void ffm_engine_destroy(ffm_engine *e) {
   // everything the engine has in flight -- uploads still reading the caller's page-locked arrays
   // (staged, never trained), look-ahead groupings, the side streams -- ends before anything is freed
   if (e->prep) (void)hipStreamSynchronize(e->prep);
-  if (e->aux2) (void)hipStreamSynchronize(e->aux2);
   if (e->aux3) (void)hipStreamSynchronize(e->aux3);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &r : e->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -610,20 +566,14 @@ void ffm_engine_destroy(ffm_engine *e) {
     if (sl.ev_trained) (void)hipEventDestroy(sl.ev_trained);
   }
   for (void *p : e->allocs) (void)hipFree(p);
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   for (int i = 0; i < ffm_engine::kSets; i++) {
     if (e->ev_grouped[i]) (void)hipEventDestroy(e->ev_grouped[i]);
     if (e->ev_set_free[i]) (void)hipEventDestroy(e->ev_set_free[i]);
   }
-  for (auto &ev : e->ev_row) if (ev) (void)hipEventDestroy(ev);
   if (e->h_pulled) (void)hipHostFree(e->h_pulled);
   if (e->prep) (void)hipStreamDestroy(e->prep);
 
-  if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
-  if (e->ev_join3) (void)hipEventDestroy(e->ev_join3);
   if (e->aux3) (void)hipStreamDestroy(e->aux3);
-  if (e->aux2) (void)hipStreamDestroy(e->aux2);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -662,7 +612,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   e->max_nnz = cfg->max_batch_nnz;
   if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
-  if (const char *sv = std::getenv("FFM_UPDATE_FUSED")) e->update_fused = std::atoi(sv) != 0 ? 1 : 0;
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
   // a shard's row holds ~1/n_shards of the pairs: one wave per row, so that (with the small LDS
@@ -672,8 +621,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   // measured 2.5 % per step better than 768 on an 8-GPU rank's blocks)
   if (cfg->n_shards > 1) e->grid_single = 1152;
 
-  if (const char *sv = std::getenv("FFM_PHASES")) e->phases = std::min(kMaxPhases, std::max(1, std::atoi(sv)));
-  if (const char *sv = std::getenv("FFM_CHAIN_MIN")) e->chain_min_fixed = std::max(kChainMin, std::atoi(sv));
   {
     const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
     const int64_t per = cfg->n_factors % 4 == 0 ? static_cast<int64_t>(cfg->n_fields) * cfg->n_factors / 4
@@ -695,7 +642,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.shard_rank = cfg->shard_rank;
   m.bias_own = 1;
   m.huge_min = kHugeMin;
-  m.giant_min = kGiantMin;  // (FFM: chosen per block, chain_min_for)
+  m.giant_min = kGiantMin;
   m.rec_slots = m.n_fields;
   e->n_records = cfg->n_feats;
   // field-pair partition: this shard's ranges, and (with per-field id ranges) compact storage
@@ -742,12 +689,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   }
   // (priority streams for the hot / very hot update: measured +45 % per step; for the look-ahead
   // grouping: the same)
-  TRY_HIP(hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking));
-  TRY_HIP(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
   TRY_HIP(hipStreamCreateWithFlags(&e->aux3, hipStreamNonBlocking));
-  TRY_HIP(hipEventCreateWithFlags(&e->ev_join3, hipEventDisableTiming));
-  TRY_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-  TRY_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   const size_t nf = static_cast<size_t>(cfg->n_feats);
   const size_t n_lat = static_cast<size_t>(e->n_records) * 3 * static_cast<size_t>(m.row_len);
   TRY_ALLOC(e->alloc(&m.bias3, 4));
@@ -778,7 +720,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.next, E));
   TRY_ALLOC(e->alloc(&s.rowtab, R * static_cast<size_t>(m.n_fields)));
   TRY_ALLOC(e->alloc(&s.occpos, E));
-  TRY_ALLOC(e->alloc(&s.usplit, E));
+  TRY_ALLOC(e->alloc(&s.uflag, E));
   const bool ffm_model = m.type == FFM_MODEL_FFM;
   const bool masks = ffm_model && m.n_fields <= 64;
   if (masks) {
@@ -862,7 +804,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.giant, E / kChainMin + 1));
     TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
     TRY_ALLOC(e->alloc(&t.occpos, E));
-    TRY_ALLOC(e->alloc(&t.usplit, E));
+    TRY_ALLOC(e->alloc(&t.uflag, E));
     if (masks) {
       TRY_ALLOC(e->alloc(&t.rowmask, 2 * R));
       TRY_ALLOC(e->alloc(&t.gmask, E));
@@ -896,7 +838,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     e->own_sort = !(ffm4 && phase_us / std::max(1, m.n_shards) >= 100.0);  // (a shard does 1/n_shards of the pairs)
     if (const char *sv = std::getenv("FFM_OWN_SORT")) e->own_sort = std::atoi(sv) != 0;
   }
-  for (auto &ev : e->ev_row) TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   for (int i = 0; i < ffm_engine::kSets; i++) {
     TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&e->ev_set_free[i], hipEventDisableTiming));

@@ -68,13 +68,13 @@ int ffm_engine_profile_read(ffm_engine *e, int32_t *n_launches, double *total_ms
     std::string name = kKernelNames[best];
     if (best == K_REFRESH) name = "ffm_refresh_kernel";
     else if (best == K_LATENT_UPDATE_SINGLE) name = "ffm_update_single_kernel";
-    else if (best == K_ROW || best == K_PREDICT_ROW || best == K_LATENT_UPDATE || best == K_LATENT_UPDATE_HOT ||
-        best == K_LATENT_UPDATE_HUGE)
+    else if (best == K_LATENT_UPDATE_FEW) name = "ffm_update_small_flat_kernel";
+    else if (best == K_LATENT_UPDATE)
+      name = e->m.type == FFM_MODEL_FM ? "fm_update_kernel"
+             : e->m.n_factors % 4 == 0 && e->m.n_fields <= 64 ? "ffm_update_all_kernel" : "ffm_update_generic_kernel";
+    else if (best == K_ROW || best == K_PREDICT_ROW)
       name = std::string(e->m.type == FFM_MODEL_FM ? "fm_" : "ffm_") +
-             (best == K_LATENT_UPDATE ? (e->m.type == FFM_MODEL_FM ? "update_kernel" : "update_small_kernel")
-              : best == K_LATENT_UPDATE_HOT ? (e->m.type == FFM_MODEL_FM ? "update_hot_kernel" : "update_tile_kernel")
-              : best == K_LATENT_UPDATE_HUGE ? "update_chain_kernel"
-              : (best == K_ROW ? "row_kernel<train>" : "row_kernel<predict>"));
+             (best == K_ROW ? "row_kernel<train>" : "row_kernel<predict>");
     std::snprintf(kernel_name, kernel_name_cap, "%s", name.c_str());
   }
   return FFM_OK;

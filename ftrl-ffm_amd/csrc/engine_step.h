@@ -49,7 +49,6 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
       if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
       else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
     }
-    if (train) e->cur_phases = own_tg && vec4 ? phases_for(e, rows.n_rows) : 1;
     // LDS parking (round 4): the first vectors of (n, z) that a row's refresh reads for its once-only
     // features stay in LDS for the row's own in-row update instead of coming back over the fabric.  As
     // many as fit beside the staging arrays in 30 KB of dynamic LDS (five rows per CU: 527 us per C5 block
@@ -68,15 +67,10 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
       if (park > 0) shmem_park = base + 32 * static_cast<size_t>(park);
     }
     if (train && vec4) {
-      // one launch per row phase; the update streams pick each phase up at its event
-      for (int ph = 0; ph < e->cur_phases; ph++) {
-        const int r0 = phase_row(rows.n_rows, e->cur_phases, ph), r1 = phase_row(rows.n_rows, e->cur_phases, ph + 1);
-        if (r1 > r0 && own_tg)
-          LAUNCH(e, kid, (ffm_row_kernel<true, true, true>), r1 - r0, e->row_threads, shmem_park, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, r0, park);
-        else if (r1 > r0)  // a shard: the logit is whole only after the all-reduce
-          LAUNCH(e, kid, (ffm_row_kernel<true, true, false>), r1 - r0, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, 0, r0, 0);
-        if (e->cur_phases > 1) (void)hipEventRecord(e->ev_row[ph], e->stream);
-      }
+      if (own_tg)
+        LAUNCH(e, kid, (ffm_row_kernel<true, true, true>), rows.n_rows, e->row_threads, shmem_park, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, 0, park);
+      else  // a shard: the logit is whole only after the all-reduce
+        LAUNCH(e, kid, (ffm_row_kernel<true, true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, 0, 0, 0);
     }
     else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, 0, 0);
     else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0, 0);
@@ -100,27 +94,6 @@ __global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_c
 
 // Groups `rows` by feature into scratch set `set` on stream `st`.
 // timed = false: from the staging thread (no HIP-event bookkeeping of the profiler there).
-// From how many occurrences in a block a feature's update takes the touch-parallel DPP chains
-// (kernels_chain.h) instead of the tile kernel (kernels_tile.h).  The tile kernel applies a hot
-// feature's touches as one chain per element at ~0.2 us per touch of one wave (a tile of 16 touches
-// in ~3 us: s_memtime stamps at FFM 39 x 16); the DPP chains take ~0.03 us per touch of a chain at
-// two to three times the instructions.  So the tile kernel's longest chain should last about as
-// long as what bounds the update phase anyway -- its throughput-bound time (0.88 touch-elements per
-// ns measured with round 3's kernels; the tile kernel needs half the instructions, hence the 0.3
-// below where its 0.2 us per touch would say 0.2) or the bias chain (12 ns per row) -- and only
-// longer chains are worth the DPP kernel's instructions: the top id of every field of an 8192 x 39
-// block (~1030 touches; boundary 733: 1.011 -> 0.978 ms per step, 512 the same, 384 and 256 slower:
-// the DPP kernel's extra instructions then bound the phase), the few hundred-touch features of a
-// 4096 x 8 block.  Never above kGiantMin.
-static int chain_min_for(const ffm_engine *e, const Rows &rows) {
-  if (e->m.type != FFM_MODEL_FFM || rows.n_rows <= 0) return e->m.giant_min;
-  if (e->chain_min_fixed) return std::min(e->chain_min_fixed, kGiantMin);
-  const double per_row = static_cast<double>(rows.nnz) / rows.n_rows;
-  const double touch_elems = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / std::max(1, e->m.n_shards);
-  const double span_us = std::max(touch_elems / 0.88e6, rows.n_rows * 0.012);
-  return static_cast<int>(std::min<double>(kGiantMin, std::max<double>(kChainMin, span_us / 0.3)));
-}
-
 static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t st, bool timed = true) {
   Scratch &sc = e->sc[set];
   ScopedTimer tm_all("grouping:all");
@@ -151,13 +124,8 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
                                         static_cast<size_t>(nnz), 0u, e->sort_bits, st));
     }
     if (timed) e->prof_end(st);
-    ModelDev mf = e->m;  // (the only kernel that deals features into the hot / very hot / giant lists)
-    mf.giant_min = chain_min_for(e, rows);
-    mf.huge_min = std::min(mf.huge_min, mf.giant_min - 1);
-    if (timed) LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, mf, rows, sc,
-                         phases_for(e, rows.n_rows));
-    else hipLaunchKernelGGL(group_finish_kernel, dim3(cdiv(nnz, kFinishThreads)), dim3(kFinishThreads), 0, st, mf, rows, sc,
-                            phases_for(e, rows.n_rows));
+    if (timed) LAUNCH_ON(e, st, K_GROUP_FINISH, group_finish_kernel, cdiv(nnz, kFinishThreads), kFinishThreads, 0, e->m, rows, sc);
+    else hipLaunchKernelGGL(group_finish_kernel, dim3(cdiv(nnz, kFinishThreads)), dim3(kFinishThreads), 0, st, e->m, rows, sc);
   }
   HIP_TRY(hipGetLastError());
   return FFM_OK;
@@ -274,120 +242,59 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->sc[e->cur].tg, e->sc[e->cur].loss, logit_out);
   if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0 && !own_tg)
     LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
-  // this shard runs the bias chain / a linear update when it owns the bias / any field's linear terms
+  // Everything below runs on the main stream: the update has no long dependent chains (every
+  // accumulator is folded by reductions, kernels_fold.h), so nothing needs a queue of its own.
   // FM, whole step: fm_row_wave_kernel has applied the touches of the once-only features itself
   const int fm_in_row = e->m.type == FFM_MODEL_FM && own_tg && e->singles_in_row ? 1 : 0;
+  // this shard folds the bias / runs a linear update when it owns the bias / any field's linear terms
   const bool lin_owner = e->m.bias_own != 0 || e->lin_any;
   const bool ffm = e->m.type == FFM_MODEL_FFM && rows.nnz > 0;
   const bool vec4 = e->m.n_factors % 4 == 0;
+  const bool masks = e->sc[e->cur].cmask != nullptr;  // (n_fields <= 64)
   const int lin_blocks = rows.nnz > 0 ? std::min(cdiv(rows.nnz, kUpdThreads), 1024) : 0;
-  // The bias and linear chains are short and serial: they run beside the latent update -- inside
-  // the hot-feature launch when there is one (side_blocks), else on the side stream.
-  const bool side_in_hot = ffm && vec4 && lin_owner && rows.n_rows > 0;
-  const int side_blocks = side_in_hot ? 1 + lin_blocks : 0;
-  // FM: the same inside the launch of the few-occurrence features' latent update
-  const bool side_in_fm = e->m.type == FFM_MODEL_FM && lin_owner && rows.n_rows > 0 && rows.nnz > 0 && !e->serial;
-  const int fm_side_blocks = side_in_fm ? 1 + lin_blocks : 0;
-  const bool forked = rows.n_rows > 0 && lin_owner && !e->serial && !side_in_hot && !side_in_fm;
-  if (rows.n_rows > 0 && lin_owner && e->serial && !side_in_hot) {
-    LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, kUpdThreads, 0, e->m, rows.n_rows, e->sc[e->cur]);
-    if (rows.nnz > 0)
-      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
-  }
-  if (forked || (ffm && vec4)) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
-  if (forked) {
-    HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_fork, 0));
-    // the bias chain (one wave, as long as the block has rows) alone on the side stream; the linear
-    // update shares the main stream with the latent update of the few-occurrence features
-    LAUNCH_ON(e, e->aux2, K_BIAS_UPDATE, bias_update_kernel, 1, kUpdThreads, 0, e->m, rows.n_rows, e->sc[e->cur]);
-    HIP_TRY(hipEventRecord(e->ev_join, e->aux2));
-    if (rows.nnz > 0)
-      LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row);
-  }
-  // small features on the main stream: the once-only ones through their descriptor kernel
-  auto launch_small = [&]() {
+  const int side_blocks = lin_owner && rows.n_rows > 0 ? 1 + lin_blocks : 0;
+  bool loss_done = false;
+  if (ffm && vec4 && masks) {
     const bool single = e->single_kernel;
+    const int span4 = e->m.rec_slots * (e->m.n_factors / 4);  // 16-byte vectors of a stored record
+    const bool flat = flat_pays(e, span4);
     if (single && !e->singles_in_row) {  // (else: already applied by the row kernel)
-      const int span4 = e->m.rec_slots * (e->m.n_factors / 4);  // 16-byte vectors of a stored record
-      if (flat_pays(e, span4)) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_flat_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      if (flat) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_flat_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else if (span4 <= 64) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<1>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else if (span4 <= 128) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
       else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     }
-    if (flat_pays(e, e->m.rec_slots * (e->m.n_factors / 4)))
-      LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
-    else
-      LAUNCH(e, K_LATENT_UPDATE, ffm_update_small_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
-  };
-  if (ffm && vec4 && e->serial) {
-    launch_ffm_chain(e, e->stream, rows);
-    launch_ffm_hot(e, e->stream, rows, side_blocks);
-    launch_small();
-  } else if (ffm && vec4) {
-    // the three owner shapes touch disjoint features: run them side by side (long sequential
-    // chains of the hot ones beside the bandwidth-shaped small-feature pass).  With row phases the
-    // two side streams take each phase's touches as soon as its rows are done -- beside the forward
-    // pass of the next phase (which reads w; the update writes n and z).
-    const int P = own_tg ? e->cur_phases : 1;
-    // Small blocks: the whole update in one launch (kernels_tile.h: ffm_update_all_tile_kernel) -- the
-    // fork / join hops between the three streams cost more than the fused kernel's extra registers.
-    // An estimate of the phase's length from the touch-elements of the block (0.44 per ns measured at FFM 39 x 16).
-    const double per_row = rows.n_rows > 0 ? static_cast<double>(rows.nnz) / rows.n_rows : 0.0;
-    const double phase_us = static_cast<double>(rows.nnz) * std::max(0.0, per_row - 1.0) * e->m.n_factors / 0.44e6;
-    const bool fused = e->update_fused >= 0 ? e->update_fused != 0 : phase_us < 100.0;
-    if (fused && P == 1 && own_tg && e->singles_in_row && e->m.n_shards == 1) {
-      const int fc = e->grid_huge, fh = e->grid_hot, fs = e->grid_small, nf = tile_nf(e);
-      const int gb = rows.nnz < kGiantMin ? 0 : std::min(e->grid_giant, 64);
-      const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
-      const int grid = side_blocks + gb + fc + fh + fs + lb;
-#define FTRL_LAUNCH_ALL(NF, G)                                                                                     \
-      LAUNCH(e, K_LATENT_UPDATE_HOT, (ffm_update_all_tile_kernel<NF, G>), grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-             side_blocks, gb, fc, fh, fs, 1, lb, loss_sum_out, e->d_loss_part)
-      if (nf == 1) FTRL_LAUNCH_ALL(1, 4);       // k >= 16: four groups of four factors per slot and wave
-      else if (nf == 2) FTRL_LAUNCH_ALL(2, 2);  // k = 8 / 12
-      else FTRL_LAUNCH_ALL(4, 1);               // k = 4
+    if (flat) LAUNCH(e, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
+    const int nt = e->grid_hot, ns = flat ? 0 : e->grid_small, nw = e->grid_walk, nf = tile_nf(e);
+    const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
+    const int grid = side_blocks + nt + ns + nw + lb;
+#define FTRL_LAUNCH_ALL(NF)                                                                                   \
+    LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
+           side_blocks, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part)
+    if (nf == 1) FTRL_LAUNCH_ALL(1);       // k >= 16
+    else if (nf == 2) FTRL_LAUNCH_ALL(2);  // k = 8 / 12
+    else FTRL_LAUNCH_ALL(4);               // k = 4
 #undef FTRL_LAUNCH_ALL
-    } else {
-    for (int ph = 0; ph < P; ph++) {
-      HIP_TRY(hipStreamWaitEvent(e->aux3, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
-      launch_ffm_chain(e, e->aux3, rows, ph, P);
+    loss_done = loss_sum_out != nullptr;
+  } else {
+    if (side_blocks > 0 && e->m.type != FFM_MODEL_FM) {
+      LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, kUpdThreads, 0, e->m, rows.n_rows, e->sc[e->cur]);
+      if (rows.nnz > 0)
+        LAUNCH(e, K_LINEAR_UPDATE, linear_update_kernel, lin_blocks, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 0);
     }
-    HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
-    for (int ph = 0; ph < P; ph++) {
-      HIP_TRY(hipStreamWaitEvent(e->aux2, P > 1 ? e->ev_row[ph] : e->ev_fork, 0));
-      launch_ffm_hot(e, e->aux2, rows, side_blocks, ph, P);
-    }
-    HIP_TRY(hipEventRecord(e->ev_join2, e->aux2));
-    launch_small();
-    if (loss_sum_out)
-      LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
-    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));
-    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
-    }
-  } else if (ffm) {
-    LAUNCH(e, K_LATENT_UPDATE_HOT, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-  } else if (e->m.type == FFM_MODEL_FM && rows.nnz > 0) {
-    // the very hot features' long chains on their own stream, lane = (factor, touch)
-    if (side_in_fm) {
-      // everything in one launch on the main stream: bias + linear, the very hot chains, the lists
-      const int chain_blocks = 1024;
-      LAUNCH(e, K_LATENT_UPDATE, fm_update_all_kernel, fm_side_blocks + chain_blocks + 2048, kUpdThreads, 0, e->m, rows,
-             e->sc[e->cur], fm_in_row, fm_side_blocks, chain_blocks);
-    } else {
-      if (forked) {
-        HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0));
-        LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-        HIP_TRY(hipEventRecord(e->ev_join3, e->aux3));
-      } else {
-        LAUNCH(e, K_LATENT_UPDATE_HUGE, fm_update_chain_kernel<4>, 1024, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-      }
-      LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 1, fm_in_row, 0);
-      if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
+    if (ffm) {
+      // n_factors % 4 != 0, or more than 64 fields (no field masks: every slot keeps the row-order
+      // walk): the general owner for every feature, the once-only ones included
+      LAUNCH(e, K_LATENT_UPDATE, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 0);
+    } else if (e->m.type == FFM_MODEL_FM) {
+      if (rows.nnz > 0)
+        LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, side_blocks + 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row, side_blocks);
+      else if (side_blocks > 0)
+        LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, kUpdThreads, 0, e->m, rows.n_rows, e->sc[e->cur]);
     }
   }
-  if (loss_sum_out && !(ffm && vec4 && !e->serial))
+  if (loss_sum_out && !loss_done)
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(rows.n_rows), 256, 0, rows.n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
-  if (forked) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
   HIP_TRY(hipEventRecord(e->ev_set_free[e->cur], e->stream));
   e->trained_set[1] = e->trained_set[0];
   e->trained_set[0] = e->cur;

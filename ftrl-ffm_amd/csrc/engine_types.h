@@ -56,7 +56,8 @@ struct ModelDev {
   const int *lin_own;         // [n_fields] 1 when this shard owns the field's linear terms; null: all
   int bias_own;               // 1 when this shard owns the bias
   int huge_min;               // occurrences per block above which a hot feature is listed as "very hot" (kHugeMin)
-  int giant_min;              // ... from which it is listed as "giant": the touch-parallel chains' (FFM: per block)
+  int giant_min;              // ... from which it is listed as "giant": its occurrences are cut into
+                              //     segment ranges that several waves fold side by side (kGiantMin)
 };
 
 enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };
@@ -158,8 +159,7 @@ struct Scratch {
                                 //      some row of the block touches slot fp of the feature
   unsigned long long *cmask;    // [nnz] the same for slots whose partner field is MULTI-VALUED in some
                                 //      row of the feature (the row holds >= 2 entries of field fp)
-  int *usplit;    // [nnz] row phases (see phase_row): for a hot feature whose group starts at `start`,
-                  //      usplit[start + j] = how many of its occurrences lie in rows before phase j+1
+  int *uflag;     // [nnz] per distinct feature, at index ustart[u]: UF_* bits (all model types)
   int *occpos;    // [nnz] entry -> its position t in occ when its feature is hot, else
                   //      OCC_FEW (2..kSmallMax occurrences) or OCC_ONCE (this entry only)
   int4 *haux;     // [nnz*n_fields] per (occurrence t, partner field): {partner value bits,
@@ -172,20 +172,16 @@ struct Scratch {
   float *svx;     // [n_rows*n_factors] FM per-row factor sums (sum_vx, fm.h:24)
 };
 
-// Row phases: a block's rows may be cut into P consecutive ranges ("phases") so that the update of
-// the hot features' touches from one range runs beside the forward pass of the next (the forward
-// reads w, the update writes n and z: no hazard inside a block).  Phase j covers rows
-// [phase_row(j), phase_row(j + 1)); a hot feature's occurrences are in row order, so a phase owns
-// a contiguous run [lo, hi) of them.
-constexpr int kMaxPhases = 4;
-__host__ __device__ inline int phase_row(int n_rows, int phases, int j) {
-  return static_cast<int>(static_cast<long long>(n_rows) * j / phases);
-}
-__device__ __forceinline__ void phase_touches(const Scratch &s, int start, int c, int ph, int phases,
-                                              int &lo, int &hi) {
-  lo = ph == 0 ? 0 : s.usplit[start + ph - 1];
-  hi = ph == phases - 1 ? c : s.usplit[start + ph];
-}
+// UF_DUP: the feature occurs twice (or more) in ONE row of the block -- the reference's running
+// update inside a row is not a sum, so everything of that feature which the row touches keeps the
+// row-order walk for the block (the checker under oracle/: mark_serial); for FFM the affected slots are in
+// cmask as well.
+enum { UF_DUP = 1 };
+
+// The block update folds the touches of an accumulator by reductions over SEGMENTS of kSeg
+// consecutive occurrences of its feature in the block (rows of the block for the bias), joined left
+// to right -- the tree the checker under oracle/ (FO_SEG) restates; see kernels_fold.h.
+constexpr int kSeg = 64;
 
 // Every counter that takes atomics sits on a 64-byte line of its own (kLineInts apart):
 // device-scope atomics are performed at the memory side, one line at a time, and the grouping's
@@ -198,22 +194,18 @@ enum { CNT_NUNIQ = 0, CNT_CURSOR = 1 * kLineInts, CNT_NMULTI = 2 * kLineInts, CN
 constexpr int kNumCounters = 12 * kLineInts;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 // Occurrence classes of a block's hot features (more than kSmallMax occurrences):
-//   big   (.. huge_min]             tile kernel (FFM) / list kernel (FM)
-//   huge  (huge_min .. giant_min)   FFM: the tile kernel too, started first and at raised issue
-//                                   priority; FM: the touch-parallel chain kernel
-//   giant [giant_min ..             touch-parallel DPP chains (kernels_chain.h); one chain per wave
-//                                   from kGiantMin occurrences on
-// huge_min = kHugeMin; giant_min = kGiantMin for FM, chosen per block for FFM (engine_step.h:
-// chain_min_for).
+//   big   (.. huge_min]             one wave folds all touches of (feature, 64 elements)
+//   huge  (huge_min .. giant_min)   the same, started first (the longest folds bound the phase)
+//   giant [giant_min ..             segment ranges of one feature folded by several waves side by
+//                                   side, partial sums joined afterwards (kernels_tile.h)
 #ifndef FFM_HUGE_MIN
 #define FFM_HUGE_MIN 192
 #endif
 constexpr int kHugeMin = FFM_HUGE_MIN;
 #ifndef FFM_GIANT_MIN
-#define FFM_GIANT_MIN 2048
+#define FFM_GIANT_MIN 1024
 #endif
-// ... and from which its chains are so long that their LATENCY sets the update phase's span: such
-// "giant" features are listed apart (s.giant) and walked one group of 4 factors per wave
+// ... and from which one wave per (feature, 64 elements) would be the update phase's span
 constexpr int kGiantMin = FFM_GIANT_MIN;
 constexpr int kChainMin = 64;  // the least giant_min an engine may choose (sizes Scratch::giant)
 enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry

@@ -1,0 +1,229 @@
+// kernels_fold.h -- the block update of ONE (n, z) accumulator as reductions.
+//
+// With w and tmp_grad frozen over a block, the reference's per-sample step
+//   sigma = (sqrtf(n + q) - sqrtf(n)) / alpha ;  z' = z + g - sigma*w ;  n' = n + g*g
+// (src/model/ftrl_model.cpp:69-74, :81-84; src/model/ffm.cpp:112-120; src/model/fm.cpp:90-94)
+// applied by every touching row in turn is, in exact arithmetic,
+//   n_T = n_0 + sum g*g ,   z_T = z_0 + sum g - w * sum sigma_t
+// and for "plain" touches (q = g*g: linear, bias, FM, the first slot of an FFM pair) the step sizes
+// telescope: sum sigma_t = (sqrtf(n_T) - sqrtf(n_0)) / alpha.  A touch of the
+// ffm.cpp:118 kind (q = g2*g1) does not telescope: it is evaluated on its own against the prefix
+// sum n_t.  The floating-point TREE these kernels and the oracle (the checker under oracle/, "block
+// update by reductions") share:
+//   * the occurrences of a feature in the block, in row order, are cut into segments of kSeg
+//     (rows of the block for the bias); inside a segment the sums run left to right from -0.0f
+//     (the identity of fp addition), the segment totals are joined left to right:
+//       B_0 = n_0,  B_{s+1} = B_s + P_s,  n_T = B_S ;  n_t = B_s + (partial P before touch t)
+//   * from the accumulator's first :118 touch t0 on, every touch adds
+//     m_t = ((sqrtf(n_t + q_t) - sqrtf(n_t)) / alpha) * w ; the plain touches before it telescope to
+//     H = ((sqrtf(n_t0) - sqrtf(n_0)) / alpha) * w  (t0 = T when there is none);
+//   * latent z_T = (z_0 + G) - (H + M),  linear / bias z_T = z_0 + (G - sigma*w).
+// One touch is the reference's expression literally.  Accumulators that one row touches twice
+// ("serial": s.cmask / UF_DUP) are not folded -- they keep the row-order walk (ffm_walk_* below).
+// No float atomics: every sum has ONE owner and a fixed order.
+#pragma once
+#include "engine_types.h"
+#include "kernels_touch.h"
+
+namespace ftrl_dev {
+
+// A sqrt operand of the per-touch terms: +0 (a fresh model's n) or inside [2^-70, 2^96] -- there
+// sqrt_fast0 is exact and the difference of two such roots is +0 or has magnitude in
+// [2^-58, 2^48], inside div_alpha_fast's proven range.
+__device__ __forceinline__ bool fold_operand_ok(float x) {
+  return __float_as_uint(x) == 0u || __builtin_amdgcn_fmed3f(x, 0x1p-70f, 0x1p96f) == x;
+}
+
+// One accumulator per lane.
+struct Fold {
+  float P, G, M;        // the running segment: sum g*g, sum g, sum m
+  float B, Gacc, Macc;  // the segments before it (B starts at n_0)
+  float ncap;           // n_t at the first :118 touch
+  bool any, seen, head_plain;
+  __device__ __forceinline__ void init(float n0) {
+    P = G = M = Gacc = Macc = -0.0f;
+    B = n0;
+    ncap = 0.0f;
+    any = seen = head_plain = false;
+  }
+  // a segment ends (joining an empty one adds -0.0f: nothing)
+  __device__ __forceinline__ void flush() {
+    B = B + P;
+    Gacc = Gacc + G;
+    Macc = Macc + M;
+    P = G = M = -0.0f;
+  }
+  // plain touches only (linear, bias, FM): gradient g of a live touch
+  __device__ __forceinline__ void plain(bool live, float g) {
+    const float gg = g * g;
+    G = live ? G + g : G;
+    P = live ? P + gg : P;
+    any = any || live;
+    head_plain = any;
+  }
+};
+
+// N consecutive touches of one FFM accumulator per lane (lane = element).  live: the touch exists
+// for this lane's slot; first: its own entry is the pair's first (ffm.cpp:112-115; else :117-120
+// with the :118 quirk); g = tmp_grad * vp * x as the reference associates it.
+template <int N>
+__device__ __forceinline__ void fold_ffm_group(const Hyper &h, Fold &a, float w, const bool (&live)[N],
+                                               const bool (&first)[N], const float (&tg)[N],
+                                               const float (&x)[N], const float (&vp)[N]) {
+  float g[N], gg[N];
+  bool quirk[N], anyq = false;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    g[j] = tg[j] * vp[j] * x[j];
+    gg[j] = g[j] * g[j];
+    quirk[j] = live[j] && !first[j];
+    anyq = anyq || quirk[j];
+  }
+  if (__any(a.seen || anyq)) {
+    float arg[N], nb[N];
+    bool need[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const float nt = a.B + a.P;
+      if (quirk[j] && !a.seen) { a.seen = true; a.ncap = nt; }
+      need[j] = a.seen && live[j];
+      const float g1 = tg[j] * w * x[j];  // the pair's first entry's gradient (ffm.cpp:112)
+      arg[j] = nt + (first[j] ? gg[j] : g[j] * g1);  // ffm.cpp:113 / :118
+      nb[j] = nt;
+      a.P = live[j] ? a.P + gg[j] : a.P;
+    }
+    bool ok = h.fast_div != 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) ok = ok && (!need[j] || (fold_operand_ok(arg[j]) && fold_operand_ok(nb[j])));
+    float mt[N];
+    if (__all(ok)) {
+#pragma unroll
+      for (int j = 0; j < N; j++) mt[j] = div_alpha_fast(h, sqrt_fast0(arg[j]) - sqrt_fast0(nb[j])) * w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; j++) mt[j] = ((sqrtf(arg[j]) - sqrtf(nb[j])) / h.alpha) * w;
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) a.M = need[j] ? a.M + mt[j] : a.M;
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; j++) a.P = live[j] ? a.P + gg[j] : a.P;
+  }
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    a.G = live[j] ? a.G + g[j] : a.G;
+    if (live[j] && !a.any) { a.any = true; a.head_plain = first[j]; }
+  }
+}
+
+// ONE touch of E accumulators held by one lane that share the touch's flags (the factors of one
+// slot), for features with at most kSeg occurrences: a single segment, so B stays n_0 and the
+// running sums are the totals.  any / seen / head_plain are the lane's (the E factors move together).
+template <int E>
+struct FoldFew {
+  float P[E], G[E], M[E], ncap[E];
+  bool any, seen, head_plain;
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int i = 0; i < E; i++) { P[i] = G[i] = M[i] = -0.0f; ncap[i] = 0.0f; }
+    any = seen = head_plain = false;
+  }
+  __device__ __forceinline__ void touch(const Hyper &h, const float (&n0)[E], const float (&w)[E], bool live,
+                                        bool first, float tg, float x, const float (&vp)[E]) {
+    float g[E], gg[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+      g[i] = tg * vp[i] * x;
+      gg[i] = g[i] * g[i];
+    }
+    const bool quirk = live && !first;
+    if (__any(seen || quirk)) {
+      const bool flip = quirk && !seen;
+      float arg[E], nb[E], mt[E];
+#pragma unroll
+      for (int i = 0; i < E; i++) {
+        const float nt = n0[i] + P[i];
+        ncap[i] = flip ? nt : ncap[i];
+        const float g1 = tg * w[i] * x;  // the pair's first entry's gradient (ffm.cpp:112)
+        arg[i] = nt + (first ? gg[i] : g[i] * g1);  // ffm.cpp:113 / :118
+        nb[i] = nt;
+      }
+      seen = seen || flip;
+      const bool need = seen && live;
+      bool ok = h.fast_div != 0;
+#pragma unroll
+      for (int i = 0; i < E; i++) ok = ok && (!need || (fold_operand_ok(arg[i]) && fold_operand_ok(nb[i])));
+      if (__all(ok)) {
+#pragma unroll
+        for (int i = 0; i < E; i++) mt[i] = div_alpha_fast(h, sqrt_fast0(arg[i]) - sqrt_fast0(nb[i])) * w[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < E; i++) mt[i] = ((sqrtf(arg[i]) - sqrtf(nb[i])) / h.alpha) * w[i];
+      }
+#pragma unroll
+      for (int i = 0; i < E; i++) M[i] = need ? M[i] + mt[i] : M[i];
+    }
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+      P[i] = live ? P[i] + gg[i] : P[i];
+      G[i] = live ? G[i] + g[i] : G[i];
+    }
+    if (live && !any) { any = true; head_plain = first; }
+  }
+  // (n, z) in, (n_T, z_T) out for the lane's E accumulators; false when no touch reached them
+  __device__ __forceinline__ bool finish(const Hyper &h, const float (&w)[E], float (&n)[E], float (&z)[E]) {
+    float nT[E], sa[E], sb[E], d[E], q[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+      nT[i] = n[i] + P[i];
+      sa[i] = seen ? ncap[i] : nT[i];
+      sb[i] = n[i];
+    }
+    float ra[E], rb[E];
+    sqrt_cr_n<E>(sa, ra);
+    sqrt_cr_n<E>(sb, rb);
+#pragma unroll
+    for (int i = 0; i < E; i++) d[i] = ra[i] - rb[i];
+    div_alpha_n<E>(h, d, q);
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+      const float hh = q[i] * w[i];
+      float m = -0.0f;
+      m = head_plain ? m + hh : m;
+      m = m + M[i];
+      if (any) {
+        z[i] = (z[i] + G[i]) - m;
+        n[i] = nT[i];
+      }
+    }
+    return any;
+  }
+};
+
+// The end of a latent accumulator's block: joins the last segment; (n, z) in, (n_T, z_T) out.
+// Returns false (and leaves n, z alone) when no touch reached the accumulator.
+__device__ __forceinline__ bool fold_finish_latent(const Hyper &h, Fold &a, float w, float &n, float &z) {
+  a.flush();
+  const float ncap = a.seen ? a.ncap : a.B;
+  const float hh = div_alpha(h, sqrt_cr(ncap) - sqrt_cr(n)) * w;
+  float m = -0.0f;
+  m = a.head_plain ? m + hh : m;
+  m = m + a.Macc;
+  if (a.any) {
+    z = (z + a.Gacc) - m;
+    n = a.B;
+  }
+  return a.any;
+}
+// ... of a linear / bias accumulator (every touch plain): z += g - sigma*w summed is z + (G - sigma*w)
+__device__ __forceinline__ bool fold_finish_linear(const Hyper &h, Fold &a, float w, float &n, float &z) {
+  a.flush();
+  const float si = div_alpha(h, sqrt_cr(a.B) - sqrt_cr(n));
+  if (a.any) {
+    z = z + (a.Gacc - si * w);
+    n = a.B;
+  }
+  return a.any;
+}
+
+}  // namespace ftrl_dev

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, R
     s.row_of[p] = lo;
     s.key[p] = valid ? static_cast<unsigned>(i) : static_cast<unsigned>(m.n_feats);
     s.occpos[p] = OCC_FEW;
+    s.uflag[p] = 0;
     if (s.gmask) { s.gmask[p] = 0ull; s.cmask[p] = 0ull; }
   }
   valid = valid && in;
@@ -138,7 +139,7 @@ __device__ __forceinline__ int sorted_bound(const unsigned *skey, int n, unsigne
 // position publishes {entry, row}, its entry's occurrence class, and ORs its touched-slot mask
 // into the group's (one atomic per group piece per wave).
 __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m, Rows rows,
-                                                                     Scratch s, int phases) {
+                                                                     Scratch s) {
   if (s.counters[CNT_ERROR]) return;  // untrainable block: no groups, no owners, nothing runs
   const int nnz = rows.nnz;
   const int lane = threadIdx.x & 63;
@@ -172,21 +173,17 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
   }
   const int c = upper - lower;
   int p = 0;
+  // dup: the feature occurs in this position's row a second time (equal keys are in entry order, so
+  // two occurrences of one row are neighbours): UF_DUP for the group, and every slot this row
+  // touches joins the feature's serial slots below (the checker under oracle/: mark_serial)
+  bool dup = false;
   if (valid) {
     p = s.occ[t];
-    s.occ2[t] = make_int2(p, s.row_of[p]);
+    const int r = s.row_of[p];
+    s.occ2[t] = make_int2(p, r);
     s.occpos[p] = c > kSmallMax ? t : (c == 1 ? OCC_ONCE : OCC_FEW);
-    if (phases > 1 && c > kSmallMax) {
-      // where the row phases cut this hot feature's occurrences: for boundary row b the position
-      // whose row is the last one before b writes the count (or the head writes 0): one writer each
-      const int r = s.row_of[p];
-      const int rn = last ? 0x7fffffff : s.row_of[s.occ[t + 1]];
-      for (int j = 1; j < phases; j++) {
-        const int b = phase_row(rows.n_rows, phases, j);
-        if (r < b && rn >= b) s.usplit[lower + j - 1] = t + 1 - lower;
-        if (head && r >= b) s.usplit[lower + j - 1] = 0;
-      }
-    }
+    dup = (!head && s.row_of[s.occ[t - 1]] == r) || (!last && s.row_of[s.occ[t + 1]] == r);
+    if (dup) atomicOr(&s.uflag[lower], UF_DUP);
   }
   // distinct features and their owner lists: slots handed out per workgroup (one atomic per
   // list per workgroup -- per-wave atomics on five shared counters would be a serial chain)
@@ -240,6 +237,7 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
       const unsigned long long self = 1ull << f;
       tm = ((once & ~self) | (twice & self)) & m.ownmask[f];
       tc = twice & m.ownmask[f];  // partner fields that hold several entries in this row
+      if (dup) tc |= tm;
     }
     const int seg0 = hl >= 0 ? hl : 0;  // first lane of my group's piece in this wave
 #pragma unroll

@@ -4,21 +4,22 @@
 //   FFM::update_vector_nz                          src/model/ffm.cpp:90-136  (incl. :118)
 //   FM::update_vector_nz                           src/model/fm.cpp:80-101
 //
-// Every distinct feature of the block has exactly one owner.  The owner keeps (n, z, w) in
-// registers and applies the block's touches to them in row order -- the same sequence of fp32
-// operations the reference's one-thread loop performs with w and tmp_grad frozen at the block
-// start -- then writes (n, z) back once.  No float atomics, no locks, bit-reproducible.
+// Every distinct feature of the block has exactly one owner per accumulator.  The owner folds the
+// block's touches of the accumulator -- w and tmp_grad frozen at the block start -- by reductions
+// in row order (kernels_fold.h has the tree, the checker under oracle/ restates it) and writes (n, z)
+// back once.  No float atomics, no locks, bit-reproducible.  Accumulators that ONE row touches twice
+// (a multi-valued field, a repeated id: s.cmask / UF_DUP) keep the row-order walk.
 //
-// Two shapes of owner (the grouping pass sorts features into two lists by occurrence count):
-//  * "small" features (<= kSmallMax occurrences, the vast majority): ONE wave owns the whole
+// Shapes of owner (the grouping pass deals the features into lists by occurrence count):
+//  * "few" (2 .. kSmallMax occurrences, and the once-only ones of a shard): ONE wave owns the whole
 //    record, each lane holding 4 consecutive factors of one slot (16-byte loads of n, z, w and of
 //    each partner slot), all of a record's gathers in flight together -- bandwidth-shaped.
 //  * "hot" features: one wave per 64 elements of the record, sixteen touches at a time, their
-//    operands loaded touch-parallel and transposed through LDS (kernels_tile.h); the giant ones --
-//    thousands of occurrences -- as touch-parallel DPP chains (kernels_chain.h).
+//    operands loaded touch-parallel and transposed through LDS (kernels_tile.h).
 #pragma once
 #include "engine_types.h"
 #include "kernels_touch.h"
+#include "kernels_fold.h"
 
 namespace ftrl_dev {
 
@@ -31,13 +32,6 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 // the 64-bit float offset a haux entry carries in its .z (lo) and .w (hi)
 __device__ __forceinline__ int64_t haux_offset(int lo, int hi) {
   return (static_cast<int64_t>(hi) << 32) | static_cast<unsigned>(lo);
-}
-
-// (Very hot features -- more than kHugeMin occurrences -- are kernels_chain.h's.)
-
-__device__ __forceinline__ float dpp_row_shr1(float keep, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v),
-                                                    0x111 /* row_shr:1 */, 0xf, 0xf, false));
 }
 
 // Strictly left-to-right running sum over the 64 lanes: returns S_j = ((carry + a_0) + a_1) ... + a_j
@@ -62,53 +56,17 @@ __device__ __forceinline__ float wave_sequential_prefix(float carry, float a) {
   return s;
 }
 
-// Two such prefixes at once, interleaved instruction by instruction: each chain's add fills the
-// other's DPP wait state, so two chains cost what one costs (measured, tools/dpp_probe2.hip:
-// 3.5 ns per dependent step for either).  sa / sb in, running prefixes out.
-__device__ __forceinline__ void wave_sequential_prefix2(float carry_a, float a, float &sa,
-                                                        float carry_b, float b, float &sb) {
-  const int lane = threadIdx.x & 63;
-  sa = lane == 0 ? carry_a + a : a;
-  sb = lane == 0 ? carry_b + b : b;
-#define FTRL_WSHR2 "v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-                   "v_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-#define FTRL_REP7(x) x x x x x x x
-  asm volatile("s_nop 1\n\t" FTRL_REP7(FTRL_REP7(FTRL_WSHR2)) FTRL_REP7(FTRL_WSHR2) FTRL_REP7(FTRL_WSHR2)
-               : "+v"(sa), "+v"(sb)
-               : "v"(a), "v"(b));
-#undef FTRL_REP7
-#undef FTRL_WSHR2
-}
-
-// The linear/bias accumulator chain over up to 64 gradients held one per lane (lane j = the j-th
-// touch, in order; lanes >= count idle).  Sequential semantics of nz_step_linear, evaluated as:
-// (1) running n by a strictly sequential prefix sum, (2) every touch's z increment in parallel,
-// (3) z by a second sequential prefix -- the same operations on the same values in the same
-// order as the one-thread loop, so bit-identical.
-__device__ __forceinline__ void linear_chain64(const Hyper &h, float w, float g, int count,
-                                               float &n, float &z) {
-  const int lane = threadIdx.x & 63;
-  const bool live = lane < count;
-  const float n_after = wave_sequential_prefix(n, live ? g * g : -0.0f);
-  float n_before = __int_as_float(__builtin_amdgcn_update_dpp(
-      __float_as_int(n), __float_as_int(n_after), 0x138, 0xf, 0xf, false));
-  if (lane == 0) n_before = n;
-  const float sgm = div_alpha(h, sqrt_cr(n_after) - sqrt_cr(n_before));  // n_after = n_before + g*g
-  const float z_run = wave_sequential_prefix(z, live ? g - sgm * w : -0.0f);
-  n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n_after), 63));
-  z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_run), 63));
-}
-
-// Linear update (update_linear_nz, ftrl_model.cpp:66-77).  Small features: one thread each,
-// touches applied one after another; hot features: one wave each, 64 touches per pass.
-// ph of `phases` (row phases, engine_types.h): a hot feature's touches of this phase's rows; the
-// small features' few touches all in the last phase.
+// Linear update (update_linear_nz, ftrl_model.cpp:66-77): g = tmp_grad * x, every touch plain.
+// Few-occurrence features: one thread each (a single segment).  Hot features: one wave each, lane =
+// segment of kSeg occurrences -- every lane sums its segment left to right, the segment totals are
+// joined in lane order (v_readlane: a strictly sequential chain of adds in uniform registers).
+// A feature that repeats inside a row (UF_DUP) is walked touch by touch.
 // skip_once: the linear terms of the features that occur once in the block were updated by their
 // row (fm_row_wave_kernel)
 __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows &rows,
                                                    const Scratch &s, int block, int n_blocks,
-                                                   int ph = 0, int phases = 1, int skip_once = 0) {
-  const int n_small = ph == phases - 1 ? s.counters[CNT_NSMALL] : 0, n_big = s.counters[CNT_NBIG];
+                                                   int skip_once = 0) {
+  const int n_small = s.counters[CNT_NSMALL], n_big = s.counters[CNT_NBIG];
   const int gtid = block * blockDim.x + threadIdx.x;
   for (int li = gtid; li < n_small; li += n_blocks * blockDim.x) {
     const int u = s.small[li];
@@ -119,10 +77,20 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
     if (skip_once && c == 1) continue;
     float n = m.lin_n[i], z = m.lin_z[i];
     const float w = m.lin_w[i];
-    float sqn = sqrt_cr(n);
-    for (int t = 0; t < c; t++) {
-      const int2 pr = s.occ2[start + t];
-      nz_step_linear_carry(m.h, w, s.tg[pr.y] * rows.val[pr.x], n, z, sqn);
+    if (s.uflag[start] & UF_DUP) {
+      float sqn = sqrt_cr(n);
+      for (int t = 0; t < c; t++) {
+        const int2 pr = s.occ2[start + t];
+        nz_step_linear_carry(m.h, w, s.tg[pr.y] * rows.val[pr.x], n, z, sqn);
+      }
+    } else {
+      Fold a;
+      a.init(n);
+      for (int t = 0; t < c; t++) {  // c <= kSmallMax <= kSeg: one segment
+        const int2 pr = s.occ2[start + t];
+        a.plain(true, s.tg[pr.y] * rows.val[pr.x]);
+      }
+      fold_finish_linear(m.h, a, w, n, z);
     }
     m.lin_n[i] = n;
     m.lin_z[i] = z;
@@ -132,28 +100,60 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
   const int n_waves = n_blocks * kUpdWaves;
   const int n_huge = s.counters[CNT_NHUGE], n_giant = s.counters[CNT_NGIANT];
   for (int li = wave; li < n_big + n_huge + n_giant; li += n_waves) {
-    const int u = wave_uniform(li < n_big ? s.big[li]
-                               : li < n_big + n_huge ? s.huge[li - n_big] : s.giant[li - n_big - n_huge]);
+    // (the longest lists first)
+    const int u = wave_uniform(li < n_giant ? s.giant[li]
+                               : li < n_giant + n_huge ? s.huge[li - n_giant] : s.big[li - n_giant - n_huge]);
     const int4 ud = s.udesc[u];
     if (!owns_linear(m, wave_uniform(ud.w))) continue;
     const int i = wave_uniform(ud.x);
-    const int start = wave_uniform(ud.y);
-    int t_lo, c;  // this phase's touches [t_lo, c)
-    phase_touches(s, start, wave_uniform(ud.z), ph, phases, t_lo, c);
-    t_lo = wave_uniform(t_lo);
-    c = wave_uniform(c);
-    if (t_lo >= c) continue;
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     float n = m.lin_n[i], z = m.lin_z[i];
     const float w = m.lin_w[i];
-    for (int t0 = t_lo; t0 < c; t0 += 64) {
-      const int cnt = min(64, c - t0);
-      float g = 0.0f;
-      if (lane < cnt) {
-        const int2 pr = s.occ2[start + t0 + lane];
-        g = s.tg[pr.y] * rows.val[pr.x];
+    if (wave_uniform(s.uflag[start]) & UF_DUP) {
+      if (lane == 0) {
+        float sqn = sqrt_cr(n);
+        for (int t = 0; t < c; t++) {
+          const int2 pr = s.occ2[start + t];
+          nz_step_linear_carry(m.h, w, s.tg[pr.y] * rows.val[pr.x], n, z, sqn);
+        }
+        m.lin_n[i] = n;
+        m.lin_z[i] = z;
       }
-      linear_chain64(m.h, w, g, cnt, n, z);
+      continue;
     }
+    Fold a;  // (uniform across the wave: every lane joins the same totals)
+    a.init(n);
+    const int n_seg = (c + kSeg - 1) / kSeg;
+    for (int s0 = 0; s0 < n_seg; s0 += 64) {
+      const int t0 = (s0 + lane) * kSeg;
+      float P = -0.0f, G = -0.0f;
+      constexpr int kFly = 8;  // touches whose two dependent gathers are in flight together
+      for (int j0 = 0; j0 < kSeg; j0 += kFly) {
+        if (t0 + j0 >= c) break;
+        int2 pr[kFly];
+        float tgv[kFly], xv[kFly];
+#pragma unroll
+        for (int j = 0; j < kFly; j++) pr[j] = s.occ2[start + min(t0 + j0 + j, c - 1)];
+#pragma unroll
+        for (int j = 0; j < kFly; j++) { tgv[j] = s.tg[pr[j].y]; xv[j] = rows.val[pr[j].x]; }
+#pragma unroll
+        for (int j = 0; j < kFly; j++) {
+          if (t0 + j0 + j < c) {
+            const float g = tgv[j] * xv[j];
+            G = G + g;
+            P = P + g * g;
+          }
+        }
+      }
+      const int cnt = min(64, n_seg - s0);
+      for (int l = 0; l < cnt; l++) {
+        a.P = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P), l));
+        a.G = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(G), l));
+        a.flush();
+      }
+    }
+    a.any = a.head_plain = true;
+    fold_finish_linear(m.h, a, w, n, z);
     if (lane == 0) {
       m.lin_n[i] = n;
       m.lin_z[i] = z;
@@ -162,156 +162,143 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
 }
 __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, Rows rows,
                                                                     Scratch s, int skip_once) {
-  linear_update_body(m, rows, s, blockIdx.x, gridDim.x, 0, 1, skip_once);
+  linear_update_body(m, rows, s, blockIdx.x, gridDim.x, skip_once);
 }
 
-// Bias update: all rows of the block in order (update_bias_nz, ftrl_model.cpp:79-85) -- n_rows
-// dependent touches of ONE accumulator, the longest serial chain of a block.  Rows [row_lo, row_hi)
-// of the block (one row phase, or all of them).  Called by every thread of a 256-thread workgroup.
-//
-// The two recurrences -- n += g*g and z += g - sigma*w -- are 2 * n_rows dependent fp32 adds
-// whatever the layout (5.75 cycles each on gfx950, tools/issue_probe.hip: 39 us for 8192 rows); what
-// the r03 version added on top was the price of keeping touch t in lane t: 63 dependent
-// v_add_f32_dpp wave_shr:1 per 64 rows and chain at 15.5 cycles each (12 ns per row, 100 us per
-// 8192-row block -- the floor of FM's whole update phase).  Here a chain runs in the registers of
-// one lane instead: 64 increments go through LDS into 64 registers of lane 0 (16 ds_read_b128),
-// then 64 plain dependent adds.  Four waves form a pipeline over passes of 64 rows,
-// one workgroup barrier per pass:
-//   wave 0  pass k   : g*g of its rows (lane = row) -> LDS
-//   wave 1  pass k-1 : the running n, every prefix kept -> LDS
-//   wave 2  pass k-2 : lane = row: sigma from the n before and after the row, g - sigma*w -> LDS
-//   wave 3  pass k-3 : the running z
-// Same operations on the same values in the same order as the one-thread loop: bit-identical.
-__device__ __forceinline__ void bias_update_body(const ModelDev &m, int row_lo, int row_hi, const Scratch &sc) {
+// Bias update: every row of the block touches the one accumulator once, g = tmp_grad
+// (update_bias_nz, ftrl_model.cpp:79-85).  As a fold: thread = segment of kSeg rows (its 64 values
+// are 256 contiguous bytes, sixteen 16-byte loads), summed left to right in the thread's registers;
+// thread 0 then joins the segment totals in order.  For 8192 rows: 128 threads x 64 adds, then 128
+// adds -- where the row-order walk was 2 x 8192 dependent adds (74 us, the floor of FM's update).
+// Called by every thread of a 256-thread workgroup.
+__device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, const Scratch &sc) {
   if (!m.bias_own) return;             // another shard's
   if (sc.counters[CNT_ERROR]) return;  // untrainable block (ERR_ROW_TOO_LONG): a no-op
-  constexpr int kRing = 4;
-  __shared__ __attribute__((aligned(16))) float s_gg[kRing][64];   // g*g of a pass (-0 for rows past the end)
-  __shared__ __attribute__((aligned(16))) float s_na[kRing][64];   // n after row j of the pass
-  __shared__ float s_n0[kRing];                                    // n before the pass
-  __shared__ __attribute__((aligned(16))) float s_inc[kRing][64];  // g - sigma*w (-0 past the end)
-  const float *tg = sc.tg + row_lo;
-  const int n_rows = row_hi - row_lo;
-  const int lane = threadIdx.x & 63;
-  const int wv = wave_uniform(threadIdx.x >> 6);
-  const int passes = (n_rows + 63) >> 6;
-  const float w = m.bias3[0];
-  float acc = wv == 1 ? m.bias3[1] : wv == 3 ? m.bias3[2] : 0.0f;  // wave 1: running n; wave 3: running z
-  // the 64 values of a pass added one after another in the registers of LANE 0 (the whole chain
-  // under one branch: a predicated store per group of four cost 39 cycles each, tools/issue_probe.hip)
-  auto chain64 = [&](const float *src, float *after_out) {
-    if (lane != 0) return;
-    const float4 *s4 = reinterpret_cast<const float4 *>(src);
-    float4 *o4 = reinterpret_cast<float4 *>(after_out);
-    float4 v[16];
+  if (n_rows <= 0) return;
+  __shared__ float s_P[kUpdThreads], s_G[kUpdThreads];
+  const float *tg = sc.tg;
+  const int n_seg = (n_rows + kSeg - 1) / kSeg;
+  Fold a;
+  a.init(m.bias3[1]);
+  for (int s0 = 0; s0 < n_seg; s0 += kUpdThreads) {
+    const int seg = s0 + threadIdx.x;
+    float P = -0.0f, G = -0.0f;
+    if (seg < n_seg) {
+      const int r0 = seg * kSeg;
+      if (r0 + kSeg <= n_rows) {
+        const float4 *t4 = reinterpret_cast<const float4 *>(tg + r0);
+        float4 v[kSeg / 4];
 #pragma unroll
-    for (int j = 0; j < 16; j++) v[j] = s4[j];
+        for (int j = 0; j < kSeg / 4; j++) v[j] = t4[j];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {  // v[j] becomes the running sum after each of its four rows
-      v[j].x = acc + v[j].x;
-      v[j].y = v[j].x + v[j].y;
-      v[j].z = v[j].y + v[j].z;
-      v[j].w = v[j].z + v[j].w;
-      acc = v[j].w;
-    }
-    // (the stores after the whole chain: a store placed behind the add that produces its data holds
-    // the next add back -- in-order issue -- and doubled the pass: 1450 against 770 cycles)
-    __builtin_amdgcn_sched_barrier(0);
-    if (after_out) {
-#pragma unroll
-      for (int j = 0; j < 16; j++) o4[j] = v[j];
-    }
-  };
-  // waves 0 and 2 read tmp_grad of their rows four passes ahead (a pass takes ~600 cycles, a load
-  // that misses the L2 longer): ga = the current four passes' values, gb = the next four's.  The loop
-  // is unrolled by four so that no register in flight is ever moved.
-  const int off = wv == 2 ? 2 : 0;  // wave 2 works on pass k - 2
-  float ga[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  auto load4 = [&](int pass0, float (&g)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r = ((pass0 + q) << 6) + lane;
-      g[q] = (pass0 + q >= 0 && r < n_rows) ? tg[r] : 0.0f;
-    }
-  };
-  if (wv == 0 || wv == 2) load4(-off, ga);
-  auto step = [&](int k, float g) {
-    if (wv == 0) {
-      if (k < passes) s_gg[k % kRing][lane] = (k << 6) + lane < n_rows ? g * g : -0.0f;  // x + -0.0f == x bit for bit
-    } else if (wv == 1) {
-      if (k >= 1 && k - 1 < passes) {
-        if (lane == 0) s_n0[(k - 1) % kRing] = acc;
-        chain64(s_gg[(k - 1) % kRing], s_na[(k - 1) % kRing]);
+        for (int j = 0; j < kSeg / 4; j++) {
+          G = G + v[j].x; P = P + v[j].x * v[j].x;
+          G = G + v[j].y; P = P + v[j].y * v[j].y;
+          G = G + v[j].z; P = P + v[j].z * v[j].z;
+          G = G + v[j].w; P = P + v[j].w * v[j].w;
+        }
+      } else {
+        for (int r = r0; r < n_rows; r++) {
+          const float g = tg[r];
+          G = G + g;
+          P = P + g * g;
+        }
       }
-    } else if (wv == 2) {
-      if (k >= 2 && k - 2 < passes) {
-        const int r0 = (k - 2) << 6, rb = (k - 2) % kRing;
-        const float na = s_na[rb][lane];
-        const float nb = lane == 0 ? s_n0[rb] : s_na[rb][lane == 0 ? 0 : lane - 1];
-        const float sgm = div_alpha(m.h, sqrt_cr(na) - sqrt_cr(nb));  // na = nb + g*g
-        s_inc[rb][lane] = r0 + lane < n_rows ? g - sgm * w : -0.0f;
+    }
+    s_P[threadIdx.x] = P;
+    s_G[threadIdx.x] = G;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int cnt = min(kUpdThreads, n_seg - s0);
+      for (int l = 0; l < cnt; l++) {
+        a.P = s_P[l];
+        a.G = s_G[l];
+        a.flush();
       }
-    } else {
-      if (k >= 3) chain64(s_inc[(k - 3) % kRing], nullptr);
     }
     __syncthreads();
-  };
-  for (int k0 = 0; k0 < passes + 3; k0 += 8) {
-    if (wv == 0 || wv == 2) load4(k0 + 4 - off, gb);
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (k0 + q < passes + 3) step(k0 + q, ga[q]);
-    if (wv == 0 || wv == 2) load4(k0 + 8 - off, ga);
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (k0 + 4 + q < passes + 3) step(k0 + 4 + q, gb[q]);
   }
-  if (lane == 0 && n_rows > 0) {
-    if (wv == 1) m.bias3[1] = acc;
-    if (wv == 3) m.bias3[2] = acc;
+  if (threadIdx.x == 0) {
+    float n = m.bias3[1], z = m.bias3[2];
+    a.any = a.head_plain = true;
+    fold_finish_linear(m.h, a, m.bias3[0], n, z);
+    m.bias3[1] = n;
+    m.bias3[2] = z;
   }
 }
 __global__ __launch_bounds__(kUpdThreads) void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
-  bias_update_body(m, 0, n_rows, s);
+  bias_update_body(m, n_rows, s);
 }
 
-// n_factors not a multiple of 4: every distinct feature, hot or not, is owned per 64 elements
-// and gathers its inputs in place (no float4 path, no occurrence-ordered streams).
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDev m, Rows rows,
-                                                                         Scratch s) {
+// The general owner: work item = (distinct feature, 64 elements of its record), lane = element,
+// every input gathered in place through the row tables (no float4 path, no occurrence-ordered
+// streams).  Two jobs:
+//  * serial_only = 0 -- engines whose n_factors is not a multiple of 4: every accumulator of every
+//    distinct feature; folded (kernels_fold.h) unless its slot is serial;
+//  * serial_only = 1 -- beside the vector kernels: only the SERIAL slots (s.cmask: one row touches
+//    them twice -- a multi-valued partner field, a repeated id; without field masks, n_fields > 64:
+//    every slot) of the features with two or more occurrences, walked in row order on the running
+//    (n, z) like the reference's one-thread loop (ffm.cpp:104-120).
+__device__ __forceinline__ void ffm_generic_body(const ModelDev &m, const Rows &rows, const Scratch &s,
+                                                 int serial_only, unsigned bidx, unsigned gdim) {
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const unsigned chunks = (RL + 63) / 64;
   const int lane = threadIdx.x & 63;
-  const unsigned wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const unsigned n_waves = gridDim.x * kUpdWaves;
+  const unsigned wave = bidx * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = gdim * kUpdWaves;
   const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NUNIQ]) * chunks;
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned u = item / chunks;
     const int e = static_cast<int>(item - u * chunks) * 64 + lane;
-    if (e >= RL) continue;
     const int4 ud = s.udesc[u];
+    const int start = ud.y, c = ud.z;
+    if (serial_only && c < 2) continue;  // (the once-only features' owners walk their own chains)
+    const unsigned long long cm = s.cmask ? s.cmask[start] : ~0ull;
+    if (serial_only && cm == 0ull) continue;
+    if (e >= RL) continue;
     const int fa = ud.w;
     const int sl = e / k, kk = e - sl * k;
     const int fp = walk_field(m, fa, sl);
     if (fp < 0) continue;
+    const bool serial = !s.cmask || ((cm >> fp) & 1ull);
+    if (serial_only && !serial) continue;
     const int i = ud.x;
-    const int start = ud.y, c = ud.z;
     float *rec = lat_row(m, i, fa);
     float n = rec[LAT_N * RL + e], z = rec[LAT_Z * RL + e];
     const float w = rec[LAT_W * RL + e];
     bool touched = false;
-    for (int t = 0; t < c; t++) {
-      const int2 pr = s.occ2[start + t];
-      const int p = pr.x, r = pr.y;
-      const int fm = rows.field[p];
-      if (!owns_pair(m, fm, fp)) continue;
-      const float tg = s.tg[r], xm = rows.val[p];
-      for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
-        if (qq == p) continue;
-        const float vp = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk];
-        ffm_touch(m.h, p < qq, tg, xm, rows.val[qq], vp, w, n, z);
-        touched = true;
+    if (serial) {
+      for (int t = 0; t < c; t++) {
+        const int2 pr = s.occ2[start + t];
+        const int p = pr.x, r = pr.y;
+        const int fm = rows.field[p];
+        if (!owns_pair(m, fm, fp)) continue;
+        const float tg = s.tg[r], xm = rows.val[p];
+        for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+          if (qq == p) continue;
+          const float vp = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk];
+          ffm_touch(m.h, p < qq, tg, xm, rows.val[qq], vp, w, n, z);
+          touched = true;
+        }
       }
+    } else {
+      Fold a;
+      a.init(n);
+      for (int t = 0; t < c; t++) {
+        if (t > 0 && t % kSeg == 0) a.flush();
+        const int2 pr = s.occ2[start + t];
+        const int p = pr.x, r = pr.y;
+        const int fm = rows.field[p];
+        if (!owns_pair(m, fm, fp)) continue;
+        const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
+        const int q = rt.z;  // the field's only entry in the row (the slot is not serial), or none
+        if (q < 0 || q == p) continue;
+        const bool live[1] = {true}, first[1] = {p < q || m.h.learn != 0};
+        const float tgv[1] = {s.tg[r]}, xv[1] = {rows.val[p] * __int_as_float(rt.y)};
+        const float vp[1] = {m.lat[w_slot_offset(m, rt.x, fp, fm) + kk]};
+        fold_ffm_group<1>(m.h, a, w, live, first, tgv, xv, vp);
+      }
+      touched = fold_finish_latent(m.h, a, w, n, z);
     }
     if (touched) {
       rec[LAT_N * RL + e] = n;
@@ -319,11 +306,15 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
     }
   }
 }
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDev m, Rows rows,
+                                                                         Scratch s, int serial_only) {
+  ffm_generic_body(m, rows, s, serial_only, blockIdx.x, gridDim.x);
+}
 
-// ---- small features: one wave per feature, lanes = 4 consecutive factors of a slot ---------
-// Requires n_factors % 4 == 0.  c <= kSmallMax occurrences.  Kept lean in registers: the
-// bandwidth comes from many resident waves, each with its record's loads in flight.
-// few_only: the features that occur once are ffm_update_single_kernel's
+// ---- few-occurrence features: one wave per feature, lanes = 4 consecutive factors of a slot ------
+// Requires n_factors % 4 == 0.  c <= kSmallMax occurrences: a single segment.  Kept lean in
+// registers: the bandwidth comes from many resident waves, each with its record's loads in flight.
+// few_only: the features that occur once are ffm_update_single_kernel's (or their row's).
 #ifndef FFM_SMALL_BATCH
 #define FFM_SMALL_BATCH 4
 #endif
@@ -351,11 +342,10 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
     const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     const int fa = wave_uniform(ud.w);
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
-    // The feature's (at most kSmallMax) touches, read ONCE for all three passes over its record:
-    // entry, row, own field, own value, tmp_grad -- wave-uniform, scalar loads.  (r02: every pass
-    // walked occ2 -> rowtab -> partner weights touch after touch, three dependent round trips per
-    // touch and pass: 80 % of the kernel's wave-cycles waited on memory with 28 M VALU
-    // instructions to issue -- VERDICT r02 weak #6.)
+    // slots that one row touches twice keep the row-order walk (ffm_generic_body, serial_only)
+    const unsigned long long cm = s.cmask[start];
+    // The feature's (at most kSmallMax) touches, read ONCE for all passes over its record:
+    // entry, row, own field, own value, tmp_grad -- wave-uniform, scalar loads.
     int tp[kSmallMax], tr[kSmallMax], tfm[kSmallMax];
     float txm[kSmallMax], ttg[kSmallMax];
 #pragma unroll
@@ -373,18 +363,26 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
     }
     for (int l0 = 0; l0 < span4; l0 += 64) {
       const int l = l0 + lane;  // 16-byte vector of the stored record
-      if (l >= span4) continue;
-      int sl = static_cast<int>((l + 0.5f) * inv_k4);  // its slot
-      sl += (sl + 1) * k4 <= l ? 1 : (sl * k4 > l ? -1 : 0);
-      const int fp = walk_field(m, fa, sl);  // partner field of this lane's slot
-      if (fp < 0) continue;
-      const int kq = l - sl * k4;  // which 16-byte quarter of the slot
+      const int lc = l < span4 ? l : 0;
+      int sl = static_cast<int>((lc + 0.5f) * inv_k4);  // its slot
+      sl += (sl + 1) * k4 <= lc ? 1 : (sl * k4 > lc ? -1 : 0);
+      int fp = l < span4 ? walk_field(m, fa, sl) : -1;  // partner field of this lane's slot
+      if (fp >= 0 && ((cm >> fp) & 1ull)) fp = -1;      // serial
+      const bool mine = fp >= 0;
+      fp = mine ? fp : 0;
+      const int kq = lc - sl * k4;  // which 16-byte quarter of the slot
       const unsigned long long own_bits = owner_bits(m, fp);
-      float4 n4 = rec4[LAT_N * RL4 + l], z4 = rec4[LAT_Z * RL4 + l];
-      const float4 w4 = rec4[LAT_W * RL4 + l];
+      float n[4] = {0.0f, 0.0f, 0.0f, 0.0f}, z[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (mine) {
+        const float4 n4 = rec4[LAT_N * RL4 + lc], z4 = rec4[LAT_Z * RL4 + lc], w4 = rec4[LAT_W * RL4 + lc];
+        n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
+        z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
+        w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+      }
+      FoldFew<4> a;
+      a.init();
       // kSmallBatch touches at a time: their row-table entries in flight together, then their
-      // partners' weights, then the (n, z) steps in touch order
-      bool touched = false;
+      // partners' weights, then the touches in order
 #pragma unroll
       for (int j0 = 0; j0 < kSmallMax; j0 += kSmallBatch) {
         if (j0 >= c) break;
@@ -393,40 +391,29 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
         for (int jj = 0; jj < kSmallBatch; jj++) {
           const int j = j0 + jj;
           rt[jj] = make_int4(0, 0, -1, 0);  // "no entry of that field in the row"
-          if (j < c && owns_bit(own_bits, tfm[j])) rt[jj] = s.rowtab[static_cast<int64_t>(tr[j]) * F + fp];
+          if (mine && j < c && owns_bit(own_bits, tfm[j])) rt[jj] = s.rowtab[static_cast<int64_t>(tr[j]) * F + fp];
         }
-        float4 vp[kSmallBatch];
+        float4 vp4[kSmallBatch];
 #pragma unroll
         for (int jj = 0; jj < kSmallBatch; jj++) {
           const int j = j0 + jj;
-          vp[jj] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          vp4[jj] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           if (j < c && rt[jj].z >= 0 && rt[jj].z != tp[j])
-            vp[jj] = reinterpret_cast<const float4 *>(lat_row(m, rt[jj].x, fp))[LAT_W * RL4 + slot_of(m, fp, tfm[j]) * k4 + kq];
+            vp4[jj] = reinterpret_cast<const float4 *>(lat_row(m, rt[jj].x, fp))[LAT_W * RL4 + slot_of(m, fp, tfm[j]) * k4 + kq];
         }
 #pragma unroll
         for (int jj = 0; jj < kSmallBatch; jj++) {
           const int j = j0 + jj;
           if (j >= c) continue;
           const int p = tp[j], q = rt[jj].z;
-          if (q >= 0) {
-            if (q != p) {
-              ffm_touch4(m.h, p < q, ttg[j], txm[j], __int_as_float(rt[jj].y), vp[jj], w4, n4, z4);
-              touched = true;
-            }
-          } else if (q == -2) {  // several entries of that field in the row: walk them in row order
-            for (int qq = s.head[static_cast<int64_t>(tr[j]) * F + fp]; qq >= 0; qq = s.next[qq]) {
-              if (qq == p) continue;
-              const float4 vq = reinterpret_cast<const float4 *>(
-                  lat_row(m, rows.feat[qq], fp))[LAT_W * RL4 + slot_of(m, fp, tfm[j]) * k4 + kq];
-              ffm_touch4(m.h, p < qq, ttg[j], txm[j], rows.val[qq], vq, w4, n4, z4);
-              touched = true;
-            }
-          }
+          const bool live = q >= 0 && q != p;  // (q == -2, several entries, only on serial slots)
+          const float vp[4] = {vp4[jj].x, vp4[jj].y, vp4[jj].z, vp4[jj].w};
+          a.touch(m.h, n, w, live, p < q || m.h.learn != 0, ttg[j], txm[j] * __int_as_float(rt[jj].y), vp);
         }
       }
-      if (touched) {
-        rec4[LAT_N * RL4 + l] = n4;
-        rec4[LAT_Z * RL4 + l] = z4;
+      if (a.finish(m.h, w, n, z) && mine) {
+        rec4[LAT_N * RL4 + lc] = make_float4(n[0], n[1], n[2], n[3]);
+        rec4[LAT_Z * RL4 + lc] = make_float4(z[0], z[1], z[2], z[3]);
       }
     }
   }
@@ -448,50 +435,63 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_flat_kernel(Mode
   const double inv_span = 1.0 / static_cast<double>(span4);
   const float inv_k4 = 1.0f / static_cast<float>(k4);
   const unsigned stride = gridDim.x * blockDim.x;
-  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    int li = static_cast<int>((static_cast<double>(t) + 0.5) * inv_span);  // t / span4, corrected
-    li += static_cast<unsigned>(li + 1) * span4 <= t ? 1 : (static_cast<unsigned>(li) * span4 > t ? -1 : 0);
-    const int l = static_cast<int>(t - static_cast<unsigned>(li) * span4);  // vector of the stored record
-    int sl = static_cast<int>((l + 0.5f) * inv_k4);                         // its slot
+  const unsigned rounds = (total + stride - 1) / stride;  // (whole waves stay together: the fold votes)
+  for (unsigned rd = 0; rd < rounds; rd++) {
+    const unsigned t = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = t < total;
+    const unsigned tt = in ? t : 0u;
+    int li = static_cast<int>((static_cast<double>(tt) + 0.5) * inv_span);  // t / span4, corrected
+    li += static_cast<unsigned>(li + 1) * span4 <= tt ? 1 : (static_cast<unsigned>(li) * span4 > tt ? -1 : 0);
+    const int l = static_cast<int>(tt - static_cast<unsigned>(li) * span4);  // vector of the stored record
+    int sl = static_cast<int>((l + 0.5f) * inv_k4);                          // its slot
     sl += (sl + 1) * k4 <= l ? 1 : (sl * k4 > l ? -1 : 0);
     const int kq = l - sl * k4;
-    const int4 ud = s.udesc[list[li]];  // {feature, start, count, field}
+    int4 ud = make_int4(0, 0, 0, 0);
+    if (in) ud = s.udesc[list[li]];  // {feature, start, count, field}
     const int i = ud.x, start = ud.y, c = ud.z, fa = ud.w;
-    const int fp = walk_field(m, fa, sl);  // partner field of this vector's slot
-    if (fp < 0) continue;
+    int fp = in ? walk_field(m, fa, sl) : -1;  // partner field of this vector's slot
+    if (fp >= 0 && ((s.cmask[start] >> fp) & 1ull)) fp = -1;  // serial: ffm_generic_body's
+    const bool mine = fp >= 0;
+    fp = mine ? fp : 0;
     const unsigned long long own_bits = owner_bits(m, fp);
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
-    float4 n4 = rec4[LAT_N * RL4 + l], z4 = rec4[LAT_Z * RL4 + l];
-    const float4 w4 = rec4[LAT_W * RL4 + l];
-    bool touched = false;
-    for (int j = 0; j < c; j++) {
-      const int2 pr = s.occ2[start + j];
-      const int p = pr.x, r = pr.y;
-      const int fm = rows.field[p];
-      if (!owns_bit(own_bits, fm)) continue;
-      const float xm = rows.val[p], tg = s.tg[r];
-      const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
-      const int q = rt.z;
-      if (q >= 0) {
-        if (q != p) {
-          const float4 vp = reinterpret_cast<const float4 *>(
-              lat_row(m, rt.x, fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
-          ffm_touch4(m.h, p < q, tg, xm, __int_as_float(rt.y), vp, w4, n4, z4);
-          touched = true;
-        }
-      } else if (q == -2) {
-        for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
-          if (qq == p) continue;
-          const float4 vp = reinterpret_cast<const float4 *>(
-              lat_row(m, rows.feat[qq], fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
-          ffm_touch4(m.h, p < qq, tg, xm, rows.val[qq], vp, w4, n4, z4);
-          touched = true;
+    float n[4] = {0.0f, 0.0f, 0.0f, 0.0f}, z[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (mine) {
+      const float4 n4 = rec4[LAT_N * RL4 + l], z4 = rec4[LAT_Z * RL4 + l], w4 = rec4[LAT_W * RL4 + l];
+      n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
+      z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
+      w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+    }
+    FoldFew<4> a;
+    a.init();
+    for (int j = 0; j < kSmallMax; j++) {
+      if (!__any(mine && j < c)) break;
+      bool live = false, first = false;
+      float tg = 0.0f, x = 0.0f;
+      float vp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (mine && j < c) {
+        const int2 pr = s.occ2[start + j];
+        const int p = pr.x, r = pr.y;
+        const int fm = rows.field[p];
+        if (owns_bit(own_bits, fm)) {
+          const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
+          const int q = rt.z;
+          if (q >= 0 && q != p) {
+            const float4 v4 = reinterpret_cast<const float4 *>(
+                lat_row(m, rt.x, fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
+            vp[0] = v4.x; vp[1] = v4.y; vp[2] = v4.z; vp[3] = v4.w;
+            live = true;
+            first = p < q || m.h.learn != 0;
+            tg = s.tg[r];
+            x = rows.val[p] * __int_as_float(rt.y);
+          }
         }
       }
+      a.touch(m.h, n, w, live, first, tg, x, vp);
     }
-    if (touched) {
-      rec4[LAT_N * RL4 + l] = n4;
-      rec4[LAT_Z * RL4 + l] = z4;
+    if (a.finish(m.h, w, n, z) && mine) {
+      rec4[LAT_N * RL4 + l] = make_float4(n[0], n[1], n[2], n[3]);
+      rec4[LAT_Z * RL4 + l] = make_float4(z[0], z[1], z[2], z[3]);
     }
   }
 }
@@ -635,48 +635,60 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_flat_kernel(Mod
   }
 }
 
-// FM latent update.  Work item = (distinct feature u, chunk of 64 factors), the longest lists first.
-// skip_huge: the features with more than kHugeMin occurrences belong to fm_update_huge_kernel
+// FM latent update (fm.cpp:84-95): g = tmp_grad * (x * s_vx - v * x * x), every touch plain.
+// Work item = (distinct feature u, chunk of 64 factors), the longest lists first; lane = factor.
 // skip_once: the features that occur once in the block were updated by their row (fm_row_wave_kernel)
 //
-// A feature's touches form one dependent chain per factor (fm.cpp:84-95), but only two recurrences
-// are serial: n += g*g and z = (z + g) - s*w.  The gradients depend on the frozen w alone, so a
-// group of kFmUnroll touches is: the gradients, the running n (kFmUnroll dependent adds), ONE range
-// vote, kFmUnroll independent square roots and alpha divides, the running z.  The operands of a
-// group (touch descriptor -> value, tmp_grad, the row's s_vx) are two dependent trips to memory:
-// they are fetched one group ahead of the arithmetic, the descriptors two groups ahead.
+// The operands of a group of kFmUnroll touches (touch descriptor -> value, tmp_grad, the row's s_vx)
+// are two dependent trips to memory: they are fetched one group ahead of the arithmetic, the
+// descriptors two groups ahead.  The arithmetic of a touch is the gradient and two adds (sum g,
+// sum g*g); segments of kSeg touches are joined as they end; one square-root pair per factor and
+// block at the very end (kernels_fold.h).  A feature that repeats inside a row (UF_DUP) is walked.
 struct FmTouchOps {
   float x[kFmUnroll], tg[kFmUnroll], sv[kFmUnroll];
 };
+static_assert(kSeg % kFmUnroll == 0, "segments end between groups of touches");
 // (block of n_blocks: the workgroups of a launch that walk these lists)
 __device__ __forceinline__ void fm_update_body(const ModelDev &m, const Rows &rows, const Scratch &s,
-                                               int skip_huge, int skip_once, int block, int n_blocks) {
+                                               int skip_once, int block, int n_blocks) {
   const int k = m.n_factors;
   const int chunks = (k + 63) / 64;
   const int lane = threadIdx.x & 63;
   const int wave = block * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const int n_waves = n_blocks * kUpdWaves;
-  // skip_once: only the features with 2 .. kHugeMin occurrences are left -- the `few` and `big`
-  // lists -- instead of a walk over every distinct feature of the block
-  const int n_few = s.counters[CNT_NFEW], n_big = s.counters[CNT_NBIG];
-  const bool lists = skip_once && skip_huge;
-  const int64_t n_items = static_cast<int64_t>(lists ? n_few + n_big : s.counters[CNT_NUNIQ]) * chunks;
-  for (int64_t it = wave; it < n_items; it += n_waves) {
-    // (lists: big after few -- walk backwards so that the long chains start first)
-    const int64_t item = lists ? n_items - 1 - it : it;
+  // skip_once: only the features with two or more occurrences are left -- the giant, huge, big and
+  // few lists, in that order -- instead of a walk over every distinct feature of the block
+  const int n_giant = s.counters[CNT_NGIANT], n_huge = n_giant + s.counters[CNT_NHUGE];
+  const int n_big = n_huge + s.counters[CNT_NBIG], n_few = n_big + s.counters[CNT_NFEW];
+  const int64_t n_items = static_cast<int64_t>(skip_once ? n_few : s.counters[CNT_NUNIQ]) * chunks;
+  for (int64_t item = wave; item < n_items; item += n_waves) {
     int u = static_cast<int>(item / chunks);
     const int e = static_cast<int>(item - static_cast<int64_t>(u) * chunks) * 64 + lane;
     if (e >= k) continue;
-    if (lists) u = wave_uniform(u < n_few ? s.few[u] : s.big[u - n_few]);
+    if (skip_once)
+      u = wave_uniform(u < n_giant ? s.giant[u] : u < n_huge ? s.huge[u - n_giant]
+                       : u < n_big ? s.big[u - n_huge] : s.few[u - n_big]);
     const int4 ud = s.udesc[u];
     const int i = wave_uniform(ud.x);
     const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
-    if (skip_huge && c > m.huge_min) continue;
     if (skip_once && c == 1) continue;
     float *rec = lat_row(m, i, 0);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
     const float w = rec[LAT_W * k + e];
-    float sqn = sqrt_cr(n);
+    if (wave_uniform(s.uflag[start]) & UF_DUP) {  // the row-order walk
+      float sqn = sqrt_cr(n);
+      for (int t = 0; t < c; t++) {
+        const int2 pr = s.occ2[start + t];
+        const float x = rows.val[pr.x];
+        const float g = s.tg[pr.y] * (x * s.svx[static_cast<int64_t>(pr.y) * k + e] - w * x * x);
+        nz_step_latent_carry(m.h, w, g, n, z, sqn);
+      }
+      rec[LAT_N * k + e] = n;
+      rec[LAT_Z * k + e] = z;
+      continue;
+    }
+    Fold a;
+    a.init(n);
     const int nb = (c + kFmUnroll - 1) / kFmUnroll;
     auto load_desc = [&](int b, int2 (&pr)[kFmUnroll]) {
 #pragma unroll
@@ -691,32 +703,12 @@ __device__ __forceinline__ void fm_update_body(const ModelDev &m, const Rows &ro
       }
     };
     auto compute = [&](const FmTouchOps &o, int b) {
+      if (b > 0 && (b * kFmUnroll) % kSeg == 0) a.flush();
       const int cnt = min(kFmUnroll, c - b * kFmUnroll);
-      float g[kFmUnroll], na[kFmUnroll];
-      bool ok = m.h.fast_div != 0 && cnt == kFmUnroll && chain_operand_ok(n);
-      float run = n;
 #pragma unroll
       for (int j = 0; j < kFmUnroll; j++) {  // fm.cpp:84-95
         const float x = o.x[j];
-        g[j] = o.tg[j] * (x * o.sv[j] - w * x * x);
-        run = run + g[j] * g[j];
-        na[j] = run;
-        ok = ok && chain_operand_ok(run);
-      }
-      if (__all(ok)) {
-        float sa[kFmUnroll], sg[kFmUnroll];
-#pragma unroll
-        for (int j = 0; j < kFmUnroll; j++) sa[j] = sqrt_fast(na[j]);
-#pragma unroll
-        for (int j = 0; j < kFmUnroll; j++) sg[j] = div_alpha_fast(m.h, sa[j] - (j ? sa[j - 1] : sqn));
-#pragma unroll
-        for (int j = 0; j < kFmUnroll; j++) z = (z + g[j]) - sg[j] * w;
-        n = na[kFmUnroll - 1];
-        sqn = sa[kFmUnroll - 1];
-      } else {  // a partial group, or operands outside the short forms' range: touch by touch
-#pragma unroll
-        for (int j = 0; j < kFmUnroll; j++)
-          if (j < cnt) nz_step_latent_carry(m.h, w, g[j], n, z, sqn);
+        a.plain(j < cnt, o.tg[j] * (x * o.sv[j] - w * x * x));
       }
     };
     int2 prA[kFmUnroll], prB[kFmUnroll];
@@ -734,25 +726,22 @@ __device__ __forceinline__ void fm_update_body(const ModelDev &m, const Rows &ro
       load_desc(b + 3, prB);
       compute(opB, b + 1);
     }
-    rec[LAT_N * k + e] = n;
-    rec[LAT_Z * k + e] = z;
+    if (fold_finish_latent(m.h, a, w, n, z)) {
+      rec[LAT_N * k + e] = n;
+      rec[LAT_Z * k + e] = z;
+    }
   }
 }
-// side_blocks: the first workgroups carry the bias chain (block 0) and the linear update -- short
-// serial chains that would otherwise need a stream of their own (as in ffm_update_tile_kernel).
+// One launch for FM's whole update: the first side_blocks workgroups carry the bias fold (block 0)
+// and the linear update, the others the latent lists.
 __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s,
-                                                                int skip_huge, int skip_once,
-                                                                int side_blocks) {
+                                                                int skip_once, int side_blocks) {
   if (static_cast<int>(blockIdx.x) < side_blocks) {
-    if (blockIdx.x == 0) {
-      __builtin_amdgcn_s_setprio(3);  // one wave, n_rows dependent touches
-      bias_update_body(m, 0, rows.n_rows, s);
-    } else {
-      linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, 0, 1, skip_once);
-    }
+    if (blockIdx.x == 0) bias_update_body(m, rows.n_rows, s);
+    else linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, skip_once);
     return;
   }
-  fm_update_body(m, rows, s, skip_huge, skip_once, blockIdx.x - side_blocks, gridDim.x - side_blocks);
+  fm_update_body(m, rows, s, skip_once, blockIdx.x - side_blocks, gridDim.x - side_blocks);
 }
 
 }  // namespace ftrl_dev

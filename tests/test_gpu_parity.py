@@ -200,14 +200,13 @@ def test_refresh_modes_are_bit_identical(mode, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("k", [4, 8, 16])
-def test_update_in_one_launch_or_on_three_streams_is_bit_identical(fused, k, monkeypatch):
-    """The whole FFM update of a block as ONE launch (FFM_UPDATE_FUSED=1: what small blocks get by
-    default) or as three kernels on three streams (=0: what large blocks get): both must give the
-    oracle's bits -- on blocks with once-only, few-occurrence, hot and very hot features (a feature
-    in every row included), the bias / linear chains and the loss sum riding in the same launch."""
-    monkeypatch.setenv("FFM_UPDATE_FUSED", fused)
+def test_update_launch_folds_every_class_of_feature(k):
+    """The whole FFM update of a block is ONE launch (kernels_tile.h: ffm_update_all_kernel) whose
+    workgroup ranges fold the bias, the linear terms, the hot features' tiles (k = 4 / 8 / 16: the
+    three fact-record shapes) and the few-occurrence features and sum the losses: the oracle's bits
+    on blocks with once-only, few-occurrence, hot and very hot features (a feature in every row
+    included: sixteen segments of 64 occurrences)."""
     rng = np.random.default_rng(31 + k)
     F, per = 6, 30
     nf = F * per
@@ -222,12 +221,12 @@ def test_update_in_one_launch_or_on_three_streams_is_bit_identical(fused, k, mon
         blk.feat[::F] = 0  # field 0's entry of every row: one feature with n occurrences
         lo, so = o.train_batch(blk)
         lg, sg = e.train_batch(blk)
-        assert_bitwise(lg, lo, "fused=%s k=%d logits of a %d-row block" % (fused, k, n))
+        assert_bitwise(lg, lo, "k=%d logits of a %d-row block" % (k, n))
         if np.isnan(so):  # (the ffm.cpp:118 NaNs of n near 0 reach the logits: the loss sums are NaN too)
             assert np.isnan(sg)
         else:
             assert abs(sg - so) <= 1e-9 * max(1.0, abs(so))
-    assert_state_bitwise(e.get_state(), o.get_state(), "fused=%s k=%d" % (fused, k))
+    assert_state_bitwise(e.get_state(), o.get_state(), "k=%d" % k)
     e.close()
 
 

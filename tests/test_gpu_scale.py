@@ -109,11 +109,11 @@ def test_headline_size_model_matches_remapped_oracle(name, mt, F, k, n_feats, ne
 
 
 @pytest.mark.parametrize("F,k,per,B", [(8, 16, 40, 1024), (39, 16, 60, 2048), (6, 4, 3, 1500)])
-def test_quirk_nans_flow_through_the_chain_kernels(F, k, per, B):
+def test_quirk_nans_flow_through_the_folds(F, k, per, B):
     """No +0.05 on n here: with n near 0 the reference's sqrt(n + g2*g1) (ffm.cpp:118) goes NaN for
     many j-side touches, and with so few ids per field every feature is hot (5..192 occurrences)
-    or very hot (> 192): the NaNs must propagate through the DPP chains exactly as through the
-    oracle's sequential loop -- same positions in n, z, w and in the next block's logits."""
+    or very hot (> 192): the NaNs must come out of the per-touch terms of the folds exactly where
+    the oracle has them -- same positions in n, z, w and in the next block's logits."""
     rng = np.random.default_rng(23)
     nf = F * per
     o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
@@ -134,32 +134,6 @@ def test_quirk_nans_flow_through_the_chain_kernels(F, k, per, B):
     _, cnt = np.unique(blk.rows(0, B).feat, return_counts=True)
     assert (cnt > 192).any()  # very hot chains are exercised ...
     assert F == 6 or ((cnt > 8) & (cnt <= 192)).any()  # ... and (but for the tiny case) hot ones
-    e.close()
-
-
-@pytest.mark.parametrize("phases", [2, 3, 4])
-def test_row_phases_are_bit_identical(phases, monkeypatch):
-    """FFM_PHASES cuts a block's rows into ranges and runs the hot / very hot update of one range
-    beside the forward pass of the next (off by default: measured slower).  Same touches in the
-    same order, so the oracle's bits -- NaNs of ffm.cpp:118 included -- on blocks where every
-    feature is hot or very hot and the ranges cut through all of their chains."""
-    monkeypatch.setenv("FFM_PHASES", str(phases))
-    rng = np.random.default_rng(29)
-    F, k, per, B = 12, 16, 50, 4096
-    nf = F * per
-    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
-    st = rand_state(rng, o, n_hi=0.02)
-    st["vec_n"][rng.random(st["vec_n"].shape) < 0.2] = 0.0
-    o.set_state(st)
-    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=B, **STRESS_HP)
-    e.set_state(st)
-    blk = synth.Generator(F, nf, "zipf", seed=12).block(B + 1500)
-    for r0, r1 in ((0, B), (B, B + 1500)):  # (the short block trains unphased)
-        sub = blk.rows(r0, r1)
-        lo, _ = o.train_batch(sub)
-        lg, _ = e.train_batch(sub)
-        assert_bitwise(lg, lo, "phases=%d logits of block at %d" % (phases, r0))
-    assert_state_bitwise(e.get_state(), o.get_state(), "phases=%d" % phases)
     e.close()
 
 

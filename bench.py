@@ -46,32 +46,7 @@ CONFIGS = {
     "c4": dict(model="FM", fields=39, factors=64, rows=8192, feats=10_000_000),
 }
 PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-SMALL_MAX, HUGE_MIN, GIANT_MIN = 8, 192, 2048  # occurrence classes of the update kernels (csrc/engine_types.h)
-
-
-def chain_min_for(n_rows, nnz_block, k, n_shards, ffm=True):
-    """From how many occurrences a feature takes the DPP chain kernel instead of the tile kernel
-    (csrc/engine_step.h: chain_min_for; FFM_CHAIN_MIN overrides): for the two kernels' byte shares."""
-    env = os.environ.get("FFM_CHAIN_MIN")
-    if env:
-        return min(GIANT_MIN, max(64, int(env)))
-    if not ffm or n_rows <= 0:
-        return GIANT_MIN
-    touch_elems = nnz_block * max(0.0, nnz_block / n_rows - 1.0) * k / max(1, n_shards)
-    span_us = max(touch_elems / 0.88e6, n_rows * 0.012)
-    return int(min(float(GIANT_MIN), max(64.0, span_us / 0.3)))
-
-
-def update_fused(n_rows, nnz_block, k, n_shards):
-    """Whether the engine runs a block's whole FFM update as ONE launch (csrc/engine_step.h: small
-    blocks on one shard; FFM_UPDATE_FUSED overrides): the launch is timed under the hot
-    kernel's name and owns the bytes of all three occurrence classes."""
-    env = os.environ.get("FFM_UPDATE_FUSED")
-    if n_shards != 1 or n_rows <= 0:
-        return False
-    if env is not None:
-        return int(env) != 0
-    return nnz_block * max(0.0, nnz_block / n_rows - 1.0) * k / 0.44e6 < 100.0
+SMALL_MAX = 8  # occurrences per block up to which a feature is "few" (csrc/engine_types.h)
 
 
 def algorithmic_bytes_per_row(nnz, k):
@@ -102,9 +77,11 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
                              in the block, whose 12 B belong to the row kernel
       row kernel           : CSR in, linear weights, logit / tmp_grad / loss out (+ the above; + in
                              mode 3 the once-only features' update)
-      update               : write (n,z) = 8 B per slot-factor of the occurrences each kernel owns
-                             (features with 1, 2..8, 9 .. -- the tile kernel --, chain_min_for() or more
-                             -- the chain kernel -- occurrences in the block)
+      update               : write (n,z) = 8 B per slot-factor of the occurrences each kernel owns:
+                             ffm_update_all_kernel every feature with two or more occurrences (on a
+                             compact shard the few-occurrence ones have a launch of their own,
+                             ffm_update_small_flat_kernel), ffm_update_single_kernel the once-only
+                             features where their row could not update them (shards)
     Under field-pair sharding every rank moves 1/n_shards of the slot-factors."""
     if MODEL == "FM":
         return fm_kernel_share_bytes(kernel, blocks_feat, nnz, k)
@@ -122,18 +99,17 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
                               for r, o in zip(rows, once)]))
     if "single" in kernel and mode == 3:
         return 0.0
+    flat = n_shards > 1  # (csrc/engine.hip: flat_pays -- compact shards' short records)
     shares = []
-    for f in blocks_feat:
-        _, c = np.unique(f, return_counts=True)
-        cm = chain_min_for(len(f) // nnz, len(f), k, n_shards)
-        occ = {"single": c[c == 1].sum(), "small": c[(c > 1) & (c <= SMALL_MAX)].sum(),
-               "hot": c[(c > SMALL_MAX) & (c < cm)].sum(), "huge": c[c >= cm].sum()}
-        key = ("huge" if "chain" in kernel or "huge" in kernel else
-               next((kk for kk in ("single", "small") if kk in kernel), "hot"))
-        if key == "hot" and update_fused(len(f) // nnz, len(f), k, n_shards):
-            shares.append((occ["small"] + occ["hot"] + occ["huge"]) * per_occ * 8)
-        else:
-            shares.append(occ[key] * per_occ * 8 / n_shards)
+    for c in counts:
+        occ = {"single": c[c == 1].sum(), "few": c[(c > 1) & (c <= SMALL_MAX)].sum(), "hot": c[c > SMALL_MAX].sum()}
+        if "single" in kernel:
+            owned = occ["single"]
+        elif "small_flat" in kernel:
+            owned = occ["few"]
+        else:  # ffm_update_all_kernel / ffm_update_generic_kernel
+            owned = occ["hot"] + (0 if flat else occ["few"])
+        shares.append(owned * per_occ * 8 / n_shards)
     return float(np.mean(shares))
 
 
@@ -142,18 +118,14 @@ def fm_kernel_share_bytes(kernel, blocks_feat, nnz, k):
     row; a feature's record is k slot-factors).  fm_row_wave_kernel (csrc/kernels_fm.h) refreshes
     every OCCURRENCE's record (read n,z + write w = 12 B per factor), reads the CSR entries, the
     linear terms, writes logit / tmp_grad / loss / the row's k factor sums, and applies the (n, z)
-    step (8 B per factor) of the features that occur once in the block; fm_update_all_kernel owns every
-    other feature (8 B per factor-occurrence): the lists of 2..HUGE_MIN occurrences and the chains."""
+    step (8 B per factor) of the features that occur once in the block; fm_update_kernel owns every
+    other feature (8 B per factor-occurrence)."""
     rows = [len(f) // nnz for f in blocks_feat]
     counts = [np.unique(f, return_counts=True)[1] for f in blocks_feat]
     if "row_kernel" in kernel:
         return float(np.mean([r * (nnz * k * 12 + nnz * 12 + (nnz * 8 + 8) + 4 + 16 + 4 * k) + int((c == 1).sum()) * (k * 8 + 8)
                               for r, c in zip(rows, counts)]))
-    if "chain" in kernel or "huge" in kernel:  # (a launch of its own only with FFM_ENGINE_SERIAL=1)
-        return float(np.mean([c[c > HUGE_MIN].sum() * k * 8 for c in counts]))
-    if os.environ.get("FFM_ENGINE_SERIAL", "0") == "1":
-        return float(np.mean([c[(c > 1) & (c <= HUGE_MIN)].sum() * k * 8 for c in counts]))
-    # fm_update_all_kernel: every feature in more than one row of the block, chains included
+    # fm_update_kernel: every feature in more than one row of the block
     return float(np.mean([c[c > 1].sum() * k * 8 for c in counts]))
 
 
@@ -691,8 +663,6 @@ def main():
             out["eval"] = eval_leg
         if kname:
             share = kernel_share_bytes(kname, blocks_feat, N_FIELDS, N_FACTORS, n_shards)
-            per_step = max(1, round(klaunches / max(args.steps, 1)))  # (FFM_PHASES > 1: several launches per block)
-            share /= per_step
             avg_s = kms / 1000.0 / max(klaunches, 1)
             achieved = share / avg_s / 1e9
             traffic = None
@@ -713,9 +683,7 @@ def main():
                                "frac": round(out["step_algorithmic_GBps"] / PEAK_HBM_GBPS, 4),
                                "bytes_per_row": int(bytes_row)},
                 "note": "traffic = bytes leaving the L2 (Infinity-Cache hits included, FETCH_SIZE x2 for "
-                        "float4 record streams: tools/summarize_profile.py); the update kernels run side "
-                        "by side on separate streams, so their spans include waiting for CUs, and they "
-                        "are bound by dependent-load latency and wave slots, not HBM (DESIGN.md 6); "
+                        "float4 record streams: tools/summarize_profile.py); "
                         "warm-up spans of all kernels are in other_kernels",
             }
             # the other big kernels, from the fully timed warm-up launches (same accounting)
@@ -723,14 +691,13 @@ def main():
             for line in table.splitlines():
                 parts = line.split()
                 nm = parts[0]
-                full = {"row_kernel<train>": "fm_row_kernel<train>", "latent_update_kernel": "fm_update_kernel",
-                        "latent_update_huge_kernel": "fm_update_chain_kernel"}.get(nm) if model == "FM" else \
+                full = {"row_kernel<train>": "fm_row_kernel<train>", "update_kernel": "fm_update_kernel"}.get(nm) \
+                    if model == "FM" else \
                        {"row_kernel<train>": "ffm_row_kernel<train>",
                         "refresh_kernel": "ffm_refresh_kernel",
-                        "latent_update_single_kernel": "ffm_update_single_kernel",
-                        "latent_update_kernel": "ffm_update_small_kernel",
-                        "latent_update_hot_kernel": "ffm_update_tile_kernel",
-                        "latent_update_huge_kernel": "ffm_update_chain_kernel"}.get(nm)
+                        "update_single_kernel": "ffm_update_single_kernel",
+                        "update_few_flat_kernel": "ffm_update_small_flat_kernel",
+                        "update_kernel": "ffm_update_all_kernel"}.get(nm)
                 if not full:
                     continue
                 us = float(parts[-1])

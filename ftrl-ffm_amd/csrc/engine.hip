@@ -105,13 +105,13 @@ int fail(int code, const std::string &msg) {
 enum KernelId {
   K_GROUP_KEYS, K_GROUP_SORT, K_GROUP_FINISH, K_ROW, K_TMP_GRAD,
   K_HOT_META,
-  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_FEW,
+  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_FEW, K_LATENT_UPDATE_WALK,
   K_PREDICT_ROW, K_REFRESH, K_LATENT_UPDATE_SINGLE,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "group_keys_kernel", "group_radix_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
-    "linear_update_kernel", "bias_update_kernel", "update_kernel", "update_few_flat_kernel",
+    "linear_update_kernel", "bias_update_kernel", "update_kernel", "update_few_kernel", "update_walk_kernel",
     "row_kernel<predict>", "refresh_kernel", "update_single_kernel"};
 
 struct ProfRec {
@@ -357,6 +357,7 @@ struct ffm_engine {
   // workgroups of the update launch's ranges: few-occurrence features, hot tiles, the row-order walk
   // of serial slots; and of the once-only kernel of a shard
   int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768;
+  bool update_split = false;  // FFM_UPDATE_SPLIT=1: the update launch's ranges as launches of their own (timing aid)
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
   // slowed the HBM-bound kernels they ran beside up to 4x (refresh of a 65536-row block 70 -> 330 us),
@@ -612,6 +613,10 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   e->max_nnz = cfg->max_batch_nnz;
   if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
+  if (const char *sv = std::getenv("FFM_UPDATE_SPLIT")) e->update_split = sv[0] == '1';
+  if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_GRID_WALK")) e->grid_walk = std::max(1, std::atoi(sv));
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
   // a shard's row holds ~1/n_shards of the pairs: one wave per row, so that (with the small LDS

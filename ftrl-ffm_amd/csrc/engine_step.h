@@ -269,8 +269,19 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
     const int grid = side_blocks + nt + ns + nw + lb;
 #define FTRL_LAUNCH_ALL(NF)                                                                                   \
-    LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-           side_blocks, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part)
+    do {                                                                                                      \
+      if (e->update_split) { /* (timing aid: one launch per range, each under a name of its own) */           \
+        LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), side_blocks + nt, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
+               side_blocks, nt, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                       \
+        LAUNCH(e, K_LATENT_UPDATE_FEW, (ffm_update_all_kernel<NF>), ns, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
+               0, 0, ns, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                                 \
+        LAUNCH(e, K_LATENT_UPDATE_WALK, (ffm_update_all_kernel<NF>), nw + lb, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
+               0, 0, 0, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                                \
+      } else {                                                                                                \
+        LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
+               side_blocks, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                    \
+      }                                                                                                       \
+    } while (0)
     if (nf == 1) FTRL_LAUNCH_ALL(1);       // k >= 16
     else if (nf == 2) FTRL_LAUNCH_ALL(2);  // k = 8 / 12
     else FTRL_LAUNCH_ALL(4);               // k = 4

@@ -92,9 +92,14 @@ __device__ __forceinline__ void fold_ffm_group(const Hyper &h, Fold &a, float w,
       nb[j] = nt;
       a.P = live[j] ? a.P + gg[j] : a.P;
     }
+    // (lanes that do not need a term vote with harmless operands: no branch per touch)
     bool ok = h.fast_div != 0;
 #pragma unroll
-    for (int j = 0; j < N; j++) ok = ok && (!need[j] || (fold_operand_ok(arg[j]) && fold_operand_ok(nb[j])));
+    for (int j = 0; j < N; j++) {
+      arg[j] = need[j] ? arg[j] : 1.0f;
+      nb[j] = need[j] ? nb[j] : 1.0f;
+      ok = ok & fold_operand_ok(arg[j]) & fold_operand_ok(nb[j]);
+    }
     float mt[N];
     if (__all(ok)) {
 #pragma unroll
@@ -152,7 +157,11 @@ struct FoldFew {
       const bool need = seen && live;
       bool ok = h.fast_div != 0;
 #pragma unroll
-      for (int i = 0; i < E; i++) ok = ok && (!need || (fold_operand_ok(arg[i]) && fold_operand_ok(nb[i])));
+      for (int i = 0; i < E; i++) {
+        arg[i] = need ? arg[i] : 1.0f;
+        nb[i] = need ? nb[i] : 1.0f;
+        ok = ok & fold_operand_ok(arg[i]) & fold_operand_ok(nb[i]);
+      }
       if (__all(ok)) {
 #pragma unroll
         for (int i = 0; i < E; i++) mt[i] = div_alpha_fast(h, sqrt_fast0(arg[i]) - sqrt_fast0(nb[i])) * w[i];

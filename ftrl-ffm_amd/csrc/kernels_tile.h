@@ -109,6 +109,16 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
       const unsigned long long gm = s.gmask[start];
       if (!__any(active && ((gm >> fp) & 1ull))) continue;
     }
+    // issue priority by length: a wave that shares its SIMD gets a fraction of the issue slots, and
+    // the longest folds bound the phase (FFM_TILE_PRIO=0: off)
+#ifndef FFM_TILE_PRIO
+#define FFM_TILE_PRIO 1
+#endif
+    if (FFM_TILE_PRIO) {
+      if (c > 640) __builtin_amdgcn_s_setprio(3);
+      else if (c > 192) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     float *rec = lat_row(m, i, fa) + (fp >= 0 ? sb + es : sb) * K + ekk;
     float n = rec[LAT_N * RL], z = rec[LAT_Z * RL];
     const float w = rec[LAT_W * RL];
@@ -257,6 +267,7 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
       rec[LAT_Z * RL] = z;
     }
   }
+  if (FFM_TILE_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // The whole FFM update of a block in ONE launch on the main stream.  Workgroup ranges:

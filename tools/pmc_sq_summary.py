@@ -8,10 +8,10 @@ for tag in sys.argv[1:]:
         for fn in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
             if part == "a":
                 for r in csv.DictReader(open(fn)):
-                    dur[r['Kernel_Name'].split('(')[0][-40:]].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+                    dur[r['Kernel_Name'].split('(')[0][-34:] + ':' + str(r.get('Grid_Size', r.get('Grid_Size_X', '')))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
         for fn in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
             for r in csv.DictReader(open(fn)):
-                k = r['Kernel_Name'].split('(')[0][-40:]
+                k = r['Kernel_Name'].split('(')[0][-34:] + ':' + str(r.get('Grid_Size', r.get('Grid_Size_X', '')))
                 agg[k][r['Counter_Name']] += float(r['Counter_Value'])
                 cnt[k][r['Counter_Name']] += 1
     print("==", tag)

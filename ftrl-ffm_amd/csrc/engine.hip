@@ -105,13 +105,13 @@ int fail(int code, const std::string &msg) {
 enum KernelId {
   K_GROUP_KEYS, K_GROUP_SORT, K_GROUP_FINISH, K_ROW, K_TMP_GRAD,
   K_HOT_META,
-  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_FEW, K_LATENT_UPDATE_WALK,
+  K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_FEW, K_LATENT_UPDATE_WALK, K_LATENT_UPDATE_GIANT,
   K_PREDICT_ROW, K_REFRESH, K_LATENT_UPDATE_SINGLE,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "group_keys_kernel", "group_radix_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
-    "linear_update_kernel", "bias_update_kernel", "update_kernel", "update_few_kernel", "update_walk_kernel",
+    "linear_update_kernel", "bias_update_kernel", "update_kernel", "update_few_kernel", "update_walk_kernel", "update_giant_kernel",
     "row_kernel<predict>", "refresh_kernel", "update_single_kernel"};
 
 struct ProfRec {
@@ -356,7 +356,7 @@ struct ffm_engine {
   std::vector<int> field_start; // copy of cfg->field_start (compact shards)
   // workgroups of the update launch's ranges: few-occurrence features, hot tiles, the row-order walk
   // of serial slots; and of the once-only kernel of a shard
-  int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768;
+  int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768, grid_giant = 1024;
   bool update_split = false;  // FFM_UPDATE_SPLIT=1: the update launch's ranges as launches of their own (timing aid)
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
@@ -716,6 +716,20 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.big, E));
   TRY_ALLOC(e->alloc(&s.huge, E));
   TRY_ALLOC(e->alloc(&s.giant, E / kChainMin + 1));
+  TRY_ALLOC(e->alloc(&s.gseg, E / kChainMin + 1));
+  TRY_ALLOC(e->alloc(&s.grange, E / kRange + E / kGiantMin + 2));
+  {
+    // partial sums of the giant features' folds (shared by the scratch sets)
+    const size_t max_segs = E / kSeg + E / kGiantMin + 2, rl = static_cast<size_t>(std::max(1, m.row_len));
+    const size_t chunks = cfg->n_factors > 0 && cfg->n_factors <= 64
+                              ? (static_cast<size_t>(m.rec_slots) + 64 / cfg->n_factors - 1) / (64 / cfg->n_factors)
+                              : static_cast<size_t>(m.rec_slots) * ((cfg->n_factors + 63) / 64);
+    TRY_ALLOC(e->alloc(&s.segP, max_segs * rl));
+    TRY_ALLOC(e->alloc(&s.segG, max_segs * rl));
+    TRY_ALLOC(e->alloc(&s.segD, max_segs * rl));
+    TRY_ALLOC(e->alloc(&s.segF, max_segs * std::max<size_t>(1, chunks) * 3));
+    TRY_ALLOC(e->alloc(&s.gcap, (E / kGiantMin + 2) * rl));
+  }
   TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
   TRY_ALLOC(e->alloc(&e->d_err, 1));
   TRY_HIP(hipMemsetAsync(e->d_err, 0, sizeof(int), e->stream));
@@ -807,6 +821,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.big, E));
     TRY_ALLOC(e->alloc(&t.huge, E));
     TRY_ALLOC(e->alloc(&t.giant, E / kChainMin + 1));
+    TRY_ALLOC(e->alloc(&t.gseg, E / kChainMin + 1));
+    TRY_ALLOC(e->alloc(&t.grange, E / kRange + E / kGiantMin + 2));
     TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
     TRY_ALLOC(e->alloc(&t.occpos, E));
     TRY_ALLOC(e->alloc(&t.uflag, E));

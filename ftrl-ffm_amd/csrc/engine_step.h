@@ -285,6 +285,16 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     if (nf == 1) FTRL_LAUNCH_ALL(1);       // k >= 16
     else if (nf == 2) FTRL_LAUNCH_ALL(2);  // k = 8 / 12
     else FTRL_LAUNCH_ALL(4);               // k = 4
+    if (rows.nnz > kRange) {
+      // giant features: their ranges' second pass and the join of their segments
+      const int gg = e->grid_giant;
+      e->prof_begin(K_LATENT_UPDATE_GIANT, e->stream);
+      if (nf == 1) hipLaunchKernelGGL(ffm_update_giant_b_kernel<1>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
+      else if (nf == 2) hipLaunchKernelGGL(ffm_update_giant_b_kernel<2>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
+      else hipLaunchKernelGGL(ffm_update_giant_b_kernel<4>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
+      hipLaunchKernelGGL(ffm_update_giant_join_kernel, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
+      e->prof_end(e->stream);
+    }
 #undef FTRL_LAUNCH_ALL
     loss_done = loss_sum_out != nullptr;
   } else {

@@ -142,7 +142,16 @@ struct Scratch {
                   //      that occur once, which ffm_update_single_kernel owns)
   int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
   int *huge;      // [nnz] ... with more, below ModelDev::giant_min ("very hot": present in many rows)
-  int *giant;     // [nnz / kChainMin + 1] ... with giant_min or more
+  int *giant;     // [nnz / kChainMin + 1] ... with giant_min or more: their occurrences are cut into
+                  //      RANGES of kRange that several waves fold side by side; per giant feature:
+  int *gseg;      // [nnz / kChainMin + 1] first of its segment slots in segP / segG / segD / segF
+  int2 *grange;   // [nnz / (kRange / 2) + 1] {index into giant, range number}: one entry per range
+  // partial sums of the giant features' folds, per segment and element of the stored record
+  // (shared by the scratch sets: one block's update ends before the next one's starts)
+  float *segP, *segG, *segD;    // [max_segs * row_len] sum g*g, sum g, sum of root differences
+  unsigned long long *segF;     // [max_segs * chunks * 3] per (segment, 64-element chunk): lanes with a
+                                //      live touch / whose first live touch is plain / with a :118 touch
+  float *gcap;                  // [(nnz / kChainMin + 1) * row_len] n_t at an element's first :118 touch
   int *counters;  // [kNumCounters] CNT_* below
   int *err;       // [1] sticky ERR_* flags, shared by all sets: what ffm_engine_sync reports
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
@@ -190,8 +199,9 @@ constexpr int kLineInts = 16;
 enum { CNT_NUNIQ = 0, CNT_CURSOR = 1 * kLineInts, CNT_NMULTI = 2 * kLineInts, CNT_ERROR = 3 * kLineInts,
        CNT_NSMALL = 4 * kLineInts, CNT_NBIG = 5 * kLineInts, CNT_NHUGE = 6 * kLineInts,
        CNT_NFEW = 7 * kLineInts, CNT_NSINGLE = 9 * kLineInts, CNT_NGIANT = 10 * kLineInts,
-       CNT_SORT_BAR = 11 * kLineInts };  // (the sort's grid barrier, kernels_sort.h)
-constexpr int kNumCounters = 12 * kLineInts;
+       CNT_SORT_BAR = 11 * kLineInts,  // (the sort's grid barrier, kernels_sort.h)
+       CNT_NSEG = 12 * kLineInts, CNT_NRANGE = 13 * kLineInts };  // the giant features' segment slots / ranges
+constexpr int kNumCounters = 14 * kLineInts;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 // Occurrence classes of a block's hot features (more than kSmallMax occurrences):
 //   big   (.. huge_min]             one wave folds all touches of (feature, 64 elements)
@@ -199,14 +209,17 @@ enum { OCC_FEW = -1, OCC_ONCE = -2 };
 //   giant [giant_min ..             segment ranges of one feature folded by several waves side by
 //                                   side, partial sums joined afterwards (kernels_tile.h)
 #ifndef FFM_HUGE_MIN
-#define FFM_HUGE_MIN 192
+#define FFM_HUGE_MIN 128
 #endif
 constexpr int kHugeMin = FFM_HUGE_MIN;
-#ifndef FFM_GIANT_MIN
-#define FFM_GIANT_MIN 1024
+// ... and from which one wave per (feature, 64 elements) would be the update phase's span: a
+// feature with more than kRange occurrences is "giant"
+#ifndef FFM_RANGE_SEGS
+#define FFM_RANGE_SEGS 4
 #endif
-// ... and from which one wave per (feature, 64 elements) would be the update phase's span
-constexpr int kGiantMin = FFM_GIANT_MIN;
+constexpr int kRangeSegs = FFM_RANGE_SEGS;
+constexpr int kRange = kRangeSegs * kSeg;  // occurrences per range of a giant feature
+constexpr int kGiantMin = kRange + 1;
 constexpr int kChainMin = 64;  // the least giant_min an engine may choose (sizes Scratch::giant)
 enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
                                                      // first / several entries share the field

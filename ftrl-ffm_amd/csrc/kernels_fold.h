@@ -4,22 +4,22 @@
 //   sigma = (sqrtf(n + q) - sqrtf(n)) / alpha ;  z' = z + g - sigma*w ;  n' = n + g*g
 // (src/model/ftrl_model.cpp:69-74, :81-84; src/model/ffm.cpp:112-120; src/model/fm.cpp:90-94)
 // applied by every touching row in turn is, in exact arithmetic,
-//   n_T = n_0 + sum g*g ,   z_T = z_0 + sum g - w * sum sigma_t
-// and for "plain" touches (q = g*g: linear, bias, FM, the first slot of an FFM pair) the step sizes
-// telescope: sum sigma_t = (sqrtf(n_T) - sqrtf(n_0)) / alpha.  A touch of the
-// ffm.cpp:118 kind (q = g2*g1) does not telescope: it is evaluated on its own against the prefix
-// sum n_t.  The floating-point TREE these kernels and the oracle (the checker under oracle/, "block
-// update by reductions") share:
+//   n_T = n_0 + sum g*g ,   z_T = z_0 + sum g - w * (sum of root differences) / alpha
+// and for "plain" touches (q = g*g: linear, bias, FM, the first slot of an FFM pair) the root
+// differences telescope to sqrtf(n_T) - sqrtf(n_0).  A touch of the
+// ffm.cpp:118 kind (q = g2*g1) does not telescope: its difference sqrtf(n_t + q_t) - sqrtf(n_t) is
+// taken on its own against the prefix sum n_t.  The floating-point TREE these kernels and the
+// checker under oracle/ ("block update by reductions") share:
 //   * the occurrences of a feature in the block, in row order, are cut into segments of kSeg
 //     (rows of the block for the bias); inside a segment the sums run left to right from -0.0f
 //     (the identity of fp addition), the segment totals are joined left to right:
 //       B_0 = n_0,  B_{s+1} = B_s + P_s,  n_T = B_S ;  n_t = B_s + (partial P before touch t)
-//   * from the accumulator's first :118 touch t0 on, every touch adds
-//     m_t = ((sqrtf(n_t + q_t) - sqrtf(n_t)) / alpha) * w ; the plain touches before it telescope to
-//     H = ((sqrtf(n_t0) - sqrtf(n_0)) / alpha) * w  (t0 = T when there is none);
-//   * latent z_T = (z_0 + G) - (H + M),  linear / bias z_T = z_0 + (G - sigma*w).
+//   * from the accumulator's first :118 touch t0 on, every touch adds its root difference to D; the
+//     plain touches before it telescope to sqrtf(n_t0) - sqrtf(n_0) (t0 = T when there is none);
+//   * latent z_T = (z_0 + G) - ((head + D) / alpha) * w,  linear / bias z_T = z_0 + (G - sigma*w):
+//     ONE alpha divide per accumulator and block.
 // One touch is the reference's expression literally.  Accumulators that one row touches twice
-// ("serial": s.cmask / UF_DUP) are not folded -- they keep the row-order walk (ffm_walk_* below).
+// ("serial": s.cmask / UF_DUP) are not folded -- they keep the row-order walk (ffm_generic_body).
 // No float atomics: every sum has ONE owner and a fixed order.
 #pragma once
 #include "engine_types.h"
@@ -27,21 +27,49 @@
 
 namespace ftrl_dev {
 
-// A sqrt operand of the per-touch terms: +0 (a fresh model's n) or inside [2^-70, 2^96] -- there
-// sqrt_fast0 is exact and the difference of two such roots is +0 or has magnitude in
-// [2^-58, 2^48], inside div_alpha_fast's proven range.
-__device__ __forceinline__ bool fold_operand_ok(float x) {
+// A sqrt operand of the per-touch root differences.  Strict: inside [2^-70, 2^96], where sqrt_fast
+// is exact (two instructions to test).  Zero-tolerant: or +0 (a fresh model's n), for sqrt_fast0.
+__device__ __forceinline__ bool fold_strict_ok(float x) {
+  return __builtin_amdgcn_fmed3f(x, 0x1p-70f, 0x1p96f) == x;
+}
+__device__ __forceinline__ bool fold_zero_ok(float x) {
   return __float_as_uint(x) == 0u || __builtin_amdgcn_fmed3f(x, 0x1p-70f, 0x1p96f) == x;
+}
+
+// d[i] = sqrtf(arg[i]) - sqrtf(nb[i]) for the lanes / entries that need it (the others get
+// anything), correctly rounded roots: the five-instruction form behind ONE vote when every needed
+// operand is comfortably normal, the same with +0 allowed behind a second vote, else sqrtf.
+template <int N>
+__device__ __forceinline__ void fold_root_diffs(const float (&arg)[N], const float (&nb)[N], const bool (&need)[N],
+                                                float (&d)[N]) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; j++) ok = ok && (!need[j] || (fold_strict_ok(arg[j]) && fold_strict_ok(nb[j])));
+  if (__all(ok)) {
+#pragma unroll
+    for (int j = 0; j < N; j++) d[j] = sqrt_fast(arg[j]) - sqrt_fast(nb[j]);
+    return;
+  }
+  ok = true;
+#pragma unroll
+  for (int j = 0; j < N; j++) ok = ok && (!need[j] || (fold_zero_ok(arg[j]) && fold_zero_ok(nb[j])));
+  if (__all(ok)) {
+#pragma unroll
+    for (int j = 0; j < N; j++) d[j] = sqrt_fast0(arg[j]) - sqrt_fast0(nb[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; j++) d[j] = sqrtf(arg[j]) - sqrtf(nb[j]);
+  }
 }
 
 // One accumulator per lane.
 struct Fold {
-  float P, G, M;        // the running segment: sum g*g, sum g, sum m
-  float B, Gacc, Macc;  // the segments before it (B starts at n_0)
+  float P, G, D;        // the running segment: sum g*g, sum g, sum of root differences
+  float B, Gacc, Dacc;  // the segments before it (B starts at n_0)
   float ncap;           // n_t at the first :118 touch
   bool any, seen, head_plain;
   __device__ __forceinline__ void init(float n0) {
-    P = G = M = Gacc = Macc = -0.0f;
+    P = G = D = Gacc = Dacc = -0.0f;
     B = n0;
     ncap = 0.0f;
     any = seen = head_plain = false;
@@ -50,8 +78,8 @@ struct Fold {
   __device__ __forceinline__ void flush() {
     B = B + P;
     Gacc = Gacc + G;
-    Macc = Macc + M;
-    P = G = M = -0.0f;
+    Dacc = Dacc + D;
+    P = G = D = -0.0f;
   }
   // plain touches only (linear, bias, FM): gradient g of a live touch
   __device__ __forceinline__ void plain(bool live, float g) {
@@ -64,10 +92,11 @@ struct Fold {
 };
 
 // N consecutive touches of one FFM accumulator per lane (lane = element).  live: the touch exists
-// for this lane's slot; first: its own entry is the pair's first (ffm.cpp:112-115; else :117-120
-// with the :118 quirk); g = tmp_grad * vp * x as the reference associates it.
+// for this lane's slot; first: live and its own entry is the pair's first (ffm.cpp:112-115; a live
+// touch that is not first is the pair's second: :117-120 with the :118 quirk); g = tmp_grad * vp * x
+// as the reference associates it.
 template <int N>
-__device__ __forceinline__ void fold_ffm_group(const Hyper &h, Fold &a, float w, const bool (&live)[N],
+__device__ __forceinline__ void fold_ffm_group(Fold &a, float w, const bool (&live)[N],
                                                const bool (&first)[N], const float (&tg)[N],
                                                const float (&x)[N], const float (&vp)[N]) {
   float g[N], gg[N];
@@ -80,36 +109,23 @@ __device__ __forceinline__ void fold_ffm_group(const Hyper &h, Fold &a, float w,
     anyq = anyq || quirk[j];
   }
   if (__any(a.seen || anyq)) {
-    float arg[N], nb[N];
+    float arg[N], nb[N], d[N];
     bool need[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
       const float nt = a.B + a.P;
-      if (quirk[j] && !a.seen) { a.seen = true; a.ncap = nt; }
+      const bool flip = quirk[j] && !a.seen;
+      if (__any(flip)) a.ncap = flip ? nt : a.ncap;
+      a.seen = a.seen || flip;
       need[j] = a.seen && live[j];
       const float g1 = tg[j] * w * x[j];  // the pair's first entry's gradient (ffm.cpp:112)
       arg[j] = nt + (first[j] ? gg[j] : g[j] * g1);  // ffm.cpp:113 / :118
       nb[j] = nt;
       a.P = live[j] ? a.P + gg[j] : a.P;
     }
-    // (lanes that do not need a term vote with harmless operands: no branch per touch)
-    bool ok = h.fast_div != 0;
+    fold_root_diffs<N>(arg, nb, need, d);
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-      arg[j] = need[j] ? arg[j] : 1.0f;
-      nb[j] = need[j] ? nb[j] : 1.0f;
-      ok = ok & fold_operand_ok(arg[j]) & fold_operand_ok(nb[j]);
-    }
-    float mt[N];
-    if (__all(ok)) {
-#pragma unroll
-      for (int j = 0; j < N; j++) mt[j] = div_alpha_fast(h, sqrt_fast0(arg[j]) - sqrt_fast0(nb[j])) * w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < N; j++) mt[j] = ((sqrtf(arg[j]) - sqrtf(nb[j])) / h.alpha) * w;
-    }
-#pragma unroll
-    for (int j = 0; j < N; j++) a.M = need[j] ? a.M + mt[j] : a.M;
+    for (int j = 0; j < N; j++) a.D = need[j] ? a.D + d[j] : a.D;
   } else {
 #pragma unroll
     for (int j = 0; j < N; j++) a.P = live[j] ? a.P + gg[j] : a.P;
@@ -117,7 +133,8 @@ __device__ __forceinline__ void fold_ffm_group(const Hyper &h, Fold &a, float w,
 #pragma unroll
   for (int j = 0; j < N; j++) {
     a.G = live[j] ? a.G + g[j] : a.G;
-    if (live[j] && !a.any) { a.any = true; a.head_plain = first[j]; }
+    if (!a.any) a.head_plain = first[j];  // (kept from the first live touch on)
+    a.any = a.any || live[j];
   }
 }
 
@@ -126,15 +143,16 @@ __device__ __forceinline__ void fold_ffm_group(const Hyper &h, Fold &a, float w,
 // running sums are the totals.  any / seen / head_plain are the lane's (the E factors move together).
 template <int E>
 struct FoldFew {
-  float P[E], G[E], M[E], ncap[E];
+  float P[E], G[E], D[E], ncap[E];
   bool any, seen, head_plain;
   __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int i = 0; i < E; i++) { P[i] = G[i] = M[i] = -0.0f; ncap[i] = 0.0f; }
+    for (int i = 0; i < E; i++) { P[i] = G[i] = D[i] = -0.0f; ncap[i] = 0.0f; }
     any = seen = head_plain = false;
   }
-  __device__ __forceinline__ void touch(const Hyper &h, const float (&n0)[E], const float (&w)[E], bool live,
-                                        bool first, float tg, float x, const float (&vp)[E]) {
+  // first: the own entry is the pair's first (or the learning variant: g2*g2 at ffm.cpp:118)
+  __device__ __forceinline__ void touch(const float (&n0)[E], const float (&w)[E], bool live, bool first,
+                                        float tg, float x, const float (&vp)[E]) {
     float g[E], gg[E];
 #pragma unroll
     for (int i = 0; i < E; i++) {
@@ -144,7 +162,9 @@ struct FoldFew {
     const bool quirk = live && !first;
     if (__any(seen || quirk)) {
       const bool flip = quirk && !seen;
-      float arg[E], nb[E], mt[E];
+      float arg[E], nb[E], d[E];
+      bool need[E];
+      seen = seen || flip;
 #pragma unroll
       for (int i = 0; i < E; i++) {
         const float nt = n0[i] + P[i];
@@ -152,25 +172,11 @@ struct FoldFew {
         const float g1 = tg * w[i] * x;  // the pair's first entry's gradient (ffm.cpp:112)
         arg[i] = nt + (first ? gg[i] : g[i] * g1);  // ffm.cpp:113 / :118
         nb[i] = nt;
+        need[i] = seen && live;
       }
-      seen = seen || flip;
-      const bool need = seen && live;
-      bool ok = h.fast_div != 0;
+      fold_root_diffs<E>(arg, nb, need, d);
 #pragma unroll
-      for (int i = 0; i < E; i++) {
-        arg[i] = need ? arg[i] : 1.0f;
-        nb[i] = need ? nb[i] : 1.0f;
-        ok = ok & fold_operand_ok(arg[i]) & fold_operand_ok(nb[i]);
-      }
-      if (__all(ok)) {
-#pragma unroll
-        for (int i = 0; i < E; i++) mt[i] = div_alpha_fast(h, sqrt_fast0(arg[i]) - sqrt_fast0(nb[i])) * w[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < E; i++) mt[i] = ((sqrtf(arg[i]) - sqrtf(nb[i])) / h.alpha) * w[i];
-      }
-#pragma unroll
-      for (int i = 0; i < E; i++) M[i] = need ? M[i] + mt[i] : M[i];
+      for (int i = 0; i < E; i++) D[i] = need[i] ? D[i] + d[i] : D[i];
     }
 #pragma unroll
     for (int i = 0; i < E; i++) {
@@ -181,7 +187,7 @@ struct FoldFew {
   }
   // (n, z) in, (n_T, z_T) out for the lane's E accumulators; false when no touch reached them
   __device__ __forceinline__ bool finish(const Hyper &h, const float (&w)[E], float (&n)[E], float (&z)[E]) {
-    float nT[E], sa[E], sb[E], d[E], q[E];
+    float nT[E], sa[E], sb[E], S[E], q[E];
 #pragma unroll
     for (int i = 0; i < E; i++) {
       nT[i] = n[i] + P[i];
@@ -192,16 +198,16 @@ struct FoldFew {
     sqrt_cr_n<E>(sa, ra);
     sqrt_cr_n<E>(sb, rb);
 #pragma unroll
-    for (int i = 0; i < E; i++) d[i] = ra[i] - rb[i];
-    div_alpha_n<E>(h, d, q);
+    for (int i = 0; i < E; i++) {
+      float t = -0.0f;
+      t = head_plain ? t + (ra[i] - rb[i]) : t;
+      S[i] = t + D[i];
+    }
+    div_alpha_n<E>(h, S, q);
 #pragma unroll
     for (int i = 0; i < E; i++) {
-      const float hh = q[i] * w[i];
-      float m = -0.0f;
-      m = head_plain ? m + hh : m;
-      m = m + M[i];
       if (any) {
-        z[i] = (z[i] + G[i]) - m;
+        z[i] = (z[i] + G[i]) - q[i] * w[i];
         n[i] = nT[i];
       }
     }
@@ -214,10 +220,11 @@ struct FoldFew {
 __device__ __forceinline__ bool fold_finish_latent(const Hyper &h, Fold &a, float w, float &n, float &z) {
   a.flush();
   const float ncap = a.seen ? a.ncap : a.B;
-  const float hh = div_alpha(h, sqrt_cr(ncap) - sqrt_cr(n)) * w;
-  float m = -0.0f;
-  m = a.head_plain ? m + hh : m;
-  m = m + a.Macc;
+  const float hd = sqrt_cr(ncap) - sqrt_cr(n);
+  float S = -0.0f;
+  S = a.head_plain ? S + hd : S;
+  S = S + a.Dacc;
+  const float m = div_alpha(h, S) * w;
   if (a.any) {
     z = (z + a.Gacc) - m;
     n = a.B;

@@ -224,7 +224,16 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
     if (c <= kSmallMax) s.small[is] = u;
     else if (c <= m.huge_min) s.big[ib] = u;
     else if (c < m.giant_min) s.huge[ih] = u;
-    else s.giant[slot[6]] = u;
+    else {
+      // a giant feature: kSeg-occurrence segment slots for its partial sums, one list entry per
+      // range of kRange occurrences (kernels_tile.h: the ranges are folded side by side)
+      const int gi = slot[6];
+      s.giant[gi] = u;
+      const int n_seg = (c + kSeg - 1) / kSeg, n_rng = (c + kRange - 1) / kRange;
+      s.gseg[gi] = atomicAdd(&s.counters[CNT_NSEG], n_seg);
+      const int rb = atomicAdd(&s.counters[CNT_NRANGE], n_rng);
+      for (int r = 0; r < n_rng; r++) s.grange[rb + r] = make_int2(gi, r);
+    }
   }
   // slots of the feature that p's row touches: slot fp is touched when the row holds ANOTHER
   // entry of field fp (FFM::update_vector_w refreshes exactly those, ffm.cpp:72-88), within the

@@ -49,10 +49,13 @@ constexpr int kTileNR = kTileDV == 1 ? 2 : 4;  // fact-record buffers (a power o
 #endif
 constexpr int kTileG = FFM_TILE_G;  // touches per arithmetic group (one range vote per group)
 
-// flags word of an LDS fact record: bits 0..7 high bits of the weights' offset, 8..10 HF_* flags,
-// 16..23 the touch's own field
-__device__ __forceinline__ int tile_hiword(int off_hi, int flags, int own_field) {
-  return (off_hi & 0xff) | (flags << 8) | (own_field << 16);
+// flags word of an LDS fact record: bits 0..7 high bits of the weights' offset, bit 31 the touch is
+// live (one plain partner: HF_SIMPLE), bit 30 live and the own entry is the pair's first (HF_FIRST) --
+// so that the fold reads them with one compare each (hw < 0, hw >= 0xC0000000 unsigned)
+__device__ __forceinline__ int tile_hiword(int off_hi, int flags) {
+  const bool live = (flags & HF_SIMPLE) != 0;
+  return (off_hi & 0xff) | (live ? static_cast<int>(0x80000000u) : 0) |
+         (live && (flags & HF_FIRST) ? 0x40000000 : 0);
 }
 
 struct TileWeights {  // a loader lane's four 16-byte quads of one tile's partner weights
@@ -63,219 +66,417 @@ struct TileFacts {  // what a stager lane holds of one tile: NF facts of its tou
   float2 mt;
 };
 
+// Geometry of the (feature, chunk) work items.
+struct TileGeom {
+  int K, F, RL, SPC, cps, slots;
+  unsigned per_feat;  // chunks per stored record
+};
+__device__ __forceinline__ TileGeom tile_geom(const ModelDev &m) {
+  TileGeom g;
+  g.K = m.n_factors;
+  g.F = m.n_fields;
+  g.RL = m.row_len;
+  g.SPC = g.K <= 64 ? 64 / g.K : 1;          // slots per chunk
+  g.cps = g.K <= 64 ? 1 : (g.K + 63) >> 6;   // chunks per slot
+  g.slots = record_span(m, 1);
+  g.per_feat = g.K <= 64 ? (g.slots + g.SPC - 1) / g.SPC : g.slots * g.cps;
+  return g;
+}
+// Chunk ci of the stored record of a feature whose field is fa, as this lane sees it in the fold
+// layout (lane = element of the chunk; idle lanes repeat the first four).
+struct TileChunk {
+  int sb, kk0, width, fp0;  // first slot, first factor (k > 64), elements, partner field of the first slot
+  int es, ekk, fp;          // this lane's slot within the chunk, factor, partner field (-1: none)
+  bool inw;
+};
+__device__ __forceinline__ TileChunk tile_chunk(const ModelDev &m, const TileGeom &g, int fa, int ci) {
+  const int lane = threadIdx.x & 63;
+  TileChunk c;
+  c.sb = g.K <= 64 ? ci * g.SPC : ci / g.cps;
+  c.kk0 = g.K <= 64 ? 0 : (ci - c.sb * g.cps) * 64;
+  c.width = g.K <= 64 ? g.SPC * g.K : min(64, g.K - c.kk0);
+  c.fp0 = wave_uniform(walk_field(m, fa, c.sb));  // (< 0: valid walk positions are a prefix -- nothing stored here)
+  c.inw = lane < c.width;
+  const int le = c.inw ? lane : (lane & 3);
+  c.es = g.K <= 64 ? le / g.K : 0;
+  c.ekk = g.K <= 64 ? le - c.es * g.K : c.kk0 + le;
+  c.fp = c.sb + c.es < g.slots ? walk_field(m, fa, c.sb + c.es) : -1;
+  return c;
+}
+
+// Streams the touches [t_lo, t_hi) of one hot feature (its occurrences start at `start` in the
+// grouped order) for the chunk `ch` through the wave's LDS, tile by tile (see the header), and hands
+// every tile to apply(st, Rc, Tc): st = tile number from t_lo, Rc = the tile's fact records as this
+// lane's slot sees them (record of touch j at Rc[j * RS]: {tmp_grad, x_own * x_other, flags, ..}),
+// Tc = this lane's column of the transposer (partner weight of touch j at Tc[j * kTileRow]).
 // NF: facts a stager lane carries per tile = ceil(slots per chunk / 4): 1 for k >= 16, 2 for
 // k = 8 / 12, 4 for k = 4.  T: the wave's transposer [kTileT][kTileRow]; R: its fact records
 // [kTileNR][kTileT * 4 * NF].
-template <int NF>
-__device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &rows, const Scratch &s,
-                                               unsigned wave, unsigned n_waves, int lists, float *T,
-                                               float4 *R) {
+template <int NF, typename Apply>
+__device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s, const TileGeom &g,
+                                            const TileChunk &ch, int fa, int start, int t_lo, int t_hi,
+                                            float *T, float4 *R, Apply &&apply) {
   constexpr int RS = 4 * NF;  // records per touch in R (>= slots per chunk)
-  const int K = m.n_factors, F = m.n_fields, RL = m.row_len;
+  const int K = g.K, F = g.F;
   const int lane = threadIdx.x & 63;
   const int tl = lane >> 2, cq = lane & 3;  // stager / loader layout: touch, 16-byte quad column
-  const int SPC = K <= 64 ? 64 / K : 1;     // slots per chunk
-  const int cps = K <= 64 ? 1 : (K + 63) >> 6;  // chunks per slot
-  const int slots = record_span(m, 1);
-  const unsigned per_feat = K <= 64 ? (slots + SPC - 1) / SPC : slots * cps;
-  // the lists this launch takes (bits of `lists`: 1 big, 2 huge, 4 giant), longest first:
-  // [giant | huge | big]
-  const unsigned n_giant = (lists & 4) ? static_cast<unsigned>(s.counters[CNT_NGIANT]) : 0u;
-  const unsigned n_huge = n_giant + ((lists & 2) ? static_cast<unsigned>(s.counters[CNT_NHUGE]) : 0u);
-  const unsigned n_items = (n_huge + ((lists & 1) ? static_cast<unsigned>(s.counters[CNT_NBIG]) : 0u)) * per_feat;
-  for (unsigned item = wave; item < n_items; item += n_waves) {
-    const unsigned li = item / per_feat;
-    const int ci = static_cast<int>(item - li * per_feat);
-    const int u = wave_uniform(li < n_giant ? s.giant[li] : li < n_huge ? s.huge[li - n_giant] : s.big[li - n_huge]);
-    const int4 ud = s.udesc[u];  // {feature, start, count, field}
-    const int fa = wave_uniform(ud.w);
-    const int i = wave_uniform(ud.x);
-    const int start = wave_uniform(ud.y);
-    const int t_lo = 0, c = wave_uniform(ud.z);  // the feature's occurrences [t_lo, c)
-    const int sb = K <= 64 ? ci * SPC : ci / cps;                    // first slot of the chunk
-    const int kk0 = K <= 64 ? 0 : (ci - sb * cps) * 64;              // first factor (k > 64)
-    const int width = K <= 64 ? SPC * K : min(64, K - kk0);          // elements of the chunk
-    const int fp0 = wave_uniform(walk_field(m, fa, sb));
-    if (fp0 < 0) continue;  // (valid walk positions are a prefix: nothing stored from here on)
-    // ---- fold layout: lane = element of the chunk (idle lanes repeat the first four) ----
-    const bool inw = lane < width;
-    const int le = inw ? lane : (lane & 3);
-    const int es = K <= 64 ? le / K : 0;
-    const int ekk = K <= 64 ? le - es * K : kk0 + le;
-    const int fp = sb + es < slots ? walk_field(m, fa, sb + es) : -1;
-    // (slots that one row touches twice are ffm_generic_body's: the row-order walk)
-    const bool active = inw && fp >= 0 && !((s.cmask[start] >> fp) & 1ull);
-    {  // no row of the block touches any slot of the chunk that is folded here
-      const unsigned long long gm = s.gmask[start];
-      if (!__any(active && ((gm >> fp) & 1ull))) continue;
-    }
-    // issue priority by length: a wave that shares its SIMD gets a fraction of the issue slots, and
-    // the longest folds bound the phase (FFM_TILE_PRIO=0: off)
-#ifndef FFM_TILE_PRIO
-#define FFM_TILE_PRIO 1
-#endif
-    if (FFM_TILE_PRIO) {
-      if (c > 640) __builtin_amdgcn_s_setprio(3);
-      else if (c > 192) __builtin_amdgcn_s_setprio(2);
-      else __builtin_amdgcn_s_setprio(0);
-    }
-    float *rec = lat_row(m, i, fa) + (fp >= 0 ? sb + es : sb) * K + ekk;
-    float n = rec[LAT_N * RL], z = rec[LAT_Z * RL];
-    const float w = rec[LAT_W * RL];
-    Fold acc;
-    acc.init(n);
-    // ---- stager layout: lane (touch tl, column cq) carries the facts of slots cq + 4 j ----
-    const int4 *acol[NF];
-    bool okS[NF];
+  const int c = t_hi;
+  // ---- stager layout: lane (touch tl, column cq) carries the facts of slots cq + 4 j ----
+  const int4 *acol[NF];
+  bool okS[NF];
+#pragma unroll
+  for (int j = 0; j < NF; j++) {
+    const int sj = cq + 4 * j;
+    const int f = (sj < g.SPC && ch.sb + sj < g.slots) ? walk_field(m, fa, ch.sb + sj) : -1;
+    okS[j] = f >= 0;
+    acol[j] = s.haux + static_cast<int64_t>(start) * F + (okS[j] ? f : ch.fp0);
+  }
+  const float2 *mcol = s.hmeta + start;
+  // ---- loader layout: lane (touch tl, column cq) fetches the quads 4 r + cq of the chunk ----
+  int sQ[4], kkQ[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int e4 = 4 * (4 * r + cq);
+    const bool inq = e4 < ch.width;
+    sQ[r] = inq && K <= 64 ? e4 / K : 0;
+    kkQ[r] = inq ? (K <= 64 ? e4 - sQ[r] * K : ch.kk0 + e4) : 0;
+  }
+  const int steps = (c - t_lo + kTileT - 1) / kTileT;
+  auto load_facts = [&](int st, TileFacts &f) {
+    const int t = min(t_lo + st * kTileT + tl, c - 1);  // past the end: repeats, staged as dead
+#pragma unroll
+    for (int j = 0; j < NF; j++) f.ax[j] = acol[j][static_cast<int64_t>(t) * F];
+    f.mt = mcol[t];
+  };
+  // facts of tile st -> LDS records (touches whose partner field holds several entries in the row
+  // -- HF_CHAIN -- only occur on serial slots, which are not folded here: staged dead)
+  auto stage_facts = [&](int st, const TileFacts &f) {
+    const bool in_range = t_lo + st * kTileT + tl < c;
+    float4 *Rb = R + (st & (kTileNR - 1)) * (kTileT * RS) + tl * RS;
 #pragma unroll
     for (int j = 0; j < NF; j++) {
       const int sj = cq + 4 * j;
-      const int f = (sj < SPC && sb + sj < slots) ? walk_field(m, fa, sb + sj) : -1;
-      okS[j] = f >= 0;
-      acol[j] = s.haux + static_cast<int64_t>(start) * F + (okS[j] ? f : fp0);
+      if (sj >= g.SPC) continue;
+      int fl = f.ax[j].y & 0xff;
+      if (!in_range || !okS[j]) fl = 0;
+      if (m.h.learn && (fl & HF_SIMPLE)) fl |= HF_FIRST;  // the variant uses g2*g2 at ffm.cpp:118
+      const float x = f.mt.y * __int_as_float(f.ax[j].x);
+      Rb[sj] = make_float4(f.mt.x, x, __int_as_float(tile_hiword(f.ax[j].w, fl)), __int_as_float(f.ax[j].z));
     }
-    const float2 *mcol = s.hmeta + start;
-    // ---- loader layout: lane (touch tl, column cq) fetches the quads 4 r + cq of the chunk ----
-    int sQ[4], kkQ[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int e4 = 4 * (4 * r + cq);
-      const bool inq = e4 < width;
-      sQ[r] = inq && K <= 64 ? e4 / K : 0;
-      kkQ[r] = inq ? (K <= 64 ? e4 - sQ[r] * K : kk0 + e4) : 0;
-    }
-    const int steps = (c - t_lo + kTileT - 1) / kTileT;
-    auto load_facts = [&](int st, TileFacts &f) {
-      const int t = min(t_lo + st * kTileT + tl, c - 1);  // past the end: repeats, staged as dead
-#pragma unroll
-      for (int j = 0; j < NF; j++) f.ax[j] = acol[j][static_cast<int64_t>(t) * F];
-      f.mt = mcol[t];
-    };
-    // facts of tile st -> LDS records (touches whose partner field holds several entries in the row
-    // -- HF_CHAIN -- only occur on serial slots, which are not folded here: staged dead)
-    auto stage_facts = [&](int st, const TileFacts &f) {
-      const bool in_range = t_lo + st * kTileT + tl < c;
-      float4 *Rb = R + (st & (kTileNR - 1)) * (kTileT * RS) + tl * RS;
-#pragma unroll
-      for (int j = 0; j < NF; j++) {
-        const int sj = cq + 4 * j;
-        if (sj >= SPC) continue;
-        int fl = f.ax[j].y & 0xff;
-        const int own_field = f.ax[j].y >> 8;
-        if (!in_range || !okS[j]) fl = 0;
-        if (m.h.learn && (fl & HF_SIMPLE)) fl |= HF_FIRST;  // the variant uses g2*g2 at ffm.cpp:118
-        const float x = f.mt.y * __int_as_float(f.ax[j].x);
-        Rb[sj] = make_float4(f.mt.x, x, __int_as_float(tile_hiword(f.ax[j].w, fl, own_field)),
-                             __int_as_float(f.ax[j].z));
-      }
-    };
-    // (named members, handed over by value: as arrays behind references these sixteen registers
-    // ended up in scratch memory, every load waited for at once)
-    auto issue_weight = [&](const float4 *Rb, int r) {
-      const float4 rc = Rb[sQ[r]];
-      const int64_t off = haux_offset(__float_as_int(rc.w), __float_as_int(rc.z) & 0xff);
-      return *reinterpret_cast<const float4 *>(m.lat + off + kkQ[r]);
-    };
-    auto issue_weights = [&](int st) {
-      const float4 *Rb = R + (st & (kTileNR - 1)) * (kTileT * RS) + tl * RS;
-      TileWeights v;
-      v.q0 = issue_weight(Rb, 0);
-      v.q1 = issue_weight(Rb, 1);
-      v.q2 = issue_weight(Rb, 2);
-      v.q3 = issue_weight(Rb, 3);
-      return v;
-    };
-
-    auto transpose = [&](const TileWeights &v) {
-      float4 *Tw = reinterpret_cast<float4 *>(T + tl * kTileRow + 4 * cq);
-      Tw[0] = v.q0;
-      Tw[4] = v.q1;
-      Tw[8] = v.q2;
-      Tw[12] = v.q3;
+  };
+  // (named members, handed over by value: as arrays behind references these sixteen registers
+  // ended up in scratch memory, every load waited for at once)
+  auto issue_weight = [&](const float4 *Rb, int r) {
+    const float4 rc = Rb[sQ[r]];
+    const int64_t off = haux_offset(__float_as_int(rc.w), __float_as_int(rc.z) & 0xff);
+    return *reinterpret_cast<const float4 *>(m.lat + off + kkQ[r]);
+  };
+  auto issue_weights = [&](int st) {
+    const float4 *Rb = R + (st & (kTileNR - 1)) * (kTileT * RS) + tl * RS;
+    TileWeights v;
+    v.q0 = issue_weight(Rb, 0);
+    v.q1 = issue_weight(Rb, 1);
+    v.q2 = issue_weight(Rb, 2);
+    v.q3 = issue_weight(Rb, 3);
+    return v;
+  };
+  auto transpose = [&](const TileWeights &v) {
+    float4 *Tw = reinterpret_cast<float4 *>(T + tl * kTileRow + 4 * cq);
+    Tw[0] = v.q0;
+    Tw[4] = v.q1;
+    Tw[8] = v.q2;
+    Tw[12] = v.q3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  };
+  auto apply_tile = [&](int st) {
+    apply(st, R + (st & (kTileNR - 1)) * (kTileT * RS) + ch.es, T + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  };
+  static_assert(kTileDV >= 1 && kTileDV <= 3 && kTileDV + 1 <= kTileNR, "weights of 1 .. 3 tiles in flight");
+  static_assert(kSeg % kTileT == 0 && kTileT % kTileG == 0, "segments are whole tiles, tiles whole groups");
+  TileFacts fN;
+  TileWeights V0, V1, V2;
+  {
+    TileFacts f0, f1, f2;
+    load_facts(0, f0);
+    if (kTileDV > 1 && steps > 1) load_facts(1, f1);
+    if (kTileDV > 2 && steps > 2) load_facts(2, f2);
+    if (steps > kTileDV) load_facts(kTileDV, fN);
+    stage_facts(0, f0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    V0 = issue_weights(0);
+    if (kTileDV > 1 && steps > 1) {
+      stage_facts(1, f1);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    };
-    // the fold of tile st (lane = element): kTileG touches per group, one range vote per group
-    auto apply_tile = [&](int st) {
-      if (st > 0 && (st * kTileT) % kSeg == 0) acc.flush();  // a segment of kSeg occurrences ends
-      const float4 *Rc = R + (st & (kTileNR - 1)) * (kTileT * RS) + es;
-      const float *Tc = T + lane;
-      const int cnt = min(kTileT, c - t_lo - st * kTileT);  // live touches of this tile
-      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
-        float tg[kTileG], x[kTileG], vp[kTileG];
-        bool live[kTileG], first[kTileG];
-#pragma unroll
-        for (int j = 0; j < kTileG; j++) {  // (records past the end of the feature are staged dead)
-          const float4 rc = Rc[(g0 + j) * RS];
-          const int hw = __float_as_int(rc.z);
-          tg[j] = rc.x;
-          x[j] = rc.y;
-          live[j] = active && (hw & (HF_SIMPLE << 8)) != 0;
-          first[j] = (hw & (HF_FIRST << 8)) != 0;
-          vp[j] = Tc[(g0 + j) * kTileRow];
-        }
-        fold_ffm_group<kTileG>(m.h, acc, w, live, first, tg, x, vp);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    };
-    {
-      static_assert(kTileDV >= 1 && kTileDV <= 3 && kTileDV + 1 <= kTileNR, "weights of 1 .. 3 tiles in flight");
-      static_assert(kSeg % kTileT == 0 && kTileT % kTileG == 0, "segments are whole tiles, tiles whole groups");
-      TileFacts fN;
-      TileWeights V0, V1, V2;
-      {
-        TileFacts f0, f1, f2;
-        load_facts(0, f0);
-        if (kTileDV > 1 && steps > 1) load_facts(1, f1);
-        if (kTileDV > 2 && steps > 2) load_facts(2, f2);
-        if (steps > kTileDV) load_facts(kTileDV, fN);
-        stage_facts(0, f0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        V0 = issue_weights(0);
-        if (kTileDV > 1 && steps > 1) {
-          stage_facts(1, f1);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          V1 = issue_weights(1);
-        }
-        if (kTileDV > 2 && steps > 2) {
-          stage_facts(2, f2);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          V2 = issue_weights(2);
-        }
-      }
-#define FTRL_TILE_STEP(ST, V)                                                      \
-      if ((ST) < steps) {                                                          \
-        transpose(V);                                                              \
-        const bool more__ = (ST) + kTileDV < steps;                                \
-        if (more__) {                                                              \
-          stage_facts((ST) + kTileDV, fN);                                         \
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   \
-        }                                                                          \
-        if ((ST) + kTileDV + 1 < steps) load_facts((ST) + kTileDV + 1, fN);        \
-        if (more__) V = issue_weights((ST) + kTileDV);                             \
-        apply_tile(ST);                                                            \
-      }
-      for (int st = 0; st < steps; st += kTileDV) {
-        FTRL_TILE_STEP(st, V0)
-        if (kTileDV > 1) { FTRL_TILE_STEP(st + 1, V1) }
-        if (kTileDV > 2) { FTRL_TILE_STEP(st + 2, V2) }
-      }
-#undef FTRL_TILE_STEP
+      V1 = issue_weights(1);
     }
-    const bool touched = fold_finish_latent(m.h, acc, w, n, z);
-    if (touched && active) {
-      rec[LAT_N * RL] = n;
-      rec[LAT_Z * RL] = z;
+    if (kTileDV > 2 && steps > 2) {
+      stage_facts(2, f2);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      V2 = issue_weights(2);
     }
   }
-  if (FFM_TILE_PRIO) __builtin_amdgcn_s_setprio(0);
+#define FTRL_TILE_STEP(ST, V)                                                    \
+  if ((ST) < steps) {                                                            \
+    transpose(V);                                                                \
+    const bool more__ = (ST) + kTileDV < steps;                                  \
+    if (more__) {                                                                \
+      stage_facts((ST) + kTileDV, fN);                                           \
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                     \
+    }                                                                            \
+    if ((ST) + kTileDV + 1 < steps) load_facts((ST) + kTileDV + 1, fN);          \
+    if (more__) V = issue_weights((ST) + kTileDV);                               \
+    apply_tile(ST);                                                              \
+  }
+  for (int st = 0; st < steps; st += kTileDV) {
+    FTRL_TILE_STEP(st, V0)
+    if (kTileDV > 1) { FTRL_TILE_STEP(st + 1, V1) }
+    if (kTileDV > 2) { FTRL_TILE_STEP(st + 2, V2) }
+  }
+#undef FTRL_TILE_STEP
 }
 
-// The whole FFM update of a block in ONE launch on the main stream.  Workgroup ranges:
-//   [bias fold + linear update | hot features (giant, huge, big lists: tiles) | few-occurrence
-//    features | serial slots (the row-order walk) | loss sum]
+// The touches of one tile as the fold sees them (lane = element): kTileG at a time.
+#define FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)                                         \
+  float tg[kTileG], x[kTileG], vp[kTileG];                                               \
+  bool live[kTileG], first[kTileG];                                                      \
+  _Pragma("unroll") for (int j = 0; j < kTileG; j++) {                                   \
+    const float4 rc = (Rc)[((g0) + j) * RS]; /* (records past the end are staged dead) */ \
+    const int hw = __float_as_int(rc.z);                                                 \
+    tg[j] = rc.x;                                                                        \
+    x[j] = rc.y;                                                                         \
+    live[j] = (active) && hw < 0;                                                        \
+    first[j] = (active) && static_cast<unsigned>(hw) >= 0xC0000000u;                     \
+    vp[j] = (Tc)[((g0) + j) * kTileRow];                                                 \
+  }
+
+// Where a giant feature's partial sums live: element e of segment slot `seg`.
+__device__ __forceinline__ int64_t seg_elem(const TileGeom &g, int seg, int e) {
+  return static_cast<int64_t>(seg) * g.RL + e;
+}
+__device__ __forceinline__ unsigned long long *seg_flags(const Scratch &s, const TileGeom &g, int seg, int ci) {
+  return s.segF + (static_cast<int64_t>(seg) * g.per_feat + ci) * 3;
+}
+
+// ---- hot features with at most kRange occurrences: one wave folds (feature, chunk) whole ----------
+template <int NF>
+__device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Scratch &s, unsigned wave, unsigned n_waves,
+                                               float *T, float4 *R) {
+  constexpr int RS = 4 * NF;
+  const TileGeom g = tile_geom(m);
+  // longest first: [huge | big]
+  const unsigned n_huge = static_cast<unsigned>(s.counters[CNT_NHUGE]);
+  const unsigned n_items = (n_huge + static_cast<unsigned>(s.counters[CNT_NBIG])) * g.per_feat;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned li = item / g.per_feat;
+    const int ci = static_cast<int>(item - li * g.per_feat);
+    const int u = wave_uniform(li < n_huge ? s.huge[li] : s.big[li - n_huge]);
+    const int4 ud = s.udesc[u];  // {feature, start, count, field}
+    const int fa = wave_uniform(ud.w), i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    const TileChunk ch = tile_chunk(m, g, fa, ci);
+    if (ch.fp0 < 0) continue;
+    // (slots that one row touches twice are ffm_generic_body's: the row-order walk)
+    const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
+    // no row of the block touches any slot of the chunk that is folded here
+    if (!__any(active && ((s.gmask[start] >> ch.fp) & 1ull))) continue;
+    float *rec = lat_row(m, i, fa) + (ch.fp >= 0 ? ch.sb + ch.es : ch.sb) * g.K + ch.ekk;
+    float n = rec[LAT_N * g.RL], z = rec[LAT_Z * g.RL];
+    const float w = rec[LAT_W * g.RL];
+    Fold acc;
+    acc.init(n);
+    tile_stream<NF>(m, s, g, ch, fa, start, 0, c, T, R, [&](int st, const float4 *Rc, const float *Tc) {
+      if (st > 0 && (st * kTileT) % kSeg == 0) acc.flush();  // a segment of kSeg occurrences ends
+      const int cnt = min(kTileT, c - st * kTileT);
+      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+        FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
+        fold_ffm_group<kTileG>(acc, w, live, first, tg, x, vp);
+      }
+    });
+    if (fold_finish_latent(m.h, acc, w, n, z) && active) {
+      rec[LAT_N * g.RL] = n;
+      rec[LAT_Z * g.RL] = z;
+    }
+  }
+}
+
+// ---- giant features (more than kRange occurrences): ranges of kRange occurrences side by side -----
+// Pass A, work item = (range, chunk): per segment of the range the sums of g and g*g from -0.0f and
+// three lane masks (live touch seen / first live touch plain / :118 touch seen) -> s.segP / segG / segF.
+template <int NF>
+__device__ __forceinline__ void ffm_range_items_a(const ModelDev &m, const Scratch &s, unsigned wave,
+                                                  unsigned n_waves, float *T, float4 *R) {
+  constexpr int RS = 4 * NF;
+  const TileGeom g = tile_geom(m);
+  const int lane = threadIdx.x & 63;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NRANGE]) * g.per_feat;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned ri = item / g.per_feat;
+    const int ci = static_cast<int>(item - ri * g.per_feat);
+    const int2 gr = s.grange[ri];  // {index into giant, range number}
+    const int gi = wave_uniform(gr.x), r = wave_uniform(gr.y);
+    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
+    const int fa = wave_uniform(ud.w), start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    const int seg0 = wave_uniform(s.gseg[gi]) + r * kRangeSegs;
+    const TileChunk ch = tile_chunk(m, g, fa, ci);
+    if (ch.fp0 < 0) continue;
+    const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
+    const int t_lo = r * kRange, t_hi = min(c, t_lo + kRange);
+    const bool has = ch.inw && ch.sb + ch.es < g.slots;          // this lane is an element of the stored record
+    const int e = has ? (ch.sb + ch.es) * g.K + ch.ekk : 0;
+    const int steps = (t_hi - t_lo + kTileT - 1) / kTileT;
+    if (!__any(active && ((s.gmask[start] >> ch.fp) & 1ull))) {
+      // untouched chunk: the joins still read its segments' masks
+      for (int sg = 0; sg * (kSeg / kTileT) < steps; sg++)
+        if (lane < 3) seg_flags(s, g, seg0 + sg, ci)[lane] = 0ull;
+      continue;
+    }
+    float P = -0.0f, G = -0.0f;
+    bool any = false, hp = false, q = false;
+    tile_stream<NF>(m, s, g, ch, fa, start, t_lo, t_hi, T, R, [&](int st, const float4 *Rc, const float *Tc) {
+      const int cnt = min(kTileT, t_hi - t_lo - st * kTileT);
+      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+        FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
+#pragma unroll
+        for (int j = 0; j < kTileG; j++) {
+          const float gj = tg[j] * vp[j] * x[j];
+          G = live[j] ? G + gj : G;
+          P = live[j] ? P + gj * gj : P;
+          if (!any) hp = first[j];
+          any = any || live[j];
+          q = q || (live[j] && !first[j]);
+        }
+      }
+      if ((st + 1) % (kSeg / kTileT) == 0 || st == steps - 1) {  // the segment ends
+        const int seg = seg0 + st / (kSeg / kTileT);
+        if (has) {
+          s.segP[seg_elem(g, seg, e)] = P;
+          s.segG[seg_elem(g, seg, e)] = G;
+        }
+        const unsigned long long ma = __ballot(any), mh = __ballot(any && hp), mq = __ballot(q);
+        if (lane == 0) {
+          unsigned long long *fl = seg_flags(s, g, seg, ci);
+          fl[0] = ma; fl[1] = mh; fl[2] = mq;
+        }
+        P = G = -0.0f;
+        any = hp = q = false;
+      }
+    });
+  }
+}
+
+// Pass B, same work items, only where the chunk has an element with a :118 touch: n at the start of
+// the range from the segment sums before it (joined left to right), then the range's touches again
+// for their root differences -> s.segD per segment; the n_t at an element's first :118 touch -> s.gcap.
+template <int NF>
+__device__ __forceinline__ void ffm_range_items_b(const ModelDev &m, const Scratch &s, unsigned wave,
+                                                  unsigned n_waves, float *T, float4 *R) {
+  constexpr int RS = 4 * NF;
+  const TileGeom g = tile_geom(m);
+  const int lane = threadIdx.x & 63;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NRANGE]) * g.per_feat;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned ri = item / g.per_feat;
+    const int ci = static_cast<int>(item - ri * g.per_feat);
+    const int2 gr = s.grange[ri];
+    const int gi = wave_uniform(gr.x), r = wave_uniform(gr.y);
+    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
+    const int fa = wave_uniform(ud.w), i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    const int segb = wave_uniform(s.gseg[gi]), n_seg = (c + kSeg - 1) / kSeg;
+    const TileChunk ch = tile_chunk(m, g, fa, ci);
+    if (ch.fp0 < 0) continue;
+    // which lanes meet a :118 touch anywhere in the feature / before this range
+    unsigned long long q_all = 0ull, q_before = 0ull;
+    for (int sg = 0; sg < n_seg; sg++) {
+      const unsigned long long mq = seg_flags(s, g, segb + sg, ci)[2];
+      q_all |= mq;
+      if (sg < r * kRangeSegs) q_before |= mq;
+    }
+    if (q_all == 0ull) continue;  // every touch of the chunk is plain: the join telescopes
+    const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
+    const bool has = ch.inw && ch.sb + ch.es < g.slots;
+    const int e = has ? (ch.sb + ch.es) * g.K + ch.ekk : 0;
+    const int t_lo = r * kRange, t_hi = min(c, t_lo + kRange);
+    const int steps = (t_hi - t_lo + kTileT - 1) / kTileT;
+    const float *rec = lat_row(m, i, fa) + (ch.fp >= 0 ? ch.sb + ch.es : ch.sb) * g.K + ch.ekk;
+    const float w = rec[LAT_W * g.RL];
+    Fold acc;
+    acc.init(rec[LAT_N * g.RL]);
+    for (int sg = 0; sg < r * kRangeSegs; sg++) {  // B at the start of the range
+      acc.P = s.segP[seg_elem(g, segb + sg, e)];
+      acc.B = acc.B + acc.P;
+    }
+    acc.P = -0.0f;
+    const bool seen_before = (q_before >> lane) & 1ull;
+    acc.seen = seen_before;
+    tile_stream<NF>(m, s, g, ch, fa, start, t_lo, t_hi, T, R, [&](int st, const float4 *Rc, const float *Tc) {
+      const int cnt = min(kTileT, t_hi - t_lo - st * kTileT);
+      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+        FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
+        fold_ffm_group<kTileG>(acc, w, live, first, tg, x, vp);
+      }
+      if ((st + 1) % (kSeg / kTileT) == 0 || st == steps - 1) {  // the segment ends
+        const int seg = segb + r * kRangeSegs + st / (kSeg / kTileT);
+        if (has) s.segD[seg_elem(g, seg, e)] = acc.D;
+        acc.flush();
+      }
+    });
+    if (has && acc.seen && !seen_before) s.gcap[static_cast<int64_t>(gi) * g.RL + e] = acc.ncap;
+  }
+}
+
+// The join, work item = (giant feature, chunk), lane = element: the segments' sums left to right,
+// then the accumulator's (n_T, z_T) as for any other fold.
+__device__ __forceinline__ void ffm_range_join(const ModelDev &m, const Scratch &s, unsigned wave, unsigned n_waves) {
+  const TileGeom g = tile_geom(m);
+  const int lane = threadIdx.x & 63;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NGIANT]) * g.per_feat;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned gi = item / g.per_feat;
+    const int ci = static_cast<int>(item - gi * g.per_feat);
+    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
+    const int fa = wave_uniform(ud.w), i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    const int segb = wave_uniform(s.gseg[gi]), n_seg = (c + kSeg - 1) / kSeg;
+    const TileChunk ch = tile_chunk(m, g, fa, ci);
+    if (ch.fp0 < 0) continue;
+    const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
+    if (!__any(active && ((s.gmask[start] >> ch.fp) & 1ull))) continue;
+    const int e = ch.inw && ch.sb + ch.es < g.slots ? (ch.sb + ch.es) * g.K + ch.ekk : 0;
+    unsigned long long q_all = 0ull;
+    for (int sg = 0; sg < n_seg; sg++) q_all |= seg_flags(s, g, segb + sg, ci)[2];
+    float *rec = lat_row(m, i, fa) + (ch.fp >= 0 ? ch.sb + ch.es : ch.sb) * g.K + ch.ekk;
+    float n = rec[LAT_N * g.RL], z = rec[LAT_Z * g.RL];
+    const float w = rec[LAT_W * g.RL];
+    Fold acc;
+    acc.init(n);
+    for (int sg = 0; sg < n_seg; sg++) {
+      const unsigned long long *fl = seg_flags(s, g, segb + sg, ci);
+      const bool any_s = (fl[0] >> lane) & 1ull, hp_s = (fl[1] >> lane) & 1ull;
+      acc.P = s.segP[seg_elem(g, segb + sg, e)];
+      acc.G = s.segG[seg_elem(g, segb + sg, e)];
+      acc.D = q_all ? s.segD[seg_elem(g, segb + sg, e)] : -0.0f;
+      if (!acc.any) acc.head_plain = hp_s;
+      acc.any = acc.any || any_s;
+      acc.flush();
+    }
+    acc.seen = (q_all >> lane) & 1ull;
+    acc.ncap = acc.seen ? s.gcap[static_cast<int64_t>(gi) * g.RL + e] : 0.0f;
+    if (fold_finish_latent(m.h, acc, w, n, z) && active) {
+      rec[LAT_N * g.RL] = n;
+      rec[LAT_Z * g.RL] = z;
+    }
+  }
+}
+#undef FTRL_TILE_READ_GROUP
+
+// The whole FFM update of a block: ONE launch on the main stream, plus two short ones when the
+// block has giant features.  Workgroup ranges of the first:
+//   [bias fold + linear update | giant features' ranges, pass A | hot features (huge, big lists) |
+//    few-occurrence features | serial slots (the row-order walk) | loss sum]
 // There are no long dependent chains left in the phase, so nothing needs a stream (and a hardware
 // queue hop, ~44 us for a fork + join) of its own.
-// ns_flat: the few-occurrence range runs over a flat (feature, vector) space instead (compact shards).
 template <int NF>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
                                                                      int side_blocks, int nt, int ns, int few_only,
@@ -292,7 +493,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_all_kernel(ModelDev m,
   r -= side_blocks;
   if (r < nt) {
     const unsigned wv = wave_uniform(threadIdx.x >> 6);
-    ffm_tile_items<NF>(m, rows, s, r * kUpdWaves + wv, nt * kUpdWaves, 7, lds_T[wv], lds_R[wv]);
+    ffm_range_items_a<NF>(m, s, r * kUpdWaves + wv, nt * kUpdWaves, lds_T[wv], lds_R[wv]);
+    ffm_tile_items<NF>(m, s, r * kUpdWaves + wv, nt * kUpdWaves, lds_T[wv], lds_R[wv]);
     return;
   }
   r -= nt;
@@ -300,6 +502,18 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_all_kernel(ModelDev m,
   r -= ns;
   if (r < nw) { ffm_generic_body(m, rows, s, 1, r, nw); return; }
   loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - nw, loss_blocks);
+}
+// The giant features' pass B and their join (launched after ffm_update_all_kernel; both return at
+// once when the block has none).
+template <int NF>
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_giant_b_kernel(ModelDev m, Scratch s) {
+  __shared__ __attribute__((aligned(16))) float lds_T[kUpdWaves][kTileT * kTileRow];
+  __shared__ float4 lds_R[kUpdWaves][kTileNR * kTileT * 4 * NF];
+  const unsigned wv = wave_uniform(threadIdx.x >> 6);
+  ffm_range_items_b<NF>(m, s, blockIdx.x * kUpdWaves + wv, gridDim.x * kUpdWaves, lds_T[wv], lds_R[wv]);
+}
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_giant_join_kernel(ModelDev m, Scratch s) {
+  ffm_range_join(m, s, blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6), gridDim.x * kUpdWaves);
 }
 
 }  // namespace ftrl_dev

@@ -239,71 +239,103 @@ __global__ __launch_bounds__(kUpdThreads) void bias_update_kernel(ModelDev m, in
 //    them twice -- a multi-valued partner field, a repeated id; without field masks, n_fields > 64:
 //    every slot) of the features with two or more occurrences, walked in row order on the running
 //    (n, z) like the reference's one-thread loop (ffm.cpp:104-120).
+// (one element e of the stored record of the feature described by ud = {feature, start, count, field};
+// cm = its serial slots)
+__device__ __forceinline__ void ffm_generic_element(const ModelDev &m, const Rows &rows, const Scratch &s,
+                                                    int4 ud, unsigned long long cm, int e, int serial_only) {
+  const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
+  if (e >= RL) return;
+  const int start = ud.y, c = ud.z, fa = ud.w;
+  const int sl = e / k, kk = e - sl * k;
+  const int fp = walk_field(m, fa, sl);
+  if (fp < 0) return;
+  const bool serial = !s.cmask || ((cm >> fp) & 1ull);
+  if (serial_only && !serial) return;
+  const int i = ud.x;
+  float *rec = lat_row(m, i, fa);
+  float n = rec[LAT_N * RL + e], z = rec[LAT_Z * RL + e];
+  const float w = rec[LAT_W * RL + e];
+  bool touched = false;
+  if (serial) {
+    for (int t = 0; t < c; t++) {
+      const int2 pr = s.occ2[start + t];
+      const int p = pr.x, r = pr.y;
+      const int fm = rows.field[p];
+      if (!owns_pair(m, fm, fp)) continue;
+      const float tg = s.tg[r], xm = rows.val[p];
+      for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
+        if (qq == p) continue;
+        const float vp = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk];
+        ffm_touch(m.h, p < qq, tg, xm, rows.val[qq], vp, w, n, z);
+        touched = true;
+      }
+    }
+  } else {
+    Fold a;
+    a.init(n);
+    for (int t = 0; t < c; t++) {
+      if (t > 0 && t % kSeg == 0) a.flush();
+      const int2 pr = s.occ2[start + t];
+      const int p = pr.x, r = pr.y;
+      const int fm = rows.field[p];
+      if (!owns_pair(m, fm, fp)) continue;
+      const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
+      const int q = rt.z;  // the field's only entry in the row (the slot is not serial), or none
+      if (q < 0 || q == p) continue;
+      const bool live[1] = {true}, first[1] = {p < q || m.h.learn != 0};
+      const float tgv[1] = {s.tg[r]}, xv[1] = {rows.val[p] * __int_as_float(rt.y)};
+      const float vp[1] = {m.lat[w_slot_offset(m, rt.x, fp, fm) + kk]};
+      fold_ffm_group<1>(a, w, live, first, tgv, xv, vp);
+    }
+    touched = fold_finish_latent(m.h, a, w, n, z);
+  }
+  if (touched) {
+    rec[LAT_N * RL + e] = n;
+    rec[LAT_Z * RL + e] = z;
+  }
+}
 __device__ __forceinline__ void ffm_generic_body(const ModelDev &m, const Rows &rows, const Scratch &s,
                                                  int serial_only, unsigned bidx, unsigned gdim) {
-  const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
-  const unsigned chunks = (RL + 63) / 64;
+  const unsigned chunks = (m.row_len + 63) / 64;
   const int lane = threadIdx.x & 63;
   const unsigned wave = bidx * kUpdWaves + wave_uniform(threadIdx.x >> 6);
   const unsigned n_waves = gdim * kUpdWaves;
+  if (serial_only) {
+    // one lane per feature of the few / big / huge / giant lists looks at its serial slots; the wave
+    // then walks the (rare) features that have any, one after another
+    const int n_few = s.counters[CNT_NFEW], n_big = n_few + s.counters[CNT_NBIG];
+    const int n_huge = n_big + s.counters[CNT_NHUGE], n_multi = n_huge + s.counters[CNT_NGIANT];
+    for (int base = wave * 64; base < n_multi; base += n_waves * 64) {
+      const int li = base + lane;
+      int4 ud = make_int4(0, 0, 0, 0);
+      unsigned long long cm = 0ull;
+      if (li < n_multi) {
+        const int u = li < n_few ? s.few[li] : li < n_big ? s.big[li - n_few]
+                      : li < n_huge ? s.huge[li - n_big] : s.giant[li - n_huge];
+        ud = s.udesc[u];
+        cm = s.cmask ? s.cmask[ud.y] : ~0ull;
+      }
+      unsigned long long todo = __ballot(cm != 0ull);
+      while (todo) {
+        const int l = __ffsll(static_cast<long long>(todo)) - 1;
+        todo &= todo - 1ull;
+        const int4 d = make_int4(__builtin_amdgcn_readlane(ud.x, l), __builtin_amdgcn_readlane(ud.y, l),
+                                 __builtin_amdgcn_readlane(ud.z, l), __builtin_amdgcn_readlane(ud.w, l));
+        const unsigned long long cml =
+            (static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(cm >> 32), l))) << 32) |
+            static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(cm & 0xffffffffull), l));
+        for (unsigned ci = 0; ci < chunks; ci++)
+          ffm_generic_element(m, rows, s, d, cml, static_cast<int>(ci) * 64 + lane, 1);
+      }
+    }
+    return;
+  }
   const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NUNIQ]) * chunks;
   for (unsigned item = wave; item < n_items; item += n_waves) {
     const unsigned u = item / chunks;
-    const int e = static_cast<int>(item - u * chunks) * 64 + lane;
     const int4 ud = s.udesc[u];
-    const int start = ud.y, c = ud.z;
-    if (serial_only && c < 2) continue;  // (the once-only features' owners walk their own chains)
-    const unsigned long long cm = s.cmask ? s.cmask[start] : ~0ull;
-    if (serial_only && cm == 0ull) continue;
-    if (e >= RL) continue;
-    const int fa = ud.w;
-    const int sl = e / k, kk = e - sl * k;
-    const int fp = walk_field(m, fa, sl);
-    if (fp < 0) continue;
-    const bool serial = !s.cmask || ((cm >> fp) & 1ull);
-    if (serial_only && !serial) continue;
-    const int i = ud.x;
-    float *rec = lat_row(m, i, fa);
-    float n = rec[LAT_N * RL + e], z = rec[LAT_Z * RL + e];
-    const float w = rec[LAT_W * RL + e];
-    bool touched = false;
-    if (serial) {
-      for (int t = 0; t < c; t++) {
-        const int2 pr = s.occ2[start + t];
-        const int p = pr.x, r = pr.y;
-        const int fm = rows.field[p];
-        if (!owns_pair(m, fm, fp)) continue;
-        const float tg = s.tg[r], xm = rows.val[p];
-        for (int qq = s.head[static_cast<int64_t>(r) * F + fp]; qq >= 0; qq = s.next[qq]) {
-          if (qq == p) continue;
-          const float vp = m.lat[w_slot_offset(m, rows.feat[qq], fp, fm) + kk];
-          ffm_touch(m.h, p < qq, tg, xm, rows.val[qq], vp, w, n, z);
-          touched = true;
-        }
-      }
-    } else {
-      Fold a;
-      a.init(n);
-      for (int t = 0; t < c; t++) {
-        if (t > 0 && t % kSeg == 0) a.flush();
-        const int2 pr = s.occ2[start + t];
-        const int p = pr.x, r = pr.y;
-        const int fm = rows.field[p];
-        if (!owns_pair(m, fm, fp)) continue;
-        const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
-        const int q = rt.z;  // the field's only entry in the row (the slot is not serial), or none
-        if (q < 0 || q == p) continue;
-        const bool live[1] = {true}, first[1] = {p < q || m.h.learn != 0};
-        const float tgv[1] = {s.tg[r]}, xv[1] = {rows.val[p] * __int_as_float(rt.y)};
-        const float vp[1] = {m.lat[w_slot_offset(m, rt.x, fp, fm) + kk]};
-        fold_ffm_group<1>(m.h, a, w, live, first, tgv, xv, vp);
-      }
-      touched = fold_finish_latent(m.h, a, w, n, z);
-    }
-    if (touched) {
-      rec[LAT_N * RL + e] = n;
-      rec[LAT_Z * RL + e] = z;
-    }
+    const unsigned long long cm = s.cmask ? s.cmask[ud.y] : ~0ull;
+    ffm_generic_element(m, rows, s, ud, cm, static_cast<int>(item - u * chunks) * 64 + lane, 0);
   }
 }
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDev m, Rows rows,
@@ -408,7 +440,7 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
           const int p = tp[j], q = rt[jj].z;
           const bool live = q >= 0 && q != p;  // (q == -2, several entries, only on serial slots)
           const float vp[4] = {vp4[jj].x, vp4[jj].y, vp4[jj].z, vp4[jj].w};
-          a.touch(m.h, n, w, live, p < q || m.h.learn != 0, ttg[j], txm[j] * __int_as_float(rt[jj].y), vp);
+          a.touch(n, w, live, p < q || m.h.learn != 0, ttg[j], txm[j] * __int_as_float(rt[jj].y), vp);
         }
       }
       if (a.finish(m.h, w, n, z) && mine) {
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_flat_kernel(Mode
           }
         }
       }
-      a.touch(m.h, n, w, live, first, tg, x, vp);
+      a.touch(n, w, live, first, tg, x, vp);
     }
     if (a.finish(m.h, w, n, z) && mine) {
       rec4[LAT_N * RL4 + l] = make_float4(n[0], n[1], n[2], n[3]);

@@ -472,10 +472,11 @@ double fo_train_batch_rowwalk(fo_model *m, int n_rows, const int32_t *row_ptr, c
  *   - every touch "plain" (the square root sees n + g*g: linear, bias, FM, the FFM pair's first
  *     slot): the sigmas telescope, sum sigma_t = (sqrtf(n_T) - sqrtf(n_0)) / alpha  
  *   - from the first touch t0 of the ffm.cpp:118 kind (the square root sees n + g2*g1) on, every
- *     touch contributes its own m_t = ((sqrtf(n_t + q_t) - sqrtf(n_t)) / alpha) * w, summed per
- *     segment then over the segments; the plain touches before t0 telescope to
- *     H = ((sqrtf(n_t0) - sqrtf(n_0)) / alpha) * w
- *   latent:        z_T = (z_0 + G) - M          (ffm.cpp:114/:119, fm.cpp:93: z + g - sigma*w)
+ *     touch contributes its own difference of roots d_t = sqrtf(n_t + q_t) - sqrtf(n_t), summed
+ *     per segment then over the segments (D); the plain touches before t0 telescope to
+ *     sqrtf(n_t0) - sqrtf(n_0); the step sizes' sum is (that + D) / alpha -- ONE divide
+ *   latent:        z_T = (z_0 + G) - ((sum of root differences) / alpha) * w
+ *                                               (ffm.cpp:114/:119, fm.cpp:93: z + g - sigma*w)
  *   linear / bias: z_T = z_0 + (G - sigma*w)    (ftrl_model.cpp:72/:83: z += g - sigma*w)
  * One touch evaluates the reference's expression literally, so n_rows == 1 is fo_train bit for bit
  * -- as long as no accumulator is touched twice by one row.  Where a row does that (a field with
@@ -485,14 +486,14 @@ double fo_train_batch_rowwalk(fo_model *m, int n_rows, const int32_t *row_ptr, c
 #define FO_SEG 64
 
 typedef struct {
-  float P, G, M;          /* the running segment: sum g*g, sum g, sum m */
-  float B, Gacc, Macc;    /* the segments before it */
+  float P, G, D;          /* the running segment: sum g*g, sum g, sum of root differences */
+  float B, Gacc, Dacc;    /* the segments before it */
   float ncap;             /* n_t at the first :118 touch */
   int any, seen, head_plain;
 } fo_acc;
 
 static inline void acc_init(fo_acc *a, float n0) {
-  a->P = a->G = a->M = a->Gacc = a->Macc = -0.0f;
+  a->P = a->G = a->D = a->Gacc = a->Dacc = -0.0f;
   a->B = n0;
   a->ncap = 0.0f;
   a->any = a->seen = a->head_plain = 0;
@@ -500,8 +501,8 @@ static inline void acc_init(fo_acc *a, float n0) {
 static inline void acc_flush(fo_acc *a) {
   a->B = a->B + a->P;
   a->Gacc = a->Gacc + a->G;
-  a->Macc = a->Macc + a->M;
-  a->P = a->G = a->M = -0.0f;
+  a->Dacc = a->Dacc + a->D;
+  a->P = a->G = a->D = -0.0f;
 }
 /* before the touches of the feature's occurrence number `occ` (0-based): a new segment starts at
  * every multiple of FO_SEG (joining an empty segment adds -0.0f: nothing) */
@@ -509,14 +510,11 @@ static inline void acc_at(fo_acc *a, int occ) {
   if (occ > 0 && occ % FO_SEG == 0) acc_flush(a);
 }
 /* one touch: gradient g, what the square root adds to n (q), plain = (q is g*g by construction) */
-static inline void acc_touch(const fo_model *m, fo_acc *a, float w, float g, float q, int plain) {
+static inline void acc_touch(fo_acc *a, float g, float q, int plain) {
   const float nt = a->B + a->P;
   if (!a->any) { a->any = 1; a->head_plain = plain; }
   if (!plain && !a->seen) { a->seen = 1; a->ncap = nt; }
-  if (a->seen) {
-    const float mt = ((sqrtf(nt + q) - sqrtf(nt)) / m->w_alpha) * w;
-    a->M = a->M + mt;
-  }
+  if (a->seen) a->D = a->D + (sqrtf(nt + q) - sqrtf(nt));
   a->G = a->G + g;
   a->P = a->P + g * g;
 }
@@ -524,13 +522,13 @@ static inline void acc_finish_latent(const fo_model *m, fo_acc *a, float w, floa
   if (!a->any) return;
   const float n0 = *n;
   acc_flush(a);
-  float M = -0.0f;
+  float S = -0.0f;
   if (a->head_plain) {
     const float ncap = a->seen ? a->ncap : a->B;
-    M = M + ((sqrtf(ncap) - sqrtf(n0)) / m->w_alpha) * w;
+    S = S + (sqrtf(ncap) - sqrtf(n0));
   }
-  M = M + a->Macc;
-  *z = (*z + a->Gacc) - M;
+  S = S + a->Dacc;
+  *z = (*z + a->Gacc) - (S / m->w_alpha) * w;
   *n = a->B;
 }
 static inline void acc_finish_linear(const fo_model *m, fo_acc *a, float w, float *n, float *z) {
@@ -666,7 +664,7 @@ double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int
     acc_init(&a, m->bias3[1]);
     for (int r = 0; r < n_rows; r++) {
       acc_at(&a, r);
-      acc_touch(m, &a, m->bias3[0], tg[r], tg[r] * tg[r], 1);
+      acc_touch(&a, tg[r], tg[r] * tg[r], 1);
     }
     acc_finish_linear(m, &a, m->bias3[0], &m->bias3[1], &m->bias3[2]);
   }
@@ -699,7 +697,7 @@ double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int
         const int p = g.ent[t].p;
         const float gg = tg[g.row_of[p]] * val[p];
         acc_at(&a, t - lo);
-        acc_touch(m, &a, m->lin_w[i], gg, gg * gg, 1);
+        acc_touch(&a, gg, gg * gg, 1);
       }
       acc_finish_linear(m, &a, m->lin_w[i], &m->lin_n[i], &m->lin_z[i]);
     }
@@ -721,7 +719,7 @@ double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int
             const float x = val[p];
             const float gg = tg[r] * (x * svx[(size_t)r * k + f] - w * x * x);
             acc_at(&a, t - lo);
-            acc_touch(m, &a, w, gg, gg * gg, 1);
+            acc_touch(&a, gg, gg * gg, 1);
           }
           acc_finish_latent(m, &a, w, &m->vec_n[o], &m->vec_z[o]);
         }
@@ -745,10 +743,10 @@ double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int
             const float vp = m->vec_w[feat[q] * L + (int64_t)field[p] * k + f];
             const float gg = tg[r] * vp * x;
             if (p < q || m->learn) {
-              acc_touch(m, &a, w, gg, gg * gg, 1); /* ffm.cpp:112-115 */
+              acc_touch(&a, gg, gg * gg, 1); /* ffm.cpp:112-115 */
             } else {
               const float g1 = tg[r] * w * x;      /* the pair's first entry's gradient */
-              acc_touch(m, &a, w, gg, gg * g1, 0); /* ffm.cpp:117-120 incl. :118 */
+              acc_touch(&a, gg, gg * g1, 0); /* ffm.cpp:117-120 incl. :118 */
             }
           }
           acc_finish_latent(m, &a, w, &m->vec_n[o], &m->vec_z[o]);

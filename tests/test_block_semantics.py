@@ -139,7 +139,7 @@ NEG0 = f32(-0.0)
 
 class Acc:
     def __init__(self, n0, alpha):
-        self.P = self.G = self.M = self.Gacc = self.Macc = NEG0
+        self.P = self.G = self.D = self.Gacc = self.Dacc = NEG0
         self.B = f32(n0)
         self.n0 = f32(n0)
         self.alpha = f32(alpha)
@@ -149,8 +149,8 @@ class Acc:
     def flush(self):
         self.B = f32(self.B + self.P)
         self.Gacc = f32(self.Gacc + self.G)
-        self.Macc = f32(self.Macc + self.M)
-        self.P = self.G = self.M = NEG0
+        self.Dacc = f32(self.Dacc + self.D)
+        self.P = self.G = self.D = NEG0
 
     def at(self, occ):
         """Before the touches of the feature's occurrence number occ: segments are cut by occurrence."""
@@ -166,16 +166,17 @@ class Acc:
         if self.seen:
             with np.errstate(invalid="ignore"):
                 d = f32(np.sqrt(f32(nt + q)) - np.sqrt(nt))
-            self.M = f32(self.M + f32(f32(d / self.alpha) * w))
+            self.D = f32(self.D + d)
         self.G = f32(self.G + g)
         self.P = f32(self.P + f32(g * g))
 
     def sigma_w_total(self, w):
-        M = NEG0
+        S = NEG0
         if self.head_plain:
             ncap = self.ncap if self.seen else self.B
-            M = f32(M + f32(f32(f32(np.sqrt(ncap) - np.sqrt(self.n0)) / self.alpha) * w))
-        return f32(M + self.Macc)
+            S = f32(S + f32(np.sqrt(ncap) - np.sqrt(self.n0)))
+        S = f32(S + self.Dacc)
+        return f32(f32(S / self.alpha) * w)
 
     def finish_latent(self, w, z0):
         self.flush()

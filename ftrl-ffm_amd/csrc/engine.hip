@@ -356,7 +356,7 @@ struct ffm_engine {
   std::vector<int> field_start; // copy of cfg->field_start (compact shards)
   // workgroups of the update launch's ranges: few-occurrence features, hot tiles, the row-order walk
   // of serial slots; and of the once-only kernel of a shard
-  int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768, grid_giant = 1024;
+  int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768, grid_giant = 512;
   bool update_split = false;  // FFM_UPDATE_SPLIT=1: the update launch's ranges as launches of their own (timing aid)
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
@@ -617,6 +617,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_WALK")) e->grid_walk = std::max(1, std::atoi(sv));
+  if (const char *sv = std::getenv("FFM_GRID_GIANT")) e->grid_giant = std::max(1, std::atoi(sv));
   // (a sharded rank's row holds 1/n_shards of the pairs and facts, walked directly; 64-thread row
   // workgroups measured the same as 256)
   // a shard's row holds ~1/n_shards of the pairs: one wave per row, so that (with the small LDS
@@ -721,14 +722,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   {
     // partial sums of the giant features' folds (shared by the scratch sets)
     const size_t max_segs = E / kSeg + E / kGiantMin + 2, rl = static_cast<size_t>(std::max(1, m.row_len));
-    const size_t chunks = cfg->n_factors > 0 && cfg->n_factors <= 64
-                              ? (static_cast<size_t>(m.rec_slots) + 64 / cfg->n_factors - 1) / (64 / cfg->n_factors)
-                              : static_cast<size_t>(m.rec_slots) * ((cfg->n_factors + 63) / 64);
-    TRY_ALLOC(e->alloc(&s.segP, max_segs * rl));
-    TRY_ALLOC(e->alloc(&s.segG, max_segs * rl));
-    TRY_ALLOC(e->alloc(&s.segD, max_segs * rl));
-    TRY_ALLOC(e->alloc(&s.segF, max_segs * std::max<size_t>(1, chunks) * 3));
-    TRY_ALLOC(e->alloc(&s.gcap, (E / kGiantMin + 2) * rl));
+    const bool fm_model = cfg->model_type == FFM_MODEL_FM;
+    TRY_ALLOC(e->alloc(&s.segP, fm_model ? max_segs * rl : 1));
+    TRY_ALLOC(e->alloc(&s.segG, fm_model ? max_segs * rl : 1));
   }
   TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
   TRY_ALLOC(e->alloc(&e->d_err, 1));

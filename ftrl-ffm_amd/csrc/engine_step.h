@@ -266,35 +266,28 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     }
     if (flat) LAUNCH(e, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
     const int nt = e->grid_hot, ns = flat ? 0 : e->grid_small, nw = e->grid_walk, nf = tile_nf(e);
+    const int ng = rows.nnz >= kGiantMin ? e->grid_giant : 0;  // workgroups that fold giant features together
     const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
-    const int grid = side_blocks + nt + ns + nw + lb;
+    const int grid = side_blocks + ng + nt + ns + nw + lb;
 #define FTRL_LAUNCH_ALL(NF)                                                                                   \
     do {                                                                                                      \
       if (e->update_split) { /* (timing aid: one launch per range, each under a name of its own) */           \
+        LAUNCH(e, K_LATENT_UPDATE_GIANT, (ffm_update_all_kernel<NF>), ng, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
+               0, ng, 0, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                              \
         LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), side_blocks + nt, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-               side_blocks, nt, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                       \
+               side_blocks, 0, nt, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                    \
         LAUNCH(e, K_LATENT_UPDATE_FEW, (ffm_update_all_kernel<NF>), ns, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-               0, 0, ns, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                                 \
+               0, 0, 0, ns, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                              \
         LAUNCH(e, K_LATENT_UPDATE_WALK, (ffm_update_all_kernel<NF>), nw + lb, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-               0, 0, 0, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                                \
+               0, 0, 0, 0, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                             \
       } else {                                                                                                \
         LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-               side_blocks, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                    \
+               side_blocks, ng, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                \
       }                                                                                                       \
     } while (0)
     if (nf == 1) FTRL_LAUNCH_ALL(1);       // k >= 16
     else if (nf == 2) FTRL_LAUNCH_ALL(2);  // k = 8 / 12
     else FTRL_LAUNCH_ALL(4);               // k = 4
-    if (rows.nnz > kRange) {
-      // giant features: their ranges' second pass and the join of their segments
-      const int gg = e->grid_giant;
-      e->prof_begin(K_LATENT_UPDATE_GIANT, e->stream);
-      if (nf == 1) hipLaunchKernelGGL(ffm_update_giant_b_kernel<1>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
-      else if (nf == 2) hipLaunchKernelGGL(ffm_update_giant_b_kernel<2>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
-      else hipLaunchKernelGGL(ffm_update_giant_b_kernel<4>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
-      hipLaunchKernelGGL(ffm_update_giant_join_kernel, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
-      e->prof_end(e->stream);
-    }
 #undef FTRL_LAUNCH_ALL
     loss_done = loss_sum_out != nullptr;
   } else {

@@ -142,16 +142,14 @@ struct Scratch {
                   //      that occur once, which ffm_update_single_kernel owns)
   int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
   int *huge;      // [nnz] ... with more, below ModelDev::giant_min ("very hot": present in many rows)
-  int *giant;     // [nnz / kChainMin + 1] ... with giant_min or more: their occurrences are cut into
-                  //      RANGES of kRange that several waves fold side by side; per giant feature:
-  int *gseg;      // [nnz / kChainMin + 1] first of its segment slots in segP / segG / segD / segF
-  int2 *grange;   // [nnz / (kRange / 2) + 1] {index into giant, range number}: one entry per range
-  // partial sums of the giant features' folds, per segment and element of the stored record
-  // (shared by the scratch sets: one block's update ends before the next one's starts)
-  float *segP, *segG, *segD;    // [max_segs * row_len] sum g*g, sum g, sum of root differences
-  unsigned long long *segF;     // [max_segs * chunks * 3] per (segment, 64-element chunk): lanes with a
-                                //      live touch / whose first live touch is plain / with a :118 touch
-  float *gcap;                  // [(nnz / kChainMin + 1) * row_len] n_t at an element's first :118 touch
+  int *giant;     // [nnz / kChainMin + 1] ... with giant_min or more.  FFM: a workgroup folds one together
+                  //      (kernels_tile.h).  FM: their occurrences are cut into RANGES of kRange that
+                  //      waves all over the chip fold side by side (kernels_update.h); per giant feature:
+  int *gseg;      // [nnz / kChainMin + 1] first of its segment slots in segP / segG
+  int2 *grange;   // [nnz / kRange + nnz / giant_min + 2] {index into giant, range number}: one entry per range
+  // partial sums of the FM giants' folds, per segment and factor (shared by the scratch sets: one
+  // block's update ends before the next one's starts)
+  float *segP, *segG;  // [max_segs * row_len] sum g*g, sum g
   int *counters;  // [kNumCounters] CNT_* below
   int *err;       // [1] sticky ERR_* flags, shared by all sets: what ffm_engine_sync reports
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
@@ -190,7 +188,7 @@ enum { UF_DUP = 1 };
 // The block update folds the touches of an accumulator by reductions over SEGMENTS of kSeg
 // consecutive occurrences of its feature in the block (rows of the block for the bias), joined left
 // to right -- the tree the checker under oracle/ (FO_SEG) restates; see kernels_fold.h.
-constexpr int kSeg = 64;
+constexpr int kSeg = 16;
 
 // Every counter that takes atomics sits on a 64-byte line of its own (kLineInts apart):
 // device-scope atomics are performed at the memory side, one line at a time, and the grouping's
@@ -215,7 +213,7 @@ constexpr int kHugeMin = FFM_HUGE_MIN;
 // ... and from which one wave per (feature, 64 elements) would be the update phase's span: a
 // feature with more than kRange occurrences is "giant"
 #ifndef FFM_RANGE_SEGS
-#define FFM_RANGE_SEGS 4
+#define FFM_RANGE_SEGS 16
 #endif
 constexpr int kRangeSegs = FFM_RANGE_SEGS;
 constexpr int kRange = kRangeSegs * kSeg;  // occurrences per range of a giant feature

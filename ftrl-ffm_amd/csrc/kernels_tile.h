@@ -104,9 +104,10 @@ __device__ __forceinline__ TileChunk tile_chunk(const ModelDev &m, const TileGeo
   return c;
 }
 
-// Streams the touches [t_lo, t_hi) of one hot feature (its occurrences start at `start` in the
-// grouped order) for the chunk `ch` through the wave's LDS, tile by tile (see the header), and hands
-// every tile to apply(st, Rc, Tc): st = tile number from t_lo, Rc = the tile's fact records as this
+// Streams tiles of one hot feature's c occurrences (they start at `start` in the grouped order) for
+// the chunk `ch` through the wave's LDS (see the header): the tiles tile0, tile0 + tstride, ... --
+// `steps` of them; tile number T covers the occurrences [16 T, 16 T + 16), those at or beyond c are
+// staged dead -- and hands every tile to apply(st, Rc, Tc): st = 0 .. steps-1, Rc = the tile's fact records as this
 // lane's slot sees them (record of touch j at Rc[j * RS]: {tmp_grad, x_own * x_other, flags, ..}),
 // Tc = this lane's column of the transposer (partner weight of touch j at Tc[j * kTileRow]).
 // NF: facts a stager lane carries per tile = ceil(slots per chunk / 4): 1 for k >= 16, 2 for
@@ -114,13 +115,12 @@ __device__ __forceinline__ TileChunk tile_chunk(const ModelDev &m, const TileGeo
 // [kTileNR][kTileT * 4 * NF].
 template <int NF, typename Apply>
 __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s, const TileGeom &g,
-                                            const TileChunk &ch, int fa, int start, int t_lo, int t_hi,
-                                            float *T, float4 *R, Apply &&apply) {
+                                            const TileChunk &ch, int fa, int start, int tile0, int tstride,
+                                            int steps, int c, float *T, float4 *R, Apply &&apply) {
   constexpr int RS = 4 * NF;  // records per touch in R (>= slots per chunk)
   const int K = g.K, F = g.F;
   const int lane = threadIdx.x & 63;
   const int tl = lane >> 2, cq = lane & 3;  // stager / loader layout: touch, 16-byte quad column
-  const int c = t_hi;
   // ---- stager layout: lane (touch tl, column cq) carries the facts of slots cq + 4 j ----
   const int4 *acol[NF];
   bool okS[NF];
@@ -141,9 +141,8 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     sQ[r] = inq && K <= 64 ? e4 / K : 0;
     kkQ[r] = inq ? (K <= 64 ? e4 - sQ[r] * K : ch.kk0 + e4) : 0;
   }
-  const int steps = (c - t_lo + kTileT - 1) / kTileT;
   auto load_facts = [&](int st, TileFacts &f) {
-    const int t = min(t_lo + st * kTileT + tl, c - 1);  // past the end: repeats, staged as dead
+    const int t = min((tile0 + st * tstride) * kTileT + tl, c - 1);  // past the end: repeats, staged as dead
 #pragma unroll
     for (int j = 0; j < NF; j++) f.ax[j] = acol[j][static_cast<int64_t>(t) * F];
     f.mt = mcol[t];
@@ -151,7 +150,7 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
   // facts of tile st -> LDS records (touches whose partner field holds several entries in the row
   // -- HF_CHAIN -- only occur on serial slots, which are not folded here: staged dead)
   auto stage_facts = [&](int st, const TileFacts &f) {
-    const bool in_range = t_lo + st * kTileT + tl < c;
+    const bool in_range = (tile0 + st * tstride) * kTileT + tl < c;
     float4 *Rb = R + (st & (kTileNR - 1)) * (kTileT * RS) + tl * RS;
 #pragma unroll
     for (int j = 0; j < NF; j++) {
@@ -250,15 +249,7 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     vp[j] = (Tc)[((g0) + j) * kTileRow];                                                 \
   }
 
-// Where a giant feature's partial sums live: element e of segment slot `seg`.
-__device__ __forceinline__ int64_t seg_elem(const TileGeom &g, int seg, int e) {
-  return static_cast<int64_t>(seg) * g.RL + e;
-}
-__device__ __forceinline__ unsigned long long *seg_flags(const Scratch &s, const TileGeom &g, int seg, int ci) {
-  return s.segF + (static_cast<int64_t>(seg) * g.per_feat + ci) * 3;
-}
-
-// ---- hot features with at most kRange occurrences: one wave folds (feature, chunk) whole ----------
+// ---- hot features below giant_min occurrences: one wave folds (feature, chunk) whole --------------
 template <int NF>
 __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Scratch &s, unsigned wave, unsigned n_waves,
                                                float *T, float4 *R) {
@@ -285,8 +276,9 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Scratch 
     const float w = rec[LAT_W * g.RL];
     Fold acc;
     acc.init(n);
-    tile_stream<NF>(m, s, g, ch, fa, start, 0, c, T, R, [&](int st, const float4 *Rc, const float *Tc) {
-      if (st > 0 && (st * kTileT) % kSeg == 0) acc.flush();  // a segment of kSeg occurrences ends
+    tile_stream<NF>(m, s, g, ch, fa, start, 0, 1, (c + kTileT - 1) / kTileT, c, T, R,
+                    [&](int st, const float4 *Rc, const float *Tc) {
+      if (st > 0) acc.flush();  // a segment (= a tile of kSeg occurrences) ends
       const int cnt = min(kTileT, c - st * kTileT);
       for (int g0 = 0; g0 < cnt; g0 += kTileG) {
         FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
@@ -300,220 +292,141 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Scratch 
   }
 }
 
-// ---- giant features (more than kRange occurrences): ranges of kRange occurrences side by side -----
-// Pass A, work item = (range, chunk): per segment of the range the sums of g and g*g from -0.0f and
-// three lane masks (live touch seen / first live touch plain / :118 touch seen) -> s.segP / segG / segF.
+// ---- giant features (giant_min occurrences or more): the waves of a workgroup fold ONE (feature,
+// chunk) together.  A segment is a tile, so the heavy work of a tile -- gathers, gradients, root
+// differences -- needs from the tiles before it only n at its start (B_s) and whether the element has
+// met a :118 touch yet; everything else it sums from -0.0f.  Super-step k: wave w takes tile
+// k W + w;  (A) the tile's sums of g and g*g and its lane masks -> LDS;  barrier;  (B) B_s and the
+// :118 flag from the running state plus the tiles of the super-step before this one, then the
+// tile's root differences -> LDS;  barrier;  every wave joins the W tiles, in order, to its copy of
+// the running state.  Same tree as one wave walking the tiles: bit-identical.
+struct CoopLds {
+  float P[2][kUpdWaves][64], G[2][kUpdWaves][64], D[2][kUpdWaves][64];
+  unsigned long long fl[2][kUpdWaves][3];  // lanes with a live touch / whose first live touch is plain / with a :118 touch
+  float ncap[64];
+};
 template <int NF>
-__device__ __forceinline__ void ffm_range_items_a(const ModelDev &m, const Scratch &s, unsigned wave,
-                                                  unsigned n_waves, float *T, float4 *R) {
+__device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Scratch &s, unsigned bidx, unsigned gdim,
+                                               float *T, float4 *R, CoopLds &cl) {
   constexpr int RS = 4 * NF;
+  constexpr int W = kUpdWaves;
   const TileGeom g = tile_geom(m);
   const int lane = threadIdx.x & 63;
-  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NRANGE]) * g.per_feat;
-  for (unsigned item = wave; item < n_items; item += n_waves) {
-    const unsigned ri = item / g.per_feat;
-    const int ci = static_cast<int>(item - ri * g.per_feat);
-    const int2 gr = s.grange[ri];  // {index into giant, range number}
-    const int gi = wave_uniform(gr.x), r = wave_uniform(gr.y);
-    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
-    const int fa = wave_uniform(ud.w), start = wave_uniform(ud.y), c = wave_uniform(ud.z);
-    const int seg0 = wave_uniform(s.gseg[gi]) + r * kRangeSegs;
-    const TileChunk ch = tile_chunk(m, g, fa, ci);
-    if (ch.fp0 < 0) continue;
-    const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
-    const int t_lo = r * kRange, t_hi = min(c, t_lo + kRange);
-    const bool has = ch.inw && ch.sb + ch.es < g.slots;          // this lane is an element of the stored record
-    const int e = has ? (ch.sb + ch.es) * g.K + ch.ekk : 0;
-    const int steps = (t_hi - t_lo + kTileT - 1) / kTileT;
-    if (!__any(active && ((s.gmask[start] >> ch.fp) & 1ull))) {
-      // untouched chunk: the joins still read its segments' masks
-      for (int sg = 0; sg * (kSeg / kTileT) < steps; sg++)
-        if (lane < 3) seg_flags(s, g, seg0 + sg, ci)[lane] = 0ull;
-      continue;
-    }
-    float P = -0.0f, G = -0.0f;
-    bool any = false, hp = false, q = false;
-    tile_stream<NF>(m, s, g, ch, fa, start, t_lo, t_hi, T, R, [&](int st, const float4 *Rc, const float *Tc) {
-      const int cnt = min(kTileT, t_hi - t_lo - st * kTileT);
-      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
-        FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
-#pragma unroll
-        for (int j = 0; j < kTileG; j++) {
-          const float gj = tg[j] * vp[j] * x[j];
-          G = live[j] ? G + gj : G;
-          P = live[j] ? P + gj * gj : P;
-          if (!any) hp = first[j];
-          any = any || live[j];
-          q = q || (live[j] && !first[j]);
-        }
-      }
-      if ((st + 1) % (kSeg / kTileT) == 0 || st == steps - 1) {  // the segment ends
-        const int seg = seg0 + st / (kSeg / kTileT);
-        if (has) {
-          s.segP[seg_elem(g, seg, e)] = P;
-          s.segG[seg_elem(g, seg, e)] = G;
-        }
-        const unsigned long long ma = __ballot(any), mh = __ballot(any && hp), mq = __ballot(q);
-        if (lane == 0) {
-          unsigned long long *fl = seg_flags(s, g, seg, ci);
-          fl[0] = ma; fl[1] = mh; fl[2] = mq;
-        }
-        P = G = -0.0f;
-        any = hp = q = false;
-      }
-    });
-  }
-}
-
-// Pass B, same work items, only where the chunk has an element with a :118 touch: n at the start of
-// the range from the segment sums before it (joined left to right), then the range's touches again
-// for their root differences -> s.segD per segment; the n_t at an element's first :118 touch -> s.gcap.
-template <int NF>
-__device__ __forceinline__ void ffm_range_items_b(const ModelDev &m, const Scratch &s, unsigned wave,
-                                                  unsigned n_waves, float *T, float4 *R) {
-  constexpr int RS = 4 * NF;
-  const TileGeom g = tile_geom(m);
-  const int lane = threadIdx.x & 63;
-  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NRANGE]) * g.per_feat;
-  for (unsigned item = wave; item < n_items; item += n_waves) {
-    const unsigned ri = item / g.per_feat;
-    const int ci = static_cast<int>(item - ri * g.per_feat);
-    const int2 gr = s.grange[ri];
-    const int gi = wave_uniform(gr.x), r = wave_uniform(gr.y);
-    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
-    const int fa = wave_uniform(ud.w), i = wave_uniform(ud.x);
-    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
-    const int segb = wave_uniform(s.gseg[gi]), n_seg = (c + kSeg - 1) / kSeg;
-    const TileChunk ch = tile_chunk(m, g, fa, ci);
-    if (ch.fp0 < 0) continue;
-    // which lanes meet a :118 touch anywhere in the feature / before this range
-    unsigned long long q_all = 0ull, q_before = 0ull;
-    for (int sg = 0; sg < n_seg; sg++) {
-      const unsigned long long mq = seg_flags(s, g, segb + sg, ci)[2];
-      q_all |= mq;
-      if (sg < r * kRangeSegs) q_before |= mq;
-    }
-    if (q_all == 0ull) continue;  // every touch of the chunk is plain: the join telescopes
-    const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
-    const bool has = ch.inw && ch.sb + ch.es < g.slots;
-    const int e = has ? (ch.sb + ch.es) * g.K + ch.ekk : 0;
-    const int t_lo = r * kRange, t_hi = min(c, t_lo + kRange);
-    const int steps = (t_hi - t_lo + kTileT - 1) / kTileT;
-    const float *rec = lat_row(m, i, fa) + (ch.fp >= 0 ? ch.sb + ch.es : ch.sb) * g.K + ch.ekk;
-    const float w = rec[LAT_W * g.RL];
-    Fold acc;
-    acc.init(rec[LAT_N * g.RL]);
-    for (int sg = 0; sg < r * kRangeSegs; sg++) {  // B at the start of the range
-      acc.P = s.segP[seg_elem(g, segb + sg, e)];
-      acc.B = acc.B + acc.P;
-    }
-    acc.P = -0.0f;
-    const bool seen_before = (q_before >> lane) & 1ull;
-    acc.seen = seen_before;
-    tile_stream<NF>(m, s, g, ch, fa, start, t_lo, t_hi, T, R, [&](int st, const float4 *Rc, const float *Tc) {
-      const int cnt = min(kTileT, t_hi - t_lo - st * kTileT);
-      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
-        FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
-        fold_ffm_group<kTileG>(acc, w, live, first, tg, x, vp);
-      }
-      if ((st + 1) % (kSeg / kTileT) == 0 || st == steps - 1) {  // the segment ends
-        const int seg = segb + r * kRangeSegs + st / (kSeg / kTileT);
-        if (has) s.segD[seg_elem(g, seg, e)] = acc.D;
-        acc.flush();
-      }
-    });
-    if (has && acc.seen && !seen_before) s.gcap[static_cast<int64_t>(gi) * g.RL + e] = acc.ncap;
-  }
-}
-
-// The join, work item = (giant feature, chunk), lane = element: the segments' sums left to right,
-// then the accumulator's (n_T, z_T) as for any other fold.
-__device__ __forceinline__ void ffm_range_join(const ModelDev &m, const Scratch &s, unsigned wave, unsigned n_waves) {
-  const TileGeom g = tile_geom(m);
-  const int lane = threadIdx.x & 63;
+  const int wv = wave_uniform(threadIdx.x >> 6);
   const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NGIANT]) * g.per_feat;
-  for (unsigned item = wave; item < n_items; item += n_waves) {
-    const unsigned gi = item / g.per_feat;
-    const int ci = static_cast<int>(item - gi * g.per_feat);
-    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
+  for (unsigned item = bidx; item < n_items; item += gdim) {  // (the whole workgroup on one item)
+    const unsigned li = item / g.per_feat;
+    const int ci = static_cast<int>(item - li * g.per_feat);
+    const int4 ud = s.udesc[wave_uniform(s.giant[li])];  // {feature, start, count, field}
     const int fa = wave_uniform(ud.w), i = wave_uniform(ud.x);
     const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
-    const int segb = wave_uniform(s.gseg[gi]), n_seg = (c + kSeg - 1) / kSeg;
     const TileChunk ch = tile_chunk(m, g, fa, ci);
     if (ch.fp0 < 0) continue;
     const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
     if (!__any(active && ((s.gmask[start] >> ch.fp) & 1ull))) continue;
-    const int e = ch.inw && ch.sb + ch.es < g.slots ? (ch.sb + ch.es) * g.K + ch.ekk : 0;
-    unsigned long long q_all = 0ull;
-    for (int sg = 0; sg < n_seg; sg++) q_all |= seg_flags(s, g, segb + sg, ci)[2];
     float *rec = lat_row(m, i, fa) + (ch.fp >= 0 ? ch.sb + ch.es : ch.sb) * g.K + ch.ekk;
     float n = rec[LAT_N * g.RL], z = rec[LAT_Z * g.RL];
     const float w = rec[LAT_W * g.RL];
-    Fold acc;
-    acc.init(n);
-    for (int sg = 0; sg < n_seg; sg++) {
-      const unsigned long long *fl = seg_flags(s, g, segb + sg, ci);
-      const bool any_s = (fl[0] >> lane) & 1ull, hp_s = (fl[1] >> lane) & 1ull;
-      acc.P = s.segP[seg_elem(g, segb + sg, e)];
-      acc.G = s.segG[seg_elem(g, segb + sg, e)];
-      acc.D = q_all ? s.segD[seg_elem(g, segb + sg, e)] : -0.0f;
-      if (!acc.any) acc.head_plain = hp_s;
-      acc.any = acc.any || any_s;
-      acc.flush();
-    }
-    acc.seen = (q_all >> lane) & 1ull;
-    acc.ncap = acc.seen ? s.gcap[static_cast<int64_t>(gi) * g.RL + e] : 0.0f;
-    if (fold_finish_latent(m.h, acc, w, n, z) && active) {
-      rec[LAT_N * g.RL] = n;
-      rec[LAT_Z * g.RL] = z;
+    Fold run;  // the running state, the same in every wave
+    run.init(n);
+    const int n_tiles = (c + kTileT - 1) / kTileT, n_super = (n_tiles + W - 1) / W;
+    tile_stream<NF>(m, s, g, ch, fa, start, wv, W, n_super, c, T, R, [&](int k, const float4 *Rc, const float *Tc) {
+      const int buf = k & 1;
+      const int cnt = max(0, min(kTileT, c - (k * W + wv) * kTileT));
+      // (A) the tile's plain sums and masks
+      {
+        float P = -0.0f, G = -0.0f;
+        bool any = false, hp = false, q = false;
+        for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+          FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
+#pragma unroll
+          for (int j = 0; j < kTileG; j++) {
+            const float gj = tg[j] * vp[j] * x[j];
+            G = live[j] ? G + gj : G;
+            P = live[j] ? P + gj * gj : P;
+            if (!any) hp = first[j];
+            any = any || live[j];
+            q = q || (live[j] && !first[j]);
+          }
+        }
+        cl.P[buf][wv][lane] = P;
+        cl.G[buf][wv][lane] = G;
+        const unsigned long long ma = __ballot(any), mh = __ballot(any && hp), mq = __ballot(q);
+        if (lane == 0) { cl.fl[buf][wv][0] = ma; cl.fl[buf][wv][1] = mh; cl.fl[buf][wv][2] = mq; }
+      }
+      __syncthreads();
+      // (B) this tile's start from the running state and the super-step's earlier tiles
+      {
+        Fold acc;
+        acc.init(run.B);
+        bool seen0 = run.seen;
+        for (int w2 = 0; w2 < wv; w2++) {
+          acc.B = acc.B + cl.P[buf][w2][lane];
+          seen0 = seen0 || ((cl.fl[buf][w2][2] >> lane) & 1ull);
+        }
+        acc.seen = seen0;
+        for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+          FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
+          fold_ffm_group<kTileG>(acc, w, live, first, tg, x, vp);
+        }
+        cl.D[buf][wv][lane] = acc.D;
+        if (acc.seen && !seen0) cl.ncap[lane] = acc.ncap;  // (an element's first :118 touch: once per item)
+      }
+      __syncthreads();
+      // the W tiles of the super-step join the running state, in order
+#pragma unroll
+      for (int w2 = 0; w2 < W; w2++) {
+        const bool any_s = (cl.fl[buf][w2][0] >> lane) & 1ull, hp_s = (cl.fl[buf][w2][1] >> lane) & 1ull;
+        run.P = cl.P[buf][w2][lane];
+        run.G = cl.G[buf][w2][lane];
+        run.D = cl.D[buf][w2][lane];
+        if (!run.any) run.head_plain = hp_s;
+        run.any = run.any || any_s;
+        run.seen = run.seen || ((cl.fl[buf][w2][2] >> lane) & 1ull);
+        run.flush();
+      }
+    });
+    __syncthreads();
+    if (wv == 0) {
+      run.ncap = run.seen ? cl.ncap[lane] : 0.0f;
+      if (fold_finish_latent(m.h, run, w, n, z) && active) {
+        rec[LAT_N * g.RL] = n;
+        rec[LAT_Z * g.RL] = z;
+      }
     }
   }
 }
 #undef FTRL_TILE_READ_GROUP
 
-// The whole FFM update of a block: ONE launch on the main stream, plus two short ones when the
-// block has giant features.  Workgroup ranges of the first:
-//   [bias fold + linear update | giant features' ranges, pass A | hot features (huge, big lists) |
-//    few-occurrence features | serial slots (the row-order walk) | loss sum]
+// The whole FFM update of a block: ONE launch on the main stream.  Workgroup ranges:
+//   [bias fold + linear update | giant features (a workgroup per item) | hot features (huge, big
+//    lists: a wave per item) | few-occurrence features | serial slots (the row-order walk) | loss sum]
 // There are no long dependent chains left in the phase, so nothing needs a stream (and a hardware
 // queue hop, ~44 us for a fork + join) of its own.
 template <int NF>
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
-                                                                     int side_blocks, int nt, int ns, int few_only,
-                                                                     int nw, int loss_blocks, double *loss_out,
-                                                                     double *loss_scratch) {
+                                                                     int side_blocks, int ng, int nt, int ns,
+                                                                     int few_only, int nw, int loss_blocks,
+                                                                     double *loss_out, double *loss_scratch) {
   __shared__ __attribute__((aligned(16))) float lds_T[kUpdWaves][kTileT * kTileRow];
   __shared__ float4 lds_R[kUpdWaves][kTileNR * kTileT * 4 * NF];
+  __shared__ CoopLds lds_coop;
   int r = blockIdx.x;
+  const unsigned wv = wave_uniform(threadIdx.x >> 6);
   if (r < side_blocks) {
     if (r == 0) bias_update_body(m, rows.n_rows, s);
     else linear_update_body(m, rows, s, r - 1, side_blocks - 1);
     return;
   }
   r -= side_blocks;
-  if (r < nt) {
-    const unsigned wv = wave_uniform(threadIdx.x >> 6);
-    ffm_range_items_a<NF>(m, s, r * kUpdWaves + wv, nt * kUpdWaves, lds_T[wv], lds_R[wv]);
-    ffm_tile_items<NF>(m, s, r * kUpdWaves + wv, nt * kUpdWaves, lds_T[wv], lds_R[wv]);
-    return;
-  }
+  if (r < ng) { ffm_coop_items<NF>(m, s, r, ng, lds_T[wv], lds_R[wv], lds_coop); return; }
+  r -= ng;
+  if (r < nt) { ffm_tile_items<NF>(m, s, r * kUpdWaves + wv, nt * kUpdWaves, lds_T[wv], lds_R[wv]); return; }
   r -= nt;
   if (r < ns) { ffm_small_body(m, rows, s, few_only, r, ns); return; }
   r -= ns;
   if (r < nw) { ffm_generic_body(m, rows, s, 1, r, nw); return; }
   loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - nw, loss_blocks);
-}
-// The giant features' pass B and their join (launched after ffm_update_all_kernel; both return at
-// once when the block has none).
-template <int NF>
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_giant_b_kernel(ModelDev m, Scratch s) {
-  __shared__ __attribute__((aligned(16))) float lds_T[kUpdWaves][kTileT * kTileRow];
-  __shared__ float4 lds_R[kUpdWaves][kTileNR * kTileT * 4 * NF];
-  const unsigned wv = wave_uniform(threadIdx.x >> 6);
-  ffm_range_items_b<NF>(m, s, blockIdx.x * kUpdWaves + wv, gridDim.x * kUpdWaves, lds_T[wv], lds_R[wv]);
-}
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_giant_join_kernel(ModelDev m, Scratch s) {
-  ffm_range_join(m, s, blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6), gridDim.x * kUpdWaves);
 }
 
 }  // namespace ftrl_dev

@@ -18,7 +18,7 @@ from oracle import pyoracle
 from oracle.pyoracle import CpuModel, Csr
 from util import DEFAULT_HP, STRESS_HP, assert_bitwise, assert_close, assert_state_bitwise, rand_state
 
-SEG = 64  # FO_SEG
+SEG = 16  # FO_SEG
 
 
 def rand_rows(rng, n, F, nf, multi=False, dup=False, ordered=True, zipf=1.5, drop=0.15):

@@ -356,7 +356,7 @@ struct ffm_engine {
   std::vector<int> field_start; // copy of cfg->field_start (compact shards)
   // workgroups of the update launch's ranges: few-occurrence features, hot tiles, the row-order walk
   // of serial slots; and of the once-only kernel of a shard
-  int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768, grid_giant = 512;
+  int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768, grid_giant = 1024;
   bool update_split = false;  // FFM_UPDATE_SPLIT=1: the update launch's ranges as launches of their own (timing aid)
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
@@ -927,6 +927,10 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
       TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fm_row_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fm_row_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
+    // the FFM update launch: the tile pipelines' per-wave LDS regions of its (up to 16-wave) workgroups
+    TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_update_all_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes(1))));
+    TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_update_all_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes(2))));
+    TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_update_all_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes(4))));
   }
   if (!(cfg->flags & FFM_FLAG_SKIP_INIT))
     hipLaunchKernelGGL(init_weights_kernel, dim3(2048), dim3(256), 0, e->stream, m, e->logical_len,

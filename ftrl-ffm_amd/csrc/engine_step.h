@@ -265,24 +265,30 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
     }
     if (flat) LAUNCH(e, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
-    const int nt = e->grid_hot, ns = flat ? 0 : e->grid_small, nw = e->grid_walk, nf = tile_nf(e);
+    // (the ranges' sizes are kept in 256-thread units and scaled to the launch's workgroup size)
+    const int nf = tile_nf(e), wpb = tile_waves(nf), scale = wpb / kUpdWaves, threads = 64 * wpb;
+    const size_t lds = tile_lds_bytes(nf);
+    const int nt = cdiv(e->grid_hot, scale), ns = flat ? 0 : cdiv(e->grid_small, scale), nw = cdiv(e->grid_walk, scale);
     const int ng = rows.nnz >= kGiantMin ? e->grid_giant : 0;  // workgroups that fold giant features together
     const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
-    const int grid = side_blocks + ng + nt + ns + nw + lb;
+    const int side = side_blocks > 0 ? 1 + cdiv(lin_blocks, scale) : 0;
+    const int grid = side + ng + nt + ns + nw + lb;
 #define FTRL_LAUNCH_ALL(NF)                                                                                   \
     do {                                                                                                      \
       if (e->update_split) { /* (timing aid: one launch per range, each under a name of its own) */           \
-        LAUNCH(e, K_LATENT_UPDATE_GIANT, (ffm_update_all_kernel<NF>), ng, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-               0, ng, 0, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                              \
-        LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), side_blocks + nt, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-               side_blocks, 0, nt, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                    \
-        LAUNCH(e, K_LATENT_UPDATE_FEW, (ffm_update_all_kernel<NF>), ns, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-               0, 0, 0, ns, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                              \
-        LAUNCH(e, K_LATENT_UPDATE_WALK, (ffm_update_all_kernel<NF>), nw + lb, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
+        if (ng > 0)                                                                                           \
+          LAUNCH(e, K_LATENT_UPDATE_GIANT, (ffm_update_all_kernel<NF>), ng, threads, lds, e->m, rows, e->sc[e->cur], \
+                 0, ng, 0, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                            \
+        LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), side + nt, threads, lds, e->m, rows, e->sc[e->cur], \
+               side, 0, nt, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                           \
+        if (ns > 0)                                                                                           \
+          LAUNCH(e, K_LATENT_UPDATE_FEW, (ffm_update_all_kernel<NF>), ns, threads, lds, e->m, rows, e->sc[e->cur], \
+                 0, 0, 0, ns, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                            \
+        LAUNCH(e, K_LATENT_UPDATE_WALK, (ffm_update_all_kernel<NF>), nw + lb, threads, lds, e->m, rows, e->sc[e->cur], \
                0, 0, 0, 0, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                             \
       } else {                                                                                                \
-        LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), grid, kUpdThreads, 0, e->m, rows, e->sc[e->cur], \
-               side_blocks, ng, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                \
+        LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), grid, threads, lds, e->m, rows, e->sc[e->cur], \
+               side, ng, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                       \
       }                                                                                                       \
     } while (0)
     if (nf == 1) FTRL_LAUNCH_ALL(1);       // k >= 16
@@ -301,8 +307,11 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       // walk): the general owner for every feature, the once-only ones included
       LAUNCH(e, K_LATENT_UPDATE, ffm_update_generic_kernel, 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], 0);
     } else if (e->m.type == FFM_MODEL_FM) {
-      if (rows.nnz > 0)
+      if (rows.nnz > 0) {
         LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, side_blocks + 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row, side_blocks);
+        if (rows.nnz >= kGiantMin)  // the giant features' segments joined
+          LAUNCH(e, K_LATENT_UPDATE_GIANT, fm_update_join_kernel, 256, kUpdThreads, 0, e->m, e->sc[e->cur]);
+      }
       else if (side_blocks > 0)
         LAUNCH(e, K_BIAS_UPDATE, bias_update_kernel, 1, kUpdThreads, 0, e->m, rows.n_rows, e->sc[e->cur]);
     }

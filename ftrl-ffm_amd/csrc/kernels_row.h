@@ -840,9 +840,12 @@ __device__ __forceinline__ void loss_sum_body(int n_rows, const double *loss, do
   __shared__ bool last;
   const int per = (n_rows + gdim - 1) / gdim;
   const int r0 = bidx * per, r1 = min(n_rows, r0 + per);
-  double acc = 0.0;
-  for (int r = r0 + threadIdx.x; r < r1; r += 256) acc += loss[r];
-  part[threadIdx.x] = acc;
+  // (the first 256 threads of the workgroup sum; a larger workgroup's others only keep the barriers)
+  if (threadIdx.x < 256) {
+    double acc = 0.0;
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) acc += loss[r];
+    part[threadIdx.x] = acc;
+  }
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
     if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];

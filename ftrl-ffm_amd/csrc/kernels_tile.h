@@ -300,16 +300,16 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Scratch 
 // :118 flag from the running state plus the tiles of the super-step before this one, then the
 // tile's root differences -> LDS;  barrier;  every wave joins the W tiles, in order, to its copy of
 // the running state.  Same tree as one wave walking the tiles: bit-identical.
+template <int W>
 struct CoopLds {
-  float P[2][kUpdWaves][64], G[2][kUpdWaves][64], D[2][kUpdWaves][64];
-  unsigned long long fl[2][kUpdWaves][3];  // lanes with a live touch / whose first live touch is plain / with a :118 touch
+  float P[2][W][64], G[2][W][64], D[2][W][64];
+  unsigned long long fl[2][W][3];  // lanes with a live touch / whose first live touch is plain / with a :118 touch
   float ncap[64];
 };
-template <int NF>
+template <int NF, int W>
 __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Scratch &s, unsigned bidx, unsigned gdim,
-                                               float *T, float4 *R, CoopLds &cl) {
+                                               float *T, float4 *R, CoopLds<W> &cl) {
   constexpr int RS = 4 * NF;
-  constexpr int W = kUpdWaves;
   const TileGeom g = tile_geom(m);
   const int lane = threadIdx.x & 63;
   const int wv = wave_uniform(threadIdx.x >> 6);
@@ -355,8 +355,19 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Scratch 
         if (lane == 0) { cl.fl[buf][wv][0] = ma; cl.fl[buf][wv][1] = mh; cl.fl[buf][wv][2] = mq; }
       }
       __syncthreads();
-      // (B) this tile's start from the running state and the super-step's earlier tiles
-      {
+      // (B) this tile's start from the running state and the super-step's earlier tiles -- only when
+      // some element of the chunk has met a :118 touch by the end of this super-step (every wave
+      // sees the same masks and running state: a uniform decision); else the root differences
+      // telescope and D stays -0.0f
+      bool quirky = run.seen;
+#pragma unroll
+      for (int w2 = 0; w2 < W; w2++) quirky = quirky || ((cl.fl[buf][w2][2] >> lane) & 1ull);
+#ifdef FFM_EXP_NO_PHASE_B
+      quirky = false;
+#endif
+      if (!__any(quirky)) {
+        cl.D[buf][wv][lane] = -0.0f;
+      } else {
         Fold acc;
         acc.init(run.B);
         bool seen0 = run.seen;
@@ -403,25 +414,39 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Scratch 
 //    lists: a wave per item) | few-occurrence features | serial slots (the row-order walk) | loss sum]
 // There are no long dependent chains left in the phase, so nothing needs a stream (and a hardware
 // queue hop, ~44 us for a fork + join) of its own.
+// WAVES per workgroup: the waves that fold ONE giant feature's chunk together (every other range
+// treats its waves as independent).  Four: with sixteen (one workgroup per CU, 1024-thread barriers,
+// sixteen tiles joined per super-step) a super-step took three times as long and the giant range
+// of a C5 block 506 us instead of 170 (profiles/r05_experiments.md).
+// Dynamic LDS: the transposers [WAVES][kTileT * kTileRow] floats, then the fact records.
+#ifndef FFM_TILE_WAVES
+#define FFM_TILE_WAVES 4
+#endif
+constexpr int tile_waves(int nf) { return nf == 4 && FFM_TILE_WAVES > 4 ? 4 : nf == 2 && FFM_TILE_WAVES > 8 ? 8 : FFM_TILE_WAVES; }
+constexpr size_t tile_lds_bytes(int nf) {
+  return static_cast<size_t>(tile_waves(nf)) * (kTileT * kTileRow * sizeof(float) + kTileNR * kTileT * 4 * nf * sizeof(float4));
+}
 template <int NF>
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
+__global__ __launch_bounds__(64 * tile_waves(NF)) void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
                                                                      int side_blocks, int ng, int nt, int ns,
                                                                      int few_only, int nw, int loss_blocks,
                                                                      double *loss_out, double *loss_scratch) {
-  __shared__ __attribute__((aligned(16))) float lds_T[kUpdWaves][kTileT * kTileRow];
-  __shared__ float4 lds_R[kUpdWaves][kTileNR * kTileT * 4 * NF];
-  __shared__ CoopLds lds_coop;
+  constexpr int WAVES = tile_waves(NF);
+  extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
+  __shared__ CoopLds<WAVES> lds_coop;
   int r = blockIdx.x;
   const unsigned wv = wave_uniform(threadIdx.x >> 6);
+  float *T = reinterpret_cast<float *>(lds_dyn) + wv * (kTileT * kTileRow);
+  float4 *R = reinterpret_cast<float4 *>(lds_dyn + WAVES * kTileT * kTileRow * sizeof(float)) + wv * (kTileNR * kTileT * 4 * NF);
   if (r < side_blocks) {
     if (r == 0) bias_update_body(m, rows.n_rows, s);
     else linear_update_body(m, rows, s, r - 1, side_blocks - 1);
     return;
   }
   r -= side_blocks;
-  if (r < ng) { ffm_coop_items<NF>(m, s, r, ng, lds_T[wv], lds_R[wv], lds_coop); return; }
+  if (r < ng) { ffm_coop_items<NF, WAVES>(m, s, r, ng, T, R, lds_coop); return; }
   r -= ng;
-  if (r < nt) { ffm_tile_items<NF>(m, s, r * kUpdWaves + wv, nt * kUpdWaves, lds_T[wv], lds_R[wv]); return; }
+  if (r < nt) { ffm_tile_items<NF>(m, s, r * WAVES + wv, nt * WAVES, T, R); return; }
   r -= nt;
   if (r < ns) { ffm_small_body(m, rows, s, few_only, r, ns); return; }
   r -= ns;

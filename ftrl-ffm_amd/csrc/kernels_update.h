@@ -25,6 +25,7 @@ namespace ftrl_dev {
 
 constexpr int kUpdThreads = 256;
 constexpr int kUpdWaves = kUpdThreads / 64;
+constexpr int kUpdMaxThreads = 1024;  // the FFM update launch's workgroups (kernels_tile.h) are up to this large
 constexpr int kFmUnroll = 8;  // touches per prefetch group in the FM update kernel
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -96,8 +97,9 @@ __device__ __forceinline__ void linear_update_body(const ModelDev &m, const Rows
     m.lin_z[i] = z;
   }
   const int lane = threadIdx.x & 63;
-  const int wave = block * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const int n_waves = n_blocks * kUpdWaves;
+  const int upd_waves = blockDim.x >> 6;  // (256-thread launches, or the FFM update launch's larger workgroups)
+  const int wave = block * upd_waves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = n_blocks * upd_waves;
   const int n_huge = s.counters[CNT_NHUGE], n_giant = s.counters[CNT_NGIANT];
   for (int li = wave; li < n_big + n_huge + n_giant; li += n_waves) {
     // (the longest lists first)
@@ -170,17 +172,18 @@ __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, 
 // are 256 contiguous bytes, sixteen 16-byte loads), summed left to right in the thread's registers;
 // thread 0 then joins the segment totals in order.  For 8192 rows: 128 threads x 64 adds, then 128
 // adds -- where the row-order walk was 2 x 8192 dependent adds (74 us, the floor of FM's update).
-// Called by every thread of a 256-thread workgroup.
+// Called by every thread of a workgroup (of up to kUpdMaxThreads threads).
 __device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, const Scratch &sc) {
   if (!m.bias_own) return;             // another shard's
   if (sc.counters[CNT_ERROR]) return;  // untrainable block (ERR_ROW_TOO_LONG): a no-op
   if (n_rows <= 0) return;
-  __shared__ float s_P[kUpdThreads], s_G[kUpdThreads];
+  __shared__ float s_P[kUpdMaxThreads], s_G[kUpdMaxThreads];
+  const int n_thr = blockDim.x;
   const float *tg = sc.tg;
   const int n_seg = (n_rows + kSeg - 1) / kSeg;
   Fold a;
   a.init(m.bias3[1]);
-  for (int s0 = 0; s0 < n_seg; s0 += kUpdThreads) {
+  for (int s0 = 0; s0 < n_seg; s0 += n_thr) {
     const int seg = s0 + threadIdx.x;
     float P = -0.0f, G = -0.0f;
     if (seg < n_seg) {
@@ -209,7 +212,7 @@ __device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, 
     s_G[threadIdx.x] = G;
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int cnt = min(kUpdThreads, n_seg - s0);
+      const int cnt = min(n_thr, n_seg - s0);
       for (int l = 0; l < cnt; l++) {
         a.P = s_P[l];
         a.G = s_G[l];
@@ -298,8 +301,9 @@ __device__ __forceinline__ void ffm_generic_body(const ModelDev &m, const Rows &
                                                  int serial_only, unsigned bidx, unsigned gdim) {
   const unsigned chunks = (m.row_len + 63) / 64;
   const int lane = threadIdx.x & 63;
-  const unsigned wave = bidx * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const unsigned n_waves = gdim * kUpdWaves;
+  const unsigned upd_waves = blockDim.x >> 6;
+  const unsigned wave = bidx * upd_waves + wave_uniform(threadIdx.x >> 6);
+  const unsigned n_waves = gdim * upd_waves;
   if (serial_only) {
     // one lane per feature of the few / big / huge / giant lists looks at its serial slots; the wave
     // then walks the (rare) features that have any, one after another
@@ -361,8 +365,9 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int RL4 = RL >> 2, k4 = k >> 2;
   const int lane = threadIdx.x & 63;
-  const int wave = bidx * kUpdWaves + wave_uniform(threadIdx.x >> 6);
-  const int n_waves = gdim * kUpdWaves;
+  const int upd_waves = blockDim.x >> 6;
+  const int wave = bidx * upd_waves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = gdim * upd_waves;
   const int *list = few_only ? s.few : s.small;
   const int n_small = s.counters[few_only ? CNT_NFEW : CNT_NSMALL];
   const float inv_k4 = 1.0f / static_cast<float>(k4);
@@ -704,10 +709,12 @@ __device__ __forceinline__ void fm_update_body(const ModelDev &m, const Rows &ro
     const int i = wave_uniform(ud.x);
     const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
     if (skip_once && c == 1) continue;
+    const bool dup = (wave_uniform(s.uflag[start]) & UF_DUP) != 0;
+    if (c >= m.giant_min && !dup) continue;  // folded as ranges side by side (fm_range_items)
     float *rec = lat_row(m, i, 0);
     float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
     const float w = rec[LAT_W * k + e];
-    if (wave_uniform(s.uflag[start]) & UF_DUP) {  // the row-order walk
+    if (dup) {  // the row-order walk
       float sqn = sqrt_cr(n);
       for (int t = 0; t < c; t++) {
         const int2 pr = s.occ2[start + t];
@@ -764,6 +771,124 @@ __device__ __forceinline__ void fm_update_body(const ModelDev &m, const Rows &ro
     }
   }
 }
+// Giant FM features (giant_min occurrences or more: under a Zipf law over all ids the top features
+// sit in most rows of a block): their occurrences are cut into ranges of kRange that waves all over
+// the chip fold side by side -- per segment the sums of g and g*g from -0.0f into s.segP / s.segG --
+// and a second short launch joins the segments of each (feature, chunk) left to right.  Every
+// touch is plain, so the join needs nothing else.
+__device__ __forceinline__ void fm_range_items(const ModelDev &m, const Rows &rows, const Scratch &s,
+                                               int block, int n_blocks) {
+  const int k = m.n_factors;
+  const int chunks = (k + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = block * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = n_blocks * kUpdWaves;
+  const int64_t n_items = static_cast<int64_t>(s.counters[CNT_NRANGE]) * chunks;
+  for (int64_t item = wave; item < n_items; item += n_waves) {
+    const int ri = static_cast<int>(item / chunks);
+    const int e = static_cast<int>(item - static_cast<int64_t>(ri) * chunks) * 64 + lane;
+    const int2 gr = s.grange[ri];  // {index into giant, range number}
+    const int gi = wave_uniform(gr.x), r = wave_uniform(gr.y);
+    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
+    const int i = wave_uniform(ud.x), start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    if (wave_uniform(s.uflag[start]) & UF_DUP) continue;  // walked in row order by fm_update_body
+    if (e >= k) continue;
+    const float w = lat_row(m, i, 0)[LAT_W * k + e];
+    const int seg0 = wave_uniform(s.gseg[gi]) + r * kRangeSegs;
+    const int t_lo = r * kRange, t_hi = min(c, t_lo + kRange);
+    const int nb = (t_hi - t_lo + kFmUnroll - 1) / kFmUnroll;
+    auto load_desc = [&](int b, int2 (&pr)[kFmUnroll]) {
+#pragma unroll
+      for (int j = 0; j < kFmUnroll; j++) pr[j] = s.occ2[start + min(t_lo + b * kFmUnroll + j, c - 1)];
+    };
+    auto load_ops = [&](const int2 (&pr)[kFmUnroll], FmTouchOps &o) {
+#pragma unroll
+      for (int j = 0; j < kFmUnroll; j++) {
+        o.x[j] = rows.val[pr[j].x];
+        o.tg[j] = s.tg[pr[j].y];
+        o.sv[j] = s.svx[static_cast<int64_t>(pr[j].y) * k + e];
+      }
+    };
+    float P = -0.0f, G = -0.0f;
+    auto compute = [&](const FmTouchOps &o, int b) {
+      const int cnt = min(kFmUnroll, t_hi - t_lo - b * kFmUnroll);
+#pragma unroll
+      for (int j = 0; j < kFmUnroll; j++) {  // fm.cpp:84-95
+        const float x = o.x[j];
+        const float g = o.tg[j] * (x * o.sv[j] - w * x * x);
+        G = j < cnt ? G + g : G;
+        P = j < cnt ? P + g * g : P;
+      }
+      if (((b + 1) * kFmUnroll) % kSeg == 0 || b == nb - 1) {  // the segment ends
+        const int64_t at = static_cast<int64_t>(seg0 + b * kFmUnroll / kSeg) * k + e;
+        s.segP[at] = P;
+        s.segG[at] = G;
+        P = G = -0.0f;
+      }
+    };
+    int2 prA[kFmUnroll], prB[kFmUnroll];
+    FmTouchOps opA, opB;
+    load_desc(0, prA);
+    load_ops(prA, opA);
+    load_desc(1, prB);
+    for (int b = 0; b < nb; b += 2) {
+      load_ops(prB, opB);
+      load_desc(b + 2, prA);
+      compute(opA, b);
+      if (b + 1 >= nb) break;
+      load_ops(prA, opA);
+      load_desc(b + 3, prB);
+      compute(opB, b + 1);
+    }
+  }
+}
+__global__ __launch_bounds__(kUpdThreads) void fm_update_join_kernel(ModelDev m, Scratch s) {
+  const int k = m.n_factors;
+  const int chunks = (k + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6);
+  const int n_waves = gridDim.x * kUpdWaves;
+  const int64_t n_items = static_cast<int64_t>(s.counters[CNT_NGIANT]) * chunks;
+  for (int64_t item = wave; item < n_items; item += n_waves) {
+    const int gi = static_cast<int>(item / chunks);
+    const int e = static_cast<int>(item - static_cast<int64_t>(gi) * chunks) * 64 + lane;
+    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
+    const int i = wave_uniform(ud.x), start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    if (wave_uniform(s.uflag[start]) & UF_DUP) continue;
+    if (e >= k) continue;
+    float *rec = lat_row(m, i, 0);
+    float n = rec[LAT_N * k + e], z = rec[LAT_Z * k + e];
+    const float w = rec[LAT_W * k + e];
+    const int64_t base = static_cast<int64_t>(wave_uniform(s.gseg[gi])) * k + e;
+    const int n_seg = (c + kSeg - 1) / kSeg;
+    Fold a;
+    a.init(n);
+    constexpr int kFly = 8;  // segments whose sums are in flight together
+    for (int s0 = 0; s0 < n_seg; s0 += kFly) {
+      float p[kFly], g[kFly];
+#pragma unroll
+      for (int j = 0; j < kFly; j++) {
+        const int64_t at = base + static_cast<int64_t>(min(s0 + j, n_seg - 1)) * k;
+        p[j] = s.segP[at];
+        g[j] = s.segG[at];
+      }
+#pragma unroll
+      for (int j = 0; j < kFly; j++) {
+        if (s0 + j < n_seg) {
+          a.P = p[j];
+          a.G = g[j];
+          a.flush();
+        }
+      }
+    }
+    a.any = a.head_plain = true;
+    if (fold_finish_latent(m.h, a, w, n, z)) {
+      rec[LAT_N * k + e] = n;
+      rec[LAT_Z * k + e] = z;
+    }
+  }
+}
+
 // One launch for FM's whole update: the first side_blocks workgroups carry the bias fold (block 0)
 // and the linear update, the others the latent lists.
 __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s,
@@ -773,6 +898,7 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows
     else linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, skip_once);
     return;
   }
+  fm_range_items(m, rows, s, blockIdx.x - side_blocks, gridDim.x - side_blocks);
   fm_update_body(m, rows, s, skip_once, blockIdx.x - side_blocks, gridDim.x - side_blocks);
 }
 

@@ -283,7 +283,9 @@ struct ffm_engine {
   bool own_stream = false;
   // Streams: the runtime multiplexes streams onto few hardware queues (4 by default), and two
   // streams on one queue run one after the other -- so no more than stream + 2 side + prep here.
-  hipStream_t aux3 = nullptr;  // side stream: uploads of long-step engines (see `copy`)
+  hipStream_t aux3 = nullptr;  // side stream: uploads of long-step engines (see `copy`); a shard's once-only /
+                               // few-occurrence launches beside its update launch
+  hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
   int max_rows = 0, max_nnz = 0, max_row_nnz = 1024;
   // longest row of the block being staged from host memory (known there; 0 = unknown: device
   // callers).  The row kernels size their LDS by it, which decides how many rows a CU holds.
@@ -558,6 +560,9 @@ void ffm_engine_destroy(ffm_engine *e) {
   // (staged, never trained), look-ahead groupings, the side streams -- ends before anything is freed
   if (e->prep) (void)hipStreamSynchronize(e->prep);
   if (e->aux3) (void)hipStreamSynchronize(e->aux3);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &r : e->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
@@ -649,6 +654,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.bias_own = 1;
   m.huge_min = kHugeMin;
   m.giant_min = kGiantMin;
+  m.super_min = kSuperMin;
+  if (const char *sv = std::getenv("FFM_SUPER_MIN")) m.super_min = std::max(kGiantMin, std::atoi(sv));
   m.rec_slots = m.n_fields;
   e->n_records = cfg->n_feats;
   // field-pair partition: this shard's ranges, and (with per-field id ranges) compact storage
@@ -696,6 +703,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   // (priority streams for the hot / very hot update: measured +45 % per step; for the look-ahead
   // grouping: the same)
   TRY_HIP(hipStreamCreateWithFlags(&e->aux3, hipStreamNonBlocking));
+  TRY_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  TRY_HIP(hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming));
+  TRY_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   const size_t nf = static_cast<size_t>(cfg->n_feats);
   const size_t n_lat = static_cast<size_t>(e->n_records) * 3 * static_cast<size_t>(m.row_len);
   TRY_ALLOC(e->alloc(&m.bias3, 4));
@@ -722,9 +732,15 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   {
     // partial sums of the giant features' folds (shared by the scratch sets)
     const size_t max_segs = E / kSeg + E / kGiantMin + 2, rl = static_cast<size_t>(std::max(1, m.row_len));
-    const bool fm_model = cfg->model_type == FFM_MODEL_FM;
-    TRY_ALLOC(e->alloc(&s.segP, fm_model ? max_segs * rl : 1));
-    TRY_ALLOC(e->alloc(&s.segG, fm_model ? max_segs * rl : 1));
+    const bool lat_model = cfg->model_type != FFM_MODEL_LR, ffm_m = cfg->model_type == FFM_MODEL_FFM;
+    const size_t chunks = !ffm_m ? 1 : cfg->n_factors <= 64
+                              ? (static_cast<size_t>(m.rec_slots) + 64 / cfg->n_factors - 1) / (64 / cfg->n_factors)
+                              : static_cast<size_t>(m.rec_slots) * ((cfg->n_factors + 63) / 64);
+    TRY_ALLOC(e->alloc(&s.segP, lat_model ? max_segs * rl : 1));
+    TRY_ALLOC(e->alloc(&s.segG, lat_model ? max_segs * rl : 1));
+    TRY_ALLOC(e->alloc(&s.segD, ffm_m ? max_segs * rl : 1));
+    TRY_ALLOC(e->alloc(&s.segF, ffm_m ? max_segs * chunks * 3 : 1));
+    TRY_ALLOC(e->alloc(&s.gcap, ffm_m ? (E / kGiantMin + 2) * rl : 1));
   }
   TRY_ALLOC(e->alloc(&s.counters, kNumCounters));
   TRY_ALLOC(e->alloc(&e->d_err, 1));

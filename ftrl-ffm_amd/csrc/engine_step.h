@@ -258,13 +258,26 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     const bool single = e->single_kernel;
     const int span4 = e->m.rec_slots * (e->m.n_factors / 4);  // 16-byte vectors of a stored record
     const bool flat = flat_pays(e, span4);
-    if (single && !e->singles_in_row) {  // (else: already applied by the row kernel)
-      if (flat) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_flat_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-      else if (span4 <= 64) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<1>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-      else if (span4 <= 128) LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
-      else LAUNCH(e, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    // A shard's once-only features (their logit was only whole after the all-reduce) and, on compact
+    // storage, its few-occurrence features have launches of their own: on the side stream, beside the
+    // update launch (disjoint features; a rank's step is long, the two queue hops are not)
+    const bool side_launches = (single && !e->singles_in_row) || flat;
+    hipStream_t sst = side_launches && !e->serial ? e->aux3 : e->stream;
+    if (sst != e->stream) {
+      HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
+      HIP_TRY(hipStreamWaitEvent(sst, e->ev_fork, 0));
     }
-    if (flat) LAUNCH(e, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
+    if (single && !e->singles_in_row) {  // (else: already applied by the row kernel)
+      if (flat) LAUNCH_ON(e, sst, K_LATENT_UPDATE_SINGLE, ffm_update_single_flat_kernel, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      else if (span4 <= 64) LAUNCH_ON(e, sst, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<1>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      else if (span4 <= 128) LAUNCH_ON(e, sst, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<2>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+      else LAUNCH_ON(e, sst, K_LATENT_UPDATE_SINGLE, ffm_update_single_kernel<3>, e->grid_single, kUpdThreads, 0, e->m, rows, e->sc[e->cur]);
+    }
+    // (the few-occurrence launch further down: beside the longest features' second pass and join,
+    // which are chains of dependent loads on an otherwise idle chip)
+    const bool few_late = flat && sst != e->stream && rows.nnz >= e->m.super_min;
+    if (flat && !few_late) LAUNCH_ON(e, sst, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
+    if (sst != e->stream && !few_late) HIP_TRY(hipEventRecord(e->ev_join, sst));
     // (the ranges' sizes are kept in 256-thread units and scaled to the launch's workgroup size)
     const int nf = tile_nf(e), wpb = tile_waves(nf), scale = wpb / kUpdWaves, threads = 64 * wpb;
     const size_t lds = tile_lds_bytes(nf);
@@ -294,7 +307,24 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     if (nf == 1) FTRL_LAUNCH_ALL(1);       // k >= 16
     else if (nf == 2) FTRL_LAUNCH_ALL(2);  // k = 8 / 12
     else FTRL_LAUNCH_ALL(4);               // k = 4
+    if (few_late) {
+      HIP_TRY(hipEventRecord(e->ev_fork2, e->stream));
+      HIP_TRY(hipStreamWaitEvent(sst, e->ev_fork2, 0));
+      LAUNCH_ON(e, sst, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
+      HIP_TRY(hipEventRecord(e->ev_join, sst));
+    }
+    if (rows.nnz >= e->m.super_min) {
+      // the longest features' ranges: second pass (root differences) and the join of their tiles
+      const int gg = e->grid_giant;
+      e->prof_begin(K_LATENT_UPDATE_GIANT, e->stream);
+      if (nf == 1) hipLaunchKernelGGL(ffm_update_super_b_kernel<1>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
+      else if (nf == 2) hipLaunchKernelGGL(ffm_update_super_b_kernel<2>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
+      else hipLaunchKernelGGL(ffm_update_super_b_kernel<4>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
+      hipLaunchKernelGGL(ffm_update_super_join_kernel, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
+      e->prof_end(e->stream);
+    }
 #undef FTRL_LAUNCH_ALL
+    if (sst != e->stream) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     loss_done = loss_sum_out != nullptr;
   } else {
     if (side_blocks > 0 && e->m.type != FFM_MODEL_FM) {

@@ -56,8 +56,9 @@ struct ModelDev {
   const int *lin_own;         // [n_fields] 1 when this shard owns the field's linear terms; null: all
   int bias_own;               // 1 when this shard owns the bias
   int huge_min;               // occurrences per block above which a hot feature is listed as "very hot" (kHugeMin)
-  int giant_min;              // ... from which it is listed as "giant": its occurrences are cut into
-                              //     segment ranges that several waves fold side by side (kGiantMin)
+  int giant_min;              // ... from which it is listed as "giant" (kGiantMin): FFM -- a workgroup folds one
+                              //     together; FM, and FFM from super_min on -- ranges folded all over the chip
+  int super_min;              // FFM: occurrences from which a giant feature's ranges are folded side by side
 };
 
 enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };
@@ -142,14 +143,18 @@ struct Scratch {
                   //      that occur once, which ffm_update_single_kernel owns)
   int *big;       // [nnz] ... with kSmallMax < occurrences <= kHugeMin ("hot" features)
   int *huge;      // [nnz] ... with more, below ModelDev::giant_min ("very hot": present in many rows)
-  int *giant;     // [nnz / kChainMin + 1] ... with giant_min or more.  FFM: a workgroup folds one together
-                  //      (kernels_tile.h).  FM: their occurrences are cut into RANGES of kRange that
-                  //      waves all over the chip fold side by side (kernels_update.h); per giant feature:
-  int *gseg;      // [nnz / kChainMin + 1] first of its segment slots in segP / segG
+  int *giant;     // [nnz / kChainMin + 1] ... with giant_min or more.  FFM below super_min: a workgroup folds
+                  //      one together (kernels_tile.h).  FM, and FFM from super_min on: their occurrences
+                  //      are cut into RANGES of kRange that waves all over the chip fold side by side, the
+                  //      segments' partial sums joined by a later launch; per giant feature:
+  int *gseg;      // [nnz / kChainMin + 1] first of its segment slots in segP / segG / segD / segF
   int2 *grange;   // [nnz / kRange + nnz / giant_min + 2] {index into giant, range number}: one entry per range
-  // partial sums of the FM giants' folds, per segment and factor (shared by the scratch sets: one
-  // block's update ends before the next one's starts)
-  float *segP, *segG;  // [max_segs * row_len] sum g*g, sum g
+  // partial sums of those folds, per segment and element of the stored record (shared by the scratch
+  // sets: one block's update ends before the next one's starts)
+  float *segP, *segG, *segD;    // [max_segs * row_len] sum g*g, sum g, sum of root differences (FFM)
+  unsigned long long *segF;     // [max_segs * chunks * 3] FFM, per (segment, 64-element chunk): lanes with a
+                                //      live touch / whose first live touch is plain / with a :118 touch
+  float *gcap;                  // [(nnz / giant_min + 2) * row_len] FFM: n_t at an element's first :118 touch
   int *counters;  // [kNumCounters] CNT_* below
   int *err;       // [1] sticky ERR_* flags, shared by all sets: what ffm_engine_sync reports
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
@@ -218,6 +223,12 @@ constexpr int kHugeMin = FFM_HUGE_MIN;
 constexpr int kRangeSegs = FFM_RANGE_SEGS;
 constexpr int kRange = kRangeSegs * kSeg;  // occurrences per range of a giant feature
 constexpr int kGiantMin = kRange + 1;
+// FFM: from here on one workgroup per (feature, chunk) would be the phase's span again (a feature in
+// every tenth row of a 65536-row block is 400 tiles): ranges all over the chip, two short launches more
+#ifndef FFM_SUPER_MIN
+#define FFM_SUPER_MIN 2048
+#endif
+constexpr int kSuperMin = FFM_SUPER_MIN;
 constexpr int kChainMin = 64;  // the least giant_min an engine may choose (sizes Scratch::giant)
 enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
                                                      // first / several entries share the field

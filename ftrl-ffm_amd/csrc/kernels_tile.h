@@ -320,6 +320,7 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Scratch 
     const int4 ud = s.udesc[wave_uniform(s.giant[li])];  // {feature, start, count, field}
     const int fa = wave_uniform(ud.w), i = wave_uniform(ud.x);
     const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    if (c >= m.super_min) continue;  // folded as ranges all over the chip (ffm_range_items_a / _b)
     const TileChunk ch = tile_chunk(m, g, fa, ci);
     if (ch.fp0 < 0) continue;
     const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
@@ -407,6 +408,208 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Scratch 
     }
   }
 }
+// ---- the longest features (super_min occurrences or more): ranges of kRange occurrences folded by
+// waves all over the chip, through global partial sums per segment (= tile) ---------------------------
+__device__ __forceinline__ int64_t seg_elem(const TileGeom &g, int seg, int e) {
+  return static_cast<int64_t>(seg) * g.RL + e;
+}
+__device__ __forceinline__ unsigned long long *seg_flags(const Scratch &s, const TileGeom &g, int seg, int ci) {
+  return s.segF + (static_cast<int64_t>(seg) * g.per_feat + ci) * 3;
+}
+// Pass A, work item = (range, chunk): per tile the sums of g and g*g from -0.0f and three lane masks
+// (live touch seen / first live touch plain / :118 touch seen) -> s.segP / segG / segF.
+template <int NF>
+__device__ __forceinline__ void ffm_range_items_a(const ModelDev &m, const Scratch &s, unsigned wave,
+                                                  unsigned n_waves, float *T, float4 *R) {
+  constexpr int RS = 4 * NF;
+  const TileGeom g = tile_geom(m);
+  const int lane = threadIdx.x & 63;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NRANGE]) * g.per_feat;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned ri = item / g.per_feat;
+    const int ci = static_cast<int>(item - ri * g.per_feat);
+    const int2 gr = s.grange[ri];  // {index into giant, range number}
+    const int gi = wave_uniform(gr.x), r = wave_uniform(gr.y);
+    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
+    const int fa = wave_uniform(ud.w), start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    if (c < m.super_min) continue;  // a workgroup folds it together (ffm_coop_items)
+    const int seg0 = wave_uniform(s.gseg[gi]) + r * kRangeSegs;
+    const TileChunk ch = tile_chunk(m, g, fa, ci);
+    if (ch.fp0 < 0) continue;
+    const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
+    const bool has = ch.inw && ch.sb + ch.es < g.slots;  // this lane is an element of the stored record
+    const int e = has ? (ch.sb + ch.es) * g.K + ch.ekk : 0;
+    const int t_lo = r * kRange, t_hi = min(c, t_lo + kRange);
+    const int steps = (t_hi - t_lo + kTileT - 1) / kTileT;
+    if (!__any(active && ((s.gmask[start] >> ch.fp) & 1ull))) {
+      // untouched chunk: pass B and the join still read its tiles' masks
+      for (int st = 0; st < steps; st++)
+        if (lane < 3) seg_flags(s, g, seg0 + st, ci)[lane] = 0ull;
+      continue;
+    }
+    tile_stream<NF>(m, s, g, ch, fa, start, t_lo / kTileT, 1, steps, c, T, R,
+                    [&](int st, const float4 *Rc, const float *Tc) {
+      const int cnt = min(kTileT, t_hi - t_lo - st * kTileT);
+      float P = -0.0f, G = -0.0f;
+      bool any = false, hp = false, q = false;
+      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+        FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
+#pragma unroll
+        for (int j = 0; j < kTileG; j++) {
+          const float gj = tg[j] * vp[j] * x[j];
+          G = live[j] ? G + gj : G;
+          P = live[j] ? P + gj * gj : P;
+          if (!any) hp = first[j];
+          any = any || live[j];
+          q = q || (live[j] && !first[j]);
+        }
+      }
+      if (has) {
+        s.segP[seg_elem(g, seg0 + st, e)] = P;
+        s.segG[seg_elem(g, seg0 + st, e)] = G;
+      }
+      const unsigned long long ma = __ballot(any), mh = __ballot(any && hp), mq = __ballot(q);
+      if (lane == 0) {
+        unsigned long long *fl = seg_flags(s, g, seg0 + st, ci);
+        fl[0] = ma; fl[1] = mh; fl[2] = mq;
+      }
+    });
+  }
+}
+// Pass B (second launch), same work items, only where the chunk has an element with a :118 touch: n
+// at the start of the range from the tiles before it (joined left to right), then the range's tiles
+// again for their root differences -> s.segD; the n_t at an element's first :118 touch -> s.gcap.
+template <int NF>
+__device__ __forceinline__ void ffm_range_items_b(const ModelDev &m, const Scratch &s, unsigned wave,
+                                                  unsigned n_waves, float *T, float4 *R) {
+  constexpr int RS = 4 * NF;
+  constexpr int kFly = 8;  // tiles whose sums are in flight together
+  const TileGeom g = tile_geom(m);
+  const int lane = threadIdx.x & 63;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NRANGE]) * g.per_feat;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned ri = item / g.per_feat;
+    const int ci = static_cast<int>(item - ri * g.per_feat);
+    const int2 gr = s.grange[ri];
+    const int gi = wave_uniform(gr.x), r = wave_uniform(gr.y);
+    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
+    const int fa = wave_uniform(ud.w), i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    if (c < m.super_min) continue;
+    const int segb = wave_uniform(s.gseg[gi]), n_seg = (c + kSeg - 1) / kSeg, seg_lo = r * kRangeSegs;
+    const TileChunk ch = tile_chunk(m, g, fa, ci);
+    if (ch.fp0 < 0) continue;
+    // which lanes meet a :118 touch anywhere in the feature / before this range
+    unsigned long long q_all = 0ull, q_before = 0ull;
+    for (int s0 = 0; s0 < n_seg; s0 += kFly) {
+      unsigned long long mq[kFly];
+#pragma unroll
+      for (int j = 0; j < kFly; j++) mq[j] = seg_flags(s, g, segb + min(s0 + j, n_seg - 1), ci)[2];
+#pragma unroll
+      for (int j = 0; j < kFly; j++) {
+        q_all |= mq[j];
+        if (s0 + j < seg_lo) q_before |= mq[j];
+      }
+    }
+    if (q_all == 0ull) continue;  // every touch of the chunk is plain: the join telescopes
+    const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
+    const bool has = ch.inw && ch.sb + ch.es < g.slots;
+    const int e = has ? (ch.sb + ch.es) * g.K + ch.ekk : 0;
+    const int t_lo = r * kRange, t_hi = min(c, t_lo + kRange);
+    const int steps = (t_hi - t_lo + kTileT - 1) / kTileT;
+    const float *rec = lat_row(m, i, fa) + (ch.fp >= 0 ? ch.sb + ch.es : ch.sb) * g.K + ch.ekk;
+    const float w = rec[LAT_W * g.RL];
+    Fold acc;
+    acc.init(rec[LAT_N * g.RL]);
+    for (int s0 = 0; s0 < seg_lo; s0 += kFly) {  // B at the start of the range
+      float p[kFly];
+#pragma unroll
+      for (int j = 0; j < kFly; j++) p[j] = s.segP[seg_elem(g, segb + min(s0 + j, seg_lo - 1), e)];
+#pragma unroll
+      for (int j = 0; j < kFly; j++)
+        if (s0 + j < seg_lo) acc.B = acc.B + p[j];
+    }
+    const bool seen_before = (q_before >> lane) & 1ull;
+    acc.seen = seen_before;
+    tile_stream<NF>(m, s, g, ch, fa, start, t_lo / kTileT, 1, steps, c, T, R,
+                    [&](int st, const float4 *Rc, const float *Tc) {
+      const int cnt = min(kTileT, t_hi - t_lo - st * kTileT);
+      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+        FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
+        fold_ffm_group<kTileG>(acc, w, live, first, tg, x, vp);
+      }
+      if (has) s.segD[seg_elem(g, segb + seg_lo + st, e)] = acc.D;
+      acc.flush();  // the segment (= tile) ends
+    });
+    if (has && acc.seen && !seen_before) s.gcap[static_cast<int64_t>(gi) * g.RL + e] = acc.ncap;
+  }
+}
+// The join (third launch), work item = (feature, chunk), lane = element: the tiles' sums left to
+// right, then the accumulator's (n_T, z_T) as for any other fold.
+__device__ __forceinline__ void ffm_range_join(const ModelDev &m, const Scratch &s, unsigned wave, unsigned n_waves) {
+  constexpr int kFly = 16;  // (a few latency-bound chains on an otherwise idle chip: loads in flight are all that counts)
+  const TileGeom g = tile_geom(m);
+  const int lane = threadIdx.x & 63;
+  const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NGIANT]) * g.per_feat;
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const unsigned gi = item / g.per_feat;
+    const int ci = static_cast<int>(item - gi * g.per_feat);
+    const int4 ud = s.udesc[wave_uniform(s.giant[gi])];
+    const int fa = wave_uniform(ud.w), i = wave_uniform(ud.x);
+    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    if (c < m.super_min) continue;
+    const int segb = wave_uniform(s.gseg[gi]), n_seg = (c + kSeg - 1) / kSeg;
+    const TileChunk ch = tile_chunk(m, g, fa, ci);
+    if (ch.fp0 < 0) continue;
+    const bool active = ch.inw && ch.fp >= 0 && !((s.cmask[start] >> ch.fp) & 1ull);
+    if (!__any(active && ((s.gmask[start] >> ch.fp) & 1ull))) continue;
+    const int e = ch.inw && ch.sb + ch.es < g.slots ? (ch.sb + ch.es) * g.K + ch.ekk : 0;
+    unsigned long long q_all = 0ull;
+    for (int s0 = 0; s0 < n_seg; s0 += kFly) {
+      unsigned long long mq[kFly];
+#pragma unroll
+      for (int j = 0; j < kFly; j++) mq[j] = seg_flags(s, g, segb + min(s0 + j, n_seg - 1), ci)[2];
+#pragma unroll
+      for (int j = 0; j < kFly; j++) q_all |= mq[j];
+    }
+    float *rec = lat_row(m, i, fa) + (ch.fp >= 0 ? ch.sb + ch.es : ch.sb) * g.K + ch.ekk;
+    float n = rec[LAT_N * g.RL], z = rec[LAT_Z * g.RL];
+    const float w = rec[LAT_W * g.RL];
+    Fold acc;
+    acc.init(n);
+    for (int s0 = 0; s0 < n_seg; s0 += kFly) {
+      float p[kFly], gsum[kFly], d[kFly];
+      unsigned long long fa_[kFly], fh_[kFly];
+#pragma unroll
+      for (int j = 0; j < kFly; j++) {
+        const int sg = segb + min(s0 + j, n_seg - 1);
+        p[j] = s.segP[seg_elem(g, sg, e)];
+        gsum[j] = s.segG[seg_elem(g, sg, e)];
+        d[j] = q_all ? s.segD[seg_elem(g, sg, e)] : -0.0f;
+        const unsigned long long *fl = seg_flags(s, g, sg, ci);
+        fa_[j] = fl[0];
+        fh_[j] = fl[1];
+      }
+#pragma unroll
+      for (int j = 0; j < kFly; j++) {
+        if (s0 + j >= n_seg) continue;
+        const bool any_s = (fa_[j] >> lane) & 1ull, hp_s = (fh_[j] >> lane) & 1ull;
+        acc.P = p[j];
+        acc.G = gsum[j];
+        acc.D = d[j];
+        if (!acc.any) acc.head_plain = hp_s;
+        acc.any = acc.any || any_s;
+        acc.flush();
+      }
+    }
+    acc.seen = (q_all >> lane) & 1ull;
+    acc.ncap = acc.seen ? s.gcap[static_cast<int64_t>(gi) * g.RL + e] : 0.0f;
+    if (fold_finish_latent(m.h, acc, w, n, z) && active) {
+      rec[LAT_N * g.RL] = n;
+      rec[LAT_Z * g.RL] = z;
+    }
+  }
+}
 #undef FTRL_TILE_READ_GROUP
 
 // The whole FFM update of a block: ONE launch on the main stream.  Workgroup ranges:
@@ -446,12 +649,30 @@ __global__ __launch_bounds__(64 * tile_waves(NF)) void ffm_update_all_kernel(Mod
   r -= side_blocks;
   if (r < ng) { ffm_coop_items<NF, WAVES>(m, s, r, ng, T, R, lds_coop); return; }
   r -= ng;
-  if (r < nt) { ffm_tile_items<NF>(m, s, r * WAVES + wv, nt * WAVES, T, R); return; }
+  if (r < nt) {
+#ifndef FFM_EXP_NO_RANGE_A
+    ffm_range_items_a<NF>(m, s, r * WAVES + wv, nt * WAVES, T, R);
+#endif
+    ffm_tile_items<NF>(m, s, r * WAVES + wv, nt * WAVES, T, R);
+    return;
+  }
   r -= nt;
   if (r < ns) { ffm_small_body(m, rows, s, few_only, r, ns); return; }
   r -= ns;
   if (r < nw) { ffm_generic_body(m, rows, s, 1, r, nw); return; }
   loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - nw, loss_blocks);
+}
+// The longest features' pass B and their join (launched after ffm_update_all_kernel when the block is
+// large enough to have any; both return at once when it has none).
+template <int NF>
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_super_b_kernel(ModelDev m, Scratch s) {
+  __shared__ __attribute__((aligned(16))) float lds_T[kUpdWaves][kTileT * kTileRow];
+  __shared__ float4 lds_R[kUpdWaves][kTileNR * kTileT * 4 * NF];
+  const unsigned wv = wave_uniform(threadIdx.x >> 6);
+  ffm_range_items_b<NF>(m, s, blockIdx.x * kUpdWaves + wv, gridDim.x * kUpdWaves, lds_T[wv], lds_R[wv]);
+}
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_super_join_kernel(ModelDev m, Scratch s) {
+  ffm_range_join(m, s, blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6), gridDim.x * kUpdWaves);
 }
 
 }  // namespace ftrl_dev

@@ -8,6 +8,8 @@ floating-point slack is on double logloss sums, where device exp/log may differ 
 last ulp: |gpu - cpu| <= 1e-12 * max(1, |cpu|) per row summed, stated as LOSS_RTOL below.  The
 north-star bound (epoch logloss within 1e-4 of the reference CPU path) is asserted on top.
 """
+import os
+
 import numpy as np
 import pytest
 import torch  # noqa: F401  -- first: torch bundles its own HIP runtime; loading it before the
@@ -16,7 +18,7 @@ import torch  # noqa: F401  -- first: torch bundles its own HIP runtime; loading
 import ftrl_ffm_amd as fa
 from ftrl_ffm_amd import synth
 from oracle.pyoracle import CpuModel, Csr
-from util import (DEFAULT_HP, STRESS_HP, STATE_KEYS, assert_bitwise, assert_state_bitwise,
+from util import (DEFAULT_HP, GOLDEN, STRESS_HP, STATE_KEYS, assert_bitwise, assert_state_bitwise,
                   bundled_rows, golden_cases, load_case, make_cpu, rand_state)
 
 pytestmark = pytest.mark.gpu
@@ -227,6 +229,107 @@ def test_update_launch_folds_every_class_of_feature(k):
         else:
             assert abs(sg - so) <= 1e-9 * max(1.0, abs(so))
     assert_state_bitwise(e.get_state(), o.get_state(), "k=%d" % k)
+    e.close()
+
+
+@pytest.mark.parametrize("hp_name", ["default", "stress"])
+@pytest.mark.parametrize("occurrences", [1, 2], ids=["once_only_in_row_refresh", "refresh_kernel"])
+@pytest.mark.parametrize("mt", ["FFM", "FM"])
+def test_g1_weight_formula_pinned_on_the_device(mt, occurrences, hp_name):
+    """G1 (SURVEY.md 8c): FtrlModel::maybe_zero_weight (ftrl_model.h:28-33) on the reference's own
+    grid of (n, z) -- z = 0, |z| = l1, nextafter(l1), sgn(0) = -1 (tests/test_utils.cpp:13-18) -- for
+    both hyper-parameter sets, evaluated BY THE DEVICE: the 2010 pairs are injected as linear and as
+    latent accumulators, one block touches each of them (once: the row kernel refreshes them; twice:
+    ffm_refresh_kernel / the FM row kernel does), and the w the engine stored -- the refresh writes
+    W(n_0, z_0) before the forward, the update never writes w -- must be the golden w bit for bit."""
+    z = np.load(os.path.join(GOLDEN, "g1_scalars.npz"))
+    gn, gz, want = z["n"], z["z"], z["w_" + hp_name]
+    hp = dict(zip(("w_alpha", "w_beta", "w_l1", "w_l2"), [float(v) for v in z["hp_" + hp_name]]))
+    N = len(gn)
+    if mt == "FFM":
+        F, k, P = 2, 4, 256  # field 0: ids [0, P), field 1: ids [P, 2P); touched: the other field's slot
+        nf = 2 * P
+    else:
+        F, k, P = 1, 8, 252  # every factor of ids [0, P)
+        nf = N               # (the linear pairs need N features)
+    nf = max(nf, N)
+    o = CpuModel("oracle", mt, nf, F, k, **hp)
+    st = o.zero_state()
+    rng = np.random.default_rng(3)
+    st["vec_w"][...] = rng.normal(0, 0.02, st["vec_w"].shape).astype(np.float32)
+    st["lin_w"][...] = rng.normal(0, 0.02, st["lin_w"].shape).astype(np.float32)
+    st["lin_n"][:N], st["lin_z"][:N] = gn, gz
+    L = st["vec_n"].shape[1]
+    if mt == "FFM":
+        slots = [(i, (1 if i < P else 0) * k + f) for i in range(2 * P) for f in range(k)]
+    else:
+        slots = [(i, f) for i in range(P) for f in range(k)]
+    idx = np.arange(len(slots)) % N  # (the grid, repeated where there are more touched elements than pairs)
+    rows_i = np.array([a for a, _ in slots]), np.array([b for _, b in slots])
+    st["vec_n"][rows_i] = gn[idx]
+    st["vec_z"][rows_i] = gz[idx]
+    e = fa.Engine(mt, nf, F, k, skip_init=True, max_batch_rows=4096, max_row_nnz=16, **hp)
+    e.set_state(st)
+    rows, labels = [], []
+    if mt == "FFM":
+        for r in range(P):
+            rows += [[(0, r, 1.0), (1, P + r, 0.5)]] * occurrences
+    else:
+        for r in range(P // 2):
+            rows += [[(0, 2 * r, 1.0), (0, 2 * r + 1, 0.5)]] * occurrences
+    # ... and every linear pair: 8 features per row
+    for b in range(0, N, 8):
+        ids = list(range(b, min(N, b + 8)))
+        if mt == "FFM":  # (one entry per field and row keeps the FFM slots above untouched by these rows)
+            rows += [[(0 if i < P else 1, i, 1.0)] for i in ids if i < 2 * P] * occurrences
+        else:
+            rows += [[(0, i, 1.0) for i in ids]] * occurrences
+    labels = [r % 2 for r in range(len(rows))]
+    csr = Csr.from_rows(rows, labels)
+    e.train_batch(csr)
+    got = e.get_state()
+    n_lin = min(N, 2 * P) if mt == "FFM" else N
+    assert_bitwise(got["lin_w"][:n_lin], want[:n_lin], "%s lin_w = W(n, z)" % mt)
+    assert_bitwise(got["vec_w"].reshape(nf, L)[rows_i], want[idx], "%s vec_w = W(n, z)" % mt)
+    assert np.count_nonzero(want) > 500 and np.count_nonzero(want == 0) > 10  # both branches of the formula
+    e.close()
+
+
+@pytest.mark.parametrize("super_min", ["default", "257"], ids=["workgroup_per_giant", "ranges_across_the_chip"])
+@pytest.mark.parametrize("k", [4, 16])
+def test_giant_features_fold_the_same_either_way(super_min, k, monkeypatch):
+    """Features with more than 256 occurrences in a block are folded by the waves of one workgroup
+    together (a tile per wave and super-step), the longest ones (FFM_SUPER_MIN, 2048 by default) as
+    ranges all over the chip through global partial sums and two more launches: the same tree, so
+    the oracle's bits either way -- with n near 0 (ffm.cpp:118's NaNs), a feature in every row, rows
+    that lack fields (empty tiles), and blocks whose last tile / range is partial."""
+    if super_min != "default":
+        monkeypatch.setenv("FFM_SUPER_MIN", super_min)
+    rng = np.random.default_rng(41 + k)
+    F, per = 6, 12
+    nf = F * per
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o, n_hi=0.02)
+    st["vec_n"][rng.random(st["vec_n"].shape) < 0.2] = 0.0
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=3000, **STRESS_HP)
+    e.set_state(st)
+    g = synth.Generator(F, nf, "zipf", seed=13)
+    for n in (3000, 1531, 700):
+        blk = g.block(n)
+        blk.feat[::F] = 0  # field 0's entry of every row: one feature with n occurrences
+        # a third of the rows lose their field-2 entry: the slots for partner field 2 skip those rows
+        keep = np.ones(blk.nnz, bool)
+        keep[2::F] = rng.random(n) > 0.33
+        per_row = np.add.reduceat(keep.astype(np.int64), blk.row_ptr[:-1].astype(np.int64))
+        blk = synth.Block(np.concatenate([[0], np.cumsum(per_row)]).astype(np.int32), blk.field[keep].copy(),
+                          blk.feat[keep].copy(), blk.val[keep].copy(), blk.label)
+        lo, _ = o.train_batch(blk)
+        lg, _ = e.train_batch(blk)
+        assert_bitwise(lg, lo, "super_min=%s k=%d logits of a %d-row block" % (super_min, k, n))
+    so = o.get_state()
+    assert np.isnan(so["vec_z"]).any() and np.isfinite(so["vec_z"]).any()
+    assert_state_bitwise(e.get_state(), so, "super_min=%s k=%d" % (super_min, k))
     e.close()
 
 

@@ -169,26 +169,50 @@ def cpu_baseline(args, gen_kwargs):
         tried[threads] = rows / sec
         del m
     best_t = max(tried, key=tried.get)
-    return {"value": round(tried[best_t], 1), "unit": "samples/s", "cores": best_t,
-            "kind": "reference" if kind == "ref" else "port",
-            "sample": "%d rows, %s F=%d k=%d nnz=%d Zipf(1.1), n_feats=%d, warm state; %s at n_threads in "
-                      "{1, 8, all}: %s; best reported; host has %d cores" % (
-                          rows, MODEL, N_FIELDS, N_FACTORS, N_FIELDS, n_feats,
-                          "the reference's FtrlOffline::one_epoch loop over its own model "
-                          "(oracle/_ref)" if kind == "ref" else "oracle fo_train_rows_threaded",
-                          ", ".join("%dT=%.0f/s" % kv for kv in sorted(tried.items())), ncpu)}
+    out = {"value": round(tried[best_t], 1), "unit": "samples/s", "cores": best_t,
+           "kind": "reference" if kind == "ref" else "port",
+           "sample": "%d rows, %s F=%d k=%d nnz=%d Zipf(1.1), n_feats=%d, warm state; %s at n_threads in "
+                     "{1, 8, all}: %s; best reported; host has %d cores" % (
+                         rows, MODEL, N_FIELDS, N_FACTORS, N_FIELDS, n_feats,
+                         "the reference's FtrlOffline::one_epoch loop over its own model "
+                         "(oracle/_ref)" if kind == "ref" else "oracle fo_train_rows_threaded",
+                         ", ".join("%dT=%.0f/s" % kv for kv in sorted(tried.items())), ncpu)}
+    # The same loop at the largest model this host holds comfortably ("the largest
+    # n_feats that fits"): its state then lives in DRAM instead of the caches, and a mutex per feature
+    # is rarely contended.  Zero-filled state (the harness sizes the reference's members itself: its
+    # constructor takes ~32 us per weight), so the latent part is dead as in a fresh model -- the loop
+    # does the same work per row either way (no branch in ffm.cpp:90-136 depends on the values).
+    if args.cpu_big_feats > 0 and MODEL == "FFM":
+        try:
+            import psutil
+            avail = psutil.virtual_memory().available
+        except Exception:  # noqa: BLE001
+            avail = 0
+        big = args.cpu_big_feats - args.cpu_big_feats % N_FIELDS
+        need = big * (N_FIELDS * N_FACTORS + 1) * 4 * 3 * 1.3
+        if avail and need > avail * 0.6:
+            big = int(avail * 0.6 / ((N_FIELDS * N_FACTORS + 1) * 12 * 1.3))
+            big -= big % N_FIELDS
+        if big >= 10 * n_feats:
+            gb = synth.Generator(N_FIELDS, big, **gen_kwargs)
+            blk_b = gb.block(args.cpu_big_rows)
+            mb = CpuModel(kind, MODEL, big, N_FIELDS, N_FACTORS)
+            sec, _ = mb.train_rows_threaded(blk_b, best_t)
+            out["large_model"] = {"value": round(args.cpu_big_rows / sec, 1), "unit": "samples/s", "cores": best_t,
+                                  "n_feats": big, "state_GB": round(big * (N_FIELDS * N_FACTORS + 1) * 12 / 1e9, 1),
+                                  "rows": args.cpu_big_rows,
+                                  "note": "same loop, same thread count, zero-filled state (fresh model)"}
+            del mb
+    return out
 
 
 def spawn_ranks(n):
     """One rank per GPU through torch.distributed.run, as the driver would launch them
     (rendezvous on 127.0.0.1, a free port); returns the launcher's exit code."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # (--standalone: the launcher picks a free port itself -- no bind-then-close race)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+           "--nnodes=1", "--nproc-per-node", str(n), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
     return subprocess.call(cmd, env=env)
@@ -214,9 +238,23 @@ def block_logloss_cost(rows):
     return best[1] if best else None
 
 
-def latest_pmc_summary():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.json")))
-    return files[-1] if files else None
+def workload_key(config, dist, state, rows, n_feats, n_shards):
+    """What identifies the block stream a kernel's counters were collected on."""
+    return "%s|%s|%s|rows=%d|n_feats=%d|shards=%d" % (config, dist, state, rows, n_feats, n_shards)
+
+
+def matching_pmc_summary(key):
+    """The newest committed PMC summary (tools/summarize_profile.py) whose capture ran THIS workload:
+    the summary records the workload key of the bench line printed under the profiler."""
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary*.json")), reverse=True):
+        try:
+            with open(fn) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("_capture", {}).get("workload_key") == key:
+            return fn, d
+    return None, None
 
 
 def main():
@@ -231,6 +269,9 @@ def main():
     ap.add_argument("--state", default="warm", choices=["warm", "fresh"])
     ap.add_argument("--n-blocks", type=int, default=0, help="distinct synthetic blocks cycled (default 64)")
     ap.add_argument("--cpu-rows", type=int, default=100000)
+    ap.add_argument("--cpu-big-feats", type=int, default=2_000_000,
+                    help="second CPU-baseline leg at this many features (0: off); shrunk to fit host RAM")
+    ap.add_argument("--cpu-big-rows", type=int, default=60000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident leg")
@@ -638,6 +679,7 @@ def main():
                                     "%d distinct blocks streamed from %s host memory (H2D in the timed region)"
                                     % (n_blocks, "page-locked" if zero_copy else "pageable")
                                     if host_leg else "blocks resident in HBM (no H2D)"),
+                "workload_key": workload_key(args.config, args.dist, args.state, rows, n_feats, n_shards),
                 "rows_per_step": rows, "n_feats": n_feats, "n_feats_reduced_to_fit": reduced,
                 "n_blocks": n_blocks,
                 "sharding": "field-pair x%d (%s), one all-reduce of %d partial logits per step"
@@ -666,12 +708,11 @@ def main():
             avg_s = kms / 1000.0 / max(klaunches, 1)
             achieved = share / avg_s / 1e9
             traffic = None
-            pmc = latest_pmc_summary()
-            if pmc and world == 1 and not emu and not args.n_feats and not args.rows and args.config == "c5":
-                with open(pmc) as f:  # rocprofv3 --pmc passes of this same command (tools/)
-                    for name, v in json.load(f).items():
-                        if name.split("<")[0] == kname.split("<")[0]:
-                            traffic = v["hbm_bytes_per_launch"]
+            pmc, pmc_d = matching_pmc_summary(out["config"]["workload_key"]) if world == 1 and not emu else (None, None)
+            if pmc_d:  # rocprofv3 --pmc passes of this same workload (tools/profile_round.sh)
+                for name, v in pmc_d.items():
+                    if not name.startswith("_") and name.split("<")[0] == kname.split("<")[0]:
+                        traffic = v["hbm_bytes_per_launch"]
             out["roofline"] = {
                 "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
@@ -683,7 +724,8 @@ def main():
                                "frac": round(out["step_algorithmic_GBps"] / PEAK_HBM_GBPS, 4),
                                "bytes_per_row": int(bytes_row)},
                 "note": "traffic = bytes leaving the L2 (Infinity-Cache hits included, FETCH_SIZE x2 for "
-                        "float4 record streams: tools/summarize_profile.py); "
+                        "float4 record streams: tools/summarize_profile.py), from the committed capture of "
+                        "this same workload (config.workload_key), else null; "
                         "warm-up spans of all kernels are in other_kernels",
             }
             # the other big kernels, from the fully timed warm-up launches (same accounting)

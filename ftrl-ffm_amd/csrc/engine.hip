@@ -257,6 +257,8 @@ struct ffm_engine {
   static constexpr int kSets = 4;
   Scratch sc[kSets]{};
   int cur = 0;                 // set of the block being trained
+  bool cur_prepared = false;   // ... was grouped ahead (ev_grouped[cur] marks the end of its grouping)
+  int *h_super = nullptr;      // [kSets] page-locked: Scratch::n_super of every set, as the host reads it
   // groupings made ahead by ffm_engine_prepare_device, oldest first (at most kSets - 1)
   int n_prepared = 0;
   int prepared_set[kSets] = {};
@@ -269,6 +271,7 @@ struct ffm_engine {
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
   hipStream_t copy = nullptr;  // the upload kernel's stream: prep, or aux3 for long steps (ffm_engine_create)
   bool own_sort = false;        // the grouping's sort: kernels_sort.h (short steps) or rocPRIM Onesweep (ffm_engine_create)
+  int sort_grid_cap = 1;        // workgroups of the one-launch sort the device holds at once (its grid barrier needs them all)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
   // Scheduling of a look-ahead grouping (FFM_PREP_WINDOW=0 turns it off): the block being
   // prepared will start training when its predecessor's update ends; its grouping is made to
@@ -577,6 +580,7 @@ void ffm_engine_destroy(ffm_engine *e) {
     if (e->ev_set_free[i]) (void)hipEventDestroy(e->ev_set_free[i]);
   }
   if (e->h_pulled) (void)hipHostFree(e->h_pulled);
+  if (e->h_super) (void)hipHostFree(e->h_super);
   if (e->prep) (void)hipStreamDestroy(e->prep);
 
   if (e->aux3) (void)hipStreamDestroy(e->aux3);
@@ -818,9 +822,17 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&tmp, e->sort_tmp_bytes));
     e->d_sort_tmp[0] = tmp;
   }
+  {
+    TRY_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->h_super), sizeof(int) * ffm_engine::kSets, hipHostMallocMapped));
+    std::memset(e->h_super, 0, sizeof(int) * ffm_engine::kSets);
+    int *d_super = nullptr;
+    TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_super), e->h_super, 0));
+    s.n_super = d_super;
+  }
   for (int si = 1; si < ffm_engine::kSets; si++) {
     Scratch &t = e->sc[si];
     t = s;  // shared: head/next/rowtab/haux/hmeta/logit/tg/loss/svx
+    t.n_super = s.n_super + si;
     TRY_ALLOC(e->alloc(&t.key, E));
     TRY_ALLOC(e->alloc(&t.skey, E));
     TRY_ALLOC(e->alloc(&t.row_of, E));
@@ -849,27 +861,34 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipMemsetAsync(t.counters, 0, kNumCounters * sizeof(int), e->stream));
   }
   TRY_HIP(hipStreamCreateWithFlags(&e->prep, hipStreamNonBlocking));
-  // Two choices that depend on how long a step of this engine is (estimated like the update phase in
-  // ffm_engine_train_update_device, from the largest block the engine was sized for):
-  // * where the upload kernel runs.  Beside the grouping on the prep queue it costs a long step ~30 us
-  //   (0.990 -> 0.957 ms at FFM 39 x 16 with the launch knocked out): it sits between two groupings and
-  //   lands on the step boundary.  On the longest chains' stream (idle once they end) it runs in the tail
-  //   of the update phase instead: 0.990 -> 0.960 ms.  Steps under ~0.5 ms (C2, C3, FM) measured 1-3 %
-  //   slower that way, and a shard rank's chain kernel fills that stream to the end of the step.
-  // * which sort the grouping uses.  Short steps wait for the look-ahead queue's chain of ~17 launches
-  //   one to one (FM k = 64: 0.32 ms per step of which 0.23 ms are its two kernels) and take the
-  //   one-launch sort of kernels_sort.h (FM 0.323 -> 0.294 ms, FFM 8 x 16 at 4096 rows 0.139 -> 0.122);
-  //   a long FFM step is saturated by its row kernel, a sort that actually runs beside it slows it
-  //   (0.950 -> 0.993 ms), and the library sort's 1024-thread workgroups -- which only find room in
-  //   the gaps -- are the better neighbour.  FFM 39 x 4 is the crossover (no difference).
+  // Which sort the grouping uses depends on how long a step of this engine is (estimated from the
+  // largest block the engine was sized for).  Short steps wait for the look-ahead queue's chain of ~17
+  // launches one to one (FM k = 64: 0.32 ms per step of which 0.23 ms are its two kernels) and take the
+  // one-launch sort of kernels_sort.h (FM 0.323 -> 0.294 ms, FFM 8 x 16 at 4096 rows 0.139 -> 0.122); a
+  // long FFM step is saturated by its row kernel, a sort that actually runs beside it slows it (r05:
+  // 1.048 -> 1.094 ms), and the library sort's 1024-thread workgroups -- which only find room in the
+  // gaps -- are the better neighbour.  FFM 39 x 4 is the crossover (no difference).
+  // The upload kernel runs on the prep queue, ahead of the block's grouping.  (Round 4 moved it, for
+  // long steps, behind the update's chain kernel on that kernel's stream; the update is one launch on
+  // the main stream now and that stream is otherwise empty: 1.060 ms there, 1.048 ms on the prep
+  // queue.)
   {
     const double per_row = e->max_rows > 0 ? static_cast<double>(e->max_nnz) / e->max_rows : 0.0;
     const double phase_us = static_cast<double>(e->max_nnz) * std::max(0.0, per_row - 1.0) * m.n_factors / 0.44e6;
     const bool ffm4 = m.type == FFM_MODEL_FFM && m.n_factors % 4 == 0;
-    const bool long_step = ffm4 && m.n_shards == 1 && phase_us >= 200.0;
-    e->copy = long_step ? e->aux3 : e->prep;
+    e->copy = e->prep;
     e->own_sort = !(ffm4 && phase_us / std::max(1, m.n_shards) >= 100.0);  // (a shard does 1/n_shards of the pairs)
     if (const char *sv = std::getenv("FFM_OWN_SORT")) e->own_sort = std::atoi(sv) != 0;
+    // the one-launch sort meets at a grid barrier: never more workgroups than the device holds of it,
+    // and only on the architecture its hand-over of data between workgroups was validated on
+    {
+      hipDeviceProp_t prop;
+      TRY_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
+      int per_cu = 0;
+      TRY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, group_sort_kernel, kSortThreads, 0));
+      e->sort_grid_cap = std::max(1, per_cu * prop.multiProcessorCount);
+      if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && std::strncmp(prop.gcnArchName, "gfx942", 6) != 0) e->own_sort = false;
+    }
   }
   for (int i = 0; i < ffm_engine::kSets; i++) {
     TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));
@@ -1011,6 +1030,10 @@ static int check_device_errors(ffm_engine *e) {
   if (flags & ERR_FIELD_MAP)
     return fail(FFM_E_INVALID, "an entry's feature id lies outside its field's id range (field_start): "
                                "its block was not trained");
+  if (flags & ERR_SORT_BARRIER)
+    return fail(FFM_E_DEVICE, "the grouping's one-launch sort could not get its workgroups on the device "
+                              "together (grid barrier timed out): its block was not trained; FFM_OWN_SORT=0 "
+                              "selects the library sort");
   if (flags) return fail(FFM_E_DEVICE, "device error flags " + std::to_string(flags));
   return FFM_OK;
 }

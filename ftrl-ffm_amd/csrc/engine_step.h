@@ -86,8 +86,9 @@ static bool same_block(const Rows &a, const Rows &b) {
 // Zeroes the grouping's counters and per-row field masks (a kernel: hipMemsetAsync costs the
 // submitting thread ~100 us per call here, a launch ~5).
 __global__ __launch_bounds__(256) void group_clear_kernel(int *counters, int n_counters,
-                                                          unsigned long long *rowmask, int n_mask) {
+                                                          unsigned long long *rowmask, int n_mask, int *n_super) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (tid == 0) __hip_atomic_store(n_super, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (int i = tid; i < n_counters; i += stride) counters[i] = 0;
   for (int i = tid; i < n_mask; i += stride) rowmask[i] = 0ull;
 }
@@ -101,7 +102,7 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
     ScopedTimer tm_clear("grouping:clear");
     const int n_mask = rows.nnz > 0 && sc.rowmask ? 2 * rows.n_rows : 0;
     hipLaunchKernelGGL(group_clear_kernel, dim3(std::max(1, std::min(64, cdiv(n_mask, 1024)))), dim3(256), 0, st,
-                       sc.counters, kNumCounters, sc.rowmask, n_mask);
+                       sc.counters, kNumCounters, sc.rowmask, n_mask, sc.n_super);
   }
   if (rows.nnz > 0) {
     const int nnz = rows.nnz;
@@ -115,9 +116,9 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
         const size_t n_al = (static_cast<size_t>(nnz) + 63) & ~static_cast<size_t>(63);
         unsigned char *tmp = static_cast<unsigned char *>(e->d_sort_tmp[set]);
         SortJob job{sc.key, sc.skey, sc.occ, reinterpret_cast<unsigned *>(tmp), reinterpret_cast<int *>(tmp + 4 * n_al),
-                    reinterpret_cast<unsigned *>(tmp + 8 * n_al), sc.counters + CNT_SORT_BAR, nnz,
-                    static_cast<int>((e->sort_bits + 7) / 8)};
-        hipLaunchKernelGGL(group_sort_kernel, dim3(sort_grid(nnz)), dim3(kSortThreads), 0, st, job);
+                    reinterpret_cast<unsigned *>(tmp + 8 * n_al), sc.counters + CNT_SORT_BAR,
+                    sc.counters + CNT_ERROR, sc.err, nnz, static_cast<int>((e->sort_bits + 7) / 8)};
+        hipLaunchKernelGGL(group_sort_kernel, dim3(sort_grid(nnz, e->sort_grid_cap)), dim3(kSortThreads), 0, st, job);
       } else
       HIP_TRY(rocprim::radix_sort_pairs<GroupSortConfig>(e->d_sort_tmp[set], bytes, sc.key, sc.skey,
                                         rocprim::counting_iterator<int>(0), sc.occ,
@@ -205,6 +206,7 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
     for (int i = 0; i < e->n_prepared; i++) HIP_TRY(hipEventRecord(e->ev_set_free[e->prepared_set[i]], e->prep));
     e->n_prepared = 0;
   }
+  e->cur_prepared = use_prepared;
   if (use_prepared) {
     e->cur = e->prepared_set[0];
     for (int i = 1; i < e->n_prepared; i++) {
@@ -313,7 +315,12 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       LAUNCH_ON(e, sst, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
       HIP_TRY(hipEventRecord(e->ev_join, sst));
     }
-    if (rows.nnz >= e->m.super_min) {
+    // (the grouping counted the block's longest features into page-locked host memory; it ran blocks
+    // ahead, so its event has usually completed and the count can be read: none -> no launches)
+    bool supers = rows.nnz >= e->m.super_min;
+    if (supers && e->cur_prepared && hipEventQuery(e->ev_grouped[e->cur]) == hipSuccess && e->h_super[e->cur] == 0)
+      supers = false;
+    if (supers) {
       // the longest features' ranges: second pass (root differences) and the join of their tiles
       const int gg = e->grid_giant;
       e->prof_begin(K_LATENT_UPDATE_GIANT, e->stream);

@@ -156,6 +156,8 @@ struct Scratch {
                                 //      live touch / whose first live touch is plain / with a :118 touch
   float *gcap;                  // [(nnz / giant_min + 2) * row_len] FFM: n_t at an element's first :118 touch
   int *counters;  // [kNumCounters] CNT_* below
+  int *n_super;   // [1] in page-locked HOST memory: how many features of the block have super_min
+                  //     occurrences or more -- so that the host can skip their two extra launches
   int *err;       // [1] sticky ERR_* flags, shared by all sets: what ffm_engine_sync reports
   int *head;      // [n_rows*n_fields] first entry of each field in each row (FFM), -1 if none
   int *next;      // [nnz] next entry of the same row with the same field, -1 at the end
@@ -237,6 +239,6 @@ enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain pa
 #define FFM_SMALL_MAX 8
 #endif
 constexpr int kSmallMax = FFM_SMALL_MAX;  // occurrences per block up to which a feature takes the "small" path
-enum { ERR_ROW_TOO_LONG = 1, ERR_FIELD_MAP = 2 };
+enum { ERR_ROW_TOO_LONG = 1, ERR_FIELD_MAP = 2, ERR_SORT_BARRIER = 4 };
 
 }  // namespace ftrl_dev

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
       // range of kRange occurrences (kernels_tile.h: the ranges are folded side by side)
       const int gi = slot[6];
       s.giant[gi] = u;
+      if (c >= m.super_min) __hip_atomic_fetch_add(s.n_super, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       const int n_seg = (c + kSeg - 1) / kSeg, n_rng = (c + kRange - 1) / kRange;
       s.gseg[gi] = atomicAdd(&s.counters[CNT_NSEG], n_seg);
       const int rb = atomicAdd(&s.counters[CNT_NRANGE], n_rng);

@@ -40,6 +40,8 @@ struct SortJob {
   int *tval;            // [n] scratch
   unsigned *cnt;        // [256][gridDim.x] scratch
   int *bar;             // grid barrier word, zero at launch (the grouping's counters are cleared per block)
+  int *block_err;       // the block's CNT_ERROR word and the engine's sticky flags: where a barrier that
+  int *err;             //   never completes reports ERR_SORT_BARRIER (the block is then skipped as a whole)
   int n, passes;
 };
 
@@ -48,6 +50,12 @@ struct SortJob {
 // write-back or an invalidate of the whole L2 of the XCD it runs on, ~450 of each per block with 64
 // workgroups and seven barriers -- beside a row kernel that lives on that L2 (measured: row kernel
 // 518 -> 577 us, the step 0.95 -> 1.01 ms with fences).
+// MEMORY-MODEL NOTE: relaxed agent-scope atomics order nothing in the HIP memory model; handing data
+// over with them plus s_waitcnt is formally a data race.  It relies on what gfx942 / gfx950 do: an
+// sc1 store is written through to the memory side before the wave's vmcnt for it retires, and an
+// sc1 load does not hit in a non-coherent L2 line.  ffm_engine_create takes this sort only on the
+// architecture it was validated on (gfx950: tests/test_gpu_parity.py, a 2.5 M-entry four-pass
+// block against the library sort and the oracle); anything else keeps rocPRIM.
 template <class T> __device__ __forceinline__ T coh_load(const T *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -55,17 +63,35 @@ template <class T> __device__ __forceinline__ void coh_store(T *p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Every workgroup of the launch is resident (the grid is at most kSortMaxWgs small workgroups): the
-// usual counter barrier.  __syncthreads() waits for the wave's own stores (vmcnt) before it arrives.
-__device__ __forceinline__ void sort_grid_barrier(int *bar, int n_wg, int &target) {
+// The usual counter barrier.  It needs every workgroup of the launch on the machine at once: the
+// grid is clamped to what the device can hold of this kernel (engine: sort_grid_cap, from
+// hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs) -- other kernels on the device never wait for
+// the sort, so its workgroups all arrive once those drain -- and the spin is BOUNDED: a workgroup
+// that has waited ~a second (CU masks, a partitioned device, ...) raises ERR_SORT_BARRIER, the block
+// is skipped as a whole (CNT_ERROR, like an over-long row) and the caller learns about it at the
+// next sync.  Returns false then; every workgroup leaves within the same bound.
+// __syncthreads() waits for the wave's own stores (vmcnt) before it arrives.
+constexpr int kSortSpinMax = 1 << 22;  // x s_sleep 8 (~0.25 us)
+__device__ __forceinline__ bool sort_grid_barrier(const SortJob &a, int n_wg, int &target) {
+  __shared__ int ok;
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
     target += n_wg;
-    __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+    __hip_atomic_fetch_add(a.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < kSortSpinMax) {
+      __builtin_amdgcn_s_sleep(8);
+      spins++;
+    }
+    ok = spins < kSortSpinMax;
+    if (!ok) {
+      atomicOr(a.block_err, ERR_SORT_BARRIER);
+      atomicOr(a.err, ERR_SORT_BARRIER);
+    }
   }
   __syncthreads();
+  return ok != 0;
 }
 
 // One tile of 256 keys of phase C.  `it` counts the tiles of the pass: the wave counts rotate over
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(kSortThreads) void group_sort_kernel(SortJob a) {
     }
     __syncthreads();
     coh_store(a.cnt + t * W + w, l.hist[0][t]);
-    sort_grid_barrier(a.bar, W, target);
+    if (!sort_grid_barrier(a, W, target)) return;
     // ---- B: thread t owns digit t
     unsigned total = 0u, before = 0u;
     for (int v = 0; v < W; v++) {
@@ -167,13 +193,13 @@ __global__ __launch_bounds__(kSortThreads) void group_sort_kernel(SortJob a) {
         sort_tile(l, it++, base + j * kSortThreads + t < c1, k[j], val[j], shift, kout, vout);
       }
     }
-    if (p + 1 < a.passes) sort_grid_barrier(a.bar, W, target);
+    if (p + 1 < a.passes && !sort_grid_barrier(a, W, target)) return;
   }
 }
 
 // workgroups for n keys: chunks of ~5000 keys (20 tiles), at most 64 (32 / 128 / 16 workgroups for a
 // 320 k-entry block measured 8 / 13 / 35 % slower per FM step: every barrier needs them all resident)
-static inline int sort_grid(int n) { return std::max(1, std::min(kSortMaxWgs, (n + 4999) / 5000)); }
+static inline int sort_grid(int n, int cap) { return std::max(1, std::min(std::min(kSortMaxWgs, cap), (n + 4999) / 5000)); }
 static inline size_t sort_scratch_bytes(size_t n) {
   return 8 * ((n + 63) & ~static_cast<size_t>(63)) + sizeof(unsigned) * 256 * kSortMaxWgs + 256;
 }

@@ -227,11 +227,16 @@ CsrData load_csr(const std::string &path, const std::string &file_type, int n_th
   }
   if (st.st_size == 0) return out;
   CsrStream stream(path, file_type, n_threads);
-  // a token is >= 4 bytes (libsvm) / 6 (libffm), a row at least a few tokens: upper bounds, reserved
-  // once (untouched reserve costs nothing; the arrays grow into it page by page)
+  // a token is >= 4 bytes (libsvm) / 6 (libffm), a row >= 2 ("1\n"): upper bounds, reserved once
+  // (untouched reserve costs nothing where memory is overcommitted; the arrays grow into it page by
+  // page).  Under strict overcommit or a virtual-memory limit the reservation may be refused: the
+  // arrays then simply grow geometrically as they are filled.
   const size_t bytes = static_cast<size_t>(st.st_size), tok = file_type == "libffm" ? 6 : 4;
-  out.field.reserve(bytes / tok); out.feat.reserve(bytes / tok); out.val.reserve(bytes / tok);
-  out.row_ptr.reserve(bytes / 8 + 2); out.label.reserve(bytes / 8 + 1);
+  try {
+    out.field.reserve(bytes / tok); out.feat.reserve(bytes / tok); out.val.reserve(bytes / tok);
+    out.row_ptr.reserve(bytes / 2 + 2); out.label.reserve(bytes / 2 + 1);
+  } catch (const std::bad_alloc &) {
+  }
   // first touch of ~1 GB per million rows is what this loop would otherwise spend its time on: ask for
   // huge pages (512 times fewer faults where transparent huge pages are on "madvise" or "always")
   auto huge = [](void *p, size_t n) {

@@ -128,7 +128,7 @@ void CsrStream::release_chunk() {
   cv_work_.notify_all();
 }
 
-size_t CsrStream::next(size_t want, CsrBlock &out, size_t max_nnz) {
+size_t CsrStream::next(size_t want, CsrBlock &out, size_t max_nnz, bool fixed_capacity) {
   out.clear();
   size_t got = 0;
   while (got < want) {
@@ -161,10 +161,10 @@ size_t CsrStream::next(size_t want, CsrBlock &out, size_t max_nnz) {
     while (take > 0 && out.feat.size() + entries(take) > max_nnz) { take--; cut = true; }
     if (take == 0) {
       if (got > 0) break;
-      // a single row beyond the budget: `out` may be a page-locked ring entry whose vectors are
-      // registered at their current capacity -- growing them would free pages the runtime still
-      // maps -- so the row is refused here instead of being written
-      if (out.feat.capacity() > 0 && entries(1) > out.feat.capacity())
+      // a single row beyond the budget: a page-locked ring entry's vectors are registered at their
+      // size -- growing them would free pages the runtime still maps -- so the row is refused here
+      // instead of being written (the caller says which kind of block `out` is)
+      if (fixed_capacity)
         throw std::length_error("a row has more entries than a block can hold (max_nnz)");
       take = 1;  // (a growable block: the row goes out alone and the model splits or rejects it)
     }

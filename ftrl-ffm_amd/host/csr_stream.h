@@ -27,7 +27,9 @@ class CsrStream {
   CsrStream &operator=(const CsrStream &) = delete;
   // The next `want` rows (fewer at the end of the file) into `out` (replaced); 0 at the end.
   // max_nnz: stop early rather than exceed that many entries (a block must fit one engine call).
-  size_t next(size_t want, CsrBlock &out, size_t max_nnz = static_cast<size_t>(-1));
+  // fixed_capacity: `out` must not grow (a page-locked ring entry, registered at its size): a single
+  // row with more entries than max_nnz is then refused (std::length_error) instead of going out alone.
+  size_t next(size_t want, CsrBlock &out, size_t max_nnz = static_cast<size_t>(-1), bool fixed_capacity = false);
   // The next parsed chunk in place, no copy (the whole-file loader): valid until release_chunk().
   // Not to be mixed with a partly consumed chunk of next().  false at the end of the file.
   bool acquire_chunk(const CsrPart **part, const std::vector<int64_t> **row_ptr);

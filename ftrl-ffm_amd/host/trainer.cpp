@@ -169,7 +169,7 @@ void FtrlOnline::run_train_file() {
     size_t got;
     if (ring) {
       CsrBlock &rb = ring_->acquire();
-      got = train_stream_->next(std::min(want, ring_->row_capacity()), rb, ring_->nnz_capacity());
+      got = train_stream_->next(std::min(want, ring_->row_capacity()), rb, ring_->nnz_capacity(), true);
       if (got == 0) break;
       ring_->handed_over(model_ptr->train_block_pinned(rb));
     } else {
@@ -236,7 +236,7 @@ void Evaluator::run() {
     size_t got;
     if (ring) {
       CsrBlock &rb = ring_->acquire();
-      got = stream_->next(std::min<size_t>(batch_, ring_->row_capacity()), rb, ring_->nnz_capacity());
+      got = stream_->next(std::min<size_t>(batch_, ring_->row_capacity()), rb, ring_->nnz_capacity(), true);
       if (got == 0) break;
       ring_->handed_over(eval_model->predict_block_async(rb, true));
     } else {

@@ -19,11 +19,20 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-profile --no-resident > $OUT/pmc_write.json 2>/dev/null
 python3 tools/timeline.py $OUT/trace > $OUT/timeline.txt 2>&1
 python3 tools/step_gaps.py $OUT/trace > $OUT/step_gaps.txt 2>&1
+# the other workloads: kernel stats and HBM counters of their own (bench.py attaches a traffic figure
+# only to runs of the workload it was captured on)
+pmc_of() {  # <tag> <bench args...>
+  tag=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_trace -o bench -- python3 bench.py "$@" --steps 60 --warmup 6 --no-cpu-baseline --no-resident > /dev/null 2>&1
+  cp $OUT/${tag}_trace/bench_kernel_stats.csv $OUT/${tag}_kernel_stats.csv 2>/dev/null || cp $(ls $OUT/${tag}_trace/*/*kernel_stats.csv | head -1) $OUT/${tag}_kernel_stats.csv
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$tag -o bench -- python3 bench.py "$@" --steps 8 --warmup 3 --no-cpu-baseline --no-profile --no-resident > $OUT/pmc_fetch_$tag.json 2>/dev/null
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$tag -o bench -- python3 bench.py "$@" --steps 8 --warmup 3 --no-cpu-baseline --no-profile --no-resident > /dev/null 2>&1
+}
 for c in c2 c3 c4; do
   python3 bench.py --config $c > $OUT/$c.json 2> $OUT/$c.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${c}_trace -o bench -- python3 bench.py --config $c --steps 60 --warmup 6 --no-cpu-baseline --no-resident > /dev/null 2>&1
-  cp $OUT/${c}_trace/bench_kernel_stats.csv $OUT/${c}_kernel_stats.csv 2>/dev/null || cp $(ls $OUT/${c}_trace/*/*kernel_stats.csv | head -1) $OUT/${c}_kernel_stats.csv
+  pmc_of $c --config $c
 done
+pmc_of uniform --dist uniform
 python3 bench.py --dist uniform --no-cpu-baseline > $OUT/uniform.json 2>/dev/null
 python3 bench.py --state fresh --no-cpu-baseline > $OUT/fresh.json 2>/dev/null
 for r in 0 1 2 3 4 5 6 7; do python3 bench.py --emulate-shards 8 --emulate-rank $r --steps 40 --warmup 6 --no-profile > $OUT/emu8_rank$r.json 2>/dev/null; done

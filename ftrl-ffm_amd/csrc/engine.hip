@@ -632,6 +632,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   // a shard's row holds ~1/n_shards of the pairs: one wave per row, so that (with the small LDS
   // footprint of short rows) many more rows are in flight per CU
   if (cfg->n_shards > 1) e->row_threads = 64;
+  if (const char *sv = std::getenv("FFM_ROW_THREADS")) e->row_threads = std::max(64, std::min(kRowMaxThreads, std::atoi(sv) / 64 * 64));
   // (the lean once-only kernel of a compact shard holds six waves per SIMD: 1152 workgroups
   // measured 2.5 % per step better than 768 on an 8-GPU rank's blocks)
   if (cfg->n_shards > 1) e->grid_single = 1152;
@@ -952,8 +953,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
       ffm_engine_destroy(e);
       return fail(FFM_E_UNSUPPORTED, "max_row_nnz too large for the 160 KB of LDS per workgroup");
     }
-    if (lds > 32 * 1024) {
-      const int bytes = static_cast<int>(lds);
+    const size_t park_budget = std::getenv("FFM_ROW_PARK_BUDGET") ? static_cast<size_t>(std::atoi(std::getenv("FFM_ROW_PARK_BUDGET"))) : 0;
+    if (lds > 32 * 1024 || park_budget > 32 * 1024) {
+      const int bytes = static_cast<int>(std::max(lds, park_budget));
       TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_row_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));

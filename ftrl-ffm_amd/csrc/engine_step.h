@@ -59,7 +59,8 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
     size_t shmem_park = shmem;
     if (refreshed == 3) {
       static const int park_env = std::getenv("FFM_ROW_PARK") ? std::atoi(std::getenv("FFM_ROW_PARK")) : -1;
-      const size_t base = (shmem + 15) & ~static_cast<size_t>(15), budget = 30 * 1024;
+      static const int budget_env = std::getenv("FFM_ROW_PARK_BUDGET") ? std::atoi(std::getenv("FFM_ROW_PARK_BUDGET")) : 0;
+      const size_t base = (shmem + 15) & ~static_cast<size_t>(15), budget = budget_env > 0 ? budget_env : 30 * 1024;
       long long bytes = park_env >= 0 ? park_env : (base < budget ? static_cast<long long>(budget - base) : 0);
       bytes = std::min<long long>(bytes, 32ll * row_cap * (e->m.row_len / 4));
       bytes = std::min<long long>(bytes, static_cast<long long>(budget) - static_cast<long long>(std::min(base, budget)));

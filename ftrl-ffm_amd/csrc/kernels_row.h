@@ -29,6 +29,10 @@ namespace ftrl_dev {
 #define FFM_ROW_NT 7
 #endif
 constexpr int kRowThreads = 256;
+#ifndef FFM_ROW_MAXT
+#define FFM_ROW_MAXT 256
+#endif
+constexpr int kRowMaxThreads = FFM_ROW_MAXT;  // launch bound of the FFM row kernel (experiments: 512 / 1024)
 constexpr int kTermsCap = 2048;  // most pair terms staged in LDS per pass
 // Terms buffer a row kernel actually needs (a multiple of 4, at most kTermsCap): all pairs of the
 // longest admissible row -- or, on a shard, its entries times the slots of a record -- or the
@@ -265,7 +269,7 @@ __device__ __forceinline__ float wave_add_terms_in_order(const float *terms, int
 // apply the once-only features' update (own_tg, refreshed == 3).  A shard's instantiation leaves all
 // of that out -- and the registers it costs: more rows in flight per SIMD.
 template <bool TRAIN, bool VEC4, bool WHOLE = TRAIN>
-__global__ __launch_bounds__(kRowThreads) FFM_ROW_OCC void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
+__global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(ModelDev m, Rows rows, Scratch s,
                                                               int max_row_nnz, float *out,
                                                               int output_prob, int refreshed,
                                                               int own_tg_arg, int row0, int park_vecs) {

@@ -363,6 +363,7 @@ struct ffm_engine {
   // of serial slots; and of the once-only kernel of a shard
   int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768, grid_giant = 1024;
   bool update_split = false;  // FFM_UPDATE_SPLIT=1: the update launch's ranges as launches of their own (timing aid)
+  int update_order = 210;     // FFM_UPDATE_ORDER: the update launch's big ranges, first range = last digit (0 giant, 1 hot, 2 few)
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
   // slowed the HBM-bound kernels they ran beside up to 4x (refresh of a 65536-row block 70 -> 330 us),
@@ -623,6 +624,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_UPDATE_SPLIT")) e->update_split = sv[0] == '1';
+  if (const char *sv = std::getenv("FFM_UPDATE_ORDER")) e->update_order = std::atoi(sv);
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_WALK")) e->grid_walk = std::max(1, std::atoi(sv));
@@ -658,7 +660,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   m.shard_rank = cfg->shard_rank;
   m.bias_own = 1;
   m.huge_min = kHugeMin;
-  m.giant_min = kGiantMin;
+  m.giant_min = cfg->model_type == FFM_MODEL_FM ? kFmGiantMin : kGiantMin;
+  m.range_len = cfg->model_type == FFM_MODEL_FM ? kFmRange : kRange;
+  m.huge_min = std::min(m.huge_min, m.giant_min - 1);  // (the lists: big <= huge_min < huge < giant_min <= giant)
   m.super_min = kSuperMin;
   if (const char *sv = std::getenv("FFM_SUPER_MIN")) m.super_min = std::max(kGiantMin, std::atoi(sv));
   m.rec_slots = m.n_fields;
@@ -733,10 +737,10 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_ALLOC(e->alloc(&s.huge, E));
   TRY_ALLOC(e->alloc(&s.giant, E / kChainMin + 1));
   TRY_ALLOC(e->alloc(&s.gseg, E / kChainMin + 1));
-  TRY_ALLOC(e->alloc(&s.grange, E / kRange + E / kGiantMin + 2));
+  TRY_ALLOC(e->alloc(&s.grange, E / kFmRange + E / kFmGiantMin + 2));
   {
     // partial sums of the giant features' folds (shared by the scratch sets)
-    const size_t max_segs = E / kSeg + E / kGiantMin + 2, rl = static_cast<size_t>(std::max(1, m.row_len));
+    const size_t max_segs = E / kSeg + E / kFmGiantMin + 2, rl = static_cast<size_t>(std::max(1, m.row_len));
     const bool lat_model = cfg->model_type != FFM_MODEL_LR, ffm_m = cfg->model_type == FFM_MODEL_FFM;
     const size_t chunks = !ffm_m ? 1 : cfg->n_factors <= 64
                               ? (static_cast<size_t>(m.rec_slots) + 64 / cfg->n_factors - 1) / (64 / cfg->n_factors)
@@ -847,7 +851,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_ALLOC(e->alloc(&t.huge, E));
     TRY_ALLOC(e->alloc(&t.giant, E / kChainMin + 1));
     TRY_ALLOC(e->alloc(&t.gseg, E / kChainMin + 1));
-    TRY_ALLOC(e->alloc(&t.grange, E / kRange + E / kGiantMin + 2));
+    TRY_ALLOC(e->alloc(&t.grange, E / kFmRange + E / kFmGiantMin + 2));
     TRY_ALLOC(e->alloc(&t.counters, kNumCounters));
     TRY_ALLOC(e->alloc(&t.occpos, E));
     TRY_ALLOC(e->alloc(&t.uflag, E));

@@ -243,7 +243,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   const bool own_tg = e->own_tg_cur && !logit;
   if (rows.n_rows > 0 && !own_tg)
     LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->sc[e->cur].tg, e->sc[e->cur].loss, logit_out);
-  if (e->m.type == FFM_MODEL_FFM && rows.nnz > 0 && !own_tg)
+  if (!FFM_TILE_ROWTAB && e->m.type == FFM_MODEL_FFM && rows.nnz > 0 && !own_tg)
     LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
   // Everything below runs on the main stream: the update has no long dependent chains (every
   // accumulator is folded by reductions, kernels_fold.h), so nothing needs a queue of its own.
@@ -284,8 +284,13 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // (the ranges' sizes are kept in 256-thread units and scaled to the launch's workgroup size)
     const int nf = tile_nf(e), wpb = tile_waves(nf), scale = wpb / kUpdWaves, threads = 64 * wpb;
     const size_t lds = tile_lds_bytes(nf);
-    const int nt = cdiv(e->grid_hot, scale), ns = flat ? 0 : cdiv(e->grid_small, scale), nw = cdiv(e->grid_walk, scale);
-    const int ng = rows.nnz >= kGiantMin ? e->grid_giant : 0;  // workgroups that fold giant features together
+    // (... and to the block: a workgroup that finds its range's lists empty still costs a dispatch and
+    // a few dependent loads -- 4100 of them were a fifth of a 4096 x 8 block's update)
+    auto sized = [&](int grid, int per_wg, int least) { return std::max(least, std::min(grid, cdiv(rows.nnz, per_wg))); };
+    const int nt = cdiv(sized(e->grid_hot, 32, 64), scale), ns = flat ? 0 : cdiv(sized(e->grid_small, 128, 64), scale);
+    const int nw = cdiv(sized(e->grid_walk, 1024, 16), scale);
+    const int ng = rows.nnz >= kGiantMin ? sized(e->grid_giant, 256, 32) : 0;  // workgroups that fold giant features together
+    const int order = e->update_order;  // (which of the three big ranges the dispatcher sees first)
     const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
     const int side = side_blocks > 0 ? 1 + cdiv(lin_blocks, scale) : 0;
     const int grid = side + ng + nt + ns + nw + lb;
@@ -294,17 +299,17 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       if (e->update_split) { /* (timing aid: one launch per range, each under a name of its own) */           \
         if (ng > 0)                                                                                           \
           LAUNCH(e, K_LATENT_UPDATE_GIANT, (ffm_update_all_kernel<NF>), ng, threads, lds, e->m, rows, e->sc[e->cur], \
-                 0, ng, 0, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                            \
+                 0, ng, 0, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part, order);                         \
         LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), side + nt, threads, lds, e->m, rows, e->sc[e->cur], \
-               side, 0, nt, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                           \
+               side, 0, nt, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part, order);                        \
         if (ns > 0)                                                                                           \
           LAUNCH(e, K_LATENT_UPDATE_FEW, (ffm_update_all_kernel<NF>), ns, threads, lds, e->m, rows, e->sc[e->cur], \
-                 0, 0, 0, ns, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part);                            \
+                 0, 0, 0, ns, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part, order);                         \
         LAUNCH(e, K_LATENT_UPDATE_WALK, (ffm_update_all_kernel<NF>), nw + lb, threads, lds, e->m, rows, e->sc[e->cur], \
-               0, 0, 0, 0, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                             \
+               0, 0, 0, 0, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part, order);                          \
       } else {                                                                                                \
         LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), grid, threads, lds, e->m, rows, e->sc[e->cur], \
-               side, ng, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part);                       \
+               side, ng, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part, order);                  \
       }                                                                                                       \
     } while (0)
     if (nf == 1) FTRL_LAUNCH_ALL(1);       // k >= 16
@@ -325,9 +330,9 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       // the longest features' ranges: second pass (root differences) and the join of their tiles
       const int gg = e->grid_giant;
       e->prof_begin(K_LATENT_UPDATE_GIANT, e->stream);
-      if (nf == 1) hipLaunchKernelGGL(ffm_update_super_b_kernel<1>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
-      else if (nf == 2) hipLaunchKernelGGL(ffm_update_super_b_kernel<2>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
-      else hipLaunchKernelGGL(ffm_update_super_b_kernel<4>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
+      if (nf == 1) hipLaunchKernelGGL(ffm_update_super_b_kernel<1>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, rows, e->sc[e->cur]);
+      else if (nf == 2) hipLaunchKernelGGL(ffm_update_super_b_kernel<2>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, rows, e->sc[e->cur]);
+      else hipLaunchKernelGGL(ffm_update_super_b_kernel<4>, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, rows, e->sc[e->cur]);
       hipLaunchKernelGGL(ffm_update_super_join_kernel, dim3(gg), dim3(kUpdThreads), 0, e->stream, e->m, e->sc[e->cur]);
       e->prof_end(e->stream);
     }
@@ -347,7 +352,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     } else if (e->m.type == FFM_MODEL_FM) {
       if (rows.nnz > 0) {
         LAUNCH(e, K_LATENT_UPDATE, fm_update_kernel, side_blocks + 2048, kUpdThreads, 0, e->m, rows, e->sc[e->cur], fm_in_row, side_blocks);
-        if (rows.nnz >= kGiantMin)  // the giant features' segments joined
+        if (rows.nnz >= e->m.giant_min)  // the giant features' segments joined
           LAUNCH(e, K_LATENT_UPDATE_GIANT, fm_update_join_kernel, 256, kUpdThreads, 0, e->m, e->sc[e->cur]);
       }
       else if (side_blocks > 0)

@@ -59,6 +59,9 @@ struct ModelDev {
   int giant_min;              // ... from which it is listed as "giant" (kGiantMin): FFM -- a workgroup folds one
                               //     together; FM, and FFM from super_min on -- ranges folded all over the chip
   int super_min;              // FFM: occurrences from which a giant feature's ranges are folded side by side
+  int range_len;              // occurrences per range of such a feature (a multiple of kSeg): FFM kRange,
+                              //     FM kFmRange -- an FM touch is three dependent loads and a dozen instructions,
+                              //     its ranges are short so that many waves share one feature
 };
 
 enum { LAT_N = 0, LAT_Z = 1, LAT_W = 2 };
@@ -225,6 +228,7 @@ constexpr int kHugeMin = FFM_HUGE_MIN;
 constexpr int kRangeSegs = FFM_RANGE_SEGS;
 constexpr int kRange = kRangeSegs * kSeg;  // occurrences per range of a giant feature
 constexpr int kGiantMin = kRange + 1;
+constexpr int kFmRange = 64, kFmGiantMin = kFmRange + 1;
 // FFM: from here on one workgroup per (feature, chunk) would be the phase's span again (a feature in
 // every tenth row of a 65536-row block is 400 tiles): ranges all over the chip, two short launches more
 #ifndef FFM_SUPER_MIN

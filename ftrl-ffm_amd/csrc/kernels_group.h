@@ -226,11 +226,11 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
     else if (c < m.giant_min) s.huge[ih] = u;
     else {
       // a giant feature: kSeg-occurrence segment slots for its partial sums, one list entry per
-      // range of kRange occurrences (kernels_tile.h: the ranges are folded side by side)
+      // range of range_len occurrences (kernels_tile.h / kernels_update.h: the ranges are folded side by side)
       const int gi = slot[6];
       s.giant[gi] = u;
       if (c >= m.super_min) __hip_atomic_fetch_add(s.n_super, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const int n_seg = (c + kSeg - 1) / kSeg, n_rng = (c + kRange - 1) / kRange;
+      const int n_seg = (c + kSeg - 1) / kSeg, n_rng = (c + m.range_len - 1) / m.range_len;
       s.gseg[gi] = atomicAdd(&s.counters[CNT_NSEG], n_seg);
       const int rb = atomicAdd(&s.counters[CNT_NRANGE], n_rng);
       for (int r = 0; r < n_rng; r++) s.grange[rb + r] = make_int2(gi, r);

@@ -17,6 +17,10 @@
 #include "engine_types.h"
 #include "kernels_touch.h"
 
+#ifndef FFM_TILE_ROWTAB
+#define FFM_TILE_ROWTAB 1  // (kernels_tile.h: where the hot features' owners take a touch's facts from)
+#endif
+
 namespace ftrl_dev {
 
 // The once-only features' (n, z) stream through the row kernel -- read by the refresh, read again and
@@ -177,7 +181,8 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
         make_int4(__float_as_int(xo), flags | (lds.field[a] << 8), static_cast<int>(woff & 0xffffffff),
                   static_cast<int>(woff >> 32));
   };
-  {
+  if (!FFM_TILE_ROWTAB) {
+    // (rounds 3-4; the hot features' owners read the row table below instead: kernels_tile.h)
     // one fact per (hot entry, slot of its record): the partner fields this shard owns for the
     // entry's field -- all of them when the model is not sharded
     const int span = record_span(m, 1);
@@ -578,9 +583,11 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
     // {tmp_grad, own value} of this row's hot entries, by occurrence position, for their owners
     __syncthreads();
     const float tg = s_tg;
-    for (int a = threadIdx.x; a < nv; a += blockDim.x) {
-      const int op = lds.opos[a];
-      if (op >= 0) s.hmeta[op] = make_float2(tg, lds.val[a]);
+    if (!FFM_TILE_ROWTAB) {
+      for (int a = threadIdx.x; a < nv; a += blockDim.x) {
+        const int op = lds.opos[a];
+        if (op >= 0) s.hmeta[op] = make_float2(tg, lds.val[a]);
+      }
     }
     // refreshed == 3: the (n, z) update of the features that occur nowhere else in the block
     // (FFM::update_vector_nz, ffm.cpp:90-136, for their slots), right here: this row is their only

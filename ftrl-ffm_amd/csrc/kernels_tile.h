@@ -61,9 +61,18 @@ __device__ __forceinline__ int tile_hiword(int off_hi, int flags) {
 struct TileWeights {  // a loader lane's four 16-byte quads of one tile's partner weights
   float4 q0, q1, q2, q3;
 };
-struct TileFacts {  // what a stager lane holds of one tile: NF facts of its touch and the touch's meta
+// Where the stager takes a touch's facts from (FFM_TILE_ROWTAB):
+//  1  the row's per-field table (s.rowtab, 16 B per (row, field): 5 MB per 8192 x 39 block, read by
+//     every entry of the row: it stays on-die) through the occurrence's {entry, row} (s.occ2);
+//  0  rounds 3-4: an occurrence-ordered fact stream the row kernel writes per (hot entry, field)
+//     (s.haux, 104 MB per block from and to HBM) and {tmp_grad, value} per occurrence (s.hmeta).
+#ifndef FFM_TILE_ROWTAB
+#define FFM_TILE_ROWTAB 1
+#endif
+struct TileFacts {  // what a stager lane holds of one tile: NF facts of its touch and the touch's own entry
   int4 ax[4];
-  float2 mt;
+  float2 mt;   // {tmp_grad, own value}
+  int p, fm;   // (rowtab path) own entry, its field
 };
 
 // Geometry of the (feature, chunk) work items.
@@ -115,8 +124,8 @@ __device__ __forceinline__ TileChunk tile_chunk(const ModelDev &m, const TileGeo
 // [kTileNR][kTileT * 4 * NF].
 template <int NF, typename Apply>
 __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s, const TileGeom &g,
-                                            const TileChunk &ch, int fa, int start, int tile0, int tstride,
-                                            int steps, int c, float *T, float4 *R, Apply &&apply) {
+                                            const TileChunk &ch, const Rows &rows, int fa, int start, int tile0,
+                                            int tstride, int steps, int c, float *T, float4 *R, Apply &&apply) {
   constexpr int RS = 4 * NF;  // records per touch in R (>= slots per chunk)
   const int K = g.K, F = g.F;
   const int lane = threadIdx.x & 63;
@@ -124,14 +133,17 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
   // ---- stager layout: lane (touch tl, column cq) carries the facts of slots cq + 4 j ----
   const int4 *acol[NF];
   bool okS[NF];
+  int fS[NF];
 #pragma unroll
   for (int j = 0; j < NF; j++) {
     const int sj = cq + 4 * j;
     const int f = (sj < g.SPC && ch.sb + sj < g.slots) ? walk_field(m, fa, ch.sb + sj) : -1;
     okS[j] = f >= 0;
-    acol[j] = s.haux + static_cast<int64_t>(start) * F + (okS[j] ? f : ch.fp0);
+    fS[j] = okS[j] ? f : ch.fp0;
+    acol[j] = s.haux + static_cast<int64_t>(start) * F + fS[j];
   }
   const float2 *mcol = s.hmeta + start;
+  (void)acol; (void)mcol;
   // ---- loader layout: lane (touch tl, column cq) fetches the quads 4 r + cq of the chunk ----
   int sQ[4], kkQ[4];
 #pragma unroll
@@ -141,6 +153,40 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     sQ[r] = inq && K <= 64 ? e4 / K : 0;
     kkQ[r] = inq ? (K <= 64 ? e4 - sQ[r] * K : ch.kk0 + e4) : 0;
   }
+#if FFM_TILE_ROWTAB
+  // {entry, row} of the stager lane's touch of tile st
+  auto load_desc = [&](int st) {
+    const int t = min((tile0 + st * tstride) * kTileT + tl, c - 1);  // past the end: repeats, staged as dead
+    return s.occ2[start + t];
+  };
+  auto load_facts = [&](const int2 d, TileFacts &f) {
+#pragma unroll
+    for (int j = 0; j < NF; j++) f.ax[j] = s.rowtab[static_cast<int64_t>(d.y) * F + fS[j]];
+    f.mt = make_float2(s.tg[d.y], rows.val[d.x]);
+    f.p = d.x;
+    f.fm = rows.field[d.x];
+  };
+  // facts of tile st -> LDS records {tmp_grad, x_own * x_other, flags | offset}: a touch is live
+  // when the row holds exactly one entry of the slot's partner field, another than the own one, and
+  // this shard owns the pair (several entries: only on serial slots, which are not folded here)
+  auto stage_facts = [&](int st, const TileFacts &f) {
+    const bool in_range = (tile0 + st * tstride) * kTileT + tl < c;
+    float4 *Rb = R + (st & (kTileNR - 1)) * (kTileT * RS) + tl * RS;
+#pragma unroll
+    for (int j = 0; j < NF; j++) {
+      const int sj = cq + 4 * j;
+      if (sj >= g.SPC) continue;
+      const int4 rt = f.ax[j];  // {partner feature, its value, its entry (-1 none, -2 several), count}
+      const bool live = in_range && okS[j] && rt.z >= 0 && rt.z != f.p && owns_pair(m, f.fm, fS[j]);
+      const int fl = live ? (HF_SIMPLE | ((f.p < rt.z || m.h.learn) ? HF_FIRST : 0)) : 0;
+      // (a dead touch gathers from the start of the tensor: any valid address)
+      const int64_t off = live ? w_slot_offset(m, rt.x, fS[j], f.fm) : 0;
+      const float x = f.mt.y * __int_as_float(rt.y);
+      Rb[sj] = make_float4(f.mt.x, x, __int_as_float(tile_hiword(static_cast<int>(off >> 32), fl)),
+                           __int_as_float(static_cast<int>(off & 0xffffffff)));
+    }
+  };
+#else
   auto load_facts = [&](int st, TileFacts &f) {
     const int t = min((tile0 + st * tstride) * kTileT + tl, c - 1);  // past the end: repeats, staged as dead
 #pragma unroll
@@ -163,6 +209,7 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
       Rb[sj] = make_float4(f.mt.x, x, __int_as_float(tile_hiword(f.ax[j].w, fl)), __int_as_float(f.ax[j].z));
     }
   };
+#endif
   // (named members, handed over by value: as arrays behind references these sixteen registers
   // ended up in scratch memory, every load waited for at once)
   auto issue_weight = [&](const float4 *Rb, int r) {
@@ -191,8 +238,40 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     apply(st, R + (st & (kTileNR - 1)) * (kTileT * RS) + ch.es, T + lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   };
-  static_assert(kTileDV >= 1 && kTileDV <= 3 && kTileDV + 1 <= kTileNR, "weights of 1 .. 3 tiles in flight");
   static_assert(kSeg % kTileT == 0 && kTileT % kTileG == 0, "segments are whole tiles, tiles whole groups");
+#if FFM_TILE_ROWTAB
+  // One tile of weights in flight, facts one tile further, descriptors one more (deeper pipelines
+  // measured slower: profiles/r05_experiments.md).  The requests of a step in consumption order --
+  // vmcnt retires loads in issue order: facts(ST+2), descriptors(ST+3), weights(ST+1).
+  static_assert(kTileDV == 1 && kTileNR >= 2, "one tile of weights in flight");
+  TileFacts fN;
+  TileWeights V0;
+  int2 dN = make_int2(0, 0);
+  {
+    TileFacts f0;
+    const int2 d0 = load_desc(0);
+    const int2 d1 = steps > 1 ? load_desc(1) : d0;
+    if (steps > 2) dN = load_desc(2);
+    load_facts(d0, f0);
+    if (steps > 1) load_facts(d1, fN);
+    stage_facts(0, f0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    V0 = issue_weights(0);
+  }
+  for (int st = 0; st < steps; st++) {
+    transpose(V0);
+    const bool more = st + 1 < steps;
+    if (more) {
+      stage_facts(st + 1, fN);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if (st + 2 < steps) load_facts(dN, fN);
+    if (st + 3 < steps) dN = load_desc(st + 3);
+    if (more) V0 = issue_weights(st + 1);
+    apply_tile(st);
+  }
+#else
+  static_assert(kTileDV >= 1 && kTileDV <= 3 && kTileDV + 1 <= kTileNR, "weights of 1 .. 3 tiles in flight");
   TileFacts fN;
   TileWeights V0, V1, V2;
   {
@@ -233,6 +312,7 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     if (kTileDV > 2) { FTRL_TILE_STEP(st + 2, V2) }
   }
 #undef FTRL_TILE_STEP
+#endif
 }
 
 // The touches of one tile as the fold sees them (lane = element): kTileG at a time.
@@ -251,8 +331,8 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
 
 // ---- hot features below giant_min occurrences: one wave folds (feature, chunk) whole --------------
 template <int NF>
-__device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Scratch &s, unsigned wave, unsigned n_waves,
-                                               float *T, float4 *R) {
+__device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &rows, const Scratch &s, unsigned wave,
+                                               unsigned n_waves, float *T, float4 *R) {
   constexpr int RS = 4 * NF;
   const TileGeom g = tile_geom(m);
   // longest first: [huge | big]
@@ -276,7 +356,7 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Scratch 
     const float w = rec[LAT_W * g.RL];
     Fold acc;
     acc.init(n);
-    tile_stream<NF>(m, s, g, ch, fa, start, 0, 1, (c + kTileT - 1) / kTileT, c, T, R,
+    tile_stream<NF>(m, s, g, ch, rows, fa, start, 0, 1, (c + kTileT - 1) / kTileT, c, T, R,
                     [&](int st, const float4 *Rc, const float *Tc) {
       if (st > 0) acc.flush();  // a segment (= a tile of kSeg occurrences) ends
       const int cnt = min(kTileT, c - st * kTileT);
@@ -307,8 +387,8 @@ struct CoopLds {
   float ncap[64];
 };
 template <int NF, int W>
-__device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Scratch &s, unsigned bidx, unsigned gdim,
-                                               float *T, float4 *R, CoopLds<W> &cl) {
+__device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Rows &rows, const Scratch &s, unsigned bidx,
+                                               unsigned gdim, float *T, float4 *R, CoopLds<W> &cl) {
   constexpr int RS = 4 * NF;
   const TileGeom g = tile_geom(m);
   const int lane = threadIdx.x & 63;
@@ -331,7 +411,7 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Scratch 
     Fold run;  // the running state, the same in every wave
     run.init(n);
     const int n_tiles = (c + kTileT - 1) / kTileT, n_super = (n_tiles + W - 1) / W;
-    tile_stream<NF>(m, s, g, ch, fa, start, wv, W, n_super, c, T, R, [&](int k, const float4 *Rc, const float *Tc) {
+    tile_stream<NF>(m, s, g, ch, rows, fa, start, wv, W, n_super, c, T, R, [&](int k, const float4 *Rc, const float *Tc) {
       const int buf = k & 1;
       const int cnt = max(0, min(kTileT, c - (k * W + wv) * kTileT));
       // (A) the tile's plain sums and masks
@@ -419,7 +499,7 @@ __device__ __forceinline__ unsigned long long *seg_flags(const Scratch &s, const
 // Pass A, work item = (range, chunk): per tile the sums of g and g*g from -0.0f and three lane masks
 // (live touch seen / first live touch plain / :118 touch seen) -> s.segP / segG / segF.
 template <int NF>
-__device__ __forceinline__ void ffm_range_items_a(const ModelDev &m, const Scratch &s, unsigned wave,
+__device__ __forceinline__ void ffm_range_items_a(const ModelDev &m, const Rows &rows, const Scratch &s, unsigned wave,
                                                   unsigned n_waves, float *T, float4 *R) {
   constexpr int RS = 4 * NF;
   const TileGeom g = tile_geom(m);
@@ -447,7 +527,7 @@ __device__ __forceinline__ void ffm_range_items_a(const ModelDev &m, const Scrat
         if (lane < 3) seg_flags(s, g, seg0 + st, ci)[lane] = 0ull;
       continue;
     }
-    tile_stream<NF>(m, s, g, ch, fa, start, t_lo / kTileT, 1, steps, c, T, R,
+    tile_stream<NF>(m, s, g, ch, rows, fa, start, t_lo / kTileT, 1, steps, c, T, R,
                     [&](int st, const float4 *Rc, const float *Tc) {
       const int cnt = min(kTileT, t_hi - t_lo - st * kTileT);
       float P = -0.0f, G = -0.0f;
@@ -480,7 +560,7 @@ __device__ __forceinline__ void ffm_range_items_a(const ModelDev &m, const Scrat
 // at the start of the range from the tiles before it (joined left to right), then the range's tiles
 // again for their root differences -> s.segD; the n_t at an element's first :118 touch -> s.gcap.
 template <int NF>
-__device__ __forceinline__ void ffm_range_items_b(const ModelDev &m, const Scratch &s, unsigned wave,
+__device__ __forceinline__ void ffm_range_items_b(const ModelDev &m, const Rows &rows, const Scratch &s, unsigned wave,
                                                   unsigned n_waves, float *T, float4 *R) {
   constexpr int RS = 4 * NF;
   constexpr int kFly = 8;  // tiles whose sums are in flight together
@@ -531,7 +611,7 @@ __device__ __forceinline__ void ffm_range_items_b(const ModelDev &m, const Scrat
     }
     const bool seen_before = (q_before >> lane) & 1ull;
     acc.seen = seen_before;
-    tile_stream<NF>(m, s, g, ch, fa, start, t_lo / kTileT, 1, steps, c, T, R,
+    tile_stream<NF>(m, s, g, ch, rows, fa, start, t_lo / kTileT, 1, steps, c, T, R,
                     [&](int st, const float4 *Rc, const float *Tc) {
       const int cnt = min(kTileT, t_hi - t_lo - st * kTileT);
       for (int g0 = 0; g0 < cnt; g0 += kTileG) {
@@ -633,7 +713,7 @@ template <int NF>
 __global__ __launch_bounds__(64 * tile_waves(NF)) void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
                                                                      int side_blocks, int ng, int nt, int ns,
                                                                      int few_only, int nw, int loss_blocks,
-                                                                     double *loss_out, double *loss_scratch) {
+                                                                     double *loss_out, double *loss_scratch, int order) {
   constexpr int WAVES = tile_waves(NF);
   extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
   __shared__ CoopLds<WAVES> lds_coop;
@@ -647,29 +727,36 @@ __global__ __launch_bounds__(64 * tile_waves(NF)) void ffm_update_all_kernel(Mod
     return;
   }
   r -= side_blocks;
-  if (r < ng) { ffm_coop_items<NF, WAVES>(m, s, r, ng, T, R, lds_coop); return; }
-  r -= ng;
-  if (r < nt) {
+  // the three big ranges in the order `order` names (digits, first range last: 0 giant, 1 hot, 2 few)
+  for (int o = order, left = 3; left > 0; left--, o /= 10) {
+    const int kind = o % 10;
+    const int n = kind == 0 ? ng : kind == 1 ? nt : ns;
+    if (r < n) {
+      if (kind == 0) {
+        ffm_coop_items<NF, WAVES>(m, rows, s, r, ng, T, R, lds_coop);
+      } else if (kind == 1) {
 #ifndef FFM_EXP_NO_RANGE_A
-    ffm_range_items_a<NF>(m, s, r * WAVES + wv, nt * WAVES, T, R);
+        ffm_range_items_a<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
 #endif
-    ffm_tile_items<NF>(m, s, r * WAVES + wv, nt * WAVES, T, R);
-    return;
+        ffm_tile_items<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
+      } else {
+        ffm_small_body(m, rows, s, few_only, r, ns);
+      }
+      return;
+    }
+    r -= n;
   }
-  r -= nt;
-  if (r < ns) { ffm_small_body(m, rows, s, few_only, r, ns); return; }
-  r -= ns;
   if (r < nw) { ffm_generic_body(m, rows, s, 1, r, nw); return; }
   loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - nw, loss_blocks);
 }
 // The longest features' pass B and their join (launched after ffm_update_all_kernel when the block is
 // large enough to have any; both return at once when it has none).
 template <int NF>
-__global__ __launch_bounds__(kUpdThreads) void ffm_update_super_b_kernel(ModelDev m, Scratch s) {
+__global__ __launch_bounds__(kUpdThreads) void ffm_update_super_b_kernel(ModelDev m, Rows rows, Scratch s) {
   __shared__ __attribute__((aligned(16))) float lds_T[kUpdWaves][kTileT * kTileRow];
   __shared__ float4 lds_R[kUpdWaves][kTileNR * kTileT * 4 * NF];
   const unsigned wv = wave_uniform(threadIdx.x >> 6);
-  ffm_range_items_b<NF>(m, s, blockIdx.x * kUpdWaves + wv, gridDim.x * kUpdWaves, lds_T[wv], lds_R[wv]);
+  ffm_range_items_b<NF>(m, rows, s, blockIdx.x * kUpdWaves + wv, gridDim.x * kUpdWaves, lds_T[wv], lds_R[wv]);
 }
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_super_join_kernel(ModelDev m, Scratch s) {
   ffm_range_join(m, s, blockIdx.x * kUpdWaves + wave_uniform(threadIdx.x >> 6), gridDim.x * kUpdWaves);

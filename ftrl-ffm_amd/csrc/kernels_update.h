@@ -772,7 +772,7 @@ __device__ __forceinline__ void fm_update_body(const ModelDev &m, const Rows &ro
   }
 }
 // Giant FM features (giant_min occurrences or more: under a Zipf law over all ids the top features
-// sit in most rows of a block): their occurrences are cut into ranges of kRange that waves all over
+// sit in most rows of a block): their occurrences are cut into ranges of kFmRange that waves all over
 // the chip fold side by side -- per segment the sums of g and g*g from -0.0f into s.segP / s.segG --
 // and a second short launch joins the segments of each (feature, chunk) left to right.  Every
 // touch is plain, so the join needs nothing else.
@@ -794,8 +794,8 @@ __device__ __forceinline__ void fm_range_items(const ModelDev &m, const Rows &ro
     if (wave_uniform(s.uflag[start]) & UF_DUP) continue;  // walked in row order by fm_update_body
     if (e >= k) continue;
     const float w = lat_row(m, i, 0)[LAT_W * k + e];
-    const int seg0 = wave_uniform(s.gseg[gi]) + r * kRangeSegs;
-    const int t_lo = r * kRange, t_hi = min(c, t_lo + kRange);
+    const int seg0 = wave_uniform(s.gseg[gi]) + r * (m.range_len / kSeg);
+    const int t_lo = r * m.range_len, t_hi = min(c, t_lo + m.range_len);
     const int nb = (t_hi - t_lo + kFmUnroll - 1) / kFmUnroll;
     auto load_desc = [&](int b, int2 (&pr)[kFmUnroll]) {
 #pragma unroll
@@ -863,7 +863,8 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_join_kernel(ModelDev m,
     const int n_seg = (c + kSeg - 1) / kSeg;
     Fold a;
     a.init(n);
-    constexpr int kFly = 8;  // segments whose sums are in flight together
+    constexpr int kFly = 32;  // segments whose sums are in flight together (a chain of dependent loads
+                              // on an otherwise idle chip: what is in flight is all that counts)
     for (int s0 = 0; s0 < n_seg; s0 += kFly) {
       float p[kFly], g[kFly];
 #pragma unroll

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One BASELINE configuration for (library, environment) variants on one box.
-# usage: tools/ab_cfg.sh c3 "tree|FFM_CHAIN_MIN=512" "tree" ...   (lib = tree or exp_libs/lib<name>.so)
+# usage: tools/ab_cfg.sh c3 "tree|FFM_SUPER_MIN=1024" "tree" ...   (lib = tree or exp_libs/lib<name>.so)
 cd "$GRAFT_REPO_ROOT"
 cfg=$1; shift
 for v in "$@"; do

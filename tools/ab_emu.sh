@@ -1,6 +1,6 @@
 #!/bin/bash
 # One emulated 8-GPU rank (bench.py --emulate-shards 8) for (library, environment) variants on one box.
-# usage: tools/ab_emu.sh <rank> "tree|FFM_CHAIN_MIN=512" tree ...
+# usage: tools/ab_emu.sh <rank> "tree|FFM_SUPER_MIN=1024" tree ...
 cd "$GRAFT_REPO_ROOT"
 rank=$1; shift
 for v in "$@"; do

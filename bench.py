@@ -626,7 +626,7 @@ def main():
 
     # ---- evaluation: predict + logloss of the same blocks, pipelined ----
     eval_leg = None
-    if host_leg and zero_copy and not sharded and not args.no_resident and not args.no_eval:
+    if (host_leg or args.resident_only) and zero_copy and not sharded and not args.no_resident and not args.no_eval:
         def run_eval(first, count):
             for i in range(count):
                 eng.predict_batch_async(host_blocks[(first + i) % n_blocks], zero_copy=True)
@@ -639,8 +639,16 @@ def main():
                 eng.predict_batch_device(blk["n_rows"], blk["nnz"], ptr(blk["row_ptr"]), ptr(blk["field"]),
                                          ptr(blk["feat"]), ptr(blk["val"]), ptr(blk["label"]), 0, ptr(logit),
                                          loss_sum.data_ptr())
-        el4, eval_loss = timed(run_eval, args.warmup, args.steps, warm=lambda: run_eval(0, 3))
         el5, _ = timed(run_eval_resident, args.warmup, args.steps, warm=lambda: run_eval_resident(0, 3))
+        # (--resident-only, the counter passes of tools/pmc_sq.sh: no host blocks -- the H2D figures repeat the resident ones)
+        el4, eval_loss = (timed(run_eval, args.warmup, args.steps, warm=lambda: run_eval(0, 3)) if host_leg
+                          else (el5, float("nan")))
+        if not args.no_profile:  # the leg's kernels, every launch timed (after the timed regions)
+            eng.profile_enable(True)
+            run_eval_resident(0, 20)
+            fence()
+            sys.stderr.write("[eval, resident] " + eng.profile_dump() + "\n")
+            eng.profile_enable(False)
         # read-only path: every touched weight once (4 B per slot-factor), CSR in, loss out
         if model == "FFM":
             eval_bytes = N_FIELDS * (N_FIELDS - 1) * N_FACTORS * 4 + N_FIELDS * 4 + 4 + (N_FIELDS * 12 + 8) + 8

@@ -42,6 +42,7 @@
 #include "kernels_update.h"
 #include "kernels_tile.h"
 #include "kernels_fm.h"
+#include "kernels_predict.h"
 #include "kernels_sort.h"
 
 using namespace ftrl_dev;
@@ -104,13 +105,12 @@ int fail(int code, const std::string &msg) {
 
 enum KernelId {
   K_GROUP_KEYS, K_GROUP_SORT, K_GROUP_FINISH, K_ROW, K_TMP_GRAD,
-  K_HOT_META,
   K_LOSS_SUM, K_LINEAR_UPDATE, K_BIAS_UPDATE, K_LATENT_UPDATE, K_LATENT_UPDATE_FEW, K_LATENT_UPDATE_WALK, K_LATENT_UPDATE_GIANT,
   K_PREDICT_ROW, K_REFRESH, K_LATENT_UPDATE_SINGLE,
   K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
-    "group_keys_kernel", "group_radix_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "hot_meta_kernel", "loss_sum_kernel",
+    "group_keys_kernel", "group_radix_sort", "group_finish_kernel", "row_kernel<train>", "tmp_grad_kernel", "loss_sum_kernel",
     "linear_update_kernel", "bias_update_kernel", "update_kernel", "update_few_kernel", "update_walk_kernel", "update_giant_kernel",
     "row_kernel<predict>", "refresh_kernel", "update_single_kernel"};
 
@@ -344,7 +344,7 @@ struct ffm_engine {
   bool has_pending = false;
   bool whole_step = false;  // the call in flight is train_batch_device (forward + update in one)
   // train_batch_device on one shard: the row kernel has the whole logit, so it also produces
-  // tmp_grad, the row losses and the hot occurrences' facts (no tmp_grad / hot_meta passes)
+  // tmp_grad and the row losses (no tmp_grad pass)
   bool own_tg_cur = false;
   float *own_logit_out = nullptr;
   // the block's lazy refresh as one pass over its distinct features (ffm_refresh_kernel) instead
@@ -363,6 +363,7 @@ struct ffm_engine {
   // of serial slots; and of the once-only kernel of a shard
   int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768, grid_giant = 1024;
   bool update_split = false;  // FFM_UPDATE_SPLIT=1: the update launch's ranges as launches of their own (timing aid)
+  bool predict_waves = true;  // FFM_PREDICT_WAVE=0: evaluation rows through ffm_row_kernel (one workgroup per row)
   int update_order = 210;     // FFM_UPDATE_ORDER: the update launch's big ranges, first range = last digit (0 giant, 1 hot, 2 few)
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
@@ -625,6 +626,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_UPDATE_SPLIT")) e->update_split = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_UPDATE_ORDER")) e->update_order = std::atoi(sv);
+  if (const char *sv = std::getenv("FFM_PREDICT_WAVE")) e->predict_waves = std::atoi(sv) != 0;
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_WALK")) e->grid_walk = std::max(1, std::atoi(sv));
@@ -809,8 +811,6 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
       m.rec_base = d_base;
     }
   }
-  TRY_ALLOC(e->alloc(&s.haux, ffm_model ? E * static_cast<size_t>(m.n_fields) : 1));
-  TRY_ALLOC(e->alloc(&s.hmeta, ffm_model ? E : 1));
   TRY_ALLOC(e->alloc(&s.logit, R));
   TRY_ALLOC(e->alloc(&s.tg, R));
   TRY_ALLOC(e->alloc(&s.loss, R));
@@ -836,7 +836,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   }
   for (int si = 1; si < ffm_engine::kSets; si++) {
     Scratch &t = e->sc[si];
-    t = s;  // shared: head/next/rowtab/haux/hmeta/logit/tg/loss/svx
+    t = s;  // shared: head/next/rowtab/logit/tg/loss/svx
     t.n_super = s.n_super + si;
     TRY_ALLOC(e->alloc(&t.key, E));
     TRY_ALLOC(e->alloc(&t.skey, E));

@@ -17,6 +17,33 @@ static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *r
 }
 
 
+// FFM evaluation rows one wave each (kernels_predict.h) where that kernel applies: a whole model on
+// this device, k in {4, 8, 16, 32, 64}, the rows' entries within 64 KB of LDS per workgroup.
+#ifndef FFM_PRED_LPP
+#define FFM_PRED_LPP 4  // k = 16: lanes per pair (1, 2, 4) ...
+#endif
+#ifndef FFM_PRED_U
+#define FFM_PRED_U 4    // ... and steps of loads in flight together
+#endif
+static bool launch_predict_waves(ffm_engine *e, const Rows &rows, int row_cap, float *out, int output_prob) {
+  const ModelDev &m = e->m;
+  if (!e->predict_waves || m.type != FFM_MODEL_FFM || m.n_shards > 1 || m.field_start || m.own_n || m.lin_own) return false;
+  const size_t shmem = pred_lds_bytes(row_cap);
+  if (shmem > 64 * 1024) return false;
+  const int grid = cdiv(rows.n_rows, kPredRows), threads = 64 * kPredRows;
+#define PRED_LAUNCH(LPP, VPL, U) \
+  LAUNCH(e, K_PREDICT_ROW, (ffm_predict_wave_kernel<LPP, VPL, U>), grid, threads, shmem, m, rows, e->sc[e->cur], row_cap, out, output_prob)
+  switch (m.n_factors) {
+    case 4: PRED_LAUNCH(1, 1, 4); return true;
+    case 8: PRED_LAUNCH(2, 1, 4); return true;
+    case 16: PRED_LAUNCH(FFM_PRED_LPP, 4 / FFM_PRED_LPP, FFM_PRED_U); return true;
+    case 32: PRED_LAUNCH(8, 1, 2); return true;
+    case 64: PRED_LAUNCH(16, 1, 1); return true;
+    default: return false;
+  }
+#undef PRED_LAUNCH
+}
+
 static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float *out, int output_prob, int own_tg = 0) {
   const int row_cap = e->staged_row_cap > 0 ? e->staged_row_cap : e->max_row_nnz;
   e->staged_row_cap = 0;
@@ -74,6 +101,7 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
         LAUNCH(e, kid, (ffm_row_kernel<true, true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, 0, 0, 0);
     }
     else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, 0, 0);
+    else if (launch_predict_waves(e, rows, row_cap, out, output_prob)) {}
     else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0, 0);
     else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0, 0);
   }
@@ -243,8 +271,6 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
   const bool own_tg = e->own_tg_cur && !logit;
   if (rows.n_rows > 0 && !own_tg)
     LAUNCH(e, K_TMP_GRAD, tmp_grad_kernel, cdiv(rows.n_rows, 256), 256, 0, rows.n_rows, lg, rows.label, e->sc[e->cur].tg, e->sc[e->cur].loss, logit_out);
-  if (!FFM_TILE_ROWTAB && e->m.type == FFM_MODEL_FFM && rows.nnz > 0 && !own_tg)
-    LAUNCH(e, K_HOT_META, hot_meta_kernel, std::min(cdiv(rows.nnz, kGroupThreads), 1024), kGroupThreads, 0, rows, e->sc[e->cur]);
   // Everything below runs on the main stream: the update has no long dependent chains (every
   // accumulator is folded by reductions, kernels_fold.h), so nothing needs a queue of its own.
   // FM, whole step: fm_row_wave_kernel has applied the touches of the once-only features itself

@@ -179,10 +179,6 @@ struct Scratch {
   int *uflag;     // [nnz] per distinct feature, at index ustart[u]: UF_* bits (all model types)
   int *occpos;    // [nnz] entry -> its position t in occ when its feature is hot, else
                   //      OCC_FEW (2..kSmallMax occurrences) or OCC_ONCE (this entry only)
-  int4 *haux;     // [nnz*n_fields] per (occurrence t, partner field): {partner value bits,
-                  //      flags | own field << 8, offset (in floats, 64 bits: lo, hi) of the
-                  //      partner's weights for this touch inside lat} -- from the row kernel
-  float2 *hmeta;  // [nnz] {tmp_grad, own value} of occurrence t
   float *logit;   // [n_rows] this shard's (partial) logit
   float *tg;      // [n_rows] tmp_grad = sigmoid(logit) - y
   double *loss;   // [n_rows] logloss per row
@@ -236,8 +232,6 @@ constexpr int kFmRange = 64, kFmGiantMin = kFmRange + 1;
 #endif
 constexpr int kSuperMin = FFM_SUPER_MIN;
 constexpr int kChainMin = 64;  // the least giant_min an engine may choose (sizes Scratch::giant)
-enum { HF_SIMPLE = 1, HF_FIRST = 2, HF_CHAIN = 4 };  // haux flags: one plain partner / own entry
-                                                     // first / several entries share the field
 // (4 until the once-only features left the update phase; re-swept since: 8)
 #ifndef FFM_SMALL_MAX
 #define FFM_SMALL_MAX 8

@@ -263,15 +263,4 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
   }
 }
 
-// Once tmp_grad is known: per-occurrence facts of the hot features' entries, in occ order, so
-// their owners read them as one contiguous stream.
-__global__ __launch_bounds__(kGroupThreads) void hot_meta_kernel(Rows rows, Scratch s) {
-  const int n = s.counters[CNT_CURSOR];
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-    const int2 pr = s.occ2[t];
-    if (s.occpos[pr.x] < 0) continue;
-    s.hmeta[t] = make_float2(s.tg[pr.y], rows.val[pr.x]);
-  }
-}
-
 }  // namespace ftrl_dev

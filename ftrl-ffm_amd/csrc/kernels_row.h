@@ -17,9 +17,6 @@
 #include "engine_types.h"
 #include "kernels_touch.h"
 
-#ifndef FFM_TILE_ROWTAB
-#define FFM_TILE_ROWTAB 1  // (kernels_tile.h: where the hot features' owners take a touch's facts from)
-#endif
 
 namespace ftrl_dev {
 
@@ -158,50 +155,6 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
                                                    const Scratch &s, RowLds &lds, int r, int b,
                                                    int nv, int F) {
   // (lds.opos: staged with the row)
-  // For entries of hot features: what each partner field contributes to their touches
-  // ({partner value, flags | own field, offset of the partner's weights lo, hi}), laid out by occurrence position
-  // for the hot update kernel.
-  auto emit_facts = [&](int a, int f, int op) {
-    const int cnt = lds.fcnt[f];
-    const int a0 = lds.ffirst[f];
-    int flags = 0;
-    float xo = 0.0f;
-    // where the partner's weights for this touch start inside m.lat (floats): its record, the w
-    // row, the slot of the own entry's field -- the owners add their factor index and load.
-    // Without a plain partner: a harmless valid address (the own record's slot for f).
-    int64_t woff = w_slot_offset(m, lds.feat[a], lds.field[a], f);
-    if (cnt == 1 && a0 != a) {
-      flags = HF_SIMPLE | (a < a0 ? HF_FIRST : 0);
-      xo = lds.val[a0];
-      woff = w_slot_offset(m, lds.feat[a0], f, lds.field[a]);
-    } else if (cnt > 1) {
-      flags = HF_CHAIN;
-    }
-    s.haux[static_cast<int64_t>(op) * F + f] =
-        make_int4(__float_as_int(xo), flags | (lds.field[a] << 8), static_cast<int>(woff & 0xffffffff),
-                  static_cast<int>(woff >> 32));
-  };
-  if (!FFM_TILE_ROWTAB) {
-    // (rounds 3-4; the hot features' owners read the row table below instead: kernels_tile.h)
-    // one fact per (hot entry, slot of its record): the partner fields this shard owns for the
-    // entry's field -- all of them when the model is not sharded
-    const int span = record_span(m, 1);
-    for (int t = threadIdx.x; t < nv * span; t += blockDim.x) {
-      const int a = t / span, j = t - a * span;
-      const int op = lds.opos[a];
-      if (op < 0) continue;
-      const int fa = lds.field[a];
-      const int f = walk_field(m, fa, j);
-      if (f < 0) continue;
-      if (!owns_pair(m, fa, f)) {
-        // a walked slot another shard owns (full-length records of a sharded model): a dead fact, so
-        // that its owner-side readers never see what an earlier block left at this position
-        s.haux[static_cast<int64_t>(op) * F + f] = make_int4(0, fa << 8, 0, 0);
-        continue;
-      }
-      emit_facts(a, f, op);
-    }
-  }
   // Per-field view of this row for the update kernel: rowtab[r][f] = {feat, val bits, entry
   // index, count} of the only entry with field f (entry index -1: none, -2: several -- then
   // head/next chains list them in row order).
@@ -231,29 +184,19 @@ __device__ __forceinline__ void publish_row_tables(const ModelDev &m, const Rows
 }
 
 // The same sum by one whole wave: lane 0's acc + terms[0] + terms[1] + ... strictly in order, one
-// dependent add after another, but with the terms staged in registers (kTermsPerLane consecutive
-// terms per lane) and fed to the chain by v_readlane instead of one LDS round trip per four terms.
-// Terms carrying the "not this shard's pair" tag are replaced by -0.0f (x + -0.0f == x bit for
-// bit).  Every lane returns the sum.
-constexpr int kTermsPerLane = 12;
+// dependent add after another: lane l of a 64-term chunk adds its term to the running value of the
+// lane below (wave_sequential_prefix: ONE DPP add per term; rounds 2-4 fed the chain by v_readlane +
+// v_add, 24 cycles per term: C5 row kernel 515 -> 507 us, resident step 1.022 -> 0.989 ms).  Terms
+// carrying the "not this shard's pair" tag are replaced by -0.0f (x + -0.0f == x bit for bit).
+// Every lane returns the sum.
 __device__ __forceinline__ float wave_add_terms_in_order(const float *terms, int cnt, float acc0) {
   const int lane = threadIdx.x & 63;
   float acc = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(acc0)));
-  for (int base = 0; base < cnt; base += 64 * kTermsPerLane) {
-    float tl[kTermsPerLane];
-#pragma unroll
-    for (int j = 0; j < kTermsPerLane; j++) {
-      const int q = base + lane * kTermsPerLane + j;
-      const float t = q < cnt ? terms[q] : -0.0f;
-      tl[j] = __float_as_int(t) == 0x7fc00001 ? -0.0f : t;
-    }
-    const int left = cnt - base;
-    const int lanes_used = left >= 64 * kTermsPerLane ? 64 : (left + kTermsPerLane - 1) / kTermsPerLane;
-    for (int l = 0; l < lanes_used; l++) {
-#pragma unroll
-      for (int j = 0; j < kTermsPerLane; j++)
-        acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tl[j]), l));
-    }
+  for (int base = 0; base < cnt; base += 64) {
+    float t = base + lane < cnt ? terms[base + lane] : -0.0f;
+    t = __float_as_int(t) == 0x7fc00001 ? -0.0f : t;
+    const float run = wave_sequential_prefix(acc, t);
+    acc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(run), 63));
   }
   return acc;
 }
@@ -270,7 +213,7 @@ __device__ __forceinline__ float wave_add_terms_in_order(const float *terms, int
 #else
 #define FFM_ROW_OCC
 #endif
-// WHOLE: the kernel has the whole logit (one shard): it also produces tmp_grad / loss / hmeta and may
+// WHOLE: the kernel has the whole logit (one shard): it also produces tmp_grad / loss and may
 // apply the once-only features' update (own_tg, refreshed == 3).  A shard's instantiation leaves all
 // of that out -- and the registers it costs: more rows in flight per SIMD.
 template <bool TRAIN, bool VEC4, bool WHOLE = TRAIN>
@@ -580,15 +523,8 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
     }
   }
   if (TRAIN && WHOLE && own_tg && is_ffm) {
-    // {tmp_grad, own value} of this row's hot entries, by occurrence position, for their owners
     __syncthreads();
     const float tg = s_tg;
-    if (!FFM_TILE_ROWTAB) {
-      for (int a = threadIdx.x; a < nv; a += blockDim.x) {
-        const int op = lds.opos[a];
-        if (op >= 0) s.hmeta[op] = make_float2(tg, lds.val[a]);
-      }
-    }
     // refreshed == 3: the (n, z) update of the features that occur nowhere else in the block
     // (FFM::update_vector_nz, ffm.cpp:90-136, for their slots), right here: this row is their only
     // touch, tmp_grad is known, and their records and the partners' weights were read moments ago

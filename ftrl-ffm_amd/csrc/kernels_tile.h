@@ -13,19 +13,18 @@
 // half reads them back with lane = element ("transposed through LDS").
 //
 // Work item = (hot feature, chunk of its stored record): a chunk is 64 / k whole slots (k <= 64) or
-// 64 factors of one slot (k > 64).  Pipeline per wave, tile st (D = kTileDV):
+// 64 factors of one slot (k > 64).  Pipeline per wave, tile st:
 //   partner weights of tile st -> LDS transposer
-//   facts of tile st+D (registers, loaded a tile ago) -> LDS records {tmp_grad, x_own*x_other,
+//   facts of tile st+1 (registers, loaded a tile ago) -> LDS records {tmp_grad, x_own*x_other,
 //                         flags, offset}
-//   facts of tile st+D+1 requested (global -> registers)
-//   partner weights of tile st+D requested at the offsets just staged (global -> registers): with
-//                         the tiles st+1 .. st+D-1 that is 16 D touches of gathers in flight
+//   facts of tile st+2 requested (row table -> registers) at the {entry, row} loaded a tile ago
+//   {entry, row} of the touches of tile st+3 requested
+//   partner weights of tile st+1 requested at the offsets just staged (global -> registers)
 //   fold of tile st
-// The ORDER of the two requests matters: the memory counter (vmcnt) retires loads in issue order,
-// so the facts the next tile's staging waits for must be requested BEFORE this tile's gathers --
-// requested after them, every tile waited for the gathers it had just issued (a gather into a
-// 247 GB tensor is a page walk and a trip to HBM).
-// The loop is unrolled by D so that the D sets of weight registers keep their names (no moves).
+// The ORDER of the requests matters: the memory counter (vmcnt) retires loads in issue order, so
+// what the next tile's staging waits for must be requested BEFORE this tile's gathers -- requested
+// after them, every tile waited for the gathers it had just issued (a gather into a 247 GB tensor
+// is a page walk and a trip to HBM).
 // Slots that one row touches twice (s.cmask) are left to the row-order walk (ffm_generic_body).
 #pragma once
 #include "engine_types.h"
@@ -38,41 +37,32 @@ namespace ftrl_dev {
 constexpr int kTileT = 16;    // touches per tile
 constexpr int kTileRow = 80;  // floats per transposer row: 64 + 16 of padding (16-byte writes of
                               // consecutive touches land 16 banks apart)
-#ifndef FFM_TILE_DV
-#define FFM_TILE_DV 1
-#endif
-constexpr int kTileDV = FFM_TILE_DV;  // tiles whose partner weights are in flight (1 .. 3)
-constexpr int kTileNR = kTileDV == 1 ? 2 : 4;  // fact-record buffers (a power of two): the tiles in flight and the one being applied
-                                              // (k = 4: 4 KB each per wave -- two of them leave three workgroups per CU, four leave one)
+constexpr int kTileNR = 2;  // fact-record buffers (a power of two): the tile in flight and the one being
+                            // applied (k = 4: 4 KB each per wave).  One tile of partner weights in flight:
+                            // two and three measured slower (profiles/r05_experiments.md section 2)
 #ifndef FFM_TILE_G
 #define FFM_TILE_G 4
 #endif
 constexpr int kTileG = FFM_TILE_G;  // touches per arithmetic group (one range vote per group)
 
 // flags word of an LDS fact record: bits 0..7 high bits of the weights' offset, bit 31 the touch is
-// live (one plain partner: HF_SIMPLE), bit 30 live and the own entry is the pair's first (HF_FIRST) --
+// live (exactly one entry of the partner field in the row), bit 30 live and the own entry is the pair's first --
 // so that the fold reads them with one compare each (hw < 0, hw >= 0xC0000000 unsigned)
-__device__ __forceinline__ int tile_hiword(int off_hi, int flags) {
-  const bool live = (flags & HF_SIMPLE) != 0;
-  return (off_hi & 0xff) | (live ? static_cast<int>(0x80000000u) : 0) |
-         (live && (flags & HF_FIRST) ? 0x40000000 : 0);
+__device__ __forceinline__ int tile_hiword(int off_hi, bool live, bool first) {
+  return (off_hi & 0xff) | (live ? static_cast<int>(0x80000000u) : 0) | (live && first ? 0x40000000 : 0);
 }
 
 struct TileWeights {  // a loader lane's four 16-byte quads of one tile's partner weights
   float4 q0, q1, q2, q3;
 };
-// Where the stager takes a touch's facts from (FFM_TILE_ROWTAB):
-//  1  the row's per-field table (s.rowtab, 16 B per (row, field): 5 MB per 8192 x 39 block, read by
-//     every entry of the row: it stays on-die) through the occurrence's {entry, row} (s.occ2);
-//  0  rounds 3-4: an occurrence-ordered fact stream the row kernel writes per (hot entry, field)
-//     (s.haux, 104 MB per block from and to HBM) and {tmp_grad, value} per occurrence (s.hmeta).
-#ifndef FFM_TILE_ROWTAB
-#define FFM_TILE_ROWTAB 1
-#endif
+// The stager takes a touch's facts from the row's per-field table (s.rowtab, 16 B per (row, field): 5 MB
+// per 8192 x 39 block, read by every entry of the row: it stays on-die) through the occurrence's
+// {entry, row} (s.occ2).  (Rounds 3-4 had the row kernel write an occurrence-ordered fact stream per
+// (hot entry, field): 104 MB per block to HBM and back.)
 struct TileFacts {  // what a stager lane holds of one tile: NF facts of its touch and the touch's own entry
   int4 ax[4];
   float2 mt;   // {tmp_grad, own value}
-  int p, fm;   // (rowtab path) own entry, its field
+  int p, fm;   // own entry, its field
 };
 
 // Geometry of the (feature, chunk) work items.
@@ -131,7 +121,6 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
   const int lane = threadIdx.x & 63;
   const int tl = lane >> 2, cq = lane & 3;  // stager / loader layout: touch, 16-byte quad column
   // ---- stager layout: lane (touch tl, column cq) carries the facts of slots cq + 4 j ----
-  const int4 *acol[NF];
   bool okS[NF];
   int fS[NF];
 #pragma unroll
@@ -140,10 +129,7 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     const int f = (sj < g.SPC && ch.sb + sj < g.slots) ? walk_field(m, fa, ch.sb + sj) : -1;
     okS[j] = f >= 0;
     fS[j] = okS[j] ? f : ch.fp0;
-    acol[j] = s.haux + static_cast<int64_t>(start) * F + fS[j];
   }
-  const float2 *mcol = s.hmeta + start;
-  (void)acol; (void)mcol;
   // ---- loader layout: lane (touch tl, column cq) fetches the quads 4 r + cq of the chunk ----
   int sQ[4], kkQ[4];
 #pragma unroll
@@ -153,7 +139,6 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     sQ[r] = inq && K <= 64 ? e4 / K : 0;
     kkQ[r] = inq ? (K <= 64 ? e4 - sQ[r] * K : ch.kk0 + e4) : 0;
   }
-#if FFM_TILE_ROWTAB
   // {entry, row} of the stager lane's touch of tile st
   auto load_desc = [&](int st) {
     const int t = min((tile0 + st * tstride) * kTileT + tl, c - 1);  // past the end: repeats, staged as dead
@@ -178,43 +163,19 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
       if (sj >= g.SPC) continue;
       const int4 rt = f.ax[j];  // {partner feature, its value, its entry (-1 none, -2 several), count}
       const bool live = in_range && okS[j] && rt.z >= 0 && rt.z != f.p && owns_pair(m, f.fm, fS[j]);
-      const int fl = live ? (HF_SIMPLE | ((f.p < rt.z || m.h.learn) ? HF_FIRST : 0)) : 0;
+      const bool first = f.p < rt.z || m.h.learn;  // (the learning variant: g2*g2 at ffm.cpp:118)
       // (a dead touch gathers from the start of the tensor: any valid address)
       const int64_t off = live ? w_slot_offset(m, rt.x, fS[j], f.fm) : 0;
       const float x = f.mt.y * __int_as_float(rt.y);
-      Rb[sj] = make_float4(f.mt.x, x, __int_as_float(tile_hiword(static_cast<int>(off >> 32), fl)),
+      Rb[sj] = make_float4(f.mt.x, x, __int_as_float(tile_hiword(static_cast<int>(off >> 32), live, first)),
                            __int_as_float(static_cast<int>(off & 0xffffffff)));
     }
   };
-#else
-  auto load_facts = [&](int st, TileFacts &f) {
-    const int t = min((tile0 + st * tstride) * kTileT + tl, c - 1);  // past the end: repeats, staged as dead
-#pragma unroll
-    for (int j = 0; j < NF; j++) f.ax[j] = acol[j][static_cast<int64_t>(t) * F];
-    f.mt = mcol[t];
-  };
-  // facts of tile st -> LDS records (touches whose partner field holds several entries in the row
-  // -- HF_CHAIN -- only occur on serial slots, which are not folded here: staged dead)
-  auto stage_facts = [&](int st, const TileFacts &f) {
-    const bool in_range = (tile0 + st * tstride) * kTileT + tl < c;
-    float4 *Rb = R + (st & (kTileNR - 1)) * (kTileT * RS) + tl * RS;
-#pragma unroll
-    for (int j = 0; j < NF; j++) {
-      const int sj = cq + 4 * j;
-      if (sj >= g.SPC) continue;
-      int fl = f.ax[j].y & 0xff;
-      if (!in_range || !okS[j]) fl = 0;
-      if (m.h.learn && (fl & HF_SIMPLE)) fl |= HF_FIRST;  // the variant uses g2*g2 at ffm.cpp:118
-      const float x = f.mt.y * __int_as_float(f.ax[j].x);
-      Rb[sj] = make_float4(f.mt.x, x, __int_as_float(tile_hiword(f.ax[j].w, fl)), __int_as_float(f.ax[j].z));
-    }
-  };
-#endif
   // (named members, handed over by value: as arrays behind references these sixteen registers
   // ended up in scratch memory, every load waited for at once)
   auto issue_weight = [&](const float4 *Rb, int r) {
     const float4 rc = Rb[sQ[r]];
-    const int64_t off = haux_offset(__float_as_int(rc.w), __float_as_int(rc.z) & 0xff);
+    const int64_t off = fact_offset(__float_as_int(rc.w), __float_as_int(rc.z) & 0xff);
     return *reinterpret_cast<const float4 *>(m.lat + off + kkQ[r]);
   };
   auto issue_weights = [&](int st) {
@@ -239,11 +200,9 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   };
   static_assert(kSeg % kTileT == 0 && kTileT % kTileG == 0, "segments are whole tiles, tiles whole groups");
-#if FFM_TILE_ROWTAB
   // One tile of weights in flight, facts one tile further, descriptors one more (deeper pipelines
   // measured slower: profiles/r05_experiments.md).  The requests of a step in consumption order --
   // vmcnt retires loads in issue order: facts(ST+2), descriptors(ST+3), weights(ST+1).
-  static_assert(kTileDV == 1 && kTileNR >= 2, "one tile of weights in flight");
   TileFacts fN;
   TileWeights V0;
   int2 dN = make_int2(0, 0);
@@ -270,49 +229,6 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     if (more) V0 = issue_weights(st + 1);
     apply_tile(st);
   }
-#else
-  static_assert(kTileDV >= 1 && kTileDV <= 3 && kTileDV + 1 <= kTileNR, "weights of 1 .. 3 tiles in flight");
-  TileFacts fN;
-  TileWeights V0, V1, V2;
-  {
-    TileFacts f0, f1, f2;
-    load_facts(0, f0);
-    if (kTileDV > 1 && steps > 1) load_facts(1, f1);
-    if (kTileDV > 2 && steps > 2) load_facts(2, f2);
-    if (steps > kTileDV) load_facts(kTileDV, fN);
-    stage_facts(0, f0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    V0 = issue_weights(0);
-    if (kTileDV > 1 && steps > 1) {
-      stage_facts(1, f1);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      V1 = issue_weights(1);
-    }
-    if (kTileDV > 2 && steps > 2) {
-      stage_facts(2, f2);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      V2 = issue_weights(2);
-    }
-  }
-#define FTRL_TILE_STEP(ST, V)                                                    \
-  if ((ST) < steps) {                                                            \
-    transpose(V);                                                                \
-    const bool more__ = (ST) + kTileDV < steps;                                  \
-    if (more__) {                                                                \
-      stage_facts((ST) + kTileDV, fN);                                           \
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                     \
-    }                                                                            \
-    if ((ST) + kTileDV + 1 < steps) load_facts((ST) + kTileDV + 1, fN);          \
-    if (more__) V = issue_weights((ST) + kTileDV);                               \
-    apply_tile(ST);                                                              \
-  }
-  for (int st = 0; st < steps; st += kTileDV) {
-    FTRL_TILE_STEP(st, V0)
-    if (kTileDV > 1) { FTRL_TILE_STEP(st + 1, V1) }
-    if (kTileDV > 2) { FTRL_TILE_STEP(st + 2, V2) }
-  }
-#undef FTRL_TILE_STEP
-#endif
 }
 
 // The touches of one tile as the fold sees them (lane = element): kTileG at a time.
@@ -443,9 +359,6 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Rows &ro
       bool quirky = run.seen;
 #pragma unroll
       for (int w2 = 0; w2 < W; w2++) quirky = quirky || ((cl.fl[buf][w2][2] >> lane) & 1ull);
-#ifdef FFM_EXP_NO_PHASE_B
-      quirky = false;
-#endif
       if (!__any(quirky)) {
         cl.D[buf][wv][lane] = -0.0f;
       } else {
@@ -735,9 +648,7 @@ __global__ __launch_bounds__(64 * tile_waves(NF)) void ffm_update_all_kernel(Mod
       if (kind == 0) {
         ffm_coop_items<NF, WAVES>(m, rows, s, r, ng, T, R, lds_coop);
       } else if (kind == 1) {
-#ifndef FFM_EXP_NO_RANGE_A
         ffm_range_items_a<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
-#endif
         ffm_tile_items<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
       } else {
         ffm_small_body(m, rows, s, few_only, r, ns);

@@ -75,4 +75,28 @@ __device__ __forceinline__ void ffm_touch4(const Hyper &h, bool own_first, float
   z4 = make_float4(z[0], z[1], z[2], z[3]);
 }
 
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Strictly left-to-right running sum over the 64 lanes: returns S_j = ((carry + a_0) + a_1) ... + a_j
+// in lane j, every addition rounded exactly as a one-lane sequential loop would round it.  Step t
+// finalises lane t (S_t = S_{t-1} + a_t through a whole-wave shift-right-by-one DPP move); lanes
+// already final recompute the same value, so no predication is needed.  Idle lanes pass -0.0f
+// (x + -0.0f == x bit for bit, for every x including both zeros).
+// Each of the 63 steps is ONE in-place `v_add_f32_dpp s, s, a wave_shr:1`: lane t adds its a to
+// its left neighbour's running value; lane 0 has no source lane, so the hardware leaves it alone
+// (bound_ctrl off) and it keeps carry + a_0.  (As a DPP move followed by an add this chain was two
+// dependent instructions per touch: the bias chain of a 65536-row block took 1.65 ms that way.)
+__device__ __forceinline__ float wave_sequential_prefix(float carry, float a) {
+  const int lane = threadIdx.x & 63;
+  float s = lane == 0 ? carry + a : a;
+#define FTRL_WSHR "s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define FTRL_REP7(x) x x x x x x x
+  asm volatile(FTRL_REP7(FTRL_REP7(FTRL_WSHR)) FTRL_REP7(FTRL_WSHR) FTRL_REP7(FTRL_WSHR)
+               : "+v"(s)
+               : "v"(a));
+#undef FTRL_REP7
+#undef FTRL_WSHR
+  return s;
+}
+
 }  // namespace ftrl_dev

@@ -137,6 +137,52 @@ def test_ragged_empty_and_multivalued_rows():
         e.close()
 
 
+@pytest.mark.parametrize("k", [4, 8, 16, 32, 64, 12])
+def test_evaluation_rows_one_wave_each(k, monkeypatch):
+    """FFM predict (ffm.cpp:24-70 with the stored w; evaluate.cpp:23-33): the wave-per-row kernel
+    (kernels_predict.h; k = 12 keeps the workgroup-per-row kernel) against the oracle and against
+    the workgroup-per-row kernel, bitwise -- rows longer than a wave (up to 150 entries, several
+    per field), empty and one-entry rows, entries outside the feature / field range, logits,
+    probabilities and the logloss sum."""
+    rng = np.random.default_rng(23)
+    F, per = 9, 40
+    nf = F * per
+    rows, labels = [], []
+    for r in range(300):
+        row = []
+        many = r % 7 == 0
+        for f in rng.permutation(F):
+            cnt = int(rng.integers(8, 18)) if many else int(rng.integers(0, 3))
+            for i in rng.choice(per, size=cnt, replace=False):
+                row.append((int(f), int(f) * per + int(i), float(np.float32(rng.normal() * 0.7))))
+        if r % 9 == 0:
+            row += [(F + 3, 1, 1.0), (0, -5, 1.0), (1, nf + 7, 0.5), (-1, 3, 2.0)]
+            row = [row[j] for j in rng.permutation(len(row))]
+        if r % 13 == 0:
+            row = []
+        if r % 17 == 0:
+            row = row[:1]
+        rows.append(row)
+        labels.append(int(rng.integers(0, 2)))
+    csr = Csr.from_rows(rows, labels)
+    assert max(len(r) for r in rows) > 64
+    o = CpuModel("oracle", "FFM", nf, F, k, **DEFAULT_HP)
+    st = rand_state(rng, o)
+    o.set_state(st)
+    po, lo = o.predict_batch(csr)
+    pp, _ = o.predict_batch(csr, output_prob=True)
+    for waves in ("1", "0"):
+        monkeypatch.setenv("FFM_PREDICT_WAVE", waves)
+        e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=512, max_row_nnz=160, **DEFAULT_HP)
+        e.set_state(st)
+        pe, le = e.predict_batch(csr)
+        assert_bitwise(pe, po, "logits, FFM_PREDICT_WAVE=" + waves)
+        assert loss_close(le, lo)
+        pq, _ = e.predict_batch(csr, output_prob=True)
+        assert_bitwise(pq, pp, "probabilities, FFM_PREDICT_WAVE=" + waves)
+        e.close()
+
+
 @pytest.mark.parametrize("park", ["0", "96", "1024", "default"])
 def test_row_kernel_lds_parking_is_bit_identical(park, monkeypatch):
     """The first vectors of (n, z) of a row's once-only features stay in LDS between the row's refresh

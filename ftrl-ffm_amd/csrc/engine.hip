@@ -288,7 +288,8 @@ struct ffm_engine {
   // streams on one queue run one after the other -- so no more than stream + 2 side + prep here.
   hipStream_t aux3 = nullptr;  // side stream: uploads of long-step engines (see `copy`); a shard's once-only /
                                // few-occurrence launches beside its update launch
-  hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  hipStream_t aux4 = nullptr;  // second side stream of the update (FFM_UPDATE_SPLIT=2)
   int max_rows = 0, max_nnz = 0, max_row_nnz = 1024;
   // longest row of the block being staged from host memory (known there; 0 = unknown: device
   // callers).  The row kernels size their LDS by it, which decides how many rows a CU holds.
@@ -362,7 +363,10 @@ struct ffm_engine {
   // workgroups of the update launch's ranges: few-occurrence features, hot tiles, the row-order walk
   // of serial slots; and of the once-only kernel of a shard
   int grid_small = 768, grid_hot = 2048, grid_walk = 256, grid_single = 768, grid_giant = 1024;
-  bool update_split = false;  // FFM_UPDATE_SPLIT=1: the update launch's ranges as launches of their own (timing aid)
+  int update_split = -1;  // FFM_UPDATE_SPLIT: 0 the update's ranges as ONE launch; 2 as three launches side by side
+                          // on three queues (hot + bias + linear | few + serial walk + loss | giant), each with the
+                          // registers and LDS of its own path; 1 as launches one after another (timing aid);
+                          // default: 2 for a whole model's large launches (nnz * k >= 4 M: the fork / join pays), else 0
   bool predict_waves = true;  // FFM_PREDICT_WAVE=0: evaluation rows through ffm_row_kernel (one workgroup per row)
   int update_order = 210;     // FFM_UPDATE_ORDER: the update launch's big ranges, first range = last digit (0 giant, 1 hot, 2 few)
   // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
@@ -568,6 +572,8 @@ void ffm_engine_destroy(ffm_engine *e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
+  if (e->aux4) (void)hipStreamDestroy(e->aux4);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &r : e->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
@@ -624,7 +630,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   e->max_nnz = cfg->max_batch_nnz;
   if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
-  if (const char *sv = std::getenv("FFM_UPDATE_SPLIT")) e->update_split = sv[0] == '1';
+  if (const char *sv = std::getenv("FFM_UPDATE_SPLIT")) e->update_split = std::atoi(sv);
   if (const char *sv = std::getenv("FFM_UPDATE_ORDER")) e->update_order = std::atoi(sv);
   if (const char *sv = std::getenv("FFM_PREDICT_WAVE")) e->predict_waves = std::atoi(sv) != 0;
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
@@ -717,6 +723,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   TRY_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+  TRY_HIP(hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming));
+  TRY_HIP(hipStreamCreateWithFlags(&e->aux4, hipStreamNonBlocking));
   const size_t nf = static_cast<size_t>(cfg->n_feats);
   const size_t n_lat = static_cast<size_t>(e->n_records) * 3 * static_cast<size_t>(m.row_len);
   TRY_ALLOC(e->alloc(&m.bias3, 4));

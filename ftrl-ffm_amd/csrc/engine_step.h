@@ -317,21 +317,47 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     const int nw = cdiv(sized(e->grid_walk, 1024, 16), scale);
     const int ng = rows.nnz >= kGiantMin ? sized(e->grid_giant, 256, 32) : 0;  // workgroups that fold giant features together
     const int order = e->update_order;  // (which of the three big ranges the dispatcher sees first)
+    // One launch, or three side by side: the one launch runs every range at the register / LDS footprint
+    // of the hungriest (3 waves per SIMD at k = 16); side by side the few-occurrence range gets 4 and
+    // the ranges overlap as the dispatcher finds room -- C5 resident step 1.005 -> 0.95-0.97 ms, but a
+    // 4096 x 8 block 0.15 -> 0.21 ms (two more launches and a fork / join on a 100 us phase), and a
+    // shard's rank (its once-only and few-occurrence launches already sit on the side queue) 1.71 ->
+    // 1.77 ms.
+    const int split = e->update_split >= 0 ? e->update_split
+                      : (!side_launches && static_cast<int64_t>(rows.nnz) * e->m.n_factors >= (4ll << 20) ? 2 : 0);
     const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
     const int side = side_blocks > 0 ? 1 + cdiv(lin_blocks, scale) : 0;
     const int grid = side + ng + nt + ns + nw + lb;
 #define FTRL_LAUNCH_ALL(NF)                                                                                   \
     do {                                                                                                      \
-      if (e->update_split) { /* (timing aid: one launch per range, each under a name of its own) */           \
-        if (ng > 0)                                                                                           \
-          LAUNCH(e, K_LATENT_UPDATE_GIANT, (ffm_update_all_kernel<NF>), ng, threads, lds, e->m, rows, e->sc[e->cur], \
+      if (split == 2 && !e->serial) { /* side by side: few on aux3, giant on aux4 */                        \
+        HIP_TRY(hipEventRecord(e->ev_fork2, e->stream));                                                      \
+        if (ns + nw + lb > 0) {                                                                               \
+          HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork2, 0));                                               \
+          LAUNCH_ON(e, e->aux3, K_LATENT_UPDATE_FEW, (ffm_update_all_kernel<NF, UPD_FEW | UPD_REST>), ns + nw + lb, threads, 0, e->m, rows, e->sc[e->cur], \
+                 0, 0, 0, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part, order);                       \
+          HIP_TRY(hipEventRecord(e->ev_join, e->aux3));                                                       \
+        }                                                                                                     \
+        if (ng > 0) {                                                                                         \
+          HIP_TRY(hipStreamWaitEvent(e->aux4, e->ev_fork2, 0));                                               \
+          LAUNCH_ON(e, e->aux4, K_LATENT_UPDATE_GIANT, (ffm_update_all_kernel<NF, UPD_GIANT>), ng, threads, lds, e->m, rows, e->sc[e->cur], \
                  0, ng, 0, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part, order);                         \
-        LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), side + nt, threads, lds, e->m, rows, e->sc[e->cur], \
+          HIP_TRY(hipEventRecord(e->ev_join2, e->aux4));                                                      \
+        }                                                                                                     \
+        LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF, UPD_HOT | UPD_SIDE>), side + nt, threads, lds, e->m, rows, e->sc[e->cur], \
+               side, 0, nt, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part, 1);                            \
+        if (ns + nw + lb > 0) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));                          \
+        if (ng > 0) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join2, 0));                                   \
+      } else if (split) { /* (timing aid: one launch per range, each under a name of its own) */              \
+        if (ng > 0)                                                                                           \
+          LAUNCH(e, K_LATENT_UPDATE_GIANT, (ffm_update_all_kernel<NF, UPD_GIANT>), ng, threads, lds, e->m, rows, e->sc[e->cur], \
+                 0, ng, 0, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part, order);                         \
+        LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF, UPD_HOT | UPD_SIDE>), side + nt, threads, lds, e->m, rows, e->sc[e->cur], \
                side, 0, nt, 0, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part, order);                        \
         if (ns > 0)                                                                                           \
-          LAUNCH(e, K_LATENT_UPDATE_FEW, (ffm_update_all_kernel<NF>), ns, threads, lds, e->m, rows, e->sc[e->cur], \
+          LAUNCH(e, K_LATENT_UPDATE_FEW, (ffm_update_all_kernel<NF, UPD_FEW>), ns, threads, lds, e->m, rows, e->sc[e->cur], \
                  0, 0, 0, ns, single ? 1 : 0, 0, 0, loss_sum_out, e->d_loss_part, order);                         \
-        LAUNCH(e, K_LATENT_UPDATE_WALK, (ffm_update_all_kernel<NF>), nw + lb, threads, lds, e->m, rows, e->sc[e->cur], \
+        LAUNCH(e, K_LATENT_UPDATE_WALK, (ffm_update_all_kernel<NF, UPD_REST>), nw + lb, threads, lds, e->m, rows, e->sc[e->cur], \
                0, 0, 0, 0, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part, order);                          \
       } else {                                                                                                \
         LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<NF>), grid, threads, lds, e->m, rows, e->sc[e->cur], \

@@ -615,15 +615,34 @@ __device__ __forceinline__ void ffm_range_join(const ModelDev &m, const Scratch 
 // sixteen tiles joined per super-step) a super-step took three times as long and the giant range
 // of a C5 block 506 us instead of 170 (profiles/r05_experiments.md).
 // Dynamic LDS: the transposers [WAVES][kTileT * kTileRow] floats, then the fact records.
-#ifndef FFM_TILE_WAVES
-#define FFM_TILE_WAVES 4
-#endif
 constexpr int tile_waves(int nf) { return nf == 4 && FFM_TILE_WAVES > 4 ? 4 : nf == 2 && FFM_TILE_WAVES > 8 ? 8 : FFM_TILE_WAVES; }
 constexpr size_t tile_lds_bytes(int nf) {
   return static_cast<size_t>(tile_waves(nf)) * (kTileT * kTileRow * sizeof(float) + kTileNR * kTileT * 4 * nf * sizeof(float4));
 }
-template <int NF>
-__global__ __launch_bounds__(64 * tile_waves(NF)) void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
+// KINDS: which ranges this instantiation can run (their arguments must be 0 otherwise) -- the register
+// allocation, and with it the waves per SIMD, of a kernel is that of its hungriest path.
+enum { UPD_GIANT = 1, UPD_HOT = 2, UPD_FEW = 4, UPD_SIDE = 8, UPD_REST = 16, UPD_ALL = 31 };
+// waves per SIMD the register allocation of an instantiation aims at (0: the compiler's choice)
+#ifndef FFM_OCC_ALL
+#define FFM_OCC_ALL 0
+#endif
+#ifndef FFM_OCC_HOT
+#define FFM_OCC_HOT 0
+#endif
+#ifndef FFM_OCC_FEW
+#define FFM_OCC_FEW 0
+#endif
+#ifndef FFM_OCC_GIANT
+#define FFM_OCC_GIANT 4  // (131 registers by itself: 3 waves)
+#endif
+constexpr int upd_occ(int kinds) {
+  return kinds == UPD_ALL ? FFM_OCC_ALL : (kinds & UPD_GIANT) ? FFM_OCC_GIANT : (kinds & UPD_HOT) ? FFM_OCC_HOT : (kinds & UPD_FEW) ? FFM_OCC_FEW : 0;
+}
+constexpr int upd_occ_min(int kinds) { return upd_occ(kinds) > 0 ? upd_occ(kinds) : 1; }
+constexpr int upd_occ_max(int kinds) { return upd_occ(kinds) > 0 ? upd_occ(kinds) : 8; }
+#define FFM_UPD_OCC __attribute__((amdgpu_waves_per_eu(upd_occ_min(KINDS), upd_occ_max(KINDS))))
+template <int NF, int KINDS = UPD_ALL>
+__global__ __launch_bounds__(64 * tile_waves(NF)) FFM_UPD_OCC void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
                                                                      int side_blocks, int ng, int nt, int ns,
                                                                      int few_only, int nw, int loss_blocks,
                                                                      double *loss_out, double *loss_scratch, int order) {
@@ -634,7 +653,7 @@ __global__ __launch_bounds__(64 * tile_waves(NF)) void ffm_update_all_kernel(Mod
   const unsigned wv = wave_uniform(threadIdx.x >> 6);
   float *T = reinterpret_cast<float *>(lds_dyn) + wv * (kTileT * kTileRow);
   float4 *R = reinterpret_cast<float4 *>(lds_dyn + WAVES * kTileT * kTileRow * sizeof(float)) + wv * (kTileNR * kTileT * 4 * NF);
-  if (r < side_blocks) {
+  if ((KINDS & UPD_SIDE) && r < side_blocks) {
     if (r == 0) bias_update_body(m, rows.n_rows, s);
     else linear_update_body(m, rows, s, r - 1, side_blocks - 1);
     return;
@@ -646,19 +665,23 @@ __global__ __launch_bounds__(64 * tile_waves(NF)) void ffm_update_all_kernel(Mod
     const int n = kind == 0 ? ng : kind == 1 ? nt : ns;
     if (r < n) {
       if (kind == 0) {
-        ffm_coop_items<NF, WAVES>(m, rows, s, r, ng, T, R, lds_coop);
+        if (KINDS & UPD_GIANT) ffm_coop_items<NF, WAVES>(m, rows, s, r, ng, T, R, lds_coop);
       } else if (kind == 1) {
-        ffm_range_items_a<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
-        ffm_tile_items<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
+        if (KINDS & UPD_HOT) {
+          ffm_range_items_a<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
+          ffm_tile_items<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
+        }
       } else {
-        ffm_small_body(m, rows, s, few_only, r, ns);
+        if (KINDS & UPD_FEW) ffm_small_body(m, rows, s, few_only, r, ns);
       }
       return;
     }
     r -= n;
   }
-  if (r < nw) { ffm_generic_body(m, rows, s, 1, r, nw); return; }
-  loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - nw, loss_blocks);
+  if (KINDS & UPD_REST) {
+    if (r < nw) { ffm_generic_body(m, rows, s, 1, r, nw); return; }
+    loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - nw, loss_blocks);
+  }
 }
 // The longest features' pass B and their join (launched after ffm_update_all_kernel when the block is
 // large enough to have any; both return at once when it has none).

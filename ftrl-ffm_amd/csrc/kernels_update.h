@@ -25,7 +25,10 @@ namespace ftrl_dev {
 
 constexpr int kUpdThreads = 256;
 constexpr int kUpdWaves = kUpdThreads / 64;
-constexpr int kUpdMaxThreads = 1024;  // the FFM update launch's workgroups (kernels_tile.h) are up to this large
+#ifndef FFM_TILE_WAVES
+#define FFM_TILE_WAVES 4  // waves per workgroup of the FFM update launches (kernels_tile.h); 8 and 16 measured slower
+#endif
+constexpr int kUpdMaxThreads = 64 * (FFM_TILE_WAVES > 4 ? FFM_TILE_WAVES : 4);  // their workgroups are up to this large
 constexpr int kFmUnroll = 8;  // touches per prefetch group in the FM update kernel
 
 

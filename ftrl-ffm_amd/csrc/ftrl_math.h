@@ -22,27 +22,31 @@ __device__ __forceinline__ float sgn_ref(float x) { return x > 0.0f ? 1.0f : -1.
 // These kernels are VALU-bound (DESIGN.md "Rooflines"): hipcc's IEEE sqrtf/divide expand to ~15
 // instructions each.  Both replacements below return the SAME bits as sqrtf(x) and x / alpha.
 
-// sqrtf(x) in five instructions: s = v_sqrt_f32(x) (1 ulp), the exact residual e = x - s*s by FMA,
-// one correction step s + e * (0.5 / sqrt(x)) with v_rsq_f32 -- Markstein's final iteration, which
-// rounds correctly once s and the reciprocal root are this accurate.  Not taken on trust: every
-// float in [2^-96, 2^96] was compared with sqrtf on gfx950 (tools/sqrt_probe.hip: 1 610 612 737
-// inputs, 0 mismatches; with 0.5 * v_rcp_f32(s) instead of v_rsq_f32(x) 96 inputs differ), and
-// ffm_engine_create repeats that comparison on the device it runs on and refuses to start if any
-// input differs.  Used when every lane of the wave holds +0 or a value in that range; anything else
-// (tiny, huge, negative, -0, NaN) takes sqrtf.
+// sqrtf(x) in five instructions, ONE of them transcendental (a quarter-rate instruction): r =
+// v_rsq_f32(x) (1 ulp), s = x * r, the exact residual e = x - s*s by FMA, one correction step
+// s + e * (0.5 * r) -- Markstein's final iteration, which rounds correctly once s and the reciprocal
+// root are this accurate.  Not taken on trust: every float in [2^-96, 2^96] was compared with sqrtf
+// on gfx950 (tools/sqrt_probe.hip: 1 610 612 737 inputs, 0 mismatches -- candidate c; rounds 3-4 took
+// s from v_sqrt_f32, a second transcendental, equally exact; with 0.5 * v_rcp_f32(s) for the
+// correction 96 inputs differ), and ffm_engine_create repeats that comparison on the device it runs
+// on and refuses to start if any input differs.  Used when every lane of the wave holds +0 or a
+// value in that range; anything else (tiny, huge, negative, -0, NaN) takes sqrtf.
 __device__ __forceinline__ bool sqrt_fast_ok(float x) {
   return __float_as_uint(x) == 0u || __builtin_amdgcn_fmed3f(x, 0x1p-96f, 0x1p96f) == x;
 }
 __device__ __forceinline__ float sqrt_fast(float x) {  // requires x in [2^-96, 2^96]
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+  const float r = __builtin_amdgcn_rsqf(x);
+  const float s = x * r;
+  const float h = 0.5f * r;
   const float e = fmaf(-s, s, x);
   return fmaf(e, h, s);
 }
-// ... and +0: v_rsq_f32(0) is +inf; clamped, the correction is 0 * 2^100 = 0 and the result s = 0.
+// ... and +0: v_rsq_f32(0) is +inf; clamped (inert for x >= 2^-96, where it is at most 2^48), s and
+// the correction are 0 * 2^100 = 0.
 __device__ __forceinline__ float sqrt_fast0(float x) {  // requires sqrt_fast_ok(x)
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float h = fminf(0.5f * __builtin_amdgcn_rsqf(x), 0x1p100f);
+  const float r = fminf(__builtin_amdgcn_rsqf(x), 0x1p100f);
+  const float s = x * r;
+  const float h = 0.5f * r;
   const float e = fmaf(-s, s, x);
   return fmaf(e, h, s);
 }

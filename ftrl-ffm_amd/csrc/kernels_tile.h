@@ -254,13 +254,25 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
   // longest first: [huge | big]
   const unsigned n_huge = static_cast<unsigned>(s.counters[CNT_NHUGE]);
   const unsigned n_items = (n_huge + static_cast<unsigned>(s.counters[CNT_NBIG])) * g.per_feat;
-  for (unsigned item = wave; item < n_items; item += n_waves) {
+  // (an item is a chain of dependent loads -- list, descriptor, masks / record / touch descriptors,
+  // row table, partner weights -- and most items are one or two tiles long: the list entry is
+  // requested two items ahead and the descriptor one, in scalar registers)
+  auto list_at = [&](unsigned item) {
     const unsigned li = item / g.per_feat;
-    const int ci = static_cast<int>(item - li * g.per_feat);
-    const int u = wave_uniform(li < n_huge ? s.huge[li] : s.big[li - n_huge]);
-    const int4 ud = s.udesc[u];  // {feature, start, count, field}
-    const int fa = wave_uniform(ud.w), i = wave_uniform(ud.x);
-    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
+    return wave_uniform(li < n_huge ? s.huge[li] : s.big[li - n_huge]);
+  };
+  auto uniform4 = [](int4 v) { return make_int4(wave_uniform(v.x), wave_uniform(v.y), wave_uniform(v.z), wave_uniform(v.w)); };
+  int4 ud_next = make_int4(0, 0, 1, 0);
+  int u_next2 = 0;
+  if (wave < n_items) ud_next = uniform4(s.udesc[list_at(wave)]);
+  if (wave + n_waves < n_items) u_next2 = list_at(wave + n_waves);
+  for (unsigned item = wave; item < n_items; item += n_waves) {
+    const int ci = static_cast<int>(item % g.per_feat);
+    const int4 ud = ud_next;  // {feature, start, count, field}
+    if (item + n_waves < n_items) ud_next = uniform4(s.udesc[u_next2]);
+    if (item + 2 * n_waves < n_items) u_next2 = list_at(item + 2 * n_waves);
+    const int fa = ud.w, i = ud.x;
+    const int start = ud.y, c = ud.z;
     const TileChunk ch = tile_chunk(m, g, fa, ci);
     if (ch.fp0 < 0) continue;
     // (slots that one row touches twice are ffm_generic_body's: the row-order walk)

@@ -353,12 +353,20 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
   const int n_small = s.counters[few_only ? CNT_NFEW : CNT_NSMALL];
   const float inv_k4 = 1.0f / static_cast<float>(k4);
   const int span4 = record_span(m, k4);
+  // (a feature is a chain of dependent loads -- list, descriptor, touches, their entries and rows,
+  // row table, partner weights: the list entry is requested two features ahead, the descriptor one)
+  auto uniform4 = [](int4 v) { return make_int4(wave_uniform(v.x), wave_uniform(v.y), wave_uniform(v.z), wave_uniform(v.w)); };
+  int4 ud_next = make_int4(0, 0, 0, 0);
+  int u_next2 = 0;
+  if (wave < n_small) ud_next = uniform4(s.udesc[wave_uniform(list[wave])]);
+  if (wave + n_waves < n_small) u_next2 = wave_uniform(list[wave + n_waves]);
   for (int li = wave; li < n_small; li += n_waves) {
-    const int u = wave_uniform(list[li]);
-    const int4 ud = s.udesc[u];
-    const int i = wave_uniform(ud.x);
-    const int start = wave_uniform(ud.y), c = wave_uniform(ud.z);
-    const int fa = wave_uniform(ud.w);
+    const int4 ud = ud_next;
+    if (li + n_waves < n_small) ud_next = uniform4(s.udesc[u_next2]);
+    if (li + 2 * n_waves < n_small) u_next2 = wave_uniform(list[li + 2 * n_waves]);
+    const int i = ud.x;
+    const int start = ud.y, c = ud.z;
+    const int fa = ud.w;
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
     // slots that one row touches twice keep the row-order walk (ffm_generic_body, serial_only)
     const unsigned long long cm = s.cmask[start];

@@ -101,16 +101,36 @@ def kernel_share_bytes(kernel, blocks_feat, nnz, k, n_shards):
         return 0.0
     flat = n_shards > 1  # (csrc/engine.hip: flat_pays -- compact shards' short records)
     shares = []
-    for c in counts:
-        occ = {"single": c[c == 1].sum(), "few": c[(c > 1) & (c <= SMALL_MAX)].sum(), "hot": c[c > SMALL_MAX].sum()}
+    for f, c in zip(blocks_feat, counts):
+        # engine_step.h: a whole model's large update runs as three launches side by side
+        # (hot | few | giant), else as one (plus, for the longest features, a second pass and a join)
+        split = update_split(len(f), k, n_shards)
+        occ = {"single": c[c == 1].sum(), "few": c[(c > 1) & (c <= SMALL_MAX)].sum(), "hot": c[c > SMALL_MAX].sum(),
+               "giant": c[c >= GIANT_MIN].sum(), "super": c[c >= SUPER_MIN].sum()}
         if "single" in kernel:
             owned = occ["single"]
-        elif "small_flat" in kernel:
+        elif "small_flat" in kernel or "<few>" in kernel:
             owned = occ["few"]
+        elif "<giant>" in kernel:
+            owned = occ["giant"] if split else occ["super"]
+        elif split:  # the hot range's launch
+            owned = occ["hot"] - occ["giant"]
         else:  # ffm_update_all_kernel / ffm_update_generic_kernel
-            owned = occ["hot"] + (0 if flat else occ["few"])
+            owned = occ["hot"] - occ["super"] + (0 if flat else occ["few"])
         shares.append(owned * per_occ * 8 / n_shards)
     return float(np.mean(shares))
+
+
+GIANT_MIN, SUPER_MIN = 257, 2048  # csrc/engine_types.h: kGiantMin, FFM_SUPER_MIN
+
+
+def update_split(block_nnz, k, n_shards):
+    """engine_step.h's rule for the FFM update: three launches side by side for a whole model's large
+    blocks (FFM_UPDATE_SPLIT overrides)."""
+    env = os.environ.get("FFM_UPDATE_SPLIT")
+    if env is not None:
+        return int(env) != 0
+    return n_shards == 1 and block_nnz * k >= (4 << 20)
 
 
 def fm_kernel_share_bytes(kernel, blocks_feat, nnz, k):
@@ -746,7 +766,8 @@ def main():
                        {"row_kernel<train>": "ffm_row_kernel<train>",
                         "refresh_kernel": "ffm_refresh_kernel",
                         "update_single_kernel": "ffm_update_single_kernel",
-                        "update_few_flat_kernel": "ffm_update_small_flat_kernel",
+                        "update_few_kernel": "ffm_update_small_flat_kernel" if n_shards > 1 else "ffm_update_all_kernel<few>",
+                        "update_giant_kernel": "ffm_update_all_kernel<giant>",
                         "update_kernel": "ffm_update_all_kernel"}.get(nm)
                 if not full:
                     continue

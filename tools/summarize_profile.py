@@ -107,6 +107,8 @@ def main():
                  "emu8_strong_rank3.json") + tuple("emu8_rank%d.json" % r for r in range(8)):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join("profiles", rnd + "_" + name))
+    with open(os.path.join("profiles", rnd + "_pmc_hbm_summary.json")) as f:
+        summary = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
     for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["avg_us"]):
         print("%-36s avg %9.1f us  hbm %8.1f MB/launch  %7.1f GB/s" % (
             k, v["avg_us"], v["hbm_bytes_per_launch"] / 1e6, v["hbm_GBps"]))

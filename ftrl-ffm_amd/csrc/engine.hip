@@ -269,16 +269,16 @@ struct ffm_engine {
   // Uploads of staged host blocks (pull_block_kernel) go on the prep stream, ahead of the block's
   // grouping.  (A fifth stream for them shares a hardware queue with one of the four and
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
-  hipStream_t copy = nullptr;  // the upload kernel's stream: prep, or aux3 for long steps (ffm_engine_create)
+  hipStream_t copy = nullptr;  // the upload kernel's stream: the prep stream (round 4 had it on aux3 for long steps)
   bool own_sort = false;        // the grouping's sort: kernels_sort.h (short steps) or rocPRIM Onesweep (ffm_engine_create)
   int sort_grid_cap = 1;        // workgroups of the one-launch sort the device holds at once (its grid barrier needs them all)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
-  // Scheduling of a look-ahead grouping (FFM_PREP_WINDOW=0 turns it off): the block being
+  // Scheduling of a look-ahead grouping: the block being
   // prepared will start training when its predecessor's update ends; its grouping is made to
   // START when the block before that one ends -- so it runs beside the predecessor's refresh and
   // row phases (memory-bound, ~400 us, the grouping takes ~300 us there) and never beside an
-  // update phase, where the persistent chain kernels starve it (a Onesweep pass then takes
-  // 250-300 us instead of 7) and it slows them.  trained_set[0] / [1]: the scratch sets of the
+  // update phase, where the update's kernels starve it (a Onesweep pass then takes 250-300 us
+  // instead of 7) and it slows them.  trained_set[0] / [1]: the scratch sets of the
   // training blocks enqueued last / before that (their ev_set_free marks the end of the update).
   bool prep_window = true;
   int trained_set[2] = {-1, -1};
@@ -286,8 +286,8 @@ struct ffm_engine {
   bool own_stream = false;
   // Streams: the runtime multiplexes streams onto few hardware queues (4 by default), and two
   // streams on one queue run one after the other -- so no more than stream + 2 side + prep here.
-  hipStream_t aux3 = nullptr;  // side stream: uploads of long-step engines (see `copy`); a shard's once-only /
-                               // few-occurrence launches beside its update launch
+  hipStream_t aux3 = nullptr;  // side stream: a shard's once-only / few-occurrence launches beside its update
+                               // launch; the few-occurrence launch of a side-by-side update
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t aux4 = nullptr;  // second side stream of the update (FFM_UPDATE_SPLIT=2)
   int max_rows = 0, max_nnz = 0, max_row_nnz = 1024;
@@ -369,13 +369,13 @@ struct ffm_engine {
                           // default: 2 for a whole model's large launches (nnz * k >= 4 M: the fork / join pays), else 0
   bool predict_waves = true;  // FFM_PREDICT_WAVE=0: evaluation rows through ffm_row_kernel (one workgroup per row)
   int update_order = 210;     // FFM_UPDATE_ORDER: the update launch's big ranges, first range = last digit (0 giant, 1 hot, 2 few)
-  // workgroups of pull_block_kernel (FFM_GRID_PULL).  Few on purpose: its loads take microseconds
+  // workgroups of pull_block_kernel.  Few on purpose: its loads take microseconds
   // (PCIe) and every one in flight holds a miss entry of an L2; 128 workgroups (512 KB in flight)
   // slowed the HBM-bound kernels they ran beside up to 4x (refresh of a 65536-row block 70 -> 330 us),
   // 24 (96 KB, about the link's bandwidth-delay product) still move the block at link rate.
   int grid_pull = 24;
-  bool single_kernel = true;  // FFM_SINGLE_KERNEL=0: once-only features through the small kernel
-  bool single_flat = true;    // FFM_SINGLE_FLAT=0: one wave per feature also for short stored records
+  bool single_kernel = true;  // (false: once-only features through the few-occurrence kernel)
+  bool single_flat = true;    // (false: one wave per feature also for short stored records)
   int row_threads = kRowThreads;  // workgroup size of the FFM row kernel (FFM_ROW_THREADS)
   bool serial = false;  // FFM_ENGINE_SERIAL=1: no side streams (per-kernel timings without overlap)
   // ---- staging thread ------------------------------------------------------------------------

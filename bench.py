@@ -739,7 +739,8 @@ def main():
             pmc, pmc_d = matching_pmc_summary(out["config"]["workload_key"]) if world == 1 and not emu else (None, None)
             if pmc_d:  # rocprofv3 --pmc passes of this same workload (tools/profile_round.sh)
                 for name, v in pmc_d.items():
-                    if not name.startswith("_") and name.split("<")[0] == kname.split("<")[0]:
+                    # (FM rows with k <= 64 run fm_row_wave_kernel; the profile's label is fm_row_kernel)
+                    if not name.startswith("_") and name.split("<")[0].replace("_wave", "") == kname.split("<")[0]:
                         traffic = v["hbm_bytes_per_launch"]
             out["roofline"] = {
                 "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),

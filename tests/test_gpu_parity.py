@@ -248,13 +248,17 @@ def test_refresh_modes_are_bit_identical(mode, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("split", ["0", "2"], ids=["one_launch", "three_side_by_side"])
 @pytest.mark.parametrize("k", [4, 8, 16])
-def test_update_launch_folds_every_class_of_feature(k):
-    """The whole FFM update of a block is ONE launch (kernels_tile.h: ffm_update_all_kernel) whose
+def test_update_launch_folds_every_class_of_feature(k, split, monkeypatch):
+    """The FFM update of a block (kernels_tile.h: ffm_update_all_kernel) as ONE launch whose
     workgroup ranges fold the bias, the linear terms, the hot features' tiles (k = 4 / 8 / 16: the
-    three fact-record shapes) and the few-occurrence features and sum the losses: the oracle's bits
-    on blocks with once-only, few-occurrence, hot and very hot features (a feature in every row
-    included: sixteen segments of 64 occurrences)."""
+    three fact-record shapes), the giants and the few-occurrence features and sum the losses -- and
+    as the three launches side by side that large blocks get (FFM_UPDATE_SPLIT=2: hot + bias + linear
+    | few + serial walk + loss | giant, instantiated per set of ranges): the oracle's bits on blocks
+    with once-only, few-occurrence, hot and very hot features (a feature in every row included:
+    sixteen segments of 64 occurrences)."""
+    monkeypatch.setenv("FFM_UPDATE_SPLIT", split)
     rng = np.random.default_rng(31 + k)
     F, per = 6, 30
     nf = F * per
@@ -341,9 +345,10 @@ def test_g1_weight_formula_pinned_on_the_device(mt, occurrences, hp_name):
     e.close()
 
 
+@pytest.mark.parametrize("split", ["0", "2"], ids=["one_launch", "three_side_by_side"])
 @pytest.mark.parametrize("super_min", ["default", "257"], ids=["workgroup_per_giant", "ranges_across_the_chip"])
 @pytest.mark.parametrize("k", [4, 16])
-def test_giant_features_fold_the_same_either_way(super_min, k, monkeypatch):
+def test_giant_features_fold_the_same_either_way(super_min, k, split, monkeypatch):
     """Features with more than 256 occurrences in a block are folded by the waves of one workgroup
     together (a tile per wave and super-step), the longest ones (FFM_SUPER_MIN, 2048 by default) as
     ranges all over the chip through global partial sums and two more launches: the same tree, so
@@ -351,6 +356,7 @@ def test_giant_features_fold_the_same_either_way(super_min, k, monkeypatch):
     that lack fields (empty tiles), and blocks whose last tile / range is partial."""
     if super_min != "default":
         monkeypatch.setenv("FFM_SUPER_MIN", super_min)
+    monkeypatch.setenv("FFM_UPDATE_SPLIT", split)  # (the update as one launch / as three side by side)
     rng = np.random.default_rng(41 + k)
     F, per = 6, 12
     nf = F * per

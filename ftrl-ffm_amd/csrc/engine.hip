@@ -367,6 +367,7 @@ struct ffm_engine {
                           // on three queues (hot + bias + linear | few + serial walk + loss | giant), each with the
                           // registers and LDS of its own path; 1 as launches one after another (timing aid);
                           // default: 2 for a whole model's large launches (nnz * k >= 4 M: the fork / join pays), else 0
+  int wide_max_nnz = 100000;  // FFM_WIDE_NNZ: blocks below this many entries run the update launch with eight-wave workgroups (0: never)
   bool predict_waves = true;  // FFM_PREDICT_WAVE=0: evaluation rows through ffm_row_kernel (one workgroup per row)
   int update_order = 210;     // FFM_UPDATE_ORDER: the update launch's big ranges, first range = last digit (0 giant, 1 hot, 2 few)
   // workgroups of pull_block_kernel.  Few on purpose: its loads take microseconds
@@ -633,6 +634,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_UPDATE_SPLIT")) e->update_split = std::atoi(sv);
   if (const char *sv = std::getenv("FFM_UPDATE_ORDER")) e->update_order = std::atoi(sv);
   if (const char *sv = std::getenv("FFM_PREDICT_WAVE")) e->predict_waves = std::atoi(sv) != 0;
+  if (const char *sv = std::getenv("FFM_WIDE_NNZ")) e->wide_max_nnz = std::atoi(sv);
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_WALK")) e->grid_walk = std::max(1, std::atoi(sv));

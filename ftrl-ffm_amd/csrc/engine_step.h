@@ -308,15 +308,6 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     if (flat && !few_late) LAUNCH_ON(e, sst, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
     if (sst != e->stream && !few_late) HIP_TRY(hipEventRecord(e->ev_join, sst));
     // (the ranges' sizes are kept in 256-thread units and scaled to the launch's workgroup size)
-    const int nf = tile_nf(e), wpb = tile_waves(nf), scale = wpb / kUpdWaves, threads = 64 * wpb;
-    const size_t lds = tile_lds_bytes(nf);
-    // (... and to the block: a workgroup that finds its range's lists empty still costs a dispatch and
-    // a few dependent loads -- 4100 of them were a fifth of a 4096 x 8 block's update)
-    auto sized = [&](int grid, int per_wg, int least) { return std::max(least, std::min(grid, cdiv(rows.nnz, per_wg))); };
-    const int nt = cdiv(sized(e->grid_hot, 32, 64), scale), ns = flat ? 0 : cdiv(sized(e->grid_small, 128, 64), scale);
-    const int nw = cdiv(sized(e->grid_walk, 1024, 16), scale);
-    const int ng = rows.nnz >= kGiantMin ? sized(e->grid_giant, 256, 32) : 0;  // workgroups that fold giant features together
-    const int order = e->update_order;  // (which of the three big ranges the dispatcher sees first)
     // One launch, or three side by side: the one launch runs every range at the register / LDS footprint
     // of the hungriest (3 waves per SIMD at k = 16); side by side the few-occurrence range gets 4 and
     // the ranges overlap as the dispatcher finds room -- C5 resident step 1.005 -> 0.95-0.97 ms, but a
@@ -325,6 +316,18 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // 1.77 ms.
     const int split = e->update_split >= 0 ? e->update_split
                       : (!side_launches && static_cast<int64_t>(rows.nnz) * e->m.n_factors >= (4ll << 20) ? 2 : 0);
+    // (small blocks of a whole model, k >= 16: eight waves per workgroup -- kernels_tile.h kWideWaves)
+    const int nf = tile_nf(e);
+    const bool wide = nf == 1 && !side_launches && split == 0 && rows.nnz < e->wide_max_nnz;
+    const int wpb = wide ? kWideWaves : tile_waves(nf), scale = wpb / kUpdWaves, threads = 64 * wpb;
+    const size_t lds = tile_lds_bytes(nf, wpb);
+    // (... and to the block: a workgroup that finds its range's lists empty still costs a dispatch and
+    // a few dependent loads -- 4100 of them were a fifth of a 4096 x 8 block's update)
+    auto sized = [&](int grid, int per_wg, int least) { return std::max(least, std::min(grid, cdiv(rows.nnz, per_wg))); };
+    const int nt = cdiv(sized(e->grid_hot, 32, 64), scale), ns = flat ? 0 : cdiv(sized(e->grid_small, 128, 64), scale);
+    const int nw = cdiv(sized(e->grid_walk, 1024, 16), scale);
+    const int ng = rows.nnz >= kGiantMin ? sized(e->grid_giant, 256, 32) : 0;  // workgroups that fold giant features together
+    const int order = e->update_order;  // (which of the three big ranges the dispatcher sees first)
     const int lb = loss_sum_out ? loss_grid(rows.n_rows) : 0;
     const int side = side_blocks > 0 ? 1 + cdiv(lin_blocks, scale) : 0;
     const int grid = side + ng + nt + ns + nw + lb;
@@ -364,7 +367,10 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
                side, ng, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part, order);                  \
       }                                                                                                       \
     } while (0)
-    if (nf == 1) FTRL_LAUNCH_ALL(1);       // k >= 16
+    if (wide)
+      LAUNCH(e, K_LATENT_UPDATE, (ffm_update_all_kernel<1, UPD_ALL, kWideWaves>), grid, threads, lds, e->m, rows, e->sc[e->cur],
+             side, ng, nt, ns, single ? 1 : 0, nw, lb, loss_sum_out, e->d_loss_part, order);
+    else if (nf == 1) FTRL_LAUNCH_ALL(1);  // k >= 16
     else if (nf == 2) FTRL_LAUNCH_ALL(2);  // k = 8 / 12
     else FTRL_LAUNCH_ALL(4);               // k = 4
     if (few_late) {

@@ -628,9 +628,14 @@ __device__ __forceinline__ void ffm_range_join(const ModelDev &m, const Scratch 
 // of a C5 block 506 us instead of 170 (profiles/r05_experiments.md).
 // Dynamic LDS: the transposers [WAVES][kTileT * kTileRow] floats, then the fact records.
 constexpr int tile_waves(int nf) { return nf == 4 && FFM_TILE_WAVES > 4 ? 4 : nf == 2 && FFM_TILE_WAVES > 8 ? 8 : FFM_TILE_WAVES; }
-constexpr size_t tile_lds_bytes(int nf) {
-  return static_cast<size_t>(tile_waves(nf)) * (kTileT * kTileRow * sizeof(float) + kTileNR * kTileT * 4 * nf * sizeof(float4));
+constexpr size_t tile_lds_bytes(int nf, int waves) {
+  return static_cast<size_t>(waves) * (kTileT * kTileRow * sizeof(float) + kTileNR * kTileT * 4 * nf * sizeof(float4));
 }
+constexpr size_t tile_lds_bytes(int nf) { return tile_lds_bytes(nf, tile_waves(nf)); }
+// Small blocks (a 4096 x 8 block: ~1000-occurrence giants are 16 super-steps of four tiles) run the
+// launch with EIGHT waves per workgroup: half the super-steps -- 80 -> 70 us per launch; a C5 block
+// that way 438 -> 693 us (profiles/r05_experiments.md).
+constexpr int kWideWaves = 8;
 // KINDS: which ranges this instantiation can run (their arguments must be 0 otherwise) -- the register
 // allocation, and with it the waves per SIMD, of a kernel is that of its hungriest path.
 enum { UPD_GIANT = 1, UPD_HOT = 2, UPD_FEW = 4, UPD_SIDE = 8, UPD_REST = 16, UPD_ALL = 31 };
@@ -653,12 +658,11 @@ constexpr int upd_occ(int kinds) {
 constexpr int upd_occ_min(int kinds) { return upd_occ(kinds) > 0 ? upd_occ(kinds) : 1; }
 constexpr int upd_occ_max(int kinds) { return upd_occ(kinds) > 0 ? upd_occ(kinds) : 8; }
 #define FFM_UPD_OCC __attribute__((amdgpu_waves_per_eu(upd_occ_min(KINDS), upd_occ_max(KINDS))))
-template <int NF, int KINDS = UPD_ALL>
-__global__ __launch_bounds__(64 * tile_waves(NF)) FFM_UPD_OCC void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
+template <int NF, int KINDS = UPD_ALL, int WAVES = tile_waves(NF)>
+__global__ __launch_bounds__(64 * WAVES) FFM_UPD_OCC void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
                                                                      int side_blocks, int ng, int nt, int ns,
                                                                      int few_only, int nw, int loss_blocks,
                                                                      double *loss_out, double *loss_scratch, int order) {
-  constexpr int WAVES = tile_waves(NF);
   extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
   __shared__ CoopLds<WAVES> lds_coop;
   int r = blockIdx.x;

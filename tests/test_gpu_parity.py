@@ -248,7 +248,7 @@ def test_refresh_modes_are_bit_identical(mode, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("split", ["0", "2"], ids=["one_launch", "three_side_by_side"])
+@pytest.mark.parametrize("split", ["0", "0n", "2"], ids=["one_launch", "one_launch_four_waves", "three_side_by_side"])
 @pytest.mark.parametrize("k", [4, 8, 16])
 def test_update_launch_folds_every_class_of_feature(k, split, monkeypatch):
     """The FFM update of a block (kernels_tile.h: ffm_update_all_kernel) as ONE launch whose
@@ -258,7 +258,9 @@ def test_update_launch_folds_every_class_of_feature(k, split, monkeypatch):
     | few + serial walk + loss | giant, instantiated per set of ranges): the oracle's bits on blocks
     with once-only, few-occurrence, hot and very hot features (a feature in every row included:
     sixteen segments of 64 occurrences)."""
-    monkeypatch.setenv("FFM_UPDATE_SPLIT", split)
+    monkeypatch.setenv("FFM_UPDATE_SPLIT", split[0])
+    if split == "0n":  # (small blocks at k >= 16 run the one launch with eight-wave workgroups: here with four)
+        monkeypatch.setenv("FFM_WIDE_NNZ", "0")
     rng = np.random.default_rng(31 + k)
     F, per = 6, 30
     nf = F * per

@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64 * WAVES) FFM_UPD_OCC void ffm_update_all_kernel(
   float *T = reinterpret_cast<float *>(lds_dyn) + wv * (kTileT * kTileRow);
   float4 *R = reinterpret_cast<float4 *>(lds_dyn + WAVES * kTileT * kTileRow * sizeof(float)) + wv * (kTileNR * kTileT * 4 * NF);
   if ((KINDS & UPD_SIDE) && r < side_blocks) {
-    if (r == 0) bias_update_body(m, rows.n_rows, s);
+    if (r == 0) bias_update_body(m, rows.n_rows, s, reinterpret_cast<float *>(lds_dyn));
     else linear_update_body(m, rows, s, r - 1, side_blocks - 1);
     return;
   }

@@ -154,11 +154,14 @@ __global__ __launch_bounds__(kUpdThreads) void linear_update_kernel(ModelDev m, 
 // thread 0 then joins the segment totals in order.  For 8192 rows: 128 threads x 64 adds, then 128
 // adds -- where the row-order walk was 2 x 8192 dependent adds (74 us, the floor of FM's update).
 // Called by every thread of a workgroup (of up to kUpdMaxThreads threads).
-__device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, const Scratch &sc) {
+// buf: 2 * blockDim.x floats of LDS the caller has no other use for (the FFM update launch hands its
+// dynamic region over -- a static array here would be allocated by every workgroup of that launch and
+// cost its tile ranges a resident workgroup per CU at k = 4)
+__device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, const Scratch &sc, float *buf) {
   if (!m.bias_own) return;             // another shard's
   if (sc.counters[CNT_ERROR]) return;  // untrainable block (ERR_ROW_TOO_LONG): a no-op
   if (n_rows <= 0) return;
-  __shared__ float s_P[kUpdMaxThreads], s_G[kUpdMaxThreads];
+  float *s_P = buf, *s_G = buf + blockDim.x;
   const int n_thr = blockDim.x;
   const float *tg = sc.tg;
   const int n_seg = (n_rows + kSeg - 1) / kSeg;
@@ -211,7 +214,8 @@ __device__ __forceinline__ void bias_update_body(const ModelDev &m, int n_rows, 
   }
 }
 __global__ __launch_bounds__(kUpdThreads) void bias_update_kernel(ModelDev m, int n_rows, Scratch s) {
-  bias_update_body(m, n_rows, s);
+  __shared__ float s_PG[2 * kUpdThreads];
+  bias_update_body(m, n_rows, s, s_PG);
 }
 
 // The general owner: work item = (distinct feature, 64 elements of its record), lane = element,
@@ -883,8 +887,9 @@ __global__ __launch_bounds__(kUpdThreads) void fm_update_join_kernel(ModelDev m,
 // and the linear update, the others the latent lists.
 __global__ __launch_bounds__(kUpdThreads) void fm_update_kernel(ModelDev m, Rows rows, Scratch s,
                                                                 int skip_once, int side_blocks) {
+  __shared__ float s_PG[2 * kUpdThreads];  // (the bias fold's segment totals)
   if (static_cast<int>(blockIdx.x) < side_blocks) {
-    if (blockIdx.x == 0) bias_update_body(m, rows.n_rows, s);
+    if (blockIdx.x == 0) bias_update_body(m, rows.n_rows, s, s_PG);
     else linear_update_body(m, rows, s, blockIdx.x - 1, side_blocks - 1, skip_once);
     return;
   }

@@ -28,11 +28,11 @@ static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *r
 static bool launch_predict_waves(ffm_engine *e, const Rows &rows, int row_cap, float *out, int output_prob) {
   const ModelDev &m = e->m;
   if (!e->predict_waves || m.type != FFM_MODEL_FFM || m.n_shards > 1 || m.field_start || m.own_n || m.lin_own) return false;
-  const size_t shmem = pred_lds_bytes(row_cap);
-  if (shmem > 64 * 1024) return false;
+  const int lds_cap = std::min(row_cap, kPredLdsCap);
+  const size_t shmem = pred_lds_bytes(lds_cap);
   const int grid = cdiv(rows.n_rows, kPredRows), threads = 64 * kPredRows;
 #define PRED_LAUNCH(LPP, VPL, U) \
-  LAUNCH(e, K_PREDICT_ROW, (ffm_predict_wave_kernel<LPP, VPL, U>), grid, threads, shmem, m, rows, e->sc[e->cur], row_cap, out, output_prob)
+  LAUNCH(e, K_PREDICT_ROW, (ffm_predict_wave_kernel<LPP, VPL, U>), grid, threads, shmem, m, rows, e->sc[e->cur], row_cap, lds_cap, out, output_prob)
   switch (m.n_factors) {
     case 4: PRED_LAUNCH(1, 1, 4); return true;
     case 8: PRED_LAUNCH(2, 1, 4); return true;
@@ -101,7 +101,12 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
         LAUNCH(e, kid, (ffm_row_kernel<true, true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, 0, 0, 0);
     }
     else if (train) LAUNCH(e, kid, (ffm_row_kernel<true, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, refreshed, own_tg, 0, 0);
-    else if (launch_predict_waves(e, rows, row_cap, out, output_prob)) {}
+    else if (launch_predict_waves(e, rows, row_cap, out, output_prob)) {
+      // rows that may be longer than a wave stages (kernels_predict.h): the workgroup-per-row kernel
+      // for those alone (its last argument: rows of at most that many entries are not its)
+      if (row_cap > kPredLdsCap)
+        LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0, kPredLdsCap);
+    }
     else if (vec4) LAUNCH(e, kid, (ffm_row_kernel<false, true>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0, 0);
     else LAUNCH(e, kid, (ffm_row_kernel<false, false>), rows.n_rows, e->row_threads, shmem, e->m, rows, e->sc[e->cur], mr, out, output_prob, 0, 0, 0, 0);
   }

@@ -15,6 +15,9 @@
 // (dot*x1)*x2; the terms go through the wave's LDS into the strictly ordered sum
 // (wave_sequential_prefix: one DPP add per term).  U steps of loads are in flight together.
 // Sharded / compact engines, LR, and k outside {4, 8, 16, 32, 64} keep ffm_row_kernel.
+// A wave's LDS holds kPredLdsCap entries at most: when the caller's rows may be longer (a device-
+// resident block is not scanned on the host: its bound is the engine's max_row_nnz), rows beyond
+// that are left to ffm_row_kernel in a second launch, which returns at once for the others.
 #pragma once
 #include "engine_types.h"
 #include "kernels_touch.h"
@@ -24,9 +27,10 @@ namespace ftrl_dev {
 
 constexpr int kPredRows = 4;     // rows (= waves) per workgroup
 constexpr int kPredTerms = 256;  // terms staged per wave between two ordered sums (a multiple of 64)
+constexpr int kPredLdsCap = 128; // entries of a row a wave stages at most (12 KB per workgroup: eight waves per SIMD)
 
-__host__ __device__ inline size_t pred_lds_bytes(int max_row_nnz) {
-  return static_cast<size_t>(kPredRows) * (static_cast<size_t>(max_row_nnz) * 16 + kPredTerms * 4);
+__host__ __device__ inline size_t pred_lds_bytes(int lds_cap) {
+  return static_cast<size_t>(kPredRows) * (static_cast<size_t>(lds_cap) * 16 + kPredTerms * 4);
 }
 
 // the value of the lane below (row_shr:1 inside the 16-lane DPP row; the first lane of a pair's
@@ -42,7 +46,7 @@ __device__ __forceinline__ float pred_lane_below(float v) {
 #endif
 template <int LPP, int VPL, int U>
 __global__ __launch_bounds__(64 * kPredRows) FFM_PRED_OCC void ffm_predict_wave_kernel(ModelDev m, Rows rows, Scratch s,
-                                                                         int max_row_nnz, float *out,
+                                                                         int max_row_nnz, int lds_cap, float *out,
                                                                          int output_prob) {
   static_assert(LPP >= 1 && LPP <= 16 && (LPP & (LPP - 1)) == 0, "a pair's lanes sit inside one DPP row");
   static_assert(kPredTerms % 64 == 0, "whole prefix chunks");
@@ -52,8 +56,8 @@ __global__ __launch_bounds__(64 * kPredRows) FFM_PRED_OCC void ffm_predict_wave_
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = wave_uniform(blockIdx.x * kPredRows + wv);
   if (r >= rows.n_rows) return;
-  int4 *E = reinterpret_cast<int4 *>(smem + static_cast<size_t>(wv) * (static_cast<size_t>(max_row_nnz) * 16 + kPredTerms * 4));
-  float *terms = reinterpret_cast<float *>(E + max_row_nnz);
+  int4 *E = reinterpret_cast<int4 *>(smem + static_cast<size_t>(wv) * (static_cast<size_t>(lds_cap) * 16 + kPredTerms * 4));
+  float *terms = reinterpret_cast<float *>(E + lds_cap);
   const int b = wave_uniform(rows.row_ptr[r]);
   const int nnz = wave_uniform(rows.row_ptr[r + 1]) - b;
   if (nnz > max_row_nnz) {  // beyond the validated capacity: flagged, NaN outputs
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(64 * kPredRows) FFM_PRED_OCC void ffm_predict_wave_
     }
     return;
   }
+  if (nnz > lds_cap) return;  // (a longer row: ffm_row_kernel's, in the launch behind this one)
   const int k = m.n_factors, RL = m.row_len;
 
   // ---- entries: remove_out_range (ftrl_model.cpp:36-42, ffm.cpp:30-36), the survivors in row

@@ -237,6 +237,9 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
   const int r = blockIdx.x + row0;  // (row0: first row of this launch's row phase)
   const int b = rows.row_ptr[r];
   const int nnz = rows.row_ptr[r + 1] - b;
+  // (evaluation rows of at most park_vecs entries were ffm_predict_wave_kernel's: this launch is for
+  // the longer ones)
+  if (!TRAIN && park_vecs > 0 && nnz <= park_vecs) return;
   // a row beyond the LDS capacity: the grouping has flagged the whole training block (no kernel
   // touches the model); a predict call flags it here.  Its outputs are NaN.
   if ((TRAIN && s.counters[CNT_ERROR]) || nnz > max_row_nnz) {

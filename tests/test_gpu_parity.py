@@ -100,6 +100,71 @@ def test_block_semantics_match_oracle(mt, F, k, per, B, hp):
     e.close()
 
 
+@pytest.mark.parametrize("F,k", [(5, 32), (4, 64), (3, 128), (6, 12), (5, 20), (4, 96), (7, 2), (3, 200)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("B", [64, 700])
+def test_other_factor_counts_match_oracle(F, k, B):
+    """The factor counts BASELINE's configurations do not use: k = 32 / 64 (two / one slot per 64-element
+    chunk), k = 128 / 96 / 200 (a slot is several chunks, the last one partial), k = 12 / 20 (whole
+    16-byte vectors, not a power of two: evaluation keeps the workgroup-per-row kernel), k = 2 (the
+    scalar kernels) -- blocks with once-only, few-occurrence, hot and giant features, n near 0
+    (ffm.cpp:118's NaNs), bitwise against the oracle; evaluation too."""
+    rng = np.random.default_rng(100 + k)
+    per = 25
+    nf = F * per
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o, n_hi=0.05)
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=1024, **STRESS_HP)
+    e.set_state(st)
+    g = synth.Generator(F, nf, "zipf", seed=21)
+    for n in (B, B, 1):
+        blk = g.block(n)
+        if n > 300:
+            blk.feat[::F] = 0  # one feature in every row: a giant
+        lo, so = o.train_batch(blk)
+        lg, sg = e.train_batch(blk)
+        assert_bitwise(lg, lo, "F=%d k=%d logits of a %d-row block" % (F, k, n))
+        assert loss_close(sg, so)
+    assert_state_bitwise(e.get_state(), o.get_state(), "F=%d k=%d" % (F, k))
+    blk = g.block(256)
+    pe, le = e.predict_batch(blk)
+    po, lo_ = o.predict_batch(blk)
+    assert_bitwise(pe, po, "F=%d k=%d predict" % (F, k))
+    assert loss_close(le, lo_)
+    e.close()
+
+
+@pytest.mark.parametrize("k", [65, 128, 33, 4])
+def test_fm_other_factor_counts_match_oracle(k):
+    """FM beyond one wave per row (k > 64: fm_row_kernel) and at odd k: blocks with once-only,
+    repeated and giant features (ranges of 64 occurrences joined by a second launch), bitwise."""
+    rng = np.random.default_rng(200 + k)
+    nf = 400
+    o = CpuModel("oracle", "FM", nf, 1, k, **STRESS_HP)
+    st = rand_state(rng, o, n_hi=0.05)
+    o.set_state(st)
+    e = fa.Engine("FM", nf, 1, k, skip_init=True, max_batch_rows=1024, **STRESS_HP)
+    e.set_state(st)
+    g = synth.Generator(11, nf, "zipf", seed=23)
+    for n in (700, 64, 700, 1):
+        blk = g.block(n)
+        blk.field = np.zeros(blk.nnz, np.int32)
+        if n > 300:
+            blk.feat[::11] = 3  # one feature in every row
+        lo, so = o.train_batch(blk)
+        lg, sg = e.train_batch(blk)
+        assert_bitwise(lg, lo, "FM k=%d logits of a %d-row block" % (k, n))
+        assert loss_close(sg, so)
+    assert_state_bitwise(e.get_state(), o.get_state(), "FM k=%d" % k)
+    blk = g.block(256)
+    blk.field = np.zeros(blk.nnz, np.int32)
+    pe, _ = e.predict_batch(blk)
+    po, _ = o.predict_batch(blk)
+    assert_bitwise(pe, po, "FM k=%d predict" % k)
+    e.close()
+
+
 def test_ragged_empty_and_multivalued_rows():
     """Empty rows, single-entry rows, out-of-range entries, several features per field, fields
     out of order, a feature repeated across rows of the block."""

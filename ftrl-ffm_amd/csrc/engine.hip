@@ -259,6 +259,11 @@ struct ffm_engine {
   int cur = 0;                 // set of the block being trained
   bool cur_prepared = false;   // ... was grouped ahead (ev_grouped[cur] marks the end of its grouping)
   int *h_super = nullptr;      // [kSets] page-locked: Scratch::n_super of every set, as the host reads it
+  // evaluation block whose predict launch ffm_engine_predict_batch_async deferred by one call
+  struct { bool on = false; int slot = 0; bool labelled = false; } eval_pending;
+  bool eval_hold = false;       // inside predict_batch_async, before its upload is submitted
+  bool eval_defer_off = false;  // FFM_EVAL_DEFER=0
+  bool super_flag_ok = false;  // create proved that a device store to h_super reaches the host
   // groupings made ahead by ffm_engine_prepare_device, oldest first (at most kSets - 1)
   int n_prepared = 0;
   int prepared_set[kSets] = {};
@@ -537,6 +542,7 @@ static bool flat_pays(const ffm_engine *e, int span4) {
 extern "C" {
 
 int ffm_engine_abi_version(void) { return FFM_ENGINE_ABI_VERSION; }
+int ffm_engine_block_segment(void) { return ftrl_dev::kSeg; }
 const char *ffm_engine_last_error(void) { return g_last_error.c_str(); }
 
 void ffm_engine_default_config(ffm_engine_config *cfg) {
@@ -632,7 +638,14 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (cfg->max_row_nnz > 0) e->max_row_nnz = cfg->max_row_nnz;
   if (const char *sv = std::getenv("FFM_ENGINE_SERIAL")) e->serial = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_UPDATE_SPLIT")) e->update_split = std::atoi(sv);
-  if (const char *sv = std::getenv("FFM_UPDATE_ORDER")) e->update_order = std::atoi(sv);
+  if (const char *sv = std::getenv("FFM_UPDATE_ORDER")) {
+    // a permutation of the digits {0, 1, 2} (first range last) or nothing: any other value would run
+    // one range of the update launch twice and drop another
+    const int o = std::atoi(sv);
+    const int d0 = o % 10, d1 = o / 10 % 10, d2 = o / 100;
+    if (o >= 0 && d2 <= 2 && d0 <= 2 && d1 <= 2 && d0 != d1 && d0 != d2 && d1 != d2) e->update_order = o;
+  }
+  if (const char *sv = std::getenv("FFM_EVAL_DEFER")) e->eval_defer_off = sv[0] == '0';
   if (const char *sv = std::getenv("FFM_PREDICT_WAVE")) e->predict_waves = std::atoi(sv) != 0;
   if (const char *sv = std::getenv("FFM_WIDE_NNZ")) e->wide_max_nnz = std::atoi(sv);
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
@@ -843,6 +856,14 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     int *d_super = nullptr;
     TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_super), e->h_super, 0));
     s.n_super = d_super;
+    // The host skips the longest features' two extra launches when it reads 0 here -- which is only
+    // safe if a device store to this mapping actually lands: prove it once, else the
+    // launches are always made.
+    hipLaunchKernelGGL(host_word_probe_kernel, dim3(1), dim3(64), 0, e->stream, d_super, ffm_engine::kSets);
+    TRY_HIP(hipStreamSynchronize(e->stream));
+    e->super_flag_ok = true;
+    for (int si = 0; si < ffm_engine::kSets; si++) e->super_flag_ok = e->super_flag_ok && e->h_super[si] == 0x5eed + si;
+    std::memset(e->h_super, 0, sizeof(int) * ffm_engine::kSets);
   }
   for (int si = 1; si < ffm_engine::kSets; si++) {
     Scratch &t = e->sc[si];
@@ -1030,8 +1051,10 @@ int ffm_engine_eval_sigmoid(ffm_engine *e, int32_t n, const float *x, float *y) 
 // Waits for the engine's stream, then reports (and clears) what the kernels flagged since the
 // last report: the device entry points are asynchronous, so this is where their callers learn
 // that a block could not be trained.
+static int eval_launch_pending(ffm_engine *e);  // (engine_step.h)
 static int check_device_errors(ffm_engine *e) {
   int flags = 0;
+  if (int rc_e = eval_launch_pending(e)) return rc_e;
   if (int rc_w = e->drain()) return rc_w;
   // the uploads of blocks that are staged but not trained yet run on the prep stream: the
   // zero-copy contract (include/ffm_engine.h) lets the caller reuse its page-locked arrays once

@@ -4,9 +4,16 @@
 
 // ---- one block of rows ---------------------------------------------------------------------
 
+static int eval_launch_pending(ffm_engine *e);
+__global__ void loss_accumulate_kernel(double *acc, const double *one) { *acc += *one; }
+
 static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *row_ptr,
                        const void *field, const void *feat, const void *val) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
+  // an evaluation block whose predict launch predict_batch_async deferred goes first (every entry
+  // point that puts work on the main stream passes here)
+  if (e->eval_pending.on && !e->eval_hold)
+    if (int rc_e = eval_launch_pending(e)) return rc_e;
   if (n_rows < 0 || nnz < 0) return fail(FFM_E_INVALID, "negative n_rows / nnz");
   if (n_rows > e->max_rows || nnz > e->max_nnz)
     return fail(FFM_E_CAPACITY, "block exceeds max_batch_rows / max_batch_nnz");
@@ -387,7 +394,8 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // (the grouping counted the block's longest features into page-locked host memory; it ran blocks
     // ahead, so its event has usually completed and the count can be read: none -> no launches)
     bool supers = rows.nnz >= e->m.super_min;
-    if (supers && e->cur_prepared && hipEventQuery(e->ev_grouped[e->cur]) == hipSuccess && e->h_super[e->cur] == 0)
+    if (supers && e->super_flag_ok && e->cur_prepared && hipEventQuery(e->ev_grouped[e->cur]) == hipSuccess &&
+        e->h_super[e->cur] == 0)
       supers = false;
     if (supers) {
       // the longest features' ranges: second pass (root differences) and the join of their tiles
@@ -462,6 +470,26 @@ int ffm_engine_predict_batch_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   launch_row_kernel(e, rows, false, out ? out : e->d_out, output_prob);
   if (loss_sum_out && label)
     LAUNCH(e, K_LOSS_SUM, loss_sum_kernel, loss_grid(n_rows), 256, 0, n_rows, e->sc[e->cur].loss, loss_sum_out, e->d_loss_part);
+  HIP_TRY(hipGetLastError());
+  return FFM_OK;
+}
+
+// The predict launch of the block ffm_engine_predict_batch_async uploaded one call ago (engine_stage.h).
+static int eval_launch_pending(ffm_engine *e) {
+  if (!e->eval_pending.on) return FFM_OK;
+  e->eval_pending.on = false;  // (first: the launch below passes check_block)
+  ffm_engine::Slot &sl = e->slots[e->eval_pending.slot];
+  const bool labelled = e->eval_pending.labelled;
+  HIP_TRY(hipSetDevice(e->cfg.device_id));
+  HIP_TRY(hipStreamWaitEvent(e->stream, sl.ev_copied, 0));
+  e->staged_row_cap = sl.row_cap;
+  int rc = ffm_engine_predict_batch_device(e, sl.n_rows, sl.nnz, sl.row_ptr, sl.has_field ? sl.field : nullptr, sl.feat,
+                                           sl.val, labelled ? sl.label : nullptr, 0, e->d_out,
+                                           labelled ? e->d_loss_sum : nullptr);
+  if (rc) return rc;
+  if (labelled) hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->d_loss_acc, e->d_loss_sum);
+  HIP_TRY(hipEventRecord(sl.ev_trained, e->stream));  // the slot's device arrays are free again
+  sl.free_ev = sl.ev_trained;
   HIP_TRY(hipGetLastError());
   return FFM_OK;
 }

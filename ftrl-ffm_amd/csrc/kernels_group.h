@@ -229,11 +229,19 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
       // range of range_len occurrences (kernels_tile.h / kernels_update.h: the ranges are folded side by side)
       const int gi = slot[6];
       s.giant[gi] = u;
-      if (c >= m.super_min) __hip_atomic_fetch_add(s.n_super, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const int n_seg = (c + kSeg - 1) / kSeg, n_rng = (c + m.range_len - 1) / m.range_len;
-      s.gseg[gi] = atomicAdd(&s.counters[CNT_NSEG], n_seg);
-      const int rb = atomicAdd(&s.counters[CNT_NRANGE], n_rng);
-      for (int r = 0; r < n_rng; r++) s.grange[rb + r] = make_int2(gi, r);
+      // (the host only asks "any at all?": a plain system-scope store of 1 -- no read-modify-write on
+      // host memory, which would need PCIe atomics to land)
+      if (c >= m.super_min) __hip_atomic_store(s.n_super, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // segment slots and range entries only for the features that are folded as ranges: every FM
+      // giant, FFM from super_min on (below it a workgroup folds the feature: ffm_coop_items)
+      if (m.type != 2 || c >= m.super_min) {
+        const int n_seg = (c + kSeg - 1) / kSeg, n_rng = (c + m.range_len - 1) / m.range_len;
+        s.gseg[gi] = atomicAdd(&s.counters[CNT_NSEG], n_seg);
+        const int rb = atomicAdd(&s.counters[CNT_NRANGE], n_rng);
+        for (int r = 0; r < n_rng; r++) s.grange[rb + r] = make_int2(gi, r);
+      } else {
+        s.gseg[gi] = 0;
+      }
     }
   }
   // slots of the feature that p's row touches: slot fp is touched when the row holds ANOTHER
@@ -261,6 +269,12 @@ __global__ __launch_bounds__(kFinishThreads) void group_finish_kernel(ModelDev m
       if (tc) atomicOr(&s.cmask[lower], tc);
     }
   }
+}
+
+// create-time check that device stores to the mapped host words of Scratch::n_super land (engine.hip)
+__global__ void host_word_probe_kernel(int *w, int n) {
+  if (static_cast<int>(threadIdx.x) < n)
+    __hip_atomic_store(w + threadIdx.x, 0x5eed + static_cast<int>(threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace ftrl_dev

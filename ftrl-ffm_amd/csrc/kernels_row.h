@@ -29,6 +29,14 @@ namespace ftrl_dev {
 #ifndef FFM_ROW_NT
 #define FFM_ROW_NT 7
 #endif
+// Experiment builds of the FFM row kernel (tools/ab_env.sh; profiles/r06_experiments.md).  Bit 1 is
+// exact (the in-row update recomputes its own w from the (n, z) it holds instead of reading it back);
+// every other bit drops a class of memory accesses and gives WRONG results -- timing only:
+//   2 pair phase loads no weights | 4 update takes no second (n, z) read | 8 update loads no partner w
+//   16 update stores nothing | 32 refresh stores no w | 64 no in-row update at all
+#ifndef FFM_ROW_EXP
+#define FFM_ROW_EXP 0
+#endif
 constexpr int kRowThreads = 256;
 #ifndef FFM_ROW_MAXT
 #define FFM_ROW_MAXT 256
@@ -359,7 +367,10 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
         }
 #pragma unroll
         for (int u = 0; u < kRefreshFly; u++)
-          if (wp[u]) *wp[u] = latent_weight4(m.h, n4[u], z4[u], w4[u]);
+          if (wp[u]) {
+            const float4 wn = latent_weight4(m.h, n4[u], z4[u], w4[u]);
+            if (!(FFM_ROW_EXP & 32) || wn.x == 123.456f) *wp[u] = wn;
+          }
       }
     } else {
       const int total = nv * RL;
@@ -476,7 +487,10 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
             if (k == 16) {  // the common slot size: both slots' eight vectors in flight together
               float4 x[4], y[4];
 #pragma unroll
-              for (int f4 = 0; f4 < 4; f4++) { x[f4] = va4[f4]; y[f4] = vb4[f4]; }
+              for (int f4 = 0; f4 < 4; f4++) {
+                if (FFM_ROW_EXP & 2) { x[f4] = y[f4] = make_float4(lds.val[a], lds.val[bb], 0.5f, 0.25f); continue; }
+                x[f4] = va4[f4]; y[f4] = vb4[f4];
+              }
 #pragma unroll
               for (int f4 = 0; f4 < 4; f4++) {
                 dot = dot + x[f4].x * y[f4].x;
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
     // touch, tmp_grad is known, and their records and the partners' weights were read moments ago
     // (refresh and pair phase above), so the second read comes out of the caches instead of HBM.
     // Same touches in the same order as ffm_update_single_kernel, which then has nothing to do.
-    if (VEC4 && refreshed == 3) {
+    if (VEC4 && refreshed == 3 && !(FFM_ROW_EXP & 64)) {
 #ifndef FFM_UPD_FLY
 #define FFM_UPD_FLY 1
 #endif
@@ -564,6 +578,8 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
           if (t < park_vecs) {
             n4[u] = park_n[t];
             z4[u] = park_z[t];
+          } else if (FFM_ROW_EXP & 4) {
+            n4[u] = z4[u] = make_float4(tg, 1.0f, 2.0f, 3.0f);
           } else if (FFM_ROW_NT & 4) {
             n4[u] = load_nt(row + LAT_N * RL4 + c4);
             z4[u] = load_nt(row + LAT_Z * RL4 + c4);
@@ -571,12 +587,17 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
           n4[u] = row[LAT_N * RL4 + c4];
           z4[u] = row[LAT_Z * RL4 + c4];
           }
-          w4[u] = (FFM_ROW_NT & 8) ? load_nt(row + LAT_W * RL4 + c4) : row[LAT_W * RL4 + c4];
+          // (the refresh stored W(n, z) of these very (n, z) -- nobody else touches a once-only
+          // feature's record inside the block -- so recomputing it gives the stored bits; the
+          // learning variant's w depends on the old w and is read back)
+          if ((FFM_ROW_EXP & 1) && !m.h.learn) w4[u] = ftrl_weight4(m.h, n4[u], z4[u]);
+          else w4[u] = (FFM_ROW_NT & 8) ? load_nt(row + LAT_W * RL4 + c4) : row[LAT_W * RL4 + c4];
           rp[u] = row + c4;
           ia[u] = a;
           ifp[u] = fp;
           ikq[u] = c4 - sl * k4;
-          if (lds.fcnt[fp] == 1)  // (then fa != fp: the only entry of that field is the partner)
+          if (FFM_ROW_EXP & 8) vp[u] = make_float4(0.01f, 0.02f, tg, 0.03f);
+          else if (lds.fcnt[fp] == 1)  // (then fa != fp: the only entry of that field is the partner)
             vp[u] = reinterpret_cast<const float4 *>(lat_row(m, lds.feat[lds.ffirst[fp]], fp))
                 [LAT_W * RL4 + slot_of(m, fp, fa) * k4 + ikq[u]];
         }
@@ -595,7 +616,9 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
               ffm_touch4(m.h, a < bb, tg, lds.val[a], lds.val[bb], vq, w4[u], n4[u], z4[u]);
             }
           }
-          if (FFM_ROW_NT & 1) {
+          if (FFM_ROW_EXP & 16) {
+            if (n4[u].x == 123.456f) rp[u][LAT_N * RL4] = z4[u];  // (keeps the arithmetic alive)
+          } else if (FFM_ROW_NT & 1) {
             store_nt(rp[u] + LAT_N * RL4, n4[u]);
             store_nt(rp[u] + LAT_Z * RL4, z4[u]);
           } else {

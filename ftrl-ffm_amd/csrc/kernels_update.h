@@ -28,6 +28,7 @@ constexpr int kUpdWaves = kUpdThreads / 64;
 #ifndef FFM_TILE_WAVES
 #define FFM_TILE_WAVES 4  // waves per workgroup of the FFM update launches (kernels_tile.h); 8 and 16 measured slower
 #endif
+static_assert(FFM_TILE_WAVES >= 4, "loss_sum_body sums with the first 256 threads of an update workgroup");
 constexpr int kUpdMaxThreads = 64 * (FFM_TILE_WAVES > 8 ? FFM_TILE_WAVES : 8);  // their workgroups are up to this large (eight waves: small blocks)
 constexpr int kFmUnroll = 8;  // touches per prefetch group in the FM update kernel
 

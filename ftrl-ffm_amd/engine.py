@@ -54,6 +54,7 @@ ABI = [
     ("ffm_engine_destroy", None, [_vp]),
     ("ffm_engine_last_error", ctypes.c_char_p, []),
     ("ffm_engine_abi_version", ctypes.c_int, []),
+    ("ffm_engine_block_segment", ctypes.c_int, []),
     ("ffm_engine_row_len", ctypes.c_int64, [_vp]),
     ("ffm_engine_default_batch_ramp", ctypes.c_int32, [ctypes.c_float]),
     ("ffm_engine_shard_plan", ctypes.c_int,

@@ -34,7 +34,7 @@ extern "C" {
 
 /* 3: + ffm_engine_predict_batch_async, ffm_group_* (additions only: a caller built against 2 runs
  * unchanged) */
-#define FFM_ENGINE_ABI_VERSION 3
+#define FFM_ENGINE_ABI_VERSION 4
 
 /* ModelType, reference src/include/utils/types.h:21-25 */
 enum { FFM_MODEL_LR = 0, FFM_MODEL_FM = 1, FFM_MODEL_FFM = 2 };
@@ -115,6 +115,12 @@ int ffm_engine_init_weights_host(uint64_t seed, float init_mean, float init_stdd
 void ffm_engine_destroy(ffm_engine *e);
 const char *ffm_engine_last_error(void);
 int ffm_engine_abi_version(void);
+/* Block-update semantics, part of the contract (INTEGRATION.md "Block semantics"): a call with
+ * n_rows == 1 is the reference's train() bit for bit (src/model/ffm.cpp:38-49); a block of several
+ * rows folds the touches of every (n, z) accumulator by reductions over segments of this many
+ * consecutive occurrences of its feature, joined left to right (csrc/kernels_fold.h).  Two builds
+ * that return different values here train bit-different models from the same blocks. */
+int ffm_engine_block_segment(void);
 
 /* The partition behind n_shards / shard_rank, as plain host arithmetic (no device needed): the
  * fields are cut into contiguous groups and every shard owns whole group x group blocks of field

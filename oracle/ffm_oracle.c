@@ -484,6 +484,7 @@ double fo_train_batch_rowwalk(fo_model *m, int n_rows, const int32_t *row_ptr, c
  * reference's running update inside the row is not a sum, and those accumulators ("serial") keep
  * the row walk above for the whole block.  Which ones: see mark_serial(). */
 #define FO_SEG 16
+int fo_block_segment(void) { return FO_SEG; }
 
 typedef struct {
   float P, G, D;          /* the running segment: sum g*g, sum g, sum of root differences */

@@ -75,9 +75,10 @@ double fo_train_rows(fo_model *m, int n_rows, const int32_t *row_ptr, const int3
  *     n += sum g*g, z += sum g - w * sum sigma, where the sigmas of plain touches telescope to
  *     (sqrtf(n_T) - sqrtf(n_0)) / alpha and the touches of the ffm.cpp:118 kind are evaluated one
  *     by one against a prefix sum of n (ffm_oracle.c: "block update by reductions" has the exact
- *     tree: segments of 64 touches, left to right).  An accumulator that ONE row touches twice
+ *     tree: segments of FO_SEG = 16 occurrences of the feature, left to right; fo_block_segment()).  An accumulator that ONE row touches twice
  *     (multi-valued field, repeated id) keeps the row-order walk for the whole block.
  *     With n_rows == 1 this IS fo_train, bit for bit. */
+int fo_block_segment(void); /* FO_SEG: must equal the engine's ffm_engine_block_segment() */
 double fo_train_batch(fo_model *m, int n_rows, const int32_t *row_ptr, const int32_t *field,
                       const int32_t *feat, const float *val, const int32_t *label,
                       float *logit_out);

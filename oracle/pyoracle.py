@@ -117,6 +117,8 @@ def _lib(kind):
     getattr(lib, p + "maybe_zero_weight").restype = ctypes.c_float
     getattr(lib, p + "maybe_zero_weight").argtypes = [vp, ctypes.c_float, ctypes.c_float]
     if kind == "oracle":
+        lib.fo_block_segment.restype = ctypes.c_int
+        lib.fo_block_segment.argtypes = []
         for name in ("fo_train_batch", "fo_train_batch_rowwalk"):
             f = getattr(lib, name)
             f.restype = ctypes.c_double

@@ -29,7 +29,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), "libffm_engine.so lacks " + name
     bound = {n for n, _, _ in fa.ABI}
     assert set(syms) == bound, set(syms) ^ bound
-    assert lib.ffm_engine_abi_version() == 3
+    assert lib.ffm_engine_abi_version() == 4
 
 
 def test_config_struct_matches_header_defaults():

@@ -7,7 +7,7 @@ definition itself, checked on the CPU:
 * on blocks of many rows the reductions and the strict row-order walk of rounds 1-4
   (fo_train_batch_rowwalk) are the same update in exact arithmetic: same logits (the forward is
   shared), state within rounding distance, NaNs at the same places;
-* a second, independent restatement of the fold in numpy float32 scalars (segments of 64 occurrences
+* a second, independent restatement of the fold in numpy float32 scalars (segments of 16 occurrences
   of the feature, left to right; telescoped step sizes; per-touch terms from the first ffm.cpp:118 touch on)
   agrees with the C bit for bit.
 """
@@ -19,6 +19,15 @@ from oracle.pyoracle import CpuModel, Csr
 from util import DEFAULT_HP, STRESS_HP, assert_bitwise, assert_close, assert_state_bitwise, rand_state
 
 SEG = 16  # FO_SEG
+
+
+def test_the_three_statements_of_the_tree_share_one_segment_length():
+    """The segment length is part of the block semantics: the oracle (FO_SEG), this
+    file's numpy restatement (SEG) and the engine (kSeg, through the C ABI) must not drift apart."""
+    import ftrl_ffm_amd as fa
+    fa.build()
+    assert pyoracle._lib("oracle")[0].fo_block_segment() == SEG
+    assert fa.load_library().ffm_engine_block_segment() == SEG
 
 
 def rand_rows(rng, n, F, nf, multi=False, dup=False, ordered=True, zipf=1.5, drop=0.15):

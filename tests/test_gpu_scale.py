@@ -52,18 +52,21 @@ def _remapped_oracle(mt, F, k, blocks, hp, seed):
     return o, feats, st
 
 
-@pytest.mark.parametrize("name,mt,F,k,n_feats,need_gb", [
-    ("C5", "FFM", 39, 16, 33_000_000 - 33_000_000 % 39, 255.0),
-    ("C4", "FM", 39, 64, 10_000_000 - 10_000_000 % 39, 12.0),
+@pytest.mark.parametrize("name,mt,F,k,n_feats,need_gb,dist", [
+    ("C5", "FFM", 39, 16, 33_000_000 - 33_000_000 % 39, 255.0, "zipf"),
+    # SURVEY 8(d)'s second workload: nearly every one of a block's 319 k entries is a feature that
+    # occurs nowhere else in it -- the row kernel's refresh-and-update-in-place path at full size
+    ("C5-uniform", "FFM", 39, 16, 33_000_000 - 33_000_000 % 39, 255.0, "uniform"),
+    ("C4", "FM", 39, 64, 10_000_000 - 10_000_000 % 39, 12.0, "zipf"),
 ])
-def test_headline_size_model_matches_remapped_oracle(name, mt, F, k, n_feats, need_gb):
-    """Two 8192-row Zipf blocks on the full-size model: logits, and (w, n, z) of every touched
-    record, equal the oracle's on the id-remapped compact model bit for bit; a sample of untouched
-    records (incl. the very last one, beyond 2^31 floats) is unchanged."""
+def test_headline_size_model_matches_remapped_oracle(name, mt, F, k, n_feats, need_gb, dist):
+    """Two 8192-row blocks (Zipf ids; uniform ids) on the full-size model: logits, and (w, n, z) of
+    every touched record, equal the oracle's on the id-remapped compact model bit for bit; a sample
+    of untouched records (incl. the very last one, beyond 2^31 floats) is unchanged."""
     if _free_gb() < need_gb:
         pytest.skip("needs %.0f GB of free HBM, have %.0f" % (need_gb, _free_gb()))
     B = 8192
-    g = synth.Generator(F, n_feats, "zipf", seed=42)
+    g = synth.Generator(F, n_feats, dist, seed=42)
     blocks = [g.block(B) for _ in range(2)]
     if mt != "FFM":
         for b in blocks:

@@ -83,23 +83,25 @@ static void launch_row_kernel(ffm_engine *e, const Rows &rows, bool train, float
       if (vec4) LAUNCH(e, K_REFRESH, ffm_refresh_kernel<true>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
       else LAUNCH(e, K_REFRESH, ffm_refresh_kernel<false>, grid, 256, 0, e->m, e->sc[e->cur], refreshed >= 2);
     }
-    // LDS parking (round 4): the first vectors of (n, z) that a row's refresh reads for its once-only
-    // features stay in LDS for the row's own in-row update instead of coming back over the fabric.  As
-    // many as fit beside the staging arrays in 30 KB of dynamic LDS (five rows per CU: 527 us per C5 block
-    // against 543 without; 26 KB = six rows 531; 1 KB more than 30.9 KB and only four rows fit: 585; 44 KB
-    // = three rows: 690), at most what the longest row of the block can use.  FFM_ROW_PARK=bytes
-    // overrides (0: off; test_row_kernel_lds_parking_is_bit_identical pins none / partial / default).
+    // LDS parking (round 6: of w; round 4 parked (n, z)): the first vectors of w that a row's refresh
+    // computes for its once-only features stay in LDS, where the row's pair phase and its in-row update
+    // read them instead of fetching them back through an L2 they have left by then (128 rows in flight
+    // per XCD x 31 KB of once-only w is the whole 4 MB L2).  As many as fit beside the staging arrays in
+    // a 24 KB LDS budget (six rows per CU, which the kernel's 80 VGPRs allow: C5 row kernel 477 us with
+    // nothing parked, 450 with 24 KB, 478 with 30 KB = five rows, 535 with 32 KB = four;
+    // profiles/r06_experiments.md), at most what the longest row of the block can use.  FFM_ROW_PARK=bytes overrides
+    // (0: off; test_row_kernel_lds_parking_is_bit_identical pins none / partial / default).
     int park = 0;
     size_t shmem_park = shmem;
     if (refreshed == 3) {
       static const int park_env = std::getenv("FFM_ROW_PARK") ? std::atoi(std::getenv("FFM_ROW_PARK")) : -1;
       static const int budget_env = std::getenv("FFM_ROW_PARK_BUDGET") ? std::atoi(std::getenv("FFM_ROW_PARK_BUDGET")) : 0;
-      const size_t base = (shmem + 15) & ~static_cast<size_t>(15), budget = budget_env > 0 ? budget_env : 30 * 1024;
+      const size_t base = (shmem + 15) & ~static_cast<size_t>(15), budget = budget_env > 0 ? budget_env : 24 * 1024;
       long long bytes = park_env >= 0 ? park_env : (base < budget ? static_cast<long long>(budget - base) : 0);
-      bytes = std::min<long long>(bytes, 32ll * row_cap * (e->m.row_len / 4));
+      bytes = std::min<long long>(bytes, 16ll * row_cap * (e->m.row_len / 4));
       bytes = std::min<long long>(bytes, static_cast<long long>(budget) - static_cast<long long>(std::min(base, budget)));
-      park = static_cast<int>(std::max<long long>(0, bytes) / 32);
-      if (park > 0) shmem_park = base + 32 * static_cast<size_t>(park);
+      park = static_cast<int>(std::max<long long>(0, bytes) / 16);
+      if (park > 0) shmem_park = base + 16 * static_cast<size_t>(park);
     }
     if (train && vec4) {
       if (own_tg)

@@ -66,12 +66,13 @@ struct RowLds {
   float *linw;   // [max_row_nnz] linear weight
   int *opos;     // [max_row_nnz] occurrence position when the entry's feature is hot, else -1
   int *slist;    // [max_row_nnz] the entries this row refreshes itself (compact indices)
+  int *sidx;     // [max_row_nnz] position of entry a in slist, -1 when another kernel refreshes it
   int *fcnt;     // [n_fields] surviving entries per field
   int *ffirst;   // [n_fields] compact index of the first entry of the field, -1 if none
 };
 __host__ __device__ inline size_t row_lds_bytes(int max_row_nnz, int n_fields, int terms_cap) {
   const size_t M = (size_t)((max_row_nnz + 3) & ~3), Fp = (size_t)((n_fields + 3) & ~3);
-  return sizeof(float) * terms_cap + 7 * 4 * M + 2 * 4 * (Fp ? Fp : 4);
+  return sizeof(float) * terms_cap + 8 * 4 * M + 2 * 4 * (Fp ? Fp : 4);
 }
 __device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int n_fields, int terms_cap) {
   const int M = (max_row_nnz + 3) & ~3, Fp = ((n_fields + 3) & ~3) ? ((n_fields + 3) & ~3) : 4;
@@ -84,7 +85,8 @@ __device__ __forceinline__ RowLds carve_row_lds(char *base, int max_row_nnz, int
   l.linw = l.val + M;
   l.opos = reinterpret_cast<int *>(l.linw + M);
   l.slist = l.opos + M;
-  l.fcnt = l.slist + M;
+  l.sidx = l.slist + M;
+  l.fcnt = l.sidx + M;
   l.ffirst = l.fcnt + Fp;
   return l;
 }
@@ -238,10 +240,10 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
   const int F = m.n_fields, k = m.n_factors, RL = m.row_len;
   const int terms_cap = row_terms_cap(max_row_nnz, m.n_shards > 1 ? record_span(m, 1) : 0, 0);
   RowLds lds = carve_row_lds(smem, max_row_nnz, F, terms_cap);
-  // the first park_vecs 16-byte vectors of (n, z) that this row's refresh reads for its once-only
-  // features stay in LDS for its own in-row update (behind the row's staging arrays)
-  float4 *park_n = reinterpret_cast<float4 *>(smem + ((row_lds_bytes(max_row_nnz, F, terms_cap) + 15) & ~static_cast<size_t>(15)));
-  float4 *park_z = park_n + park_vecs;
+  // the first park_vecs 16-byte vectors of w that this row's refresh computes for its once-only
+  // features stay in LDS (behind the row's staging arrays): the pair phase and the in-row update take
+  // them from there instead of reading them back through an L2 they have long left
+  float4 *park_w = reinterpret_cast<float4 *>(smem + ((row_lds_bytes(max_row_nnz, F, terms_cap) + 15) & ~static_cast<size_t>(15)));
   const int r = blockIdx.x + row0;  // (row0: first row of this launch's row phase)
   const int b = rows.row_ptr[r];
   const int nnz = rows.row_ptr[r + 1] - b;
@@ -319,7 +321,9 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
           const int a = base + threadIdx.x;
           const bool mine = a < nv && (refreshed == 0 || lds.opos[a] == OCC_ONCE);
           const unsigned long long mask = __ballot(mine);
-          if (mine) lds.slist[ns + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = a;
+          const int at = ns + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+          if (mine) lds.slist[at] = a;
+          if (a < nv) lds.sidx[a] = mine ? at : -1;
           ns += __popcll(mask);
         }
         if (threadIdx.x == 0) s_ns = ns;
@@ -362,14 +366,18 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
             }
             w4[u] = m.h.learn ? row[LAT_W * RL4 + c4] : n4[u];
             wp[u] = row + LAT_W * RL4 + c4;
-            if (WHOLE && t < park_vecs) { park_n[t] = n4[u]; park_z[t] = z4[u]; }
           }
         }
 #pragma unroll
         for (int u = 0; u < kRefreshFly; u++)
           if (wp[u]) {
             const float4 wn = latent_weight4(m.h, n4[u], z4[u], w4[u]);
-            if (!(FFM_ROW_EXP & 32) || wn.x == 123.456f) *wp[u] = wn;
+            if (!(FFM_ROW_EXP & 32) || wn.x == 123.456f) {
+              if (FFM_ROW_NT & 16) store_nt(wp[u], wn);
+              else *wp[u] = wn;
+            }
+            const int t = t0 + u * blockDim.x;
+            if (WHOLE && t < park_vecs) park_w[t] = wn;
           }
       }
     } else {
@@ -484,12 +492,35 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
           if (VEC4) {
             const float4 *va4 = reinterpret_cast<const float4 *>(va);
             const float4 *vb4 = reinterpret_cast<const float4 *>(vb);
+            // a slot whose w this row's refresh parked in LDS is read there (ta / tb: its first vector)
+            int ta = -1, tb = -1;
+            if (TRAIN && WHOLE && park_vecs > 0) {
+              const int k4 = k >> 2, per4 = record_span(m, k4);
+              const int ja = lds.sidx[a], jb = lds.sidx[bb];
+              const int sa = ja * per4 + slot_of(m, fa, fb) * k4, sb = jb * per4 + slot_of(m, fb, fa) * k4;
+              ta = ja >= 0 && sa + k4 <= park_vecs ? sa : -1;
+              tb = jb >= 0 && sb + k4 <= park_vecs ? sb : -1;
+            }
             if (k == 16) {  // the common slot size: both slots' eight vectors in flight together
               float4 x[4], y[4];
+              if (FFM_ROW_EXP & 2) {
 #pragma unroll
-              for (int f4 = 0; f4 < 4; f4++) {
-                if (FFM_ROW_EXP & 2) { x[f4] = y[f4] = make_float4(lds.val[a], lds.val[bb], 0.5f, 0.25f); continue; }
-                x[f4] = va4[f4]; y[f4] = vb4[f4];
+                for (int f4 = 0; f4 < 4; f4++) x[f4] = y[f4] = make_float4(lds.val[a], lds.val[bb], 0.5f, 0.25f);
+              } else {
+                if (ta >= 0) {
+#pragma unroll
+                  for (int f4 = 0; f4 < 4; f4++) x[f4] = park_w[ta + f4];
+                } else {
+#pragma unroll
+                  for (int f4 = 0; f4 < 4; f4++) x[f4] = va4[f4];
+                }
+                if (tb >= 0) {
+#pragma unroll
+                  for (int f4 = 0; f4 < 4; f4++) y[f4] = park_w[tb + f4];
+                } else {
+#pragma unroll
+                  for (int f4 = 0; f4 < 4; f4++) y[f4] = vb4[f4];
+                }
               }
 #pragma unroll
               for (int f4 = 0; f4 < 4; f4++) {
@@ -500,7 +531,9 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
               }
             } else {
               for (int f4 = 0; f4 < (k >> 2); f4++) {
-                const float4 x = va4[f4], y = vb4[f4];
+                float4 x, y;
+                if (ta >= 0) x = park_w[ta + f4]; else x = va4[f4];
+                if (tb >= 0) y = park_w[tb + f4]; else y = vb4[f4];
                 dot = dot + x.x * y.x;
                 dot = dot + x.y * y.y;
                 dot = dot + x.z * y.z;
@@ -575,10 +608,7 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
           const int fp = walk_field(m, fa, sl);
           if (fp < 0 || (lds.fcnt[fp] - (fa == fp ? 1 : 0)) <= 0) continue;
           float4 *row = reinterpret_cast<float4 *>(lat_row(m, lds.feat[a], fa));
-          if (t < park_vecs) {
-            n4[u] = park_n[t];
-            z4[u] = park_z[t];
-          } else if (FFM_ROW_EXP & 4) {
+          if (FFM_ROW_EXP & 4) {
             n4[u] = z4[u] = make_float4(tg, 1.0f, 2.0f, 3.0f);
           } else if (FFM_ROW_NT & 4) {
             n4[u] = load_nt(row + LAT_N * RL4 + c4);
@@ -590,16 +620,22 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
           // (the refresh stored W(n, z) of these very (n, z) -- nobody else touches a once-only
           // feature's record inside the block -- so recomputing it gives the stored bits; the
           // learning variant's w depends on the old w and is read back)
-          if ((FFM_ROW_EXP & 1) && !m.h.learn) w4[u] = ftrl_weight4(m.h, n4[u], z4[u]);
+          if (t < park_vecs) w4[u] = park_w[t];
+          else if ((FFM_ROW_EXP & 1) && !m.h.learn) w4[u] = ftrl_weight4(m.h, n4[u], z4[u]);
           else w4[u] = (FFM_ROW_NT & 8) ? load_nt(row + LAT_W * RL4 + c4) : row[LAT_W * RL4 + c4];
           rp[u] = row + c4;
           ia[u] = a;
           ifp[u] = fp;
           ikq[u] = c4 - sl * k4;
           if (FFM_ROW_EXP & 8) vp[u] = make_float4(0.01f, 0.02f, tg, 0.03f);
-          else if (lds.fcnt[fp] == 1)  // (then fa != fp: the only entry of that field is the partner)
-            vp[u] = reinterpret_cast<const float4 *>(lat_row(m, lds.feat[lds.ffirst[fp]], fp))
+          else if (lds.fcnt[fp] == 1) {  // (then fa != fp: the only entry of that field is the partner)
+            const int bb = lds.ffirst[fp];
+            const int jb = lds.sidx[bb];
+            const int tp = jb * per + slot_of(m, fp, fa) * k4 + ikq[u];
+            if (jb >= 0 && tp < park_vecs) vp[u] = park_w[tp];  // the partner's w is parked, too
+            else vp[u] = reinterpret_cast<const float4 *>(lat_row(m, lds.feat[bb], fp))
                 [LAT_W * RL4 + slot_of(m, fp, fa) * k4 + ikq[u]];
+          }
         }
 #pragma unroll
         for (int u = 0; u < kUpdFly; u++) {

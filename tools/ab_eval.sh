@@ -1,11 +1,9 @@
 #!/bin/bash
-# The evaluation leg (predict + logloss) for (library, environment) variants on one box, with the
-# leg's kernel table.  usage: tools/ab_eval.sh "lib|ENV=.. ENV=.." ...   [EXP_BENCH_ARGS="--config c3"]
+# Evaluation leg (predict + logloss, H2D included / resident) for environment variants on one box.
+# usage: tools/ab_eval.sh "ENV=.. ENV=.. |<bench args>" ...
 cd "$GRAFT_REPO_ROOT"
 for v in "$@"; do
-  lib=${v%%|*}; envs=${v#*|}; [ "$envs" == "$v" ] && envs=""
-  L=""; [ "$lib" != "tree" ] && L="FFM_ENGINE_LIB=$GRAFT_REPO_ROOT/exp_libs/lib$lib.so"
-  env $L $envs python3 bench.py --no-cpu-baseline --steps 100 --warmup 10 $EXP_BENCH_ARGS > /tmp/ab.json 2> /tmp/ab.err
-  echo "[$v] $(python3 -c "import json;d=json.load(open('/tmp/ab.json'))['eval'];print('eval H2D rows/s', round(d['value']), 'resident', round(d['resident']), 'frac', d['roofline_frac'], d['roofline_frac_resident'], 'logloss', d['logloss'])")"
-  grep -A12 '^\[eval, resident\]' /tmp/ab.err | grep -E 'predict|loss_sum' 
+  envs=${v%%|*}; args=${v#*|}
+  env $envs python3 bench.py --no-cpu-baseline --no-profile $args > /tmp/ev.json 2> /tmp/ev.err
+  echo "[$v] $(python3 -c "import json;d=json.load(open('/tmp/ev.json'));e=d['eval'];print('train ms', d['ms_per_step'], 'eval H2D', round(e['value']/1e6,2), 'M rows/s', e['ms_per_step'], 'ms  frac', e['roofline_frac'], ' resident', round(e['resident']/1e6,2), e['roofline_frac_resident'])")"
 done

@@ -648,6 +648,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   if (const char *sv = std::getenv("FFM_EVAL_DEFER")) e->eval_defer_off = sv[0] == '0';
   if (const char *sv = std::getenv("FFM_PREDICT_WAVE")) e->predict_waves = std::atoi(sv) != 0;
   if (const char *sv = std::getenv("FFM_WIDE_NNZ")) e->wide_max_nnz = std::atoi(sv);
+  if (const char *sv = std::getenv("FFM_GRID_PULL")) e->grid_pull = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_HOT")) e->grid_hot = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_SMALL")) e->grid_small = std::max(1, std::atoi(sv));
   if (const char *sv = std::getenv("FFM_GRID_WALK")) e->grid_walk = std::max(1, std::atoi(sv));

@@ -385,7 +385,9 @@ def main():
     def make_engine(nf):
         # sharded: the generator's per-field id ranges go to the engine, so every shard stores only
         # its slots (~1/n_shards of the tensor) and looks only at the columns it has pairs of
-        fs = (np.arange(N_FIELDS + 1, dtype=np.int64) * (nf // N_FIELDS)).astype(np.int32) if compact else None
+        # (one shard: the ranges only tell the grouping that it may sort every field's ids by themselves)
+        known = model == "FFM" and not args.no_field_map
+        fs = (np.arange(N_FIELDS + 1, dtype=np.int64) * (nf // N_FIELDS)).astype(np.int32) if known else None
         return fa.Engine(model, nf, N_FIELDS, N_FACTORS, max_batch_rows=rows,
                          max_batch_nnz=rows * N_FIELDS, device_id=local_rank, n_shards=n_shards,
                          shard_rank=args.emulate_rank if emu else rank, stream=stream, seed=42,

@@ -276,6 +276,9 @@ struct ffm_engine {
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
   hipStream_t copy = nullptr;  // the upload kernel's stream: the prep stream (round 4 had it on aux3 for long steps)
   bool own_sort = false;        // the grouping's sort: kernels_sort.h (short steps) or rocPRIM Onesweep (ffm_engine_create)
+  bool range_sort = false;      // ... or, when the id ranges of the fields are known, a workgroup per range (kernels_sort.h)
+  int *d_sort_start = nullptr;  // [n_sort_ranges + 1] the ranges' boundaries, the last one = n_feats
+  int n_sort_ranges = 0;
   int sort_grid_cap = 1;        // workgroups of the one-launch sort the device holds at once (its grid barrier needs them all)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
   // Scheduling of a look-ahead grouping: the block being
@@ -916,6 +919,25 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     e->copy = e->prep;
     e->own_sort = !(ffm4 && phase_us / std::max(1, m.n_shards) >= 100.0);  // (a shard does 1/n_shards of the pairs)
     if (const char *sv = std::getenv("FFM_OWN_SORT")) e->own_sort = std::atoi(sv) != 0;
+    // The fields' id ranges are known (cfg->field_start): every range is sorted by a workgroup of its
+    // own, one launch, no grid barrier (kernels_sort.h: group_sort_ranges_kernel).  FFM_RANGE_SORT=0/1
+    // overrides; 1 without field_start cuts the id space into n_fields equal ranges (a block whose ids
+    // crowd into one of them is still sorted correctly, by one workgroup).
+    {
+      const char *sv = std::getenv("FFM_RANGE_SORT");
+      const bool have = !e->field_start.empty();
+      const bool want = sv ? std::atoi(sv) != 0 : have;
+      if (want && (m.type == FFM_MODEL_FFM || sv)) {
+        const int nr = have ? cfg->n_fields : std::max(1, std::min(64, cfg->n_fields));
+        std::vector<int> st(static_cast<size_t>(nr) + 1);
+        for (int f = 0; f <= nr; f++)
+          st[f] = have ? e->field_start[f] : static_cast<int>(static_cast<int64_t>(cfg->n_feats) * f / nr);
+        TRY_ALLOC(e->alloc(&e->d_sort_start, st.size()));
+        TRY_HIP(hipMemcpy(e->d_sort_start, st.data(), st.size() * sizeof(int), hipMemcpyHostToDevice));
+        e->n_sort_ranges = nr;
+        e->range_sort = true;
+      }
+    }
     // the one-launch sort meets at a grid barrier: never more workgroups than the device holds of it,
     // and only on the architecture its hand-over of data between workgroups was validated on
     {

@@ -99,16 +99,18 @@ static ShardPlan make_shard_plan(int F, int N, bool field_map) {
   }
   // Without a field map the bias and all linear terms go to the least loaded shard (a shard then
   // cannot tell a feature's field from its id).  With one, every field's linear terms go to the
-  // least loaded shard that keeps that column, and the bias (one sequential chain as long as the
-  // block) to the least loaded shard after that; loads in units of one field pair (measured at
-  // 39 fields / 8 shards: a field's linear terms ~ 2 pairs, the bias chain ~ 15).
+  // least loaded shard that keeps that column, and the bias to the least loaded shard after that;
+  // loads in units of one field pair.  Re-fitted in round 6 to the emulated per-rank steps of round 5
+  // (39 fields / 8 shards, 65 536-row blocks; step = 1.22 ms + 5 us per unit): off-diagonal shards
+  // 90 / 100 pairs -> 1.67 / 1.72 ms whatever linear terms they carry (a field's linear terms ~ 0.3
+  // pairs; the bias, a two-level fold since round 5, ~ 1 -- rounds 2-4 measured 2 and 15), the two
+  // shards made of DIAGONAL blocks -- pairs inside a group: 81 / 90 of them -> 1.76 / 1.81 ms -- cost
+  // 1.30 per pair (round 3's estimate: 1.12).
   std::vector<double> load(p.pairs.begin(), p.pairs.end());
-  // (a shard made of DIAGONAL blocks -- pairs inside a group -- keeps one useless self slot per
-  // record and measured ~6 % slower per pair than an off-diagonal one at 39 fields / 8 shards)
   for (int r = 0; r < N; r++) {
     bool diagonal = false;
     for (auto [a, b] : blocks[r]) diagonal = diagonal || (a == b && a < g);
-    if (diagonal && field_map) load[r] += 0.12 * static_cast<double>(p.pairs[r]);
+    if (diagonal && field_map) load[r] += 0.30 * static_cast<double>(p.pairs[r]);
   }
   p.bias_owner = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
   if (field_map) {
@@ -118,7 +120,7 @@ static ShardPlan make_shard_plan(int F, int N, bool field_map) {
         if (p.n(r, f) > 0 && (best < 0 || load[r] < load[best])) best = r;
       if (best < 0) best = p.bias_owner;
       p.lin_owner[f] = best;
-      load[best] += 2.0;
+      load[best] += 0.3;
     }
     p.bias_owner = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
   } else {

@@ -155,7 +155,13 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
     {
       ScopedTimer tm_sort("grouping:sort");
       size_t bytes = e->sort_tmp_bytes;
-      if (e->own_sort) {
+      if (e->range_sort) {
+        const size_t n_al = (static_cast<size_t>(nnz) + 63) & ~static_cast<size_t>(63);
+        unsigned char *tmp = static_cast<unsigned char *>(e->d_sort_tmp[set]);
+        RangeSortJob job{sc.key, sc.skey, sc.occ, reinterpret_cast<unsigned *>(tmp), reinterpret_cast<int *>(tmp + 4 * n_al),
+                         e->d_sort_start, nnz, e->n_sort_ranges, static_cast<unsigned>(e->m.n_feats)};
+        hipLaunchKernelGGL(group_sort_ranges_kernel, dim3(e->n_sort_ranges), dim3(kSortThreads), 0, st, job);
+      } else if (e->own_sort) {
         const size_t n_al = (static_cast<size_t>(nnz) + 63) & ~static_cast<size_t>(63);
         unsigned char *tmp = static_cast<unsigned char *>(e->d_sort_tmp[set]);
         SortJob job{sc.key, sc.skey, sc.occ, reinterpret_cast<unsigned *>(tmp), reinterpret_cast<int *>(tmp + 4 * n_al),

@@ -27,13 +27,17 @@
 
 namespace ftrl_dev {
 
+#ifndef FFM_FOLD_BRANCHY
+#define FFM_FOLD_BRANCHY 0
+#endif
+
 // A sqrt operand of the per-touch root differences.  Strict: inside [2^-70, 2^96], where sqrt_fast
 // is exact (two instructions to test).  Zero-tolerant: or +0 (a fresh model's n), for sqrt_fast0.
 __device__ __forceinline__ bool fold_strict_ok(float x) {
   return __builtin_amdgcn_fmed3f(x, 0x1p-70f, 0x1p96f) == x;
 }
 __device__ __forceinline__ bool fold_zero_ok(float x) {
-  return __float_as_uint(x) == 0u || __builtin_amdgcn_fmed3f(x, 0x1p-70f, 0x1p96f) == x;
+  return (__float_as_uint(x) == 0u) | (__builtin_amdgcn_fmed3f(x, 0x1p-70f, 0x1p96f) == x);
 }
 
 // d[i] = sqrtf(arg[i]) - sqrtf(nb[i]) for the lanes / entries that need it (the others get
@@ -44,7 +48,13 @@ __device__ __forceinline__ void fold_root_diffs(const float (&arg)[N], const flo
                                                 float (&d)[N]) {
   bool ok = true;
 #pragma unroll
+  // (bitwise, not short-circuit: compiled as nested exec-mask branches these tests were a dozen
+  // branches per group of four touches in the hot loop)
+#if FFM_FOLD_BRANCHY
   for (int j = 0; j < N; j++) ok = ok && (!need[j] || (fold_strict_ok(arg[j]) && fold_strict_ok(nb[j])));
+#else
+  for (int j = 0; j < N; j++) ok = ok & (!need[j] | (static_cast<int>(fold_strict_ok(arg[j])) & static_cast<int>(fold_strict_ok(nb[j]))));
+#endif
   if (__all(ok)) {
 #pragma unroll
     for (int j = 0; j < N; j++) d[j] = sqrt_fast(arg[j]) - sqrt_fast(nb[j]);
@@ -52,7 +62,11 @@ __device__ __forceinline__ void fold_root_diffs(const float (&arg)[N], const flo
   }
   ok = true;
 #pragma unroll
+#if FFM_FOLD_BRANCHY
   for (int j = 0; j < N; j++) ok = ok && (!need[j] || (fold_zero_ok(arg[j]) && fold_zero_ok(nb[j])));
+#else
+  for (int j = 0; j < N; j++) ok = ok & (!need[j] | (static_cast<int>(fold_zero_ok(arg[j])) & static_cast<int>(fold_zero_ok(nb[j]))));
+#endif
   if (__all(ok)) {
 #pragma unroll
     for (int j = 0; j < N; j++) d[j] = sqrt_fast0(arg[j]) - sqrt_fast0(nb[j]);
@@ -105,19 +119,19 @@ __device__ __forceinline__ void fold_ffm_group(Fold &a, float w, const bool (&li
   for (int j = 0; j < N; j++) {
     g[j] = tg[j] * vp[j] * x[j];
     gg[j] = g[j] * g[j];
-    quirk[j] = live[j] && !first[j];
-    anyq = anyq || quirk[j];
+    quirk[j] = live[j] & !first[j];
+    anyq = anyq | quirk[j];
   }
-  if (__any(a.seen || anyq)) {
+  if (__any(a.seen | anyq)) {
     float arg[N], nb[N], d[N];
     bool need[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
       const float nt = a.B + a.P;
-      const bool flip = quirk[j] && !a.seen;
+      const bool flip = quirk[j] & !a.seen;
       if (__any(flip)) a.ncap = flip ? nt : a.ncap;
-      a.seen = a.seen || flip;
-      need[j] = a.seen && live[j];
+      a.seen = a.seen | flip;
+      need[j] = a.seen & live[j];
       const float g1 = tg[j] * w * x[j];  // the pair's first entry's gradient (ffm.cpp:112)
       arg[j] = nt + (first[j] ? gg[j] : g[j] * g1);  // ffm.cpp:113 / :118
       nb[j] = nt;
@@ -134,7 +148,7 @@ __device__ __forceinline__ void fold_ffm_group(Fold &a, float w, const bool (&li
   for (int j = 0; j < N; j++) {
     a.G = live[j] ? a.G + g[j] : a.G;
     if (!a.any) a.head_plain = first[j];  // (kept from the first live touch on)
-    a.any = a.any || live[j];
+    a.any = a.any | live[j];
   }
 }
 

@@ -102,11 +102,11 @@ struct SortLds {
   unsigned wcnt[3][4][256];  // C: per wave, how many keys of the tile carry each digit
   unsigned wtot[4];
 };
-__device__ __forceinline__ void sort_tile(SortLds &l, int it, bool in, unsigned key, int val, int shift,
+// d: the key's digit of this pass (0 .. 255).
+__device__ __forceinline__ void sort_tile(SortLds &l, int it, bool in, unsigned key, int val, unsigned d,
                                           unsigned *kout, int *vout) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int cb = it % 3, zb = (it + 2) % 3, hb = it & 1;
-  const unsigned d = (key >> shift) & 255u;
   unsigned long long peers = __ballot(in);
 #pragma unroll
   for (int b = 0; b < 8; b++) {
@@ -190,10 +190,174 @@ __global__ __launch_bounds__(kSortThreads) void group_sort_kernel(SortJob a) {
 #pragma unroll
       for (int j = 0; j < kSortBatch; j++) {
         if (base + j * kSortThreads >= c1) break;  // (uniform)
-        sort_tile(l, it++, base + j * kSortThreads + t < c1, k[j], val[j], shift, kout, vout);
+        sort_tile(l, it++, base + j * kSortThreads + t < c1, k[j], val[j], (k[j] >> shift) & 255u, kout, vout);
       }
     }
     if (p + 1 < a.passes && !sort_grid_barrier(a, W, target)) return;
+  }
+}
+
+// ---- the same sort for ids that come in RANGES (round 6): one workgroup per range, no grid barrier ----
+// libffm data lays a field's ids out as one contiguous range (python/generate_data.py:272-306, the
+// bundled data, the synthetic generator); an engine that is told the ranges (ffm_engine_config::
+// field_start) sorts every range by itself: the sorted block is the ranges' sorted entries one after
+// the other.  Workgroup g
+//   A1  scans ALL keys once, a contiguous quarter per wave, counting the keys below its range and
+//       inside it (the first count is where its output starts: nobody waits for anybody);
+//   A2  scans them again and appends its own (key, entry) pairs in entry order (stable);
+//   B   LSD radix passes over its own pairs, 8 bits of (key - range start) per pass, as many as the
+//       range's width needs (three for 846 k ids): histogram, 256 bases, then tiles of 256 keys through
+//       sort_tile -- the ping-pong buffers are private to the workgroup.
+// Nothing depends on which field an ENTRY claims to be of: an id that sits under the "wrong" field is
+// simply sorted with the range it lies in, so the result is the stable sort by id whatever the data.
+// 39 workgroups of four waves and 14 KB of LDS each take a slot like any row of the kernels they run
+// beside; the library sort's ~14 launches of 1024-thread workgroups each waited for a whole CU to
+// drain (a pass: 7 us alone, 100-450 us beside the row / update kernels), and the look-ahead queue --
+// upload, keys, sort, finish, per block, on ONE queue -- was as long as a C5 step with the H2D and
+// longer than a C3 step.  Erased entries (key = the sentinel n_feats) fall in no range; the last
+// workgroup writes the sentinel keys behind the sorted ones.
+struct RangeSortJob {
+  const unsigned *key;  // [n] input keys (values are the indices 0 .. n-1)
+  unsigned *okey;       // [n] sorted keys
+  int *oval;            // [n] the indices in sorted order
+  unsigned *tkey;       // [n] scratch
+  int *tval;            // [n] scratch
+  const int *start;     // [n_ranges + 1] ascending range boundaries, start[0] = 0, start[n_ranges] = sentinel
+  int n, n_ranges;
+  unsigned sentinel;
+};
+constexpr int kRangeScanBatch = 8;  // 16-byte loads per lane in flight while a wave scans
+__global__ __launch_bounds__(kSortThreads) void group_sort_ranges_kernel(RangeSortJob a) {
+  __shared__ SortLds l;
+  __shared__ int w_below[4], w_mine[4];
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned lo = static_cast<unsigned>(a.start[g]), hi = static_cast<unsigned>(a.start[g + 1]);
+  // ---- A1: this wave's quarter of the keys, 16 bytes per lane and kRangeScanBatch loads in flight
+  // (every workgroup reads ALL keys, twice: what is in flight per wave is what the scans cost)
+  const int per = ((((a.n + 3) >> 2) + 255) >> 8) << 8;  // a multiple of 256 keys: whole uint4 pieces
+  const int q0 = min(a.n, wave * per), q1 = min(a.n, q0 + per);
+  const uint4 *key4 = reinterpret_cast<const uint4 *>(a.key);  // (hipMalloc'ed: 16-byte aligned; q0 is a multiple of 4)
+  auto load4 = [&](int i) {  // the keys i .. i + 3 (i a multiple of 4), 0xffffffff beyond the quarter
+    uint4 k = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    if (i + 4 <= q1) k = key4[i >> 2];
+    else if (i < q1) {
+      k.x = a.key[i];
+      if (i + 1 < q1) k.y = a.key[i + 1];
+      if (i + 2 < q1) k.z = a.key[i + 2];
+    }
+    return k;
+  };
+  auto in_range = [&](unsigned k) { return k - lo < hi - lo; };  // lo <= k < hi (unsigned wrap; hi >= lo)
+  int below = 0, mine = 0;
+  for (int i = q0; i < q1; i += 256 * kRangeScanBatch) {
+    uint4 k[kRangeScanBatch];
+#pragma unroll
+    for (int j = 0; j < kRangeScanBatch; j++) k[j] = load4(i + 256 * j + 4 * lane);
+#pragma unroll
+    for (int j = 0; j < kRangeScanBatch; j++) {
+      below += (k[j].x < lo) + (k[j].y < lo) + (k[j].z < lo) + (k[j].w < lo);
+      mine += in_range(k[j].x) + in_range(k[j].y) + in_range(k[j].z) + in_range(k[j].w);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    below += __shfl_xor(below, d, 64);
+    mine += __shfl_xor(mine, d, 64);
+  }
+  if (lane == 0) { w_below[wave] = below; w_mine[wave] = mine; }
+  __syncthreads();
+  const int off = w_below[0] + w_below[1] + w_below[2] + w_below[3];
+  const int n_g = w_mine[0] + w_mine[1] + w_mine[2] + w_mine[3];
+  int at = off;
+  for (int v = 0; v < wave; v++) at += w_mine[v];
+  const unsigned width = hi > lo ? hi - lo : 1u;
+  const int bits = width > 1u ? 32 - __clz(static_cast<int>(width - 1u)) : 0;
+  const int passes = (bits + 7) >> 3;
+  // (an even number of passes starts in the output buffers, an odd one in the scratch)
+  unsigned *const k0 = (passes & 1) ? a.tkey : a.okey, *const k1 = (passes & 1) ? a.okey : a.tkey;
+  int *const v0 = (passes & 1) ? a.tval : a.oval, *const v1 = (passes & 1) ? a.oval : a.tval;
+  // ---- A2: append this range's pairs in entry order (a lane's four keys are four consecutive entries)
+  if (n_g > 0) {
+    for (int i = q0; i < q1; i += 256 * kRangeScanBatch) {
+      uint4 k[kRangeScanBatch];
+#pragma unroll
+      for (int j = 0; j < kRangeScanBatch; j++) k[j] = load4(i + 256 * j + 4 * lane);
+#pragma unroll
+      for (int j = 0; j < kRangeScanBatch; j++) {
+        const bool mx = in_range(k[j].x), my = in_range(k[j].y), mz = in_range(k[j].z), mw = in_range(k[j].w);
+        const int c = mx + my + mz + mw;  // 0 .. 4: its exclusive prefix over the lanes from three ballots
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
+        if (b0 | b1 | b2) {
+          int dst = at + __popcll(b0 & lower) + 2 * __popcll(b1 & lower) + 4 * __popcll(b2 & lower);
+          const int e0 = i + 256 * j + 4 * lane;
+          if (mx) { coh_store(k0 + dst, k[j].x); coh_store(v0 + dst, e0); dst++; }
+          if (my) { coh_store(k0 + dst, k[j].y); coh_store(v0 + dst, e0 + 1); dst++; }
+          if (mz) { coh_store(k0 + dst, k[j].z); coh_store(v0 + dst, e0 + 2); dst++; }
+          if (mw) { coh_store(k0 + dst, k[j].w); coh_store(v0 + dst, e0 + 3); }
+          at += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+        }
+      }
+    }
+  }
+  // the sentinel keys of the erased entries, behind every range's pairs
+  if (g == a.n_ranges - 1)
+    for (int i = off + n_g + t; i < a.n; i += kSortThreads) { a.okey[i] = a.sentinel; a.oval[i] = 0; }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  // ---- B: LSD radix passes over [off, off + n_g)
+  const int c0 = off, c1 = off + n_g;
+  for (int p = 0; p < passes; p++) {
+    const unsigned *kin = (p & 1) ? k1 : k0;
+    const int *vin = (p & 1) ? v1 : v0;
+    unsigned *kout = (p & 1) ? k0 : k1;
+    int *vout = (p & 1) ? v0 : v1;
+    const int shift = 8 * p;
+    l.hist[0][t] = 0u;
+#pragma unroll
+    for (int b = 0; b < 3; b++) { l.wcnt[b][0][t] = 0u; l.wcnt[b][1][t] = 0u; l.wcnt[b][2][t] = 0u; l.wcnt[b][3][t] = 0u; }
+    __syncthreads();
+    for (int i = c0 + t; i < c1; i += kSortBatch * kSortThreads) {
+      unsigned k[kSortBatch];
+#pragma unroll
+      for (int j = 0; j < kSortBatch; j++) k[j] = i + j * kSortThreads < c1 ? coh_load(kin + i + j * kSortThreads) : 0u;
+#pragma unroll
+      for (int j = 0; j < kSortBatch; j++)
+        if (i + j * kSortThreads < c1) atomicAdd(&l.hist[0][((k[j] - lo) >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    // thread t owns digit t: where its keys start
+    const unsigned total = l.hist[0][t];
+    unsigned incl = total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned u = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += u;
+    }
+    if (lane == 63) l.wtot[wave] = incl;
+    __syncthreads();
+    unsigned prefix = incl - total;
+    for (int v = 0; v < wave; v++) prefix += l.wtot[v];
+    l.hist[0][t] = static_cast<unsigned>(c0) + prefix;
+    __syncthreads();
+    int it = 0;
+    for (int base = c0; base < c1; base += kSortBatch * kSortThreads) {
+      unsigned k[kSortBatch];
+      int val[kSortBatch];
+#pragma unroll
+      for (int j = 0; j < kSortBatch; j++) {
+        const int i = base + j * kSortThreads + t;
+        k[j] = i < c1 ? coh_load(kin + i) : lo;
+        val[j] = i < c1 ? coh_load(vin + i) : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < kSortBatch; j++) {
+        if (base + j * kSortThreads >= c1) break;  // (uniform)
+        sort_tile(l, it++, base + j * kSortThreads + t < c1, k[j], val[j], ((k[j] - lo) >> shift) & 255u, kout, vout);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
   }
 }
 

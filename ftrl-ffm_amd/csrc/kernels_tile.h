@@ -644,7 +644,7 @@ enum { UPD_GIANT = 1, UPD_HOT = 2, UPD_FEW = 4, UPD_SIDE = 8, UPD_REST = 16, UPD
 #define FFM_OCC_ALL 0
 #endif
 #ifndef FFM_OCC_HOT
-#define FFM_OCC_HOT 0
+#define FFM_OCC_HOT 4  // (137 registers by itself since the fold's range votes are branch-free: 3 waves; held to 128)
 #endif
 #ifndef FFM_OCC_FEW
 #define FFM_OCC_FEW 0

@@ -452,14 +452,19 @@ def test_giant_features_fold_the_same_either_way(super_min, k, split, monkeypatc
     e.close()
 
 
-@pytest.mark.parametrize("own", ["0", "1"], ids=["library_sort", "one_launch_sort"])
+@pytest.mark.parametrize("own", ["0", "1", "range"], ids=["library_sort", "one_launch_sort", "range_sort"])
 @pytest.mark.parametrize("rows", [8192, 65536], ids=["8192_rows", "65536_rows"])
 def test_grouping_sorts_agree_on_a_four_pass_block(own, rows, monkeypatch):
     """The grouping's two sorts (csrc/kernels_sort.h: one launch, 8 bits per pass; rocPRIM Onesweep)
     on blocks that need four passes (20 M feature ids = 25 key bits): rows x 39 Zipf entries with
     long runs of equal keys (2.5 M entries at 65 536 rows: 157 tiles per workgroup of the one-launch
     sort), and a ragged tail block: both bitwise against the oracle."""
-    monkeypatch.setenv("FFM_OWN_SORT", own)
+    if own == "range":  # (forced on a model without fields: ONE range, one workgroup, four passes)
+        if rows > 8192:
+            pytest.skip("one workgroup sorting 2.5 M entries: seconds; the 320 k-entry block covers it")
+        monkeypatch.setenv("FFM_RANGE_SORT", "1")
+    else:
+        monkeypatch.setenv("FFM_OWN_SORT", own)
     rng = np.random.default_rng(11)
     nf = 20_000_003
     o = CpuModel("oracle", "LR", nf, 1, 1, **STRESS_HP)
@@ -477,6 +482,64 @@ def test_grouping_sorts_agree_on_a_four_pass_block(own, rows, monkeypatch):
         assert_bitwise(lg, lo, "logits, block of %d" % n)
         assert loss_close(sg, so)
     assert_state_bitwise(e.get_state(), o.get_state(), "LR 20 M features, sort %s" % own)
+    e.close()
+
+
+@pytest.mark.parametrize("mode", ["ranges", "equal_cuts", "library"])
+def test_range_sort_groups_whatever_the_rows_look_like(mode, monkeypatch):
+    """The grouping's sort by id RANGES (csrc/kernels_sort.h: group_sort_ranges_kernel, one workgroup per
+    range of field_start; FFM_RANGE_SORT=1 without field_start: n_fields equal cuts of the id space)
+    against the oracle, and the library sort on the same blocks: uneven ranges with an empty one and one
+    of a single id (no radix pass at all), rows that lack fields, fields with several entries, ids that
+    sit under ANOTHER field than their range's (sorted with the range they lie in), erased entries
+    (out-of-range ids and fields), a ragged last block, keys that need one, two and three passes."""
+    F, k = 7, 4
+    widths = [1, 300, 0, 70000, 5, 2000, 40]  # ids per field: 0 and 1 wide ranges, 1 / 2 / 3 radix passes
+    fs = np.concatenate([[0], np.cumsum(widths)]).astype(np.int32)
+    nf = int(fs[-1])
+    if mode == "library":
+        monkeypatch.setenv("FFM_RANGE_SORT", "0")
+    elif mode == "equal_cuts":
+        monkeypatch.setenv("FFM_RANGE_SORT", "1")
+    rng = np.random.default_rng(41)
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o)
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=3000, max_batch_nnz=3000 * 12, max_row_nnz=12,
+                  field_start=fs if mode == "ranges" else None, **STRESS_HP)
+    e.set_state(st)
+
+    def block(n):
+        rows, labels = [], []
+        for _ in range(n):
+            row = []
+            for f in range(F):
+                if widths[f] == 0 or rng.random() < 0.15:  # the row lacks the field
+                    continue
+                for _ in range(1 + (rng.random() < 0.1)):  # ... or holds two entries of it
+                    i = int(fs[f]) + int(rng.zipf(1.3)) % widths[f]
+                    if rng.random() < 0.03:  # an id of another field's range under this field
+                        g = int(rng.integers(F))
+                        if widths[g]:
+                            i = int(fs[g]) + int(rng.integers(widths[g]))
+                    if any(i == x[1] for x in row):  # (the same id twice in a row: another test's subject)
+                        continue
+                    row.append((f, i, float(np.float32(rng.uniform(0.2, 1.5)))))
+            if rng.random() < 0.05:
+                row.append((int(rng.integers(F)), nf + int(rng.integers(5)), 1.0))  # erased: id out of range
+            if rng.random() < 0.05:
+                row.append((F + 1, int(rng.integers(nf)), 1.0))  # erased: field out of range
+            rows.append(row)
+            labels.append(int(rng.integers(2)))
+        return Csr.from_rows(rows, labels)
+
+    for n in (3000, 3000, 517, 1):
+        blk = block(n)
+        lo, so = o.train_batch(blk)
+        lg, sg = e.train_batch(blk)
+        assert_bitwise(lg, lo, "logits, block of %d, %s" % (n, mode))
+        assert loss_close(sg, so)
+    assert_state_bitwise(e.get_state(), o.get_state(), "range sort, " + mode)
     e.close()
 
 

@@ -281,6 +281,8 @@ struct ffm_engine {
   int n_sort_ranges = 0;
   int sort_grid_cap = 1;        // workgroups of the one-launch sort the device holds at once (its grid barrier needs them all)
   hipEvent_t ev_grouped[kSets] = {}, ev_set_free[kSets] = {};
+  hipEvent_t ev_row_done[kSets] = {};  // the row kernel of the block trained from the set has ended
+  bool prep_after_row = false;         // a look-ahead grouping starts beside an UPDATE phase (FFM_PREP_AFTER_ROW)
   // Scheduling of a look-ahead grouping: the block being
   // prepared will start training when its predecessor's update ends; its grouping is made to
   // START when the block before that one ends -- so it runs beside the predecessor's refresh and
@@ -596,6 +598,7 @@ void ffm_engine_destroy(ffm_engine *e) {
   for (int i = 0; i < ffm_engine::kSets; i++) {
     if (e->ev_grouped[i]) (void)hipEventDestroy(e->ev_grouped[i]);
     if (e->ev_set_free[i]) (void)hipEventDestroy(e->ev_set_free[i]);
+    if (e->ev_row_done[i]) (void)hipEventDestroy(e->ev_row_done[i]);
   }
   if (e->h_pulled) (void)hipHostFree(e->h_pulled);
   if (e->h_super) (void)hipHostFree(e->h_super);
@@ -648,6 +651,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     const int d0 = o % 10, d1 = o / 10 % 10, d2 = o / 100;
     if (o >= 0 && d2 <= 2 && d0 <= 2 && d1 <= 2 && d0 != d1 && d0 != d2 && d1 != d2) e->update_order = o;
   }
+  if (const char *sv = std::getenv("FFM_PREP_AFTER_ROW")) e->prep_after_row = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_EVAL_DEFER")) e->eval_defer_off = sv[0] == '0';
   if (const char *sv = std::getenv("FFM_PREDICT_WAVE")) e->predict_waves = std::atoi(sv) != 0;
   if (const char *sv = std::getenv("FFM_WIDE_NNZ")) e->wide_max_nnz = std::atoi(sv);
@@ -928,7 +932,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
       const bool have = !e->field_start.empty();
       const bool want = sv ? std::atoi(sv) != 0 : have;
       if (want && (m.type == FFM_MODEL_FFM || sv)) {
-        const int nr = have ? cfg->n_fields : std::max(1, std::min(64, cfg->n_fields));
+        const int nr = have ? cfg->n_fields : (sv && std::atoi(sv) > 1 ? std::min(1024, std::atoi(sv)) : std::max(1, std::min(64, cfg->n_fields)));
         std::vector<int> st(static_cast<size_t>(nr) + 1);
         for (int f = 0; f <= nr; f++)
           st[f] = have ? e->field_start[f] : static_cast<int>(static_cast<int64_t>(cfg->n_feats) * f / nr);
@@ -936,6 +940,15 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
         TRY_HIP(hipMemcpy(e->d_sort_start, st.data(), st.size() * sizeof(int), hipMemcpyHostToDevice));
         e->n_sort_ranges = nr;
         e->range_sort = true;
+        // (the regular-block short cut needs range f to be field f's: only with the caller's field_start)
+        if (have && m.type == FFM_MODEL_FFM) m.sort_start = e->d_sort_start;
+        // ... and its look-ahead starts when the ROW kernel of the block enqueued last has ended, beside
+        // that block's update launches (half of their wave slots are free, and they are not bound by
+        // bandwidth) instead of at the block's end, beside the next block's saturated row kernel -- where
+        // this sort, unlike the library's (whose 1024-thread workgroups wait for a CU to drain and so only
+        // ever fill gaps), costs the row kernel 5 %: C5 driver shape 0.970 -> 0.949 ms, C3 0.531 -> 0.521
+        // (profiles/r06_experiments.md).  FFM_PREP_AFTER_ROW=0/1 overrides.
+        if (!std::getenv("FFM_PREP_AFTER_ROW")) e->prep_after_row = true;
       }
     }
     // the one-launch sort meets at a grid barrier: never more workgroups than the device holds of it,
@@ -952,6 +965,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   for (int i = 0; i < ffm_engine::kSets; i++) {
     TRY_HIP(hipEventCreateWithFlags(&e->ev_grouped[i], hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&e->ev_set_free[i], hipEventDisableTiming));
+    TRY_HIP(hipEventCreateWithFlags(&e->ev_row_done[i], hipEventDisableTiming));
   }
   TRY_ALLOC(e->alloc(&e->d_row_ptr, R + 1));
   TRY_ALLOC(e->alloc(&e->d_field, E));

@@ -159,7 +159,8 @@ static int launch_grouping(ffm_engine *e, int set, const Rows &rows, hipStream_t
         const size_t n_al = (static_cast<size_t>(nnz) + 63) & ~static_cast<size_t>(63);
         unsigned char *tmp = static_cast<unsigned char *>(e->d_sort_tmp[set]);
         RangeSortJob job{sc.key, sc.skey, sc.occ, reinterpret_cast<unsigned *>(tmp), reinterpret_cast<int *>(tmp + 4 * n_al),
-                         e->d_sort_start, nnz, e->n_sort_ranges, static_cast<unsigned>(e->m.n_feats)};
+                         e->d_sort_start, nnz, e->n_sort_ranges, static_cast<unsigned>(e->m.n_feats),
+                         e->m.sort_start ? sc.counters + CNT_IRREGULAR : nullptr};
         hipLaunchKernelGGL(group_sort_ranges_kernel, dim3(e->n_sort_ranges), dim3(kSortThreads), 0, st, job);
       } else if (e->own_sort) {
         const size_t n_al = (static_cast<size_t>(nnz) + 63) & ~static_cast<size_t>(63);
@@ -215,7 +216,7 @@ static int prepare_plan(ffm_engine *e, const Rows &rows, PrepPlan *pl) {
 static int prepare_submit(ffm_engine *e, const PrepPlan &pl, bool timed) {
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   if (pl.wait_free) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.set], 0));
-  if (pl.ws >= 0) HIP_TRY(hipStreamWaitEvent(e->prep, e->ev_set_free[pl.ws], 0));
+  if (pl.ws >= 0) HIP_TRY(hipStreamWaitEvent(e->prep, e->prep_after_row ? e->ev_row_done[pl.ws] : e->ev_set_free[pl.ws], 0));
   int rc = launch_grouping(e, pl.set, pl.rows, e->prep, timed);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(e->ev_grouped[pl.set], e->prep));
@@ -273,6 +274,7 @@ int ffm_engine_train_forward_device(ffm_engine *e, int32_t n_rows, int32_t nnz,
   }
   e->set_used[e->cur] = true;
   launch_row_kernel(e, rows, true, e->own_tg_cur ? e->own_logit_out : nullptr, 0, e->own_tg_cur ? 1 : 0);
+  if (e->prep_after_row) HIP_TRY(hipEventRecord(e->ev_row_done[e->cur], e->stream));
   if (partial_logit && n_rows > 0)
     HIP_TRY(hipMemcpyAsync(partial_logit, e->sc[e->cur].logit, sizeof(float) * n_rows, hipMemcpyDeviceToDevice, e->stream));
   HIP_TRY(hipGetLastError());

@@ -59,6 +59,7 @@ struct ModelDev {
   int giant_min;              // ... from which it is listed as "giant" (kGiantMin): FFM -- a workgroup folds one
                               //     together; FM, and FFM from super_min on -- ranges folded all over the chip
   int super_min;              // FFM: occurrences from which a giant feature's ranges are folded side by side
+  const int *sort_start;      // [n_fields + 1] the id ranges the grouping sorts by (kernels_sort.h), or null
   int range_len;              // occurrences per range of such a feature (a multiple of kSeg): FFM kRange,
                               //     FM kFmRange -- an FM touch is three dependent loads and a dozen instructions,
                               //     its ranges are short so that many waves share one feature
@@ -204,8 +205,10 @@ enum { CNT_NUNIQ = 0, CNT_CURSOR = 1 * kLineInts, CNT_NMULTI = 2 * kLineInts, CN
        CNT_NSMALL = 4 * kLineInts, CNT_NBIG = 5 * kLineInts, CNT_NHUGE = 6 * kLineInts,
        CNT_NFEW = 7 * kLineInts, CNT_NSINGLE = 9 * kLineInts, CNT_NGIANT = 10 * kLineInts,
        CNT_SORT_BAR = 11 * kLineInts,  // (the sort's grid barrier, kernels_sort.h)
-       CNT_NSEG = 12 * kLineInts, CNT_NRANGE = 13 * kLineInts };  // the giant features' segment slots / ranges
-constexpr int kNumCounters = 14 * kLineInts;
+       CNT_NSEG = 12 * kLineInts, CNT_NRANGE = 13 * kLineInts,  // the giant features' segment slots / ranges
+       CNT_IRREGULAR = 14 * kLineInts };  // set when the block is NOT "every row = one entry per field, in field
+                                          // order, every id inside its field's range" (the range sort's short cut)
+constexpr int kNumCounters = 15 * kLineInts;
 enum { OCC_FEW = -1, OCC_ONCE = -2 };
 // Occurrence classes of a block's hot features (more than kSmallMax occurrences):
 //   big   (.. huge_min]             one wave folds all touches of (feature, 64 elements)
@@ -232,9 +235,9 @@ constexpr int kFmRange = 64, kFmGiantMin = kFmRange + 1;
 #endif
 constexpr int kSuperMin = FFM_SUPER_MIN;
 constexpr int kChainMin = 64;  // the least giant_min an engine may choose (sizes Scratch::giant)
-// (4 until the once-only features left the update phase; re-swept since: 8)
+// (4 until the once-only features left the update phase; re-swept since: 8, then 12)
 #ifndef FFM_SMALL_MAX
-#define FFM_SMALL_MAX 8
+#define FFM_SMALL_MAX 12  // (round 6, with the few-occurrence range's touch facts in LDS: 8 -> 12, C5 step -1 %)
 #endif
 constexpr int kSmallMax = FFM_SMALL_MAX;  // occurrences per block up to which a feature takes the "small" path
 enum { ERR_ROW_TOO_LONG = 1, ERR_FIELD_MAP = 2, ERR_SORT_BARRIER = 4 };

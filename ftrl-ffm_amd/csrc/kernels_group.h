@@ -80,6 +80,16 @@ __global__ __launch_bounds__(kGroupThreads) void group_keys_kernel(ModelDev m, R
     }
     valid = keeps_field(m, f);
   }
+  if (m.sort_start) {
+    // The range sort's short cut: a block whose every row holds exactly one entry per field, in field
+    // order, every id inside its field's range, has range f's entries at f, f + n_fields, ... -- no scan
+    // needed to find them.  Anything else (a missing or repeated field, an erased entry, an id under
+    // another field) takes the general path; only a wave that sees such an entry pays the atomic.
+    const int b0 = rows.row_ptr[lo];
+    bool regular = valid && rows.row_ptr[lo + 1] - b0 == m.n_fields && f == p - b0;
+    if (regular) regular = i >= m.sort_start[f] && i < m.sort_start[f + 1];
+    if (__any(in && !regular) && (threadIdx.x & 63) == 0) atomicOr(&s.counters[CNT_IRREGULAR], 1);
+  }
   if (in) {
     s.row_of[p] = lo;
     s.key[p] = valid ? static_cast<unsigned>(i) : static_cast<unsigned>(m.n_feats);

@@ -346,8 +346,16 @@ constexpr int kSmallBatch = FFM_SMALL_BATCH < kSmallMax ? FFM_SMALL_BATCH : kSma
 #else
 #define FFM_SMALL_OCC
 #endif
+#ifndef FFM_FEW_LDS
+#define FFM_FEW_LDS 1
+#endif
 __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &rows, const Scratch &s,
                                                int few_only, unsigned bidx, unsigned gdim) {
+#if FFM_FEW_LDS
+  __shared__ int4 few_facts[kUpdMaxThreads / 64][kSmallMax];  // per wave: {entry, row, own field, own value}
+  __shared__ float few_tg[kUpdMaxThreads / 64][kSmallMax];    // ... and the row's tmp_grad
+  const int wv_in_block = wave_uniform(threadIdx.x >> 6);
+#endif
   const int RL = m.row_len, k = m.n_factors, F = m.n_fields;
   const int RL4 = RL >> 2, k4 = k >> 2;
   const int lane = threadIdx.x & 63;
@@ -375,8 +383,32 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
     // slots that one row touches twice keep the row-order walk (ffm_generic_body, serial_only)
     const unsigned long long cm = s.cmask[start];
-    // The feature's (at most kSmallMax) touches, read ONCE for all passes over its record:
-    // entry, row, own field, own value, tmp_grad -- wave-uniform, scalar loads.
+    // The feature's (at most kSmallMax) touches, read ONCE for all passes over its record: entry,
+    // row, own field, own value, tmp_grad.  Lane j fetches touch j (the touches' loads fly together)
+    // and parks it in the wave's LDS record; the passes read the records back as they need them.
+    // (Rounds 4-5 kept these 40 wave-uniform values in scalar registers: 188 of them spilled into
+    // VGPR lanes, 36 bytes per lane into scratch memory -- VERDICT r05.)
+#if FFM_FEW_LDS
+    {
+      if (lane < kSmallMax) {
+        int4 f = make_int4(0, 0, 0, 0);
+        float g = 0.0f;
+        if (lane < c) {
+          const int2 pr = s.occ2[start + lane];
+          f = make_int4(pr.x, pr.y, rows.field[pr.x], __float_as_int(rows.val[pr.x]));
+          g = s.tg[pr.y];
+        }
+        few_facts[wv_in_block][lane] = f;
+        few_tg[wv_in_block][lane] = g;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+#define FEW_TP(j) (few_facts[wv_in_block][j].x)
+#define FEW_TR(j) (few_facts[wv_in_block][j].y)
+#define FEW_TFM(j) (few_facts[wv_in_block][j].z)
+#define FEW_TXM(j) (__int_as_float(few_facts[wv_in_block][j].w))
+#define FEW_TTG(j) (few_tg[wv_in_block][j])
+#else
     int tp[kSmallMax], tr[kSmallMax], tfm[kSmallMax];
     float txm[kSmallMax], ttg[kSmallMax];
 #pragma unroll
@@ -392,6 +424,12 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
         ttg[j] = __int_as_float(wave_uniform(__float_as_int(s.tg[tr[j]])));
       }
     }
+#define FEW_TP(j) (tp[j])
+#define FEW_TR(j) (tr[j])
+#define FEW_TFM(j) (tfm[j])
+#define FEW_TXM(j) (txm[j])
+#define FEW_TTG(j) (ttg[j])
+#endif
     for (int l0 = 0; l0 < span4; l0 += 64) {
       const int l = l0 + lane;  // 16-byte vector of the stored record
       const int lc = l < span4 ? l : 0;
@@ -422,24 +460,24 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
         for (int jj = 0; jj < kSmallBatch; jj++) {
           const int j = j0 + jj;
           rt[jj] = make_int4(0, 0, -1, 0);  // "no entry of that field in the row"
-          if (mine && j < c && owns_bit(own_bits, tfm[j])) rt[jj] = s.rowtab[static_cast<int64_t>(tr[j]) * F + fp];
+          if (mine && j < c && owns_bit(own_bits, FEW_TFM(j))) rt[jj] = s.rowtab[static_cast<int64_t>(FEW_TR(j)) * F + fp];
         }
         float4 vp4[kSmallBatch];
 #pragma unroll
         for (int jj = 0; jj < kSmallBatch; jj++) {
           const int j = j0 + jj;
           vp4[jj] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (j < c && rt[jj].z >= 0 && rt[jj].z != tp[j])
-            vp4[jj] = reinterpret_cast<const float4 *>(lat_row(m, rt[jj].x, fp))[LAT_W * RL4 + slot_of(m, fp, tfm[j]) * k4 + kq];
+          if (j < c && rt[jj].z >= 0 && rt[jj].z != FEW_TP(j))
+            vp4[jj] = reinterpret_cast<const float4 *>(lat_row(m, rt[jj].x, fp))[LAT_W * RL4 + slot_of(m, fp, FEW_TFM(j)) * k4 + kq];
         }
 #pragma unroll
         for (int jj = 0; jj < kSmallBatch; jj++) {
           const int j = j0 + jj;
           if (j >= c) continue;
-          const int p = tp[j], q = rt[jj].z;
+          const int p = FEW_TP(j), q = rt[jj].z;
           const bool live = q >= 0 && q != p;  // (q == -2, several entries, only on serial slots)
           const float vp[4] = {vp4[jj].x, vp4[jj].y, vp4[jj].z, vp4[jj].w};
-          a.touch(n, w, live, p < q || m.h.learn != 0, ttg[j], txm[j] * __int_as_float(rt[jj].y), vp);
+          a.touch(n, w, live, p < q || m.h.learn != 0, FEW_TTG(j), FEW_TXM(j) * __int_as_float(rt[jj].y), vp);
         }
       }
       if (a.finish(m.h, w, n, z) && mine) {
@@ -447,7 +485,15 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
         rec4[LAT_Z * RL4 + lc] = make_float4(z[0], z[1], z[2], z[3]);
       }
     }
+#if FFM_FEW_LDS
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next feature overwrites the records)
+#endif
   }
+#undef FEW_TP
+#undef FEW_TR
+#undef FEW_TFM
+#undef FEW_TXM
+#undef FEW_TTG
 }
 __global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_kernel(ModelDev m, Rows rows,
                                                                        Scratch s, int few_only) {

@@ -543,6 +543,33 @@ def test_range_sort_groups_whatever_the_rows_look_like(mode, monkeypatch):
     e.close()
 
 
+def test_range_sort_short_cut_for_regular_blocks():
+    """Blocks whose every row is one entry per field in field order, ids inside their fields' ranges,
+    take the range sort's short cut (range f = the entries f, f + F, ...: group_keys_kernel finds no
+    irregular entry); a block with ONE misplaced id in between takes the general path.  All bitwise
+    against the oracle, k = 16 and hot features included (Zipf ids, 40 ids per field)."""
+    F, k, per = 9, 16, 40
+    nf = F * per
+    fs = (np.arange(F + 1) * per).astype(np.int32)
+    rng = np.random.default_rng(43)
+    o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
+    st = rand_state(rng, o)
+    o.set_state(st)
+    e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=1024, field_start=fs, **STRESS_HP)
+    e.set_state(st)
+    gen = synth.Generator(F, nf, "zipf", seed=3)
+    for step, n in enumerate((1024, 700, 1024, 1)):
+        blk = gen.block(n)
+        if step == 1:  # one id of field 0's range under field 3: irregular
+            blk.feat[3] = 5
+        lo, so = o.train_batch(blk)
+        lg, sg = e.train_batch(blk)
+        assert_bitwise(lg, lo, "logits, block %d" % step)
+        assert loss_close(sg, so)
+    assert_state_bitwise(e.get_state(), o.get_state(), "regular blocks through the range sort")
+    e.close()
+
+
 def test_empty_block_and_capacity_errors():
     e = fa.Engine("FFM", 100, 4, 4, max_batch_rows=8, max_batch_nnz=64, max_row_nnz=16)
     empty = Csr(np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32),

@@ -930,7 +930,12 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     {
       const char *sv = std::getenv("FFM_RANGE_SORT");
       const bool have = !e->field_start.empty();
-      const bool want = sv ? std::atoi(sv) != 0 : have;
+      // (by default only where a workgroup per range is quick: a whole model -- a compact shard's dropped
+      // columns make every block irregular, so every workgroup would scan all keys twice -- and at most
+      // 16 k entries per range -- a rank's 65 536-row blocks are 256 tiles per pass for ONE workgroup:
+      // an emulated 8-GPU rank went 1.72 -> 2.25 ms per step with it)
+      const bool quick = cfg->n_shards == 1 && static_cast<int64_t>(e->max_nnz) <= 16384ll * std::max(1, cfg->n_fields);
+      const bool want = sv ? std::atoi(sv) != 0 : (have && quick);
       if (want && (m.type == FFM_MODEL_FFM || sv)) {
         const int nr = have ? cfg->n_fields : (sv && std::atoi(sv) > 1 ? std::min(1024, std::atoi(sv)) : std::max(1, std::min(64, cfg->n_fields)));
         std::vector<int> st(static_cast<size_t>(nr) + 1);
@@ -948,7 +953,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
         // this sort, unlike the library's (whose 1024-thread workgroups wait for a CU to drain and so only
         // ever fill gaps), costs the row kernel 5 %: C5 driver shape 0.970 -> 0.949 ms, C3 0.531 -> 0.521
         // (profiles/r06_experiments.md).  FFM_PREP_AFTER_ROW=0/1 overrides.
-        if (!std::getenv("FFM_PREP_AFTER_ROW")) e->prep_after_row = true;
+        // (long steps only: a 4096 x 8 block's update phase is 70 us, shorter than the chain)
+        if (!std::getenv("FFM_PREP_AFTER_ROW")) e->prep_after_row = !e->own_sort;
       }
     }
     // the one-launch sort meets at a grid barrier: never more workgroups than the device holds of it,

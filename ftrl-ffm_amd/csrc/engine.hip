@@ -263,6 +263,7 @@ struct ffm_engine {
   struct { bool on = false; int slot = 0; bool labelled = false; } eval_pending;
   bool eval_hold = false;       // inside predict_batch_async, before its upload is submitted
   bool eval_defer_off = false;  // FFM_EVAL_DEFER=0
+  bool super_wait = true;       // wait for a block's grouping before deciding on its super launches (FFM_SUPER_WAIT=0: only ask)
   bool super_flag_ok = false;  // create proved that a device store to h_super reaches the host
   // groupings made ahead by ffm_engine_prepare_device, oldest first (at most kSets - 1)
   int n_prepared = 0;
@@ -651,6 +652,7 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     const int d0 = o % 10, d1 = o / 10 % 10, d2 = o / 100;
     if (o >= 0 && d2 <= 2 && d0 <= 2 && d1 <= 2 && d0 != d1 && d0 != d2 && d1 != d2) e->update_order = o;
   }
+  if (const char *sv = std::getenv("FFM_SUPER_WAIT")) e->super_wait = sv[0] != '0';
   if (const char *sv = std::getenv("FFM_PREP_AFTER_ROW")) e->prep_after_row = sv[0] == '1';
   if (const char *sv = std::getenv("FFM_EVAL_DEFER")) e->eval_defer_off = sv[0] == '0';
   if (const char *sv = std::getenv("FFM_PREDICT_WAVE")) e->predict_waves = std::atoi(sv) != 0;

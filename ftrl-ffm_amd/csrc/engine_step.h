@@ -404,9 +404,15 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // (the grouping counted the block's longest features into page-locked host memory; it ran blocks
     // ahead, so its event has usually completed and the count can be read: none -> no launches)
     bool supers = rows.nnz >= e->m.super_min;
-    if (supers && e->super_flag_ok && e->cur_prepared && hipEventQuery(e->ev_grouped[e->cur]) == hipSuccess &&
-        e->h_super[e->cur] == 0)
-      supers = false;
+    if (supers && e->super_flag_ok && e->cur_prepared) {
+      // The count is there once the block's grouping has run -- blocks ago in device time, so this wait
+      // is over at once unless the caller is several steps ahead of the device, which it then stops
+      // being (two steps stay queued).  Rounds 4-5 only QUERIED the event: a caller that ran ahead (a
+      // zero-copy loop never blocks) found it pending in most steps and paid the two empty launches
+      // and their gaps, ~30 us per C5 step (profiles/r06_experiments.md section 9).
+      if (e->super_wait) HIP_TRY(hipEventSynchronize(e->ev_grouped[e->cur]));
+      if (hipEventQuery(e->ev_grouped[e->cur]) == hipSuccess && e->h_super[e->cur] == 0) supers = false;
+    }
     if (supers) {
       // the longest features' ranges: second pass (root differences) and the join of their tiles
       const int gg = e->grid_giant;

@@ -46,7 +46,7 @@ CONFIGS = {
     "c4": dict(model="FM", fields=39, factors=64, rows=8192, feats=10_000_000),
 }
 PEAK_HBM_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-SMALL_MAX = 12  # occurrences per block up to which a feature is "few" (csrc/engine_types.h)
+SMALL_MAX = 10  # occurrences per block up to which a feature is "few" (csrc/engine_types.h)
 
 
 def algorithmic_bytes_per_row(nnz, k):

@@ -152,6 +152,49 @@ __device__ __forceinline__ void fold_ffm_group(Fold &a, float w, const bool (&li
   }
 }
 
+// The same N touches when the BLOCK is regular -- every row holds exactly one entry per field, in field
+// order, ids inside their fields' ranges (group_keys_kernel: CNT_IRREGULAR stayed 0) -- so that a touch's
+// flags are the lane's: live = the slot is not the feature's own field's (lv), and the own entry is the
+// pair's first exactly when its field is the smaller one (q118 = lv and own field > partner field, the
+// learning variant aside).  Same arithmetic in the same order for every live lane; no per-touch flag is
+// read, decoded or selected on.  (Lanes that are not live compute on whatever the tile holds and are
+// never stored.)
+template <int N>
+__device__ __forceinline__ void fold_ffm_group_regular(Fold &a, float w, bool lv, bool q118, const float (&tg)[N],
+                                                       const float (&x)[N], const float (&vp)[N]) {
+  float g[N], gg[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    g[j] = tg[j] * vp[j] * x[j];
+    gg[j] = g[j] * g[j];
+  }
+  if (__any(q118)) {
+    float arg[N], nb[N], d[N];
+    bool need[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const float nt = a.B + a.P;
+      a.ncap = (q118 & !a.seen) ? nt : a.ncap;  // (the lane's first touch)
+      a.seen = a.seen | q118;
+      need[j] = q118;
+      const float g1 = tg[j] * w * x[j];  // the pair's first entry's gradient (ffm.cpp:112)
+      arg[j] = nt + g[j] * g1;            // ffm.cpp:118 (only the q118 lanes' values are used)
+      nb[j] = nt;
+      a.P = a.P + gg[j];
+    }
+    fold_root_diffs<N>(arg, nb, need, d);
+#pragma unroll
+    for (int j = 0; j < N; j++) a.D = q118 ? a.D + d[j] : a.D;
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; j++) a.P = a.P + gg[j];
+  }
+#pragma unroll
+  for (int j = 0; j < N; j++) a.G = a.G + g[j];
+  a.head_plain = a.any ? a.head_plain : !q118;
+  a.any = a.any | lv;
+}
+
 // ONE touch of E accumulators held by one lane that share the touch's flags (the factors of one
 // slot), for features with at most kSeg occurrences: a single segment, so B stays n_0 and the
 // running sums are the totals.  any / seen / head_plain are the lane's (the E factors move together).
@@ -198,6 +241,41 @@ struct FoldFew {
       G[i] = live ? G[i] + g[i] : G[i];
     }
     if (live && !any) { any = true; head_plain = first; }
+  }
+  // The same touch in a regular block (fold_ffm_group_regular): the lane's slot is live (lv) for every
+  // touch, and every touch is of the ffm.cpp:118 kind (q118) or none is.
+  __device__ __forceinline__ void touch_regular(const float (&n0)[E], const float (&w)[E], bool lv, bool q118,
+                                                float tg, float x, const float (&vp)[E]) {
+    float g[E], gg[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+      g[i] = tg * vp[i] * x;
+      gg[i] = g[i] * g[i];
+    }
+    if (__any(q118)) {
+      float arg[E], nb[E], d[E];
+      bool need[E];
+#pragma unroll
+      for (int i = 0; i < E; i++) {
+        const float nt = n0[i] + P[i];
+        ncap[i] = (q118 & !seen) ? nt : ncap[i];
+        const float g1 = tg * w[i] * x;  // the pair's first entry's gradient (ffm.cpp:112)
+        arg[i] = nt + g[i] * g1;         // ffm.cpp:118
+        nb[i] = nt;
+        need[i] = q118;
+      }
+      seen = seen | q118;
+      fold_root_diffs<E>(arg, nb, need, d);
+#pragma unroll
+      for (int i = 0; i < E; i++) D[i] = q118 ? D[i] + d[i] : D[i];
+    }
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+      P[i] = P[i] + gg[i];
+      G[i] = G[i] + g[i];
+    }
+    head_plain = any ? head_plain : (lv & !q118);
+    any = any | lv;
   }
   // (n, z) in, (n_T, z_T) out for the lane's E accumulators; false when no touch reached them
   __device__ __forceinline__ bool finish(const Hyper &h, const float (&w)[E], float (&n)[E], float (&z)[E]) {

@@ -43,6 +43,9 @@ constexpr int kTileNR = 2;  // fact-record buffers (a power of two): the tile in
 #ifndef FFM_TILE_G
 #define FFM_TILE_G 4
 #endif
+#ifndef FFM_FOLD_REGULAR
+#define FFM_FOLD_REGULAR 1
+#endif
 constexpr int kTileG = FFM_TILE_G;  // touches per arithmetic group (one range vote per group)
 
 // flags word of an LDS fact record: bits 0..7 high bits of the weights' offset, bit 31 the touch is
@@ -245,6 +248,24 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
     vp[j] = (Tc)[((g0) + j) * kTileRow];                                                 \
   }
 
+// ... of a regular block (kernels_fold.h: fold_ffm_group_regular): no flags to decode
+#define FTRL_TILE_READ_GROUP_REG(Rc, Tc, g0)                                             \
+  float tg[kTileG], x[kTileG], vp[kTileG];                                               \
+  _Pragma("unroll") for (int j = 0; j < kTileG; j++) {                                   \
+    const float2 rc = *reinterpret_cast<const float2 *>(&(Rc)[((g0) + j) * RS]);         \
+    tg[j] = rc.x;                                                                        \
+    x[j] = rc.y;                                                                         \
+    vp[j] = (Tc)[((g0) + j) * kTileRow];                                                 \
+  }
+// Is the block regular (see there)?  One scalar load per workgroup range.
+__device__ __forceinline__ bool tile_block_regular(const ModelDev &m, const Scratch &s) {
+#if FFM_FOLD_REGULAR
+  return m.sort_start != nullptr && m.n_shards == 1 && m.own_n == nullptr && s.counters[CNT_IRREGULAR] == 0;
+#else
+  return false;
+#endif
+}
+
 // ---- hot features below giant_min occurrences: one wave folds (feature, chunk) whole --------------
 template <int NF>
 __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &rows, const Scratch &s, unsigned wave,
@@ -262,6 +283,7 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
     return wave_uniform(li < n_huge ? s.huge[li] : s.big[li - n_huge]);
   };
   auto uniform4 = [](int4 v) { return make_int4(wave_uniform(v.x), wave_uniform(v.y), wave_uniform(v.z), wave_uniform(v.w)); };
+  const bool regular = tile_block_regular(m, s);
   int4 ud_next = make_int4(0, 0, 1, 0);
   int u_next2 = 0;
   if (wave < n_items) ud_next = uniform4(s.udesc[list_at(wave)]);
@@ -284,11 +306,19 @@ __device__ __forceinline__ void ffm_tile_items(const ModelDev &m, const Rows &ro
     const float w = rec[LAT_W * g.RL];
     Fold acc;
     acc.init(n);
+    // (a regular block: the touches' flags are the lane's)
+    const bool lv = active && ch.fp != fa, q118 = lv && !m.h.learn && ch.fp < fa;
     tile_stream<NF>(m, s, g, ch, rows, fa, start, 0, 1, (c + kTileT - 1) / kTileT, c, T, R,
                     [&](int st, const float4 *Rc, const float *Tc) {
       if (st > 0) acc.flush();  // a segment (= a tile of kSeg occurrences) ends
       const int cnt = min(kTileT, c - st * kTileT);
-      for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+      int g0 = 0;
+      if (regular)
+        for (; g0 + kTileG <= cnt; g0 += kTileG) {
+          FTRL_TILE_READ_GROUP_REG(Rc, Tc, g0)
+          fold_ffm_group_regular<kTileG>(acc, w, lv, q118, tg, x, vp);
+        }
+      for (; g0 < cnt; g0 += kTileG) {
         FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
         fold_ffm_group<kTileG>(acc, w, live, first, tg, x, vp);
       }
@@ -322,6 +352,7 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Rows &ro
   const int lane = threadIdx.x & 63;
   const int wv = wave_uniform(threadIdx.x >> 6);
   const unsigned n_items = static_cast<unsigned>(s.counters[CNT_NGIANT]) * g.per_feat;
+  const bool regular = tile_block_regular(m, s);
   for (unsigned item = bidx; item < n_items; item += gdim) {  // (the whole workgroup on one item)
     const unsigned li = item / g.per_feat;
     const int ci = static_cast<int>(item - li * g.per_feat);
@@ -338,6 +369,8 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Rows &ro
     const float w = rec[LAT_W * g.RL];
     Fold run;  // the running state, the same in every wave
     run.init(n);
+    // (a regular block: the touches' flags are the lane's -- kernels_fold.h: fold_ffm_group_regular)
+    const bool lv = active && ch.fp != fa, q118 = lv && !m.h.learn && ch.fp < fa;
     const int n_tiles = (c + kTileT - 1) / kTileT, n_super = (n_tiles + W - 1) / W;
     tile_stream<NF>(m, s, g, ch, rows, fa, start, wv, W, n_super, c, T, R, [&](int k, const float4 *Rc, const float *Tc) {
       const int buf = k & 1;
@@ -346,7 +379,20 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Rows &ro
       {
         float P = -0.0f, G = -0.0f;
         bool any = false, hp = false, q = false;
-        for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+        int g0 = 0;
+        if (regular) {
+          for (; g0 + kTileG <= cnt; g0 += kTileG) {
+            FTRL_TILE_READ_GROUP_REG(Rc, Tc, g0)
+#pragma unroll
+            for (int j = 0; j < kTileG; j++) {
+              const float gj = tg[j] * vp[j] * x[j];
+              G = G + gj;
+              P = P + gj * gj;
+            }
+          }
+          if (g0 > 0) { any = lv; hp = lv && !q118; q = q118; }
+        }
+        for (; g0 < cnt; g0 += kTileG) {
           FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
 #pragma unroll
           for (int j = 0; j < kTileG; j++) {
@@ -382,7 +428,13 @@ __device__ __forceinline__ void ffm_coop_items(const ModelDev &m, const Rows &ro
           seen0 = seen0 || ((cl.fl[buf][w2][2] >> lane) & 1ull);
         }
         acc.seen = seen0;
-        for (int g0 = 0; g0 < cnt; g0 += kTileG) {
+        int g0 = 0;
+        if (regular)
+          for (; g0 + kTileG <= cnt; g0 += kTileG) {
+            FTRL_TILE_READ_GROUP_REG(Rc, Tc, g0)
+            fold_ffm_group_regular<kTileG>(acc, w, lv, q118, tg, x, vp);
+          }
+        for (; g0 < cnt; g0 += kTileG) {
           FTRL_TILE_READ_GROUP(Rc, Tc, g0, active)
           fold_ffm_group<kTileG>(acc, w, live, first, tg, x, vp);
         }

@@ -349,6 +349,9 @@ constexpr int kSmallBatch = FFM_SMALL_BATCH < kSmallMax ? FFM_SMALL_BATCH : kSma
 #ifndef FFM_FEW_LDS
 #define FFM_FEW_LDS 1
 #endif
+#ifndef FFM_FOLD_REGULAR
+#define FFM_FOLD_REGULAR 1
+#endif
 __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &rows, const Scratch &s,
                                                int few_only, unsigned bidx, unsigned gdim) {
 #if FFM_FEW_LDS
@@ -366,6 +369,11 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
   const int n_small = s.counters[few_only ? CNT_NFEW : CNT_NSMALL];
   const float inv_k4 = 1.0f / static_cast<float>(k4);
   const int span4 = record_span(m, k4);
+#if FFM_FOLD_REGULAR
+  const bool regular = m.sort_start != nullptr && m.n_shards == 1 && m.own_n == nullptr && s.counters[CNT_IRREGULAR] == 0;
+#else
+  const bool regular = false;
+#endif
   // (a feature is a chain of dependent loads -- list, descriptor, touches, their entries and rows,
   // row table, partner weights: the list entry is requested two features ahead, the descriptor one)
   auto uniform4 = [](int4 v) { return make_int4(wave_uniform(v.x), wave_uniform(v.y), wave_uniform(v.z), wave_uniform(v.w)); };
@@ -450,6 +458,7 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
       }
       FoldFew<4> a;
       a.init();
+      const bool lv = mine && fp != fa, q118 = lv && !m.h.learn && fp < fa;
       // kSmallBatch touches at a time: their row-table entries in flight together, then their
       // partners' weights, then the touches in order
 #pragma unroll
@@ -475,8 +484,12 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
           const int j = j0 + jj;
           if (j >= c) continue;
           const int p = FEW_TP(j), q = rt[jj].z;
-          const bool live = q >= 0 && q != p;  // (q == -2, several entries, only on serial slots)
           const float vp[4] = {vp4[jj].x, vp4[jj].y, vp4[jj].z, vp4[jj].w};
+          if (regular) {  // (every row one entry per field in field order: the flags are the lane's)
+            a.touch_regular(n, w, lv, q118, FEW_TTG(j), FEW_TXM(j) * __int_as_float(rt[jj].y), vp);
+            continue;
+          }
+          const bool live = q >= 0 && q != p;  // (q == -2, several entries, only on serial slots)
           a.touch(n, w, live, p < q || m.h.learn != 0, FEW_TTG(j), FEW_TXM(j) * __int_as_float(rt[jj].y), vp);
         }
       }

@@ -543,17 +543,21 @@ def test_range_sort_groups_whatever_the_rows_look_like(mode, monkeypatch):
     e.close()
 
 
-def test_range_sort_short_cut_for_regular_blocks():
+@pytest.mark.parametrize("k,near_zero", [(16, False), (16, True), (8, False), (4, True), (32, False)])
+def test_range_sort_short_cut_for_regular_blocks(k, near_zero):
     """Blocks whose every row is one entry per field in field order, ids inside their fields' ranges,
     take the range sort's short cut (range f = the entries f, f + F, ...: group_keys_kernel finds no
-    irregular entry); a block with ONE misplaced id in between takes the general path.  All bitwise
-    against the oracle, k = 16 and hot features included (Zipf ids, 40 ids per field)."""
-    F, k, per = 9, 16, 40
+    irregular entry) AND the regular-block fold (kernels_fold.h: the touches' flags are the lane's) in
+    the few-occurrence, hot and giant ranges; a block with ONE misplaced id in between takes the general
+    paths.  All bitwise against the oracle: k = 4 / 8 / 16 / 32 (the tile pipeline's fact-record shapes),
+    Zipf ids over 40 per field (once-only, few, hot and giant features in 1024-row blocks), warm state
+    and n near 0 (the ffm.cpp:118 NaNs through the regular fold)."""
+    F, per = 9, 40
     nf = F * per
     fs = (np.arange(F + 1) * per).astype(np.int32)
     rng = np.random.default_rng(43)
     o = CpuModel("oracle", "FFM", nf, F, k, **STRESS_HP)
-    st = rand_state(rng, o)
+    st = rand_state(rng, o, n_hi=0.02) if near_zero else rand_state(rng, o)
     o.set_state(st)
     e = fa.Engine("FFM", nf, F, k, skip_init=True, max_batch_rows=1024, field_start=fs, **STRESS_HP)
     e.set_state(st)

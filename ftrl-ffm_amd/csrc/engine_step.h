@@ -337,7 +337,7 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     // shard's rank (its once-only and few-occurrence launches already sit on the side queue) 1.71 ->
     // 1.77 ms.
     const int split = e->update_split >= 0 ? e->update_split
-                      : (!side_launches && static_cast<int64_t>(rows.nnz) * e->m.n_factors >= (4ll << 20) ? 2 : 0);
+                      : (!side_launches && static_cast<int64_t>(rows.nnz) * e->m.n_factors >= (1ll << 20) ? 2 : 0);
     // (small blocks of a whole model, k >= 16: eight waves per workgroup -- kernels_tile.h kWideWaves)
     const int nf = tile_nf(e);
     const bool wide = nf == 1 && !side_launches && split == 0 && rows.nnz < e->wide_max_nnz;

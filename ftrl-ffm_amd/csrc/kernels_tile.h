@@ -704,12 +704,18 @@ enum { UPD_GIANT = 1, UPD_HOT = 2, UPD_FEW = 4, UPD_SIDE = 8, UPD_REST = 16, UPD
 #ifndef FFM_OCC_GIANT
 #define FFM_OCC_GIANT 4  // (131 registers by itself: 3 waves)
 #endif
-constexpr int upd_occ(int kinds) {
-  return kinds == UPD_ALL ? FFM_OCC_ALL : (kinds & UPD_GIANT) ? FFM_OCC_GIANT : (kinds & UPD_HOT) ? FFM_OCC_HOT : (kinds & UPD_FEW) ? FFM_OCC_FEW : 0;
+// (k = 4 -- four facts per stager lane, sixteen slots per chunk -- does not fit 128 registers: held to
+// four waves its hot and giant instantiations spill 39-46 VGPRs into 160-188 bytes of scratch per lane;
+// at three waves C3's three launches side by side are 0.476 ms against 0.505, and against 0.488 as one launch)
+constexpr int upd_occ(int kinds, int nf) {
+  return kinds == UPD_ALL ? FFM_OCC_ALL
+         : (kinds & UPD_GIANT) ? (nf == 4 ? 3 : FFM_OCC_GIANT)
+         : (kinds & UPD_HOT) ? (nf == 4 ? 3 : FFM_OCC_HOT)
+         : (kinds & UPD_FEW) ? FFM_OCC_FEW : 0;
 }
-constexpr int upd_occ_min(int kinds) { return upd_occ(kinds) > 0 ? upd_occ(kinds) : 1; }
-constexpr int upd_occ_max(int kinds) { return upd_occ(kinds) > 0 ? upd_occ(kinds) : 8; }
-#define FFM_UPD_OCC __attribute__((amdgpu_waves_per_eu(upd_occ_min(KINDS), upd_occ_max(KINDS))))
+constexpr int upd_occ_min(int kinds, int nf) { return upd_occ(kinds, nf) > 0 ? upd_occ(kinds, nf) : 1; }
+constexpr int upd_occ_max(int kinds, int nf) { return upd_occ(kinds, nf) > 0 ? upd_occ(kinds, nf) : 8; }
+#define FFM_UPD_OCC __attribute__((amdgpu_waves_per_eu(upd_occ_min(KINDS, NF), upd_occ_max(KINDS, NF))))
 template <int NF, int KINDS = UPD_ALL, int WAVES = tile_waves(NF)>
 __global__ __launch_bounds__(64 * WAVES) FFM_UPD_OCC void ffm_update_all_kernel(ModelDev m, Rows rows, Scratch s,
                                                                      int side_blocks, int ng, int nt, int ns,

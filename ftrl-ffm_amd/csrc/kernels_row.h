@@ -584,9 +584,7 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
 #ifndef FFM_UPD_FLY
 #define FFM_UPD_FLY 1
 #endif
-#ifndef FFM_UPD_HALVES
-#define FFM_UPD_HALVES 0
-#endif
+
       constexpr int kUpdFly = FFM_UPD_FLY;
       const int RL4 = RL >> 2, k4 = k >> 2;
       const int per = record_span(m, k4);
@@ -648,11 +646,7 @@ __global__ __launch_bounds__(kRowMaxThreads) FFM_ROW_OCC void ffm_row_kernel(Mod
           const int a = ia[u], fp = ifp[u], fa = lds.field[a];
           if (lds.fcnt[fp] == 1) {
             const int bb = lds.ffirst[fp];
-#if FFM_UPD_HALVES
-            ffm_touch4_halves(m.h, a < bb, tg, lds.val[a], lds.val[bb], vp[u], w4[u], n4[u], z4[u]);
-#else
             ffm_touch4(m.h, a < bb, tg, lds.val[a], lds.val[bb], vp[u], w4[u], n4[u], z4[u]);
-#endif
           } else {  // several entries of that field in the row: one touch each, in row order
             for (int bb = lds.ffirst[fp]; bb < nv; bb++) {
               if (bb == a || lds.field[bb] != fp) continue;

@@ -67,11 +67,11 @@ template <class T> __device__ __forceinline__ void coh_store(T *p, T v) {
 // grid is clamped to what the device can hold of this kernel (engine: sort_grid_cap, from
 // hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs) -- other kernels on the device never wait for
 // the sort, so its workgroups all arrive once those drain -- and the spin is BOUNDED: a workgroup
-// that has waited ~a second (CU masks, a partitioned device, ...) raises ERR_SORT_BARRIER, the block
+// that has waited two seconds (CU masks, a partitioned device, ...) raises ERR_SORT_BARRIER, the block
 // is skipped as a whole (CNT_ERROR, like an over-long row) and the caller learns about it at the
 // next sync.  Returns false then; every workgroup leaves within the same bound.
 // __syncthreads() waits for the wave's own stores (vmcnt) before it arrives.
-constexpr int kSortSpinMax = 1 << 22;  // x s_sleep 8 (~0.25 us)
+constexpr unsigned long long kSortSpinTicks = 200000000ull;  // of s_memrealtime (100 MHz): two seconds
 __device__ __forceinline__ bool sort_grid_barrier(const SortJob &a, int n_wg, int &target) {
   __shared__ int ok;
   __builtin_amdgcn_s_waitcnt(0);
@@ -79,12 +79,14 @@ __device__ __forceinline__ bool sort_grid_barrier(const SortJob &a, int n_wg, in
   if (threadIdx.x == 0) {
     target += n_wg;
     __hip_atomic_fetch_add(a.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < kSortSpinMax) {
+    // (bounded by the clock, not by an iteration count: an iteration is an agent-scope load whose
+    // latency depends on what else the chip is doing -- ADVICE r05)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool arrived;
+    while (!(arrived = __hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) &&
+           __builtin_amdgcn_s_memrealtime() - t0 < kSortSpinTicks)
       __builtin_amdgcn_s_sleep(8);
-      spins++;
-    }
-    ok = spins < kSortSpinMax;
+    ok = arrived;
     if (!ok) {
       atomicOr(a.block_err, ERR_SORT_BARRIER);
       atomicOr(a.err, ERR_SORT_BARRIER);

@@ -75,30 +75,6 @@ __device__ __forceinline__ void ffm_touch4(const Hyper &h, bool own_first, float
   z4 = make_float4(z[0], z[1], z[2], z[3]);
 }
 
-// The same touch as two halves, one after the other (a scheduling barrier between them): the same
-// arithmetic per element -- the wave votes only choose between two exact forms -- with half the
-// temporaries alive at once.  The row kernel's in-row update uses it: its registers bound how many
-// rows a CU holds.
-__device__ __forceinline__ void ffm_touch4_halves(const Hyper &h, bool own_first, float tg, float x_own,
-                                                  float x_other, float4 vp4, float4 w4, float4 &n4,
-                                                  float4 &z4) {
-  {
-    const float vp[2] = {vp4.x, vp4.y}, w[2] = {w4.x, w4.y};
-    float n[2] = {n4.x, n4.y}, z[2] = {z4.x, z4.y};
-    ffm_touch_n<2>(h, own_first, tg, x_own, x_other, vp, w, n, z);
-    n4.x = n[0]; n4.y = n[1];
-    z4.x = z[0]; z4.y = z[1];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    const float vp[2] = {vp4.z, vp4.w}, w[2] = {w4.z, w4.w};
-    float n[2] = {n4.z, n4.w}, z[2] = {z4.z, z4.w};
-    ffm_touch_n<2>(h, own_first, tg, x_own, x_other, vp, w, n, z);
-    n4.z = n[0]; n4.w = n[1];
-    z4.z = z[0]; z4.w = z[1];
-  }
-}
-
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Strictly left-to-right running sum over the 64 lanes: returns S_j = ((carry + a_0) + a_1) ... + a_j

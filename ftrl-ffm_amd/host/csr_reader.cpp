@@ -231,12 +231,19 @@ CsrData load_csr(const std::string &path, const std::string &file_type, int n_th
   // (untouched reserve costs nothing where memory is overcommitted; the arrays grow into it page by
   // page).  Under strict overcommit or a virtual-memory limit the reservation may be refused: the
   // arrays then simply grow geometrically as they are filled.
+  // Each array by itself, so that one refusal does not cost the others their reservation; the row
+  // arrays at one row per 8 bytes (a libffm row of one entry): shorter rows than that make them grow
+  // once or twice, where bytes / 2 asked for 4.5 times the file size in address space for them alone
+  // (ADVICE r05).
   const size_t bytes = static_cast<size_t>(st.st_size), tok = file_type == "libffm" ? 6 : 4;
-  try {
-    out.field.reserve(bytes / tok); out.feat.reserve(bytes / tok); out.val.reserve(bytes / tok);
-    out.row_ptr.reserve(bytes / 2 + 2); out.label.reserve(bytes / 2 + 1);
-  } catch (const std::bad_alloc &) {
-  }
+  auto try_reserve = [](auto &v, size_t n) {
+    try { v.reserve(n); } catch (const std::bad_alloc &) {}
+  };
+  try_reserve(out.field, bytes / tok);
+  try_reserve(out.feat, bytes / tok);
+  try_reserve(out.val, bytes / tok);
+  try_reserve(out.row_ptr, bytes / 8 + 2);
+  try_reserve(out.label, bytes / 8 + 1);
   // first touch of ~1 GB per million rows is what this loop would otherwise spend its time on: ask for
   // huge pages (512 times fewer faults where transparent huge pages are on "madvise" or "always")
   auto huge = [](void *p, size_t n) {

@@ -143,6 +143,9 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
                            const int32_t *label, int32_t zero_copy) {
   int32_t nnz = 0;
   int longest = 1;
+  // (LR / FM rows have no fields -- libsvm: src/data/parser.cpp:20 gives every entry field 0 -- so a
+  // field array the caller passes along is not uploaded: a third of the block's bytes over PCIe)
+  if (e && e->m.type != FFM_MODEL_FFM) field = nullptr;
   int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
   if (rc) return rc;
   if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
@@ -290,6 +293,7 @@ int ffm_engine_predict_batch_async(ffm_engine *e, int32_t n_rows, const int32_t 
                                    const int32_t *label, int32_t zero_copy) {
   int32_t nnz = 0;
   int longest = 1;
+  if (e && e->m.type != FFM_MODEL_FFM) field = nullptr;  // (LR / FM: no fields to upload)
   if (e) e->eval_hold = true;  // (the deferred block waits until this one's upload is submitted)
   int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
   if (e) e->eval_hold = false;

@@ -556,6 +556,7 @@ static int stage_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr, co
                        const int32_t *feat, const float *val, const int32_t *label, int32_t *nnz_out) {
   int32_t nnz = 0;
   int longest = 1;
+  if (e && e->m.type != FFM_MODEL_FFM) field = nullptr;  // (LR / FM: no fields to upload)
   int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
   if (rc) return rc;
   e->staged_row_cap = longest;
@@ -579,7 +580,7 @@ int ffm_engine_train_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
   if (rc) return rc;
   if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
-  rc = ffm_engine_train_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
+  rc = ffm_engine_train_batch_device(e, n_rows, nnz, e->d_row_ptr, (field && e->m.type == FFM_MODEL_FFM) ? e->d_field : nullptr,
                                      e->d_feat, e->d_val, e->d_label, e->d_out, e->d_loss_sum);
   if (rc) return rc;
   if (logit_out && n_rows > 0)
@@ -597,7 +598,7 @@ int ffm_engine_predict_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_p
   int rc = stage_block(e, n_rows, row_ptr, field, feat, val, label, &nnz);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(e->sc[e->cur].counters, 0, kNumCounters * sizeof(int), e->stream));
-  rc = ffm_engine_predict_batch_device(e, n_rows, nnz, e->d_row_ptr, field ? e->d_field : nullptr,
+  rc = ffm_engine_predict_batch_device(e, n_rows, nnz, e->d_row_ptr, (field && e->m.type == FFM_MODEL_FFM) ? e->d_field : nullptr,
                                        e->d_feat, e->d_val, label ? e->d_label : nullptr,
                                        output_prob, e->d_out, e->d_loss_sum);
   if (rc) return rc;

@@ -80,6 +80,15 @@ FtrlModel::FtrlModel(const config_options &opt, int mt)
     bias_owner_ = bo;
     std::printf("%d field-pair shards, collective: %s\n", n_gpus_, ffm_group_collective(grp_));
   } else {
+    // one engine: --field_ranges uniform is a hint (the grouping sorts every field's id range by itself,
+    // and a block whose rows are one entry per field in field order takes the short forms of the fold)
+    std::vector<int32_t> fs;
+    if (mt == FFM_MODEL_FFM && opt.field_ranges == "uniform" && opt.n_feats >= opt.n_fields) {
+      fs.resize(static_cast<size_t>(opt.n_fields) + 1);
+      const int per = opt.n_feats / opt.n_fields;
+      for (int f = 0; f <= opt.n_fields; f++) fs[f] = f == opt.n_fields ? opt.n_feats : f * per;
+      cfg.field_start = fs.data();  // (copied by ffm_engine_create)
+    }
     rc = ffm_engine_create(&cfg, &eng_);
     if (rc == FFM_E_INVALID) throw std::invalid_argument(ffm_engine_last_error());
     check(rc, "ffm_engine_create");

@@ -82,8 +82,12 @@ typedef struct ffm_engine_config {
    * fields it has pairs of, and in each record only the slots it owns -- about 1/n_shards of the
    * (n_feats x n_fields x n_factors) tensor -- and it skips the columns of the other fields; an
    * entry whose id is outside its field's range then voids its block (FFM_E_INVALID at the next
-   * sync).  Without it every shard keeps full-length records and only the work is sharded.  The
-   * array is copied; ignored when n_shards == 1. */
+   * sync).  Without it every shard keeps full-length records and only the work is sharded.
+   * With n_shards == 1 it is a HINT: the block grouping (the mini-batch scheduler that replaces the
+   * per-feature mutexes of src/include/model/ffm.h:32) sorts every field's id range by itself in one
+   * launch, and blocks whose rows are one entry per field in field order take shorter forms of the
+   * update; ids that sit under another field than their range's are still handled correctly.  The
+   * array is copied. */
   const int32_t *field_start;
   int32_t reserved[4];
 } ffm_engine_config;

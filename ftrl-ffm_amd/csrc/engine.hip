@@ -1061,6 +1061,8 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
 }
 
 // What init_weights_kernel stored, computed on the host (csrc/init_rng.h: same bits).
+static int eval_launch_pending(ffm_engine *e);  // (engine_step.h)
+
 int ffm_engine_init_weights_host(uint64_t seed, float init_mean, float init_stddev, int32_t latent,
                                  int64_t first, int64_t count, float *out) {
   if (first < 0 || count < 0 || (count > 0 && !out)) return fail(FFM_E_INVALID, "bad range or null output");
@@ -1073,6 +1075,7 @@ int ffm_engine_fill_state(ffm_engine *e, uint64_t seed, float n_lo, float n_hi, 
   if (!e) return fail(FFM_E_INVALID, "null engine");
   if (!(n_lo >= 0.0f) || !(n_hi >= n_lo)) return fail(FFM_E_INVALID, "need 0 <= n_lo <= n_hi");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if (int rc_e = eval_launch_pending(e)) return rc_e;
   hipLaunchKernelGGL(fill_state_kernel, dim3(2048), dim3(256), 0, e->stream, e->m, e->logical_len, seed, n_lo, n_hi, z_stddev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1096,7 +1099,6 @@ int ffm_engine_eval_sigmoid(ffm_engine *e, int32_t n, const float *x, float *y) 
 // Waits for the engine's stream, then reports (and clears) what the kernels flagged since the
 // last report: the device entry points are asynchronous, so this is where their callers learn
 // that a block could not be trained.
-static int eval_launch_pending(ffm_engine *e);  // (engine_step.h)
 static int check_device_errors(ffm_engine *e) {
   int flags = 0;
   if (int rc_e = eval_launch_pending(e)) return rc_e;

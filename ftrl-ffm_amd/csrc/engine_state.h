@@ -30,6 +30,7 @@ static int flat_transfer(ffm_engine *e, float *dev, float *host, size_t n, bool 
 
 int ffm_engine_set_weights(ffm_engine *e, const float *bias, const float *lin_w, const float *vec_w) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (int rc_e = eval_launch_pending(e)) return rc_e;  // (a deferred evaluation block sees the state as it was)
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   int rc;
   if ((rc = flat_transfer(e, e->m.bias3 + 0, const_cast<float *>(bias), 1, false))) return rc;
@@ -39,6 +40,7 @@ int ffm_engine_set_weights(ffm_engine *e, const float *bias, const float *lin_w,
 
 int ffm_engine_get_weights(ffm_engine *e, float *bias, float *lin_w, float *vec_w) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (int rc_e = eval_launch_pending(e)) return rc_e;  // (a deferred evaluation block sees the state as it was)
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   int rc;
   if ((rc = flat_transfer(e, e->m.bias3 + 0, bias, 1, true))) return rc;
@@ -50,6 +52,7 @@ int ffm_engine_set_state(ffm_engine *e, const float *bias_n, const float *bias_z
                          const float *lin_n, const float *lin_z, const float *vec_n,
                          const float *vec_z) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (int rc_e = eval_launch_pending(e)) return rc_e;  // (a deferred evaluation block sees the state as it was)
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   int rc;
   if ((rc = flat_transfer(e, e->m.bias3 + 1, const_cast<float *>(bias_n), 1, false))) return rc;
@@ -63,6 +66,7 @@ int ffm_engine_set_state(ffm_engine *e, const float *bias_n, const float *bias_z
 int ffm_engine_get_state(ffm_engine *e, float *bias_n, float *bias_z, float *lin_n, float *lin_z,
                          float *vec_n, float *vec_z) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
+  if (int rc_e = eval_launch_pending(e)) return rc_e;  // (a deferred evaluation block sees the state as it was)
   HIP_TRY(hipSetDevice(e->cfg.device_id));
   int rc;
   if ((rc = flat_transfer(e, e->m.bias3 + 1, bias_n, 1, true))) return rc;
@@ -81,6 +85,7 @@ static int rows_transfer(ffm_engine *e, int32_t n, const int32_t *ids, float *co
   for (int32_t j = 0; j < n; j++)
     if (ids[j] < 0 || ids[j] >= e->m.n_feats) return fail(FFM_E_INVALID, "feature id out of range");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
+  if (int rc_e = eval_launch_pending(e)) return rc_e;  // (a deferred evaluation block sees the state as it was)
   const int64_t RL = e->logical_len;
   const int64_t per = std::min<int64_t>(ffm_engine::kIdsCap, RL > 0 ? e->stage_floats / RL : ffm_engine::kIdsCap);
   float *const lin_dev[3] = {e->m.lin_n, e->m.lin_z, e->m.lin_w};

@@ -733,25 +733,27 @@ __global__ __launch_bounds__(64 * WAVES) FFM_UPD_OCC void ffm_update_all_kernel(
     return;
   }
   r -= side_blocks;
-  // the three big ranges in the order `order` names (digits, first range last: 0 giant, 1 hot, 2 few)
-  for (int o = order, left = 3; left > 0; left--, o /= 10) {
-    const int kind = o % 10;
-    const int n = kind == 0 ? ng : kind == 1 ? nt : ns;
-    if (r < n) {
-      if (kind == 0) {
-        if (KINDS & UPD_GIANT) ffm_coop_items<NF, WAVES>(m, rows, s, r, ng, T, R, lds_coop);
-      } else if (kind == 1) {
-        if (KINDS & UPD_HOT) {
-          ffm_range_items_a<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
-          ffm_tile_items<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
-        }
-      } else {
-        if (KINDS & UPD_FEW) ffm_small_body(m, rows, s, few_only, r, ns);
-      }
-      return;
-    }
-    r -= n;
+  // the three big ranges in the order `order` names (digits, first range last: 0 giant, 1 hot, 2 few);
+  // which range first, then ONE call site per range (inside the loop the unrolled copies cost the
+  // one-launch instantiations nine registers)
+  int kind = -1;
+  for (int o = order, left = 3; left > 0 && kind < 0; left--, o /= 10) {
+    const int kd = o % 10;
+    const int n = kd == 0 ? ng : kd == 1 ? nt : ns;
+    if (r < n) kind = kd;
+    else r -= n;
   }
+  if (kind == 0) {
+    if (KINDS & UPD_GIANT) ffm_coop_items<NF, WAVES>(m, rows, s, r, ng, T, R, lds_coop);
+  } else if (kind == 1) {
+    if (KINDS & UPD_HOT) {
+      ffm_range_items_a<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
+      ffm_tile_items<NF>(m, rows, s, r * WAVES + wv, nt * WAVES, T, R);
+    }
+  } else if (kind == 2) {
+    if (KINDS & UPD_FEW) ffm_small_body(m, rows, s, few_only, r, ns);
+  }
+  if (kind >= 0) return;
   if (KINDS & UPD_REST) {
     if (r < nw) { ffm_generic_body(m, rows, s, 1, r, nw); return; }
     loss_sum_body(rows.n_rows, s.loss, loss_out, loss_scratch, r - nw, loss_blocks);

@@ -16,6 +16,9 @@
 struct PullJob {
   const char *src[5]; char *dst[5]; unsigned bytes[5];
   long long ordinal; long long *pulled; unsigned *ticket;  // completion word (host memory), see h_pulled
+  // rows handed over without a field array (one entry per field in field order): the slot's field
+  // array is written here -- entry j of the block is field j mod n_fields -- instead of crossing PCIe
+  int *gen_field; unsigned gen_n; int gen_fields;
 };
 __global__ __launch_bounds__(256) void pull_block_kernel(PullJob job) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -25,10 +28,20 @@ __global__ __launch_bounds__(256) void pull_block_kernel(PullJob job) {
     const unsigned n16 = job.bytes[a] >> 4;
     const int4 *s = reinterpret_cast<const int4 *>(job.src[a]);
     int4 *d = reinterpret_cast<int4 *>(job.dst[a]);
+    // (one load per lane in flight: two, four and eight measured the same -- 42 GB/s is what a kernel reads over PCIe here)
     for (unsigned i = tid; i < n16; i += stride) d[i] = s[i];
     const unsigned tail = job.bytes[a] & 15u;  // sizes are multiples of 4
     if (tid < (tail >> 2))
       reinterpret_cast<int *>(job.dst[a])[(n16 << 2) + tid] = reinterpret_cast<const int *>(job.src[a])[(n16 << 2) + tid];
+  }
+  if (job.gen_n) {
+    const unsigned n4 = job.gen_n >> 2, F = static_cast<unsigned>(job.gen_fields);
+    for (unsigned i = tid; i < n4; i += stride) {
+      const unsigned f0 = (4u * i) % F, f1 = f0 + 1u < F ? f0 + 1u : 0u, f2 = f1 + 1u < F ? f1 + 1u : 0u;
+      reinterpret_cast<int4 *>(job.gen_field)[i] = make_int4(static_cast<int>(f0), static_cast<int>(f1), static_cast<int>(f2),
+                                                             static_cast<int>(f2 + 1u < F ? f2 + 1u : 0u));
+    }
+    if (tid < (job.gen_n & 3u)) job.gen_field[(n4 << 2) + tid] = static_cast<int>(((n4 << 2) + tid) % F);
   }
   // the workgroup that finishes last publishes the block's number to the host
   __syncthreads();  // (every load of this workgroup has returned: its stores were issued after them)
@@ -128,6 +141,11 @@ static int claim_slot(ffm_engine *e, int32_t n_rows, int32_t nnz, const int32_t 
   ScopedTimer tm("stage:copies");
   HIP_TRY(put(row_ptr, 4 * R1, sl.row_ptr));
   if (field) HIP_TRY(put(field, 4 * E, sl.field));
+  else if (e->m.type == FFM_MODEL_FFM && E > 0) {  // (validated: one entry per field in field order)
+    job.gen_field = sl.field;
+    job.gen_n = static_cast<unsigned>(E);
+    job.gen_fields = e->m.n_fields;
+  }
   HIP_TRY(put(feat, 4 * E, sl.feat));
   HIP_TRY(put(val, 4 * E, sl.val));
   HIP_TRY(put(label, 4 * static_cast<size_t>(n_rows), sl.label));
@@ -146,8 +164,9 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   // (LR / FM rows have no fields -- libsvm: src/data/parser.cpp:20 gives every entry field 0 -- so a
   // field array the caller passes along is not uploaded: a third of the block's bytes over PCIe)
   if (e && e->m.type != FFM_MODEL_FFM) field = nullptr;
-  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
+  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest, true);
   if (rc) return rc;
+  const bool has_field = field != nullptr || (e->m.type == FFM_MODEL_FFM && nnz > 0);  // (uploaded or written by the upload kernel)
   if (n_rows > 0 && !label) return fail(FFM_E_INVALID, "training needs labels");
   if ((rc = eval_launch_pending(e))) return rc;
   if (e->n_staged >= ffm_engine::kSlots - 1) return fail(FFM_E_CAPACITY, "three staged blocks are already waiting");
@@ -165,7 +184,7 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   ffm_engine::Slot &sl = e->slots[this_slot];
   // its grouping, behind its own upload on the prep stream: planned here, submitted with the upload
   PrepPlan plan;
-  if ((rc = prepare_plan(e, Rows{n_rows, nnz, sl.row_ptr, field ? sl.field : nullptr, sl.feat, sl.val, nullptr}, &plan)))
+  if ((rc = prepare_plan(e, Rows{n_rows, nnz, sl.row_ptr, has_field ? sl.field : nullptr, sl.feat, sl.val, nullptr}, &plan)))
     return rc;
   const int64_t seq = e->n_staged_total + 1;
   const int grid_pull = e->grid_pull;
@@ -196,7 +215,7 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
   sl.n_rows = n_rows;
   sl.nnz = nnz;
   sl.row_cap = longest;
-  sl.has_field = field != nullptr;
+  sl.has_field = has_field;
   sl.seq = ++e->n_staged_total;
   e->slot_next = (e->slot_next + 1) % ffm_engine::kSlots;
   e->staged[e->n_staged++] = this_slot;
@@ -295,9 +314,10 @@ int ffm_engine_predict_batch_async(ffm_engine *e, int32_t n_rows, const int32_t 
   int longest = 1;
   if (e && e->m.type != FFM_MODEL_FFM) field = nullptr;  // (LR / FM: no fields to upload)
   if (e) e->eval_hold = true;  // (the deferred block waits until this one's upload is submitted)
-  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest);
+  int rc = validate_host_block(e, n_rows, row_ptr, field, feat, val, &nnz, &longest, true);
   if (e) e->eval_hold = false;
   if (rc) return rc;
+  const bool has_field = field != nullptr || (e->m.type == FFM_MODEL_FFM && nnz > 0);  // (uploaded or written by the upload kernel)
   if (e->m.n_shards > 1) return fail(FFM_E_INVALID, "a sharded engine predicts through predict_batch_device + predict_finish_device");
   if (e->n_staged > 0 || e->has_pending) return fail(FFM_E_INVALID, "staged training blocks are still waiting");
   HIP_TRY(hipSetDevice(e->cfg.device_id));
@@ -316,7 +336,7 @@ int ffm_engine_predict_batch_async(ffm_engine *e, int32_t n_rows, const int32_t 
   sl.n_rows = n_rows;
   sl.nnz = nnz;
   sl.row_cap = longest;
-  sl.has_field = field != nullptr;
+  sl.has_field = has_field;
   sl.seq = ++e->n_staged_total;
   {
     std::lock_guard<std::mutex> lock(e->wmu);

@@ -8,7 +8,7 @@ static int eval_launch_pending(ffm_engine *e);
 __global__ void loss_accumulate_kernel(double *acc, const double *one) { *acc += *one; }
 
 static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *row_ptr,
-                       const void *field, const void *feat, const void *val) {
+                       const void *field, const void *feat, const void *val, bool implicit_fields = false) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
   // an evaluation block whose predict launch predict_batch_async deferred goes first (every entry
   // point that puts work on the main stream passes here)
@@ -18,7 +18,7 @@ static int check_block(ffm_engine *e, int32_t n_rows, int32_t nnz, const void *r
   if (n_rows > e->max_rows || nnz > e->max_nnz)
     return fail(FFM_E_CAPACITY, "block exceeds max_batch_rows / max_batch_nnz");
   if (!row_ptr || (nnz > 0 && (!feat || !val))) return fail(FFM_E_INVALID, "null CSR array");
-  if (e->m.type == FFM_MODEL_FFM && nnz > 0 && !field)
+  if (e->m.type == FFM_MODEL_FFM && nnz > 0 && !field && !implicit_fields)
     return fail(FFM_E_INVALID, "FFM requires the field array (libffm rows)");
   return FFM_OK;
 }
@@ -528,9 +528,11 @@ int ffm_engine_predict_finish_device(ffm_engine *e, int32_t n_rows, const float 
 }
 
 // Checks one block of host arrays; returns its nnz and its longest row.
+// implicit_fields (the staged entry points, FFM, field == NULL): every row must then hold exactly one
+// entry per field, entry j of a row being field j's -- the upload kernel writes the field array itself.
 static int validate_host_block(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr,
                                const int32_t *field, const int32_t *feat, const float *val,
-                               int32_t *nnz_out, int *longest_out) {
+                               int32_t *nnz_out, int *longest_out, bool implicit_fields = false) {
   if (!e) return fail(FFM_E_INVALID, "null engine");
   if (n_rows < 0) return fail(FFM_E_INVALID, "negative n_rows");
   if (!row_ptr) return fail(FFM_E_INVALID, "null row_ptr");
@@ -539,8 +541,12 @@ static int validate_host_block(ffm_engine *e, int32_t n_rows, const int32_t *row
   for (int r = 0; r < n_rows; r++)
     if (row_ptr[r + 1] < row_ptr[r]) return fail(FFM_E_INVALID, "row_ptr must be non-decreasing");
   const int32_t nnz = row_ptr[n_rows];
-  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val);
+  int rc = check_block(e, n_rows, nnz, row_ptr, field, feat, val, implicit_fields);
   if (rc) return rc;
+  if (implicit_fields && !field && e->m.type == FFM_MODEL_FFM)
+    for (int r = 0; r < n_rows; r++)
+      if (row_ptr[r + 1] - row_ptr[r] != e->m.n_fields)
+        return fail(FFM_E_INVALID, "rows without a field array need exactly one entry per field");
   int longest = 1;
   for (int r = 0; r < n_rows; r++) {
     if (row_ptr[r + 1] - row_ptr[r] > e->max_row_nnz)

@@ -680,6 +680,73 @@ def test_staged_host_blocks_equal_block_by_block(zero_copy):
             b_.unpin_block(blk)
 
 
+@pytest.mark.parametrize("zero_copy", [False, True], ids=["copied", "zero_copy"])
+def test_rows_without_a_field_array_train_and_predict_the_same(zero_copy):
+    """The staged host entry points take field == NULL for FFM when every row is one entry per
+    field in field order (include/ffm_engine.h: the upload kernel writes the field array instead
+    of pulling it over PCIe): the bits of the same blocks handed over with the array -- training
+    (stage_batch + train_staged, train_batch_async) and evaluation (predict_batch_async) --; a
+    block whose rows are not that shape is refused."""
+    import copy
+    F, k, per = 8, 16, 50
+    nf = F * per
+    g = synth.Generator(F, nf, "zipf", seed=26)
+    blocks = [g.block(n) for n in (256, 7, 256, 1, 255)]
+    for blk in blocks:  # the generator's rows ARE that shape
+        assert np.array_equal(blk.field, np.tile(np.arange(F, dtype=np.int32), blk.n_rows))
+
+    def make():
+        e = fa.Engine("FFM", nf, F, k, max_batch_rows=256, seed=3, **STRESS_HP)
+        e.fill_state(seed=9)
+        return e
+
+    def bare(blk):
+        c = copy.copy(blk)
+        c.__dict__.pop("_ffm_csr_args", None)
+        c.field = None
+        return c
+
+    a = make()
+    ref_logits = [a.train_batch(b)[0] for b in blocks]
+    sa = a.get_state()
+    ref_eval = sum(a.predict_batch(b)[1] for b in blocks)
+    a.close()
+    b_ = make()
+    nofield = [bare(blk) for blk in blocks]
+    if zero_copy:
+        nofield = [_own_pages(blk) for blk in nofield]
+        for blk in nofield:
+            b_.pin_block(blk)
+    logit = torch.zeros(256, device="cuda")
+    for i, blk in enumerate(nofield[:3]):
+        b_.stage_batch(blk, zero_copy)
+        b_.train_staged(logit.data_ptr())
+        b_.sync()
+        assert_bitwise(logit[:blk.n_rows].cpu().numpy(), ref_logits[i], "logits of rows without a field array")
+    for blk in nofield[3:]:
+        b_.train_batch_async_pinned(blk) if zero_copy else b_.train_batch_async(blk)
+    b_.train_flush()
+    assert_state_bitwise(b_.get_state(), sa, "rows without a field array")
+    for blk in nofield:
+        b_.predict_batch_async(blk, zero_copy)
+    got_eval = b_.train_flush()
+    assert abs(got_eval - ref_eval) <= 1e-9 * max(1.0, abs(ref_eval))
+    # not one entry per field: refused, and nothing was staged
+    ragged = bare(blocks[0].rows(0, 4))
+    ragged.row_ptr = np.array([0, F, 2 * F - 1, 3 * F, 4 * F], np.int32)
+    with pytest.raises(fa.EngineError) as ei:
+        b_.stage_batch(ragged, False)
+    assert ei.value.code == -1
+    # ... and the entry points that do not go through a staging slot still want the array
+    with pytest.raises(fa.EngineError):
+        b_.train_batch(bare(blocks[1]))
+    assert_state_bitwise(b_.get_state(), sa, "after the refused blocks")
+    b_.close()
+    if zero_copy:
+        for blk in nofield:
+            b_.unpin_block(blk)
+
+
 def test_pinned_async_training_equals_block_by_block():
     """ffm_engine_train_batch_async_pinned (what the offline trainer calls: blocks gathered in
     page-locked memory, no host copy, three blocks in flight) mixed with the copying

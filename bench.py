@@ -154,7 +154,7 @@ def cpu_baseline(args, gen_kwargs):
     workload: oracle/_ref (the unmodified reference model classes compiled from /root/reference by
     oracle/Makefile; the harness runs FtrlOffline::one_epoch's loop, ftrl_offline.cpp:63-91, over
     them) -- kind "reference".  Where that build is absent, the oracle's restatement -- kind "port"
-    (profiles/r02_cpu_baseline_validation.json: port/reference = 1.23 at 1 thread, 0.89 at 8).
+    (profiles/archive/r02_cpu_baseline_validation.json: port/reference = 1.23 at 1 thread, 0.89 at 8).
     Checker code, used here only as the reported baseline."""
     from oracle import pyoracle
     from oracle.pyoracle import CpuModel

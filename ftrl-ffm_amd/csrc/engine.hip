@@ -396,7 +396,7 @@ struct ffm_engine {
   // training launches that the caller's thread issues.  Why: rocPRIM's radix sort calls
   // hipMemsetAsync inside, which on this runtime can hold the submitting thread until earlier work
   // of the stream has retired -- measured 30 us per sort call on most boxes of the pool but 240 us
-  // mean / 31 ms worst on others (profiles/r03_host_leg_diag.txt), during which the caller's thread
+  // mean / 31 ms worst on others (profiles/archive/r03_host_leg_diag.txt), during which the caller's thread
   // did not enqueue the NEXT training block and the H2D-inclusive step grew from 1.13 to 1.32 ms
   // with the resident step unchanged.  All bookkeeping stays on the caller's thread; the worker only
   // replays closures in order.  staged_issued: ordinal of the last staged block whose launches are

@@ -25,7 +25,7 @@ namespace ftrl_dev {
 // the features many rows share are what the 4 MB L2 of an XCD should keep: the (n, z) traffic
 // carries the non-temporal hint (global_load / store ... nt).  Bits of FFM_ROW_NT: 1 the update's
 // stores, 2 the refresh's loads, 4 the update's loads, 8 the update's w load.  Measured on C5
-// (profiles/r03_fused_row_experiment.txt): 7 -> row kernel 550 -> 540 us; 1, 2, 3, 4 alone: noise.
+// (profiles/archive/r03_fused_row_experiment.txt): 7 -> row kernel 550 -> 540 us; 1, 2, 3, 4 alone: noise.
 #ifndef FFM_ROW_NT
 #define FFM_ROW_NT 7
 #endif

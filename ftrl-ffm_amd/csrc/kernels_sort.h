@@ -6,7 +6,7 @@
 // ~14 launches (histogram, scan, and per pass two fills + twenty 1024-thread workgroups), each of which
 // has to find room on a GPU that the row / update kernels keep full -- a 1024-thread workgroup needs
 // 16 free wave slots on ONE CU, and even a one-workgroup fill waited 50-80 us for a slot
-// (profiles/r04_experiments.md).  The grouping is two blocks ahead of its use, but it is a CHAIN: at
+// (profiles/archive/r04_experiments.md).  The grouping is two blocks ahead of its use, but it is a CHAIN: at
 // steps under ~0.5 ms (FM, FFM k = 4, small blocks) the look-ahead queue's ~17 dependent launches per
 // block took as long as the step itself and the main stream waited for them one to one.  Here the
 // sort's workgroups get on the machine once and stay until the block is sorted.

@@ -39,7 +39,7 @@ constexpr int kTileRow = 80;  // floats per transposer row: 64 + 16 of padding (
                               // consecutive touches land 16 banks apart)
 constexpr int kTileNR = 2;  // fact-record buffers (a power of two): the tile in flight and the one being
                             // applied (k = 4: 4 KB each per wave).  One tile of partner weights in flight:
-                            // two and three measured slower (profiles/r05_experiments.md section 2)
+                            // two and three measured slower (profiles/archive/r05_experiments.md section 2)
 #ifndef FFM_TILE_G
 #define FFM_TILE_G 4
 #endif
@@ -204,7 +204,7 @@ __device__ __forceinline__ void tile_stream(const ModelDev &m, const Scratch &s,
   };
   static_assert(kSeg % kTileT == 0 && kTileT % kTileG == 0, "segments are whole tiles, tiles whole groups");
   // One tile of weights in flight, facts one tile further, descriptors one more (deeper pipelines
-  // measured slower: profiles/r05_experiments.md).  The requests of a step in consumption order --
+  // measured slower: profiles/archive/r05_experiments.md).  The requests of a step in consumption order --
   // vmcnt retires loads in issue order: facts(ST+2), descriptors(ST+3), weights(ST+1).
   TileFacts fN;
   TileWeights V0;
@@ -677,7 +677,7 @@ __device__ __forceinline__ void ffm_range_join(const ModelDev &m, const Scratch 
 // WAVES per workgroup: the waves that fold ONE giant feature's chunk together (every other range
 // treats its waves as independent).  Four: with sixteen (one workgroup per CU, 1024-thread barriers,
 // sixteen tiles joined per super-step) a super-step took three times as long and the giant range
-// of a C5 block 506 us instead of 170 (profiles/r05_experiments.md).
+// of a C5 block 506 us instead of 170 (profiles/archive/r05_experiments.md).
 // Dynamic LDS: the transposers [WAVES][kTileT * kTileRow] floats, then the fact records.
 constexpr int tile_waves(int nf) { return nf == 4 && FFM_TILE_WAVES > 4 ? 4 : nf == 2 && FFM_TILE_WAVES > 8 ? 8 : FFM_TILE_WAVES; }
 constexpr size_t tile_lds_bytes(int nf, int waves) {
@@ -686,7 +686,7 @@ constexpr size_t tile_lds_bytes(int nf, int waves) {
 constexpr size_t tile_lds_bytes(int nf) { return tile_lds_bytes(nf, tile_waves(nf)); }
 // Small blocks (a 4096 x 8 block: ~1000-occurrence giants are 16 super-steps of four tiles) run the
 // launch with EIGHT waves per workgroup: half the super-steps -- 80 -> 70 us per launch; a C5 block
-// that way 438 -> 693 us (profiles/r05_experiments.md).
+// that way 438 -> 693 us (profiles/archive/r05_experiments.md).
 constexpr int kWideWaves = 8;
 // KINDS: which ranges this instantiation can run (their arguments must be 0 otherwise) -- the register
 // allocation, and with it the waves per SIMD, of a kernel is that of its hungriest path.

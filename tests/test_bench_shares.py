@@ -52,7 +52,7 @@ def test_row_kernel_owns_the_once_only_features():
 def test_traffic_only_for_the_captured_workload():
     key = None
     for fn in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-        if fn.startswith("r05_pmc_hbm_summary") and fn.endswith(".json"):
+        if fn.startswith("r06_pmc_hbm_summary") and fn.endswith(".json"):
             import json
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 key = json.load(f)["_capture"]["workload_key"]

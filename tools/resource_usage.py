@@ -29,7 +29,9 @@ def main():
     names = demangle([r["name"] for r in rows])
     print(f"{'VGPR':>5} {'AGPR':>5} {'SGPR':>5} {'sSpill':>6} {'vSpill':>6} {'scratch':>7} {'occ':>3} {'LDS':>6}  kernel")
     for r, n in zip(rows, names):
-        n = re.sub(r"\(.*", "", n).replace("ftrl_dev::", "").replace("void ", "")
+        n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "")).replace("ftrl_dev::", "").replace("void ", "")
+        if n.startswith("rocprim::"):  # (the library sort's kernels: FM, LR, ranks)
+            continue
         if filt and not any(f in n for f in filt):
             continue
         print(f"{r.get('VGPRs','?'):>5} {r.get('AGPRs','?'):>5} {r.get('TotalSGPRs','?'):>5} {r.get('SGPRs Spill','?'):>6} {r.get('VGPRs Spill','?'):>6} "

@@ -22,7 +22,7 @@ import sys
 
 # kernels whose reads are dominated by whole records streamed as 16 B per lane.  (The update launch
 # mixes such streams -- the few-occurrence features' records -- with 64-byte gathers by four lanes,
-# which the calibration counted at face value, profiles/r03_fetch_calibration.json slot_read_quad16:
+# which the calibration counted at face value, profiles/archive/r03_fetch_calibration.json slot_read_quad16:
 # it is left uncorrected, a lower bound.)
 WIDE_READERS = ("ffm_refresh_kernel", "ffm_update_single_kernel", "ffm_row_kernel<true", "fm_row_wave_kernel<true")
 

@@ -244,7 +244,7 @@ def block_logloss_cost(rows):
     GPU path equals bit for bit): the committed table's entry for the largest block <= rows, from
     its longest run."""
     best = None
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_logloss_vs_block*.json"))):
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "r*_logloss_vs_block*.json"), recursive=True)):
         try:
             d = json.load(open(fn))
         except (OSError, ValueError):

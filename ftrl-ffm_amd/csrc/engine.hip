@@ -275,6 +275,7 @@ struct ffm_engine {
   // Uploads of staged host blocks (pull_block_kernel) go on the prep stream, ahead of the block's
   // grouping.  (A fifth stream for them shares a hardware queue with one of the four and
   // serialises with it: measured 1.45-1.70 ms per step instead of 1.3.)
+  bool pull_after_row = false;  // a staged block's upload waits for the running block's row kernel to end (long steps)
   hipStream_t copy = nullptr;  // the upload kernel's stream: the prep stream (round 4 had it on aux3 for long steps)
   bool own_sort = false;        // the grouping's sort: kernels_sort.h (short steps) or rocPRIM Onesweep (ffm_engine_create)
   bool range_sort = false;      // ... or, when the id ranges of the fields are known, a workgroup per range (kernels_sort.h)
@@ -957,6 +958,11 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
         // (profiles/r06_experiments.md).  FFM_PREP_AFTER_ROW=0/1 overrides.
         // (long steps only: a 4096 x 8 block's update phase is 70 us, shorter than the chain)
         if (!std::getenv("FFM_PREP_AFTER_ROW")) e->prep_after_row = !e->own_sort;
+        // ... and from 4 M slot-factors per block on the block's upload waits for that event as well (C5: the
+        // driver's 20-step shape 0.887-0.896 -> 0.877-0.884 ms, 200 steps 0.870 -> 0.868; C3, 1.2 M: 0.472 ->
+        // 0.478, not taken).  FFM_PULL_AFTER_ROW=0/1 overrides.
+        e->pull_after_row = e->prep_after_row && static_cast<int64_t>(e->max_nnz) * m.n_factors >= (1ll << 22);
+        if (const char *pv = std::getenv("FFM_PULL_AFTER_ROW")) e->pull_after_row = pv[0] == '1';
       }
     }
     // the one-launch sort meets at a grid barrier: never more workgroups than the device holds of it,

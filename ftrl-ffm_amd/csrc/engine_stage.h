@@ -197,6 +197,9 @@ int ffm_engine_stage_batch(ffm_engine *e, int32_t n_rows, const int32_t *row_ptr
     auto body = [&]() -> int {
       HIP_TRY(hipSetDevice(e->cfg.device_id));
       if (free_ev) HIP_TRY(hipStreamWaitEvent(e->copy, free_ev, 0));  // nothing reads its device arrays
+      // (long steps: the upload too waits for the running block's row kernel to end -- beside the update
+      // launches it costs nothing, beside the row kernel, which is bound by the bytes it moves, it does)
+      if (e->pull_after_row && plan.ws >= 0) HIP_TRY(hipStreamWaitEvent(e->copy, e->prep_after_row ? e->ev_row_done[plan.ws] : e->ev_set_free[plan.ws], 0));
       hipLaunchKernelGGL(pull_block_kernel, dim3(grid_pull), dim3(256), 0, e->copy, job);
       HIP_TRY(hipEventRecord(s2.ev_copied, e->copy));
       if (e->copy != e->prep) HIP_TRY(hipStreamWaitEvent(e->prep, s2.ev_copied, 0));  // the grouping reads the slot

@@ -60,3 +60,12 @@ def test_traffic_only_for_the_captured_workload():
             assert got is not None and d["_capture"]["workload_key"] == key
     assert key is not None
     assert bench.matching_pmc_summary("no such workload") == (None, None)
+
+
+def test_block_logloss_cost_table_is_found():
+    """The sharded bench line quotes what its block size costs in logloss from the committed table
+    (profiles/**/r*_logloss_vs_block*.json): 8192- and 65 536-row blocks inside the north star's 1e-4."""
+    for rows in (8192, 16384, 65536):
+        c = bench.block_logloss_cost(rows)
+        assert c is not None and c["block_rows"] <= rows
+        assert abs(c["d_train_logloss"]) < 1e-4 and abs(c["d_eval_logloss"]) < 1e-4

@@ -747,6 +747,43 @@ def test_rows_without_a_field_array_train_and_predict_the_same(zero_copy):
             b_.unpin_block(blk)
 
 
+def test_long_step_schedule_on_small_blocks(monkeypatch):
+    """What only the headline-size engine takes by default -- the range sort with its look-ahead and the
+    staged block's upload both started at the running block's row-kernel end (engine.hip:
+    prep_after_row, pull_after_row) -- forced onto small blocks: eight zero-copy blocks three deep through
+    ffm_engine_train_batch_async_pinned, bits and loss sum of ffm_engine_train_batch block by block."""
+    F, k, per = 8, 16, 50
+    nf = F * per
+    fs = (np.arange(F + 1) * per).astype(np.int32)
+    g = synth.Generator(F, nf, "zipf", seed=36)
+    blocks = [g.block(n) for n in (256, 256, 31, 256, 256, 256, 1, 256)]
+
+    def make():
+        e = fa.Engine("FFM", nf, F, k, max_batch_rows=256, seed=3, field_start=fs, **STRESS_HP)
+        e.fill_state(seed=9)
+        return e
+
+    a = make()
+    ref_loss = sum(a.train_batch(b)[1] for b in blocks)
+    sa = a.get_state()
+    a.close()
+    monkeypatch.setenv("FFM_PREP_AFTER_ROW", "1")
+    monkeypatch.setenv("FFM_PULL_AFTER_ROW", "1")
+    b_ = make()
+    pinned = [_own_pages(blk) for blk in blocks]
+    for blk in pinned:
+        b_.pin_block(blk)
+    for blk in pinned:
+        b_.train_batch_async_pinned(blk)
+    got = b_.train_flush()
+    assert abs(got - ref_loss) <= 1e-9 * max(1.0, abs(ref_loss))
+    assert b_.blocks_pulled() == len(blocks)
+    assert_state_bitwise(b_.get_state(), sa, "long-step schedule on small blocks")
+    b_.close()
+    for blk in pinned:
+        b_.unpin_block(blk)
+
+
 def test_pinned_async_training_equals_block_by_block():
     """ffm_engine_train_batch_async_pinned (what the offline trainer calls: blocks gathered in
     page-locked memory, no host copy, three blocks in flight) mixed with the copying

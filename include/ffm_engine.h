@@ -14,7 +14,8 @@
  *   int32 (0/1) -- i.e. the reference's Sample{feat_vec x; int y} (src/include/data/sample.h:6-9,
  *   src/include/utils/types.h:18-19) flattened.  field may be NULL for LR/FM (libsvm rows, field 0).
  *   The host-buffer entry points that upload through a staging slot (ffm_engine_stage_batch,
- *   ffm_engine_train_batch_async[_pinned], ffm_engine_predict_batch_async) also take field == NULL
+ *   ffm_engine_train_batch_async[_pinned], ffm_engine_predict_batch_async, and ffm_group_train_batch[_async],
+ *   which stage through them) also take field == NULL
  *   for FFM: the block's rows must then hold exactly one entry per field, entry j of a row being
  *   field j's (what python/generate_data.py:272-306 writes and a libffm file without dropped zeros
  *   is; anything else is FFM_E_INVALID) -- the field array is then written on the device instead

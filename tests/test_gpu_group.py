@@ -108,6 +108,45 @@ def test_group_sharing_one_gpu_matches_the_unsharded_engine(n, pipelined):
     g.close()
 
 
+def test_group_takes_rows_without_a_field_array():
+    """ffm_group_train_batch[_async] stage through ffm_engine_stage_batch, so a group, too, takes FFM rows
+    that are one entry per field in field order with field == NULL (every shard's upload kernel writes
+    the array; a compact shard then drops the columns it owns nothing of as usual): two groups of the
+    same two shards, one fed with the array and one without -- the same bits, shard by shard."""
+    import copy
+    blocks = _blocks()
+    nf = F * PER
+    fs = (np.arange(F + 1) * PER).astype(np.int32)
+
+    def run(bare):
+        g = fa.Group([0, 0], "FFM", nf, F, K, max_batch_rows=B, max_batch_nnz=B * F, seed=4, max_row_nnz=F,
+                     field_start=fs, **STRESS_HP)
+        for e in g.engines:
+            e.fill_state(seed=6)
+        logits = []
+        for i, b in enumerate(blocks):
+            c = b
+            if bare:
+                c = copy.copy(b)
+                c.__dict__.pop("_ffm_csr_args", None)
+                c.field = None
+            if i % 2 == 0:
+                logits.append(g.train_batch(c)[0].copy())
+            else:
+                g.train_batch_async(c)
+                g.train_flush()
+        states = [e.get_state() for e in g.engines]
+        g.close()
+        return logits, states
+
+    lg_a, st_a = run(False)
+    lg_b, st_b = run(True)
+    for x, y in zip(lg_a, lg_b):
+        assert_bitwise(y, x, "group logits of rows without a field array")
+    for r, (a, b) in enumerate(zip(st_a, st_b)):
+        assert_state_bitwise(b, a, "shard %d" % r)
+
+
 def test_pipelined_evaluation_sums_the_block_losses():
     import torch
     blocks = _blocks()

@@ -451,7 +451,10 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
       const unsigned long long own_bits = owner_bits(m, fp);
       float n[4] = {0.0f, 0.0f, 0.0f, 0.0f}, z[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       if (mine) {
-        const float4 n4 = rec4[LAT_N * RL4 + lc], z4 = rec4[LAT_Z * RL4 + lc], w4 = rec4[LAT_W * RL4 + lc];
+        // (the record's (n, z) pass through once per block: the non-temporal hint keeps them from pushing the
+        // partners' gathered weights out of the L2 -- few launch 350 -> 340 us, C5 step -1.4 %; the same hint on
+        // the hot and giant ranges' records, or on w, bought nothing more)
+        const float4 n4 = load_nt(rec4 + LAT_N * RL4 + lc), z4 = load_nt(rec4 + LAT_Z * RL4 + lc), w4 = rec4[LAT_W * RL4 + lc];
         n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
         z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
         w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
@@ -494,8 +497,8 @@ __device__ __forceinline__ void ffm_small_body(const ModelDev &m, const Rows &ro
         }
       }
       if (a.finish(m.h, w, n, z) && mine) {
-        rec4[LAT_N * RL4 + lc] = make_float4(n[0], n[1], n[2], n[3]);
-        rec4[LAT_Z * RL4 + lc] = make_float4(z[0], z[1], z[2], z[3]);
+        store_nt(rec4 + LAT_N * RL4 + lc, make_float4(n[0], n[1], n[2], n[3]));
+        store_nt(rec4 + LAT_Z * RL4 + lc, make_float4(z[0], z[1], z[2], z[3]));
       }
     }
 #if FFM_FEW_LDS

@@ -337,6 +337,10 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_generic_kernel(ModelDe
 // Requires n_factors % 4 == 0.  c <= kSmallMax occurrences: a single segment.  Kept lean in
 // registers: the bandwidth comes from many resident waves, each with its record's loads in flight.
 // few_only: the features that occur once are ffm_update_single_kernel's (or their row's).
+// (The owners that stream a record's (n, z) through once per block -- the few-occurrence range, and on a
+// shard the flat few-occurrence kernel and the once-only kernels -- read and write them with the non-temporal
+// hint: they do not push the partners' gathered weights out of the L2.  C5 step -1.4 %, an emulated 8-GPU
+// rank 1.69 -> 1.66 ms; profiles/r06_experiments.md section 19.)
 #ifndef FFM_SMALL_BATCH
 #define FFM_SMALL_BATCH 4
 #endif
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_flat_kernel(Mode
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
     float n[4] = {0.0f, 0.0f, 0.0f, 0.0f}, z[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (mine) {
-      const float4 n4 = rec4[LAT_N * RL4 + l], z4 = rec4[LAT_Z * RL4 + l], w4 = rec4[LAT_W * RL4 + l];
+      const float4 n4 = load_nt(rec4 + LAT_N * RL4 + l), z4 = load_nt(rec4 + LAT_Z * RL4 + l), w4 = rec4[LAT_W * RL4 + l];
       n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
       z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
       w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
@@ -583,8 +587,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_flat_kernel(Mode
       a.touch(n, w, live, first, tg, x, vp);
     }
     if (a.finish(m.h, w, n, z) && mine) {
-      rec4[LAT_N * RL4 + l] = make_float4(n[0], n[1], n[2], n[3]);
-      rec4[LAT_Z * RL4 + l] = make_float4(z[0], z[1], z[2], z[3]);
+      store_nt(rec4 + LAT_N * RL4 + l, make_float4(n[0], n[1], n[2], n[3]));
+      store_nt(rec4 + LAT_Z * RL4 + l, make_float4(z[0], z[1], z[2], z[3]));
     }
   }
 }
@@ -635,8 +639,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev
         f = f < 0 ? 0 : f;
         fp[t] = f;
         if (l[t] >= 0) {
-          n4[t] = rec4[LAT_N * RL4 + ll];
-          z4[t] = rec4[LAT_Z * RL4 + ll];
+          n4[t] = load_nt(rec4 + LAT_N * RL4 + ll);
+          z4[t] = load_nt(rec4 + LAT_Z * RL4 + ll);
           w4[t] = rec4[LAT_W * RL4 + ll];
           rt[t] = rtab[f];
         }
@@ -667,8 +671,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_kernel(ModelDev
           }
         }
         if (touched) {
-          rec4[LAT_N * RL4 + l[t]] = n4[t];
-          rec4[LAT_Z * RL4 + l[t]] = z4[t];
+          store_nt(rec4 + LAT_N * RL4 + l[t], n4[t]);
+          store_nt(rec4 + LAT_Z * RL4 + l[t], z4[t]);
         }
       }
     }
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_flat_kernel(Mod
     const int q = rt.z;
     if (q == -1 || q == p) continue;  // no entry of that field in the row (or only this one)
     float4 *rec4 = reinterpret_cast<float4 *>(lat_row(m, i, fa));
-    float4 n4 = rec4[LAT_N * RL4 + ll], z4 = rec4[LAT_Z * RL4 + ll];
+    float4 n4 = load_nt(rec4 + LAT_N * RL4 + ll), z4 = load_nt(rec4 + LAT_Z * RL4 + ll);
     const float4 w4 = rec4[LAT_W * RL4 + ll];
     const float xm = rows.val[p], tg = s.tg[r];
     bool touched = false;
@@ -722,8 +726,8 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_single_flat_kernel(Mod
       }
     }
     if (touched) {
-      rec4[LAT_N * RL4 + ll] = n4;
-      rec4[LAT_Z * RL4 + ll] = z4;
+      store_nt(rec4 + LAT_N * RL4 + ll, n4);
+      store_nt(rec4 + LAT_Z * RL4 + ll, z4);
     }
   }
 }

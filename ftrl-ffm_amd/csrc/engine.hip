@@ -1054,6 +1054,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
     TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_update_all_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes(1))));
     TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_update_all_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes(2))));
     TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_update_all_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes(4))));
+    TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_update_all_kernel<1, UPD_ALL & ~UPD_FEW>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes(1))));
+    TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_update_all_kernel<2, UPD_ALL & ~UPD_FEW>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes(2))));
+    TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ffm_update_all_kernel<4, UPD_ALL & ~UPD_FEW>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(tile_lds_bytes(4))));
   }
   if (!(cfg->flags & FFM_FLAG_SKIP_INIT))
     hipLaunchKernelGGL(init_weights_kernel, dim3(2048), dim3(256), 0, e->stream, m, e->logical_len,

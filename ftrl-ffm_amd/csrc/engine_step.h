@@ -326,7 +326,21 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
     }
     // (the few-occurrence launch further down: beside the longest features' second pass and join,
     // which are chains of dependent loads on an otherwise idle chip)
-    const bool few_late = flat && sst != e->stream && rows.nnz >= e->m.super_min;
+    // (the grouping counted the block's longest features into page-locked host memory; it ran blocks
+    // ahead, so its event has usually completed and the count can be read: none -> no launches)
+    bool supers = rows.nnz >= e->m.super_min;
+    if (supers && e->super_flag_ok && e->cur_prepared) {
+      // The count is there once the block's grouping has run -- blocks ago in device time, so this wait
+      // is over at once unless the caller is several steps ahead of the device, which it then stops
+      // being (two steps stay queued).  Rounds 4-5 only QUERIED the event: a caller that ran ahead (a
+      // zero-copy loop never blocks) found it pending in most steps and paid the two empty launches
+      // and their gaps, ~30 us per C5 step (profiles/r06_experiments.md section 9).
+      if (e->super_wait) HIP_TRY(hipEventSynchronize(e->ev_grouped[e->cur]));
+      if (hipEventQuery(e->ev_grouped[e->cur]) == hipSuccess && e->h_super[e->cur] == 0) supers = false;
+    }
+    // (... and only then is the few-occurrence kernel worth deferring: a block without such features -- the
+    // strong-scaling leg's 8192 rows -- has no second pass to run it beside: 0.349 -> 0.341 ms)
+    const bool few_late = flat && sst != e->stream && supers;
     if (flat && !few_late) LAUNCH_ON(e, sst, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
     if (sst != e->stream && !few_late) HIP_TRY(hipEventRecord(e->ev_join, sst));
     // (the ranges' sizes are kept in 256-thread units and scaled to the launch's workgroup size)
@@ -405,18 +419,6 @@ int ffm_engine_train_update_device(ffm_engine *e, const float *logit, float *log
       HIP_TRY(hipStreamWaitEvent(sst, e->ev_fork2, 0));
       LAUNCH_ON(e, sst, K_LATENT_UPDATE_FEW, ffm_update_small_flat_kernel, e->grid_small, kUpdThreads, 0, e->m, rows, e->sc[e->cur], single ? 1 : 0);
       HIP_TRY(hipEventRecord(e->ev_join, sst));
-    }
-    // (the grouping counted the block's longest features into page-locked host memory; it ran blocks
-    // ahead, so its event has usually completed and the count can be read: none -> no launches)
-    bool supers = rows.nnz >= e->m.super_min;
-    if (supers && e->super_flag_ok && e->cur_prepared) {
-      // The count is there once the block's grouping has run -- blocks ago in device time, so this wait
-      // is over at once unless the caller is several steps ahead of the device, which it then stops
-      // being (two steps stay queued).  Rounds 4-5 only QUERIED the event: a caller that ran ahead (a
-      // zero-copy loop never blocks) found it pending in most steps and paid the two empty launches
-      // and their gaps, ~30 us per C5 step (profiles/r06_experiments.md section 9).
-      if (e->super_wait) HIP_TRY(hipEventSynchronize(e->ev_grouped[e->cur]));
-      if (hipEventQuery(e->ev_grouped[e->cur]) == hipSuccess && e->h_super[e->cur] == 0) supers = false;
     }
     if (supers) {
       // the longest features' ranges: second pass (root differences) and the join of their tiles

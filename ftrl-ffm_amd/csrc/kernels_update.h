@@ -522,6 +522,10 @@ __global__ __launch_bounds__(kUpdThreads) FFM_SMALL_OCC void ffm_update_small_ke
 
 // The same for SHORT stored records (a compact shard's), a lane = one (feature, vector) of a flat
 // index space -- see ffm_update_single_flat_kernel below.
+#ifndef FFM_FLAT_BATCH
+#define FFM_FLAT_BATCH 4
+#endif
+constexpr int kFlatBatch = FFM_FLAT_BATCH < kSmallMax ? FFM_FLAT_BATCH : kSmallMax;
 __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_flat_kernel(ModelDev m, Rows rows,
                                                                             Scratch s, int few_only) {
   const int RL4 = m.row_len >> 2, k4 = m.n_factors >> 2, F = m.n_fields;
@@ -561,30 +565,52 @@ __global__ __launch_bounds__(kUpdThreads) void ffm_update_small_flat_kernel(Mode
     }
     FoldFew<4> a;
     a.init();
-    for (int j = 0; j < kSmallMax; j++) {
-      if (!__any(mine && j < c)) break;
-      bool live = false, first = false;
-      float tg = 0.0f, x = 0.0f;
-      float vp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (mine && j < c) {
-        const int2 pr = s.occ2[start + j];
-        const int p = pr.x, r = pr.y;
-        const int fm = rows.field[p];
-        if (owns_bit(own_bits, fm)) {
-          const int4 rt = s.rowtab[static_cast<int64_t>(r) * F + fp];
-          const int q = rt.z;
-          if (q >= 0 && q != p) {
-            const float4 v4 = reinterpret_cast<const float4 *>(
-                lat_row(m, rt.x, fp))[LAT_W * RL4 + slot_of(m, fp, fm) * k4 + kq];
-            vp[0] = v4.x; vp[1] = v4.y; vp[2] = v4.z; vp[3] = v4.w;
-            live = true;
-            first = p < q || m.h.learn != 0;
-            tg = s.tg[r];
-            x = rows.val[p] * __int_as_float(rt.y);
-          }
+    // kFlatBatch touches at a time: their {entry, row}, then their fields / row-table entries / values /
+    // tmp_grad, then the partners' weights -- three dependent trips per BATCH, not per touch (one touch at a
+    // time the kernel was a chain of 3 c trips per item: 428 us per 65 536-row block of an 8-GPU rank,
+    // the end of the rank's step) -- and then the touches in order
+    for (int j0 = 0; j0 < kSmallMax; j0 += kFlatBatch) {
+      if (!__any(mine && j0 < c)) break;
+      int2 pr[kFlatBatch];
+#pragma unroll
+      for (int jj = 0; jj < kFlatBatch; jj++) {
+        pr[jj] = make_int2(0, 0);
+        if (mine && j0 + jj < c) pr[jj] = s.occ2[start + j0 + jj];
+      }
+      int fm[kFlatBatch];
+      int4 rt[kFlatBatch];
+      float tgv[kFlatBatch], xv[kFlatBatch];
+      bool own[kFlatBatch];
+#pragma unroll
+      for (int jj = 0; jj < kFlatBatch; jj++) {
+        fm[jj] = 0;
+        own[jj] = false;
+        rt[jj] = make_int4(0, 0, -1, 0);
+        tgv[jj] = xv[jj] = 0.0f;
+        if (mine && j0 + jj < c) {
+          fm[jj] = rows.field[pr[jj].x];
+          rt[jj] = s.rowtab[static_cast<int64_t>(pr[jj].y) * F + fp];
+          tgv[jj] = s.tg[pr[jj].y];
+          xv[jj] = rows.val[pr[jj].x];
         }
       }
-      a.touch(n, w, live, first, tg, x, vp);
+      float4 v4[kFlatBatch];
+      bool live[kFlatBatch];
+#pragma unroll
+      for (int jj = 0; jj < kFlatBatch; jj++) {
+        own[jj] = mine && j0 + jj < c && owns_bit(own_bits, fm[jj]);
+        live[jj] = own[jj] && rt[jj].z >= 0 && rt[jj].z != pr[jj].x;
+        v4[jj] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (live[jj])
+          v4[jj] = reinterpret_cast<const float4 *>(lat_row(m, rt[jj].x, fp))[LAT_W * RL4 + slot_of(m, fp, fm[jj]) * k4 + kq];
+      }
+#pragma unroll
+      for (int jj = 0; jj < kFlatBatch; jj++) {
+        if (!__any(mine && j0 + jj < c)) break;
+        const float vp[4] = {v4[jj].x, v4[jj].y, v4[jj].z, v4[jj].w};
+        const bool first = live[jj] && (pr[jj].x < rt[jj].z || m.h.learn != 0);
+        a.touch(n, w, live[jj], first, live[jj] ? tgv[jj] : 0.0f, live[jj] ? xv[jj] * __int_as_float(rt[jj].y) : 0.0f, vp);
+      }
     }
     if (a.finish(m.h, w, n, z) && mine) {
       store_nt(rec4 + LAT_N * RL4 + l, make_float4(n[0], n[1], n[2], n[3]));

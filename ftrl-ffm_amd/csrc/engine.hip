@@ -672,6 +672,9 @@ int ffm_engine_create(const ffm_engine_config *cfg, ffm_engine **out) {
   // (the lean once-only kernel of a compact shard holds six waves per SIMD: 1152 workgroups
   // measured 2.5 % per step better than 768 on an 8-GPU rank's blocks)
   if (cfg->n_shards > 1) e->grid_single = 1152;
+  // (... and its flat few-occurrence kernel, 126 VGPRs = four waves per SIMD, fills the chip at 1024
+  // workgroups: an emulated rank's step 1.615 -> 1.605 ms)
+  if (cfg->n_shards > 1 && !std::getenv("FFM_GRID_SMALL")) e->grid_small = 1024;
 
   {
     const char *rr = std::getenv("FFM_ENGINE_ROW_REFRESH");
